@@ -1,0 +1,133 @@
+"""Pin the C oracle against the unmodified reference on many random inputs.
+
+    /opt/conda/bin/python3.9 oracle/refgen/fuzz_vs_reference.py [ncases]
+
+Stage by stage (assign, clump, single-pixel elimination, small-segment
+elimination, k-means fit partition) the oracle must equal the reference bit
+for bit.  Build container only; see refenv.py.
+"""
+import sys
+import time
+
+import numpy as np
+
+import refenv
+from refenv import shepseg
+from oracle import oracle
+
+
+class FakeKM(object):
+    def __init__(self, centres):
+        self.cluster_centers_ = centres
+
+
+def make_img(rng, case):
+    kind = case % 8
+    nb = int(rng.choice([1, 3, 4, 6, 7]))
+    nr = int(rng.randint(5, 140))
+    nc = int(rng.randint(5, 140))
+    if kind == 0:      # smooth synthetic
+        img = oracle.synthimg(int(rng.randint(1, 1000)), nb, nr, nc, int(rng.randint(0, 5000)),
+                              int(rng.randint(0, 5000)))
+    elif kind == 1:    # few grey levels -> big clumps, many ties
+        img = (rng.randint(0, 3, size=(nb, nr, nc)) * 1000 + 500).astype(np.uint16)
+    elif kind == 2:    # high values: float32 sums inexact, squares large
+        img = (60000 + rng.randint(0, 5000, size=(nb, nr, nc))).astype(np.uint16)
+        img[:, : nr // 2, :] = img[:, :1, :1]      # one big flat segment
+    elif kind == 3:    # uint8 noise
+        img = rng.randint(0, 256, size=(nb, nr, nc)).astype(np.uint8)
+    elif kind == 4:    # int16 with negatives
+        img = rng.randint(-3000, 3000, size=(nb, nr, nc)).astype(np.int16)
+    elif kind == 5:    # blocky
+        base = rng.randint(0, 4000, size=(nb, nr // 6 + 1, nc // 6 + 1))
+        img = np.kron(base, np.ones((1, 6, 6), dtype=np.int64))[:, :nr, :nc]
+        img = (img + rng.randint(0, 30, size=img.shape)).astype(np.uint16)
+    elif kind == 6:    # int32 large
+        img = rng.randint(0, 1 << 20, size=(nb, nr, nc)).astype(np.int32)
+    else:              # thin shapes
+        if rng.rand() < 0.5:
+            nr = 1
+        else:
+            nc = 1
+        img = rng.randint(0, 2000, size=(nb, nr, nc)).astype(np.uint16)
+    null_val = None
+    if rng.rand() < 0.5:
+        null_val = int(np.iinfo(img.dtype).max)
+        m = rng.rand(nr, nc) < rng.choice([0.01, 0.1, 0.4])
+        if rng.rand() < 0.3:
+            m[:] = False
+            m[rng.randint(0, nr), rng.randint(0, nc)] = True     # segSize[0]==1
+        b = rng.randint(0, nb)
+        img[b][m] = null_val
+    return np.ascontiguousarray(img), null_val
+
+
+def main():
+    ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    rng = np.random.RandomState(12345)
+    nfail = 0
+    t0 = time.time()
+    for case in range(ncases):
+        img, null_val = make_img(rng, case)
+        nb, nr, nc = img.shape
+        k = int(rng.choice([2, 5, 10, 60]))
+        min_seg = int(rng.choice([2, 5, 20, 50]))
+        four = bool(rng.rand() < 0.6)
+        pcnt = int(rng.choice([1, 10, 50, 100]))
+        try:
+            ref, km = refenv.ref_stages(img, k, min_seg, null_val, four, pcnt=pcnt)
+        except Exception as e:       # e.g. too few non-null samples for k clusters
+            print('case %d skipped: %s' % (case, str(e)[:80]))
+            continue
+        c = ref['centres']
+        tag = 'case %d %s %s k=%d minSeg=%d four=%s null=%s' % (case, img.shape, img.dtype, k,
+                                                                 min_seg, four, null_val)
+        ok = True
+        cl = oracle.kmeans_assign(img, c, null_val)
+        if not np.array_equal(cl, ref['clusters']):
+            print('ASSIGN MISMATCH', tag, (cl != ref['clusters']).sum()); ok = False
+        seg, nxt = oracle.clump(ref['clusters'], 0, four, 1)
+        if not np.array_equal(seg, ref['clump']) or nxt - 1 != ref['num_clumps']:
+            print('CLUMP MISMATCH', tag); ok = False
+        seg1 = ref['clump'].copy()
+        ss = oracle.make_seg_size(seg1)
+        if not np.array_equal(ss, shepseg.makeSegSize(ref['clump'])):
+            print('SEGSIZE MISMATCH', tag); ok = False
+        oracle.eliminate_single_pixels(img, seg1, ss, 1, int(ref['num_clumps']), four)
+        if not np.array_equal(seg1, ref['seg_single']):
+            print('SINGLE MISMATCH', tag, (seg1 != ref['seg_single']).sum()); ok = False
+        seg2 = ref['seg_single'].copy()
+        ne = oracle.eliminate_small_segments(seg2, img, int(seg2.max()), min_seg,
+                                             float(ref['msd']), four)
+        if not np.array_equal(seg2, ref['seg_final']) or ne != ref['num_small']:
+            print('SMALL MISMATCH', tag, (seg2 != ref['seg_final']).sum(), ne, ref['num_small'])
+            ok = False
+        full = oracle.segment_tile(img, c, min_seg, float(ref['msd']), null_val, four)
+        if not np.array_equal(full['segimg'], ref['seg_final']):
+            print('FULL MISMATCH', tag); ok = False
+        # k-means fit: same partition + n_iter as sklearn (labels up to permutation, N12/N14)
+        x = np.transpose(img, (1, 2, 0)).reshape(nr * nc, nb)
+        if null_val is not None:
+            x = x[(x != null_val).all(axis=1)]
+        xs = x[::int(round(100. / pcnt))]
+        init = shepseg.diagonalClusterCentres(xs, k)
+        cfit, lab, nit = oracle.kmeans_fit(xs.astype(np.float64), init.astype(np.float64))
+        rl = km.labels_
+        pairs = set(zip(lab.tolist(), rl.tolist()))
+        if nit != km.n_iter_ or len(pairs) != len(set(lab.tolist())) or \
+                len(pairs) != len(set(rl.tolist())):
+            print('KMFIT MISMATCH', tag, nit, km.n_iter_, len(pairs), len(set(lab.tolist())),
+                  len(set(rl.tolist())))
+            ok = False
+        nfail += (not ok)
+        if case % 20 == 0:
+            print('case', case, 'ok' if ok else 'FAIL', tag, 'clumps', int(ref['num_clumps']),
+                  'final', int(ref['seg_final'].max()), '%.0fs' % (time.time() - t0))
+            sys.stdout.flush()
+    print('stack:', refenv.STACK)
+    print('DONE: %d cases, %d failures' % (ncases, nfail))
+    return 1 if nfail else 0
+
+
+if __name__ == '__main__':
+    sys.exit(main())

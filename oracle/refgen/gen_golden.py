@@ -1,0 +1,115 @@
+"""Generate tests/golden/*.npz from the UNMODIFIED reference (build container only).
+
+    /opt/conda/bin/python3.9 oracle/refgen/gen_golden.py
+
+Every file holds plain numpy arrays only: the inputs and the reference's
+stage-by-stage outputs (no pickled reference objects, no reference source).
+Oracle stack recorded in each file under key 'stack'.
+"""
+import os
+import sys
+
+import numpy as np
+
+import refenv
+from refenv import shepseg
+from oracle import oracle
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))),
+                   'tests', 'golden')
+
+
+def save(name, **arrs):
+    arrs['stack'] = np.array(refenv.STACK)
+    path = os.path.join(OUT, name + '.npz')
+    np.savez_compressed(path, **arrs)
+    print('%-28s %7.1f kB' % (name, os.path.getsize(path) / 1024.0))
+
+
+def tile_case(name, img, k, min_seg, null_val, four, pcnt):
+    ref, km = refenv.ref_stages(img, k, min_seg, null_val, four, pcnt=pcnt)
+    # whole-call cross-check of the staged run
+    r = shepseg.doShepherdSegmentation(img, numClusters=k, clusterSubsamplePcnt=pcnt,
+                                       minSegmentSize=min_seg, imgNullVal=null_val,
+                                       fourConnected=four, fixedKMeansInit=True, kmeansObj=km)
+    assert np.array_equal(r.segimg, ref['seg_final'])
+    assert r.singlePixelsEliminated == ref['num_single']
+    assert r.smallSegmentsEliminated == ref['num_small']
+    save(name, img=img, k=np.int64(k), min_seg=np.int64(min_seg),
+         null_val=np.int64(-1 if null_val is None else null_val),
+         has_null=np.int64(null_val is not None), four=np.int64(four), pcnt=np.int64(pcnt),
+         km_n_iter=np.int64(km.n_iter_), km_labels=km.labels_.astype(np.int32), **ref)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    # (1)/(2) synthetic 3-band 96x96, 4- and 8-connected
+    img = oracle.synthimg(1, 3, 96, 96)
+    tile_case('tile_synth96_4conn', img, 10, 20, None, True, 10)
+    tile_case('tile_synth96_8conn', img, 10, 20, None, False, 10)
+    # (3) 6-band 128^2 k=60 minSeg=50 with null border + hole
+    img = oracle.synthimg(7, 6, 128, 128, 300, 900)
+    img[:, :3, :] = 65535; img[:, -2:, :] = 65535; img[:, :, :4] = 65535; img[:, :, -1:] = 65535
+    img[2, 60:75, 40:70] = 65535                      # hole in ONE band only (any-band rule)
+    tile_case('tile_synth128_null', img, 60, 50, 65535, True, 5)
+    # (4) crafted edge cases
+    rng = np.random.RandomState(3)
+    img = rng.randint(0, 256, size=(3, 40, 50)).astype(np.uint8)
+    tile_case('tile_u8_noise', img, 5, 10, None, True, 50)
+    img = rng.randint(-500, 500, size=(4, 33, 47)).astype(np.int16)
+    tile_case('tile_i16_noise_8conn', img, 5, 10, None, False, 50)
+    img = (rng.randint(0, 3, size=(2, 60, 60)) * 700 + 100).astype(np.uint16)   # ties everywhere
+    tile_case('tile_ties', img, 4, 30, None, True, 100)
+    img = rng.randint(0, 3000, size=(3, 1, 200)).astype(np.uint16)
+    tile_case('tile_1xN', img, 5, 5, None, True, 100)
+    img = rng.randint(0, 3000, size=(3, 200, 1)).astype(np.uint16)
+    tile_case('tile_Nx1', img, 5, 5, None, True, 100)
+    img = oracle.synthimg(9, 3, 64, 64)
+    img[1, 20, 31] = 65535                            # exactly one null pixel: segSize[0]==1
+    tile_case('tile_one_null', img, 10, 20, 65535, True, 10)
+    img = oracle.synthimg(11, 3, 48, 48)
+    img[0][rng.rand(48, 48) < 0.35] = 65535            # lots of nulls: null is a merge target
+    tile_case('tile_many_null', img, 10, 20, 65535, True, 10)
+    # (6) float32-inexact spectSum: values near 60000, a > 5000-px flat segment
+    img = (60000 + rng.randint(0, 4000, size=(3, 120, 120))).astype(np.uint16)
+    img[:, :70, :] = np.array([61001, 60503, 63999], dtype=np.uint16)[:, None, None]
+    tile_case('tile_f32_inexact', img, 8, 40, None, True, 20)
+    # (5) clump splitting (N9): 150x150 uniform; two-value maze; synthetic with a big component
+    cl = np.ones((150, 150), dtype=np.int32)
+    for four in (True, False):
+        seg, nxt = shepseg.clump(cl, 0, fourConnected=four, clumpId=1)
+        save('clump_uniform150_%dconn' % (4 if four else 8), clusters=cl, four=np.int64(four),
+             clump=seg, next_id=np.int64(nxt))
+    cl = np.ones((180, 170), dtype=np.int32)
+    cl[::4, :-3] = 2; cl[2::4, 3:] = 2                # serpentine walls -> long thin component
+    cl[50:60, 20:40] = 0
+    for four in (True, False):
+        seg, nxt = shepseg.clump(cl, 0, fourConnected=four, clumpId=1)
+        save('clump_maze_%dconn' % (4 if four else 8), clusters=cl, four=np.int64(four),
+             clump=seg, next_id=np.int64(nxt))
+    img = oracle.synthimg(1, 3, 256, 256)
+    km = shepseg.fitSpectralClusters(img, 4, 1, None, True)
+    cl = shepseg.applySpectralClusters(km, img, None).astype(np.int32)
+    for four in (True, False):
+        seg, nxt = shepseg.clump(cl, 0, fourConnected=four, clumpId=1)
+        save('clump_synth256_%dconn' % (4 if four else 8), clusters=cl.astype(np.uint8),
+             four=np.int64(four), clump=seg, next_id=np.int64(nxt))
+    # (9) k-means fit on a realistic sample (partition / n_iter / centres)
+    img = oracle.synthimg(2, 6, 512, 512)
+    km = shepseg.fitSpectralClusters(img, 60, 1, None, True)
+    x = np.transpose(img, (1, 2, 0)).reshape(-1, 6)[::100]
+    init = shepseg.diagonalClusterCentres(x, 60)
+    save('kmeans_fit_synth512', sample=x, init=init, centres=km.cluster_centers_,
+         labels=km.labels_.astype(np.int32), n_iter=np.int64(km.n_iter_),
+         inertia=np.float64(km.inertia_))
+    # autoMaxSpectralDiff variants (host code): 'auto' pctiles, None, number
+    c = km.cluster_centers_
+    save('auto_msd', centres=c,
+         p50=np.float64(shepseg.autoMaxSpectralDiff(km, 'auto', 50)),
+         p25=np.float64(shepseg.autoMaxSpectralDiff(km, 'auto', 25)),
+         p90=np.float64(shepseg.autoMaxSpectralDiff(km, 'auto', 90)),
+         none=np.float64(shepseg.autoMaxSpectralDiff(km, None, 50)))
+
+
+if __name__ == '__main__':
+    sys.exit(main())

@@ -1,0 +1,612 @@
+/*
+ * shepseg_oracle.c -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+ *
+ * A plain-C, single-threaded CPU restatement of the pyshepseg per-tile hot path
+ * (ubarsc/pyshepseg v2.0.3).  It exists so that the HIP kernels in
+ * pyshepseg_amd/csrc can be checked bit-for-bit on the GPU box, where the
+ * Python/numba reference cannot travel.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may load it.  The product path never does.
+ *
+ * Parity status: PINNED.  Every function below is checked against the
+ * unmodified reference run under real numba 0.54.1 / sklearn 0.24.2 in the
+ * build container (oracle/refgen/gen_golden.py -> tests/golden/, and
+ * oracle/refgen/fuzz_vs_reference.py).
+ *
+ * Each function cites the reference file:line it restates.  Numeric typing
+ * follows SURVEY.md section 8(a0) (facts N1..N14, established by running the
+ * reference, not by reading it).
+ *
+ * Build: see oracle/Makefile  (gcc -O2 -ffp-contract=off -shared -fPIC).
+ */
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+
+#define ORC_API __attribute__((visibility("default")))
+#ifndef ORC_SKLEARN_GE_1
+#define ORC_SKLEARN_GE_1 0     /* 0: sklearn 0.24.2 (pinned oracle stack); 1: sklearn >= 1.0 variants */
+#endif
+#define ORC_RELOCATE_GUARD ORC_SKLEARN_GE_1
+
+enum { ORC_U8 = 0, ORC_I16 = 1, ORC_U16 = 2, ORC_I32 = 3, ORC_U32 = 4 };
+
+/* ------------------------------------------------------------------ */
+/* generic pixel fetch: all supported image dtypes fit in int64        */
+/* ------------------------------------------------------------------ */
+static inline int64_t px_get(const void *img, int dtype, size_t i)
+{
+    switch (dtype) {
+    case ORC_U8:  return ((const uint8_t  *)img)[i];
+    case ORC_I16: return ((const int16_t  *)img)[i];
+    case ORC_U16: return ((const uint16_t *)img)[i];
+    case ORC_I32: return ((const int32_t  *)img)[i];
+    default:      return ((const uint32_t *)img)[i];
+    }
+}
+
+ORC_API int orc_version(void) { return 1; }
+
+/* ------------------------------------------------------------------ */
+/* synthimg v1 -- integer-only synthetic image   */
+/* ------------------------------------------------------------------ */
+static inline uint64_t syn_mix(uint64_t z)
+{
+    z += 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+static inline uint64_t syn_h(uint64_t seed, uint64_t b, uint64_t o, uint64_t y, uint64_t x)
+{
+    const uint64_t P = 1000003ULL;
+    return syn_mix((((seed * P + b) * P + o) * P + y) * P + x);
+}
+static inline uint16_t syn_pixel(uint64_t seed, uint64_t b, uint64_t y, uint64_t x)
+{
+    static const int lgs[4] = {8, 6, 4, 2};
+    static const uint64_t amps[4] = {2000, 1000, 500, 250};
+    uint64_t v = 1000 + 300 * b;
+    for (int o = 0; o < 4; o++) {
+        int lg = lgs[o];
+        uint64_t c = 1ULL << lg;
+        uint64_t gy = y >> lg, gx = x >> lg, fy = y & (c - 1), fx = x & (c - 1);
+        uint64_t v00 = syn_h(seed, b, o, gy, gx) >> 48;
+        uint64_t v01 = syn_h(seed, b, o, gy, gx + 1) >> 48;
+        uint64_t v10 = syn_h(seed, b, o, gy + 1, gx) >> 48;
+        uint64_t v11 = syn_h(seed, b, o, gy + 1, gx + 1) >> 48;
+        uint64_t interp = (v00 * (c - fy) * (c - fx) + v01 * (c - fy) * fx +
+                           v10 * fy * (c - fx) + v11 * fy * fx) >> (2 * lg);
+        v += (interp * amps[o]) >> 16;
+    }
+    v += ((syn_h(seed, b, 99, y, x) >> 48) * 120) >> 16;
+    if (v > 65534) v = 65534;
+    return (uint16_t)v;
+}
+/* window [y0,y0+rows) x [x0,x0+cols) of the infinite synthetic image, band-planar */
+ORC_API void orc_synthimg(uint64_t seed, int nbands, int64_t y0, int64_t x0,
+                          int rows, int cols, uint16_t *out)
+{
+    for (int b = 0; b < nbands; b++)
+        for (int r = 0; r < rows; r++)
+            for (int c = 0; c < cols; c++)
+                out[((size_t)b * rows + r) * cols + c] =
+                    syn_pixel(seed, (uint64_t)b, (uint64_t)(y0 + r), (uint64_t)(x0 + c));
+}
+
+/* ------------------------------------------------------------------ */
+/* k-means assign: shepseg.py:317-361 applySpectralClusters +           */
+/* sklearn KMeans.predict (3rd party, sklearn/cluster/_kmeans.py         */
+/* _labels_inertia -> _k_means_lloyd.pyx _update_chunk_dense):           */
+/*   d_j = |c_j|^2 - 2 x.c_j  in float64, argmin, first minimum wins.    */
+/* Evaluation order is pinned here as a band-ordered fma chain so that   */
+/* the GPU kernel can reproduce it bit for bit; N13 shows any float64     */
+/* evaluation reproduces sklearn's labels on integer imagery.            */
+/* ------------------------------------------------------------------ */
+ORC_API void orc_kmeans_prepare(const double *centres, int k, int nbands,
+                                double *m2c /* k*nbands: -2*c */, double *cnorm /* k */)
+{
+    for (int j = 0; j < k; j++) {
+        double s = 0.0;
+        for (int b = 0; b < nbands; b++) {
+            double c = centres[j * nbands + b];
+            s = fma(c, c, s);
+            m2c[j * nbands + b] = -2.0 * c;
+        }
+        cnorm[j] = s;
+    }
+}
+
+ORC_API int orc_kmeans_assign(const void *img, int dtype, int nbands, int nrows, int ncols,
+                              const double *centres, int k, int has_null, int64_t null_val,
+                              int32_t *clusters_out)
+{
+    size_t npix = (size_t)nrows * ncols;
+    double *m2c = (double *)malloc(sizeof(double) * k * nbands);
+    double *cnorm = (double *)malloc(sizeof(double) * k);
+    double x[64];
+    if (nbands > 64) return -1;
+    orc_kmeans_prepare(centres, k, nbands, m2c, cnorm);
+    for (size_t p = 0; p < npix; p++) {
+        int isnull = 0;
+        for (int b = 0; b < nbands; b++) {
+            int64_t v = px_get(img, dtype, (size_t)b * npix + p);
+            if (has_null && v == null_val) isnull = 1;      /* shepseg.py:357-359 any band */
+            x[b] = (double)v;
+        }
+        int best = 0;
+        double bestd = 0.0;
+        for (int j = 0; j < k; j++) {
+            double d = cnorm[j];
+            for (int b = 0; b < nbands; b++) d = fma(x[b], m2c[j * nbands + b], d);
+            if (j == 0 || d < bestd) { bestd = d; best = j; }
+        }
+        clusters_out[p] = isnull ? 0 : best + 1;             /* shepseg.py:356 */
+    }
+    free(m2c); free(cnorm);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* clump: shepseg.py:452-541.  Raster scan + explicit LIFO stack,       */
+/* neighbours pushed cx outer / cy inner, labelled when pushed,          */
+/* MAX_CLUMP_SIZE=10000 counted on pixels added after the seed (N9).     */
+/* Returns next clump id (highest used + 1).                             */
+/* ------------------------------------------------------------------ */
+ORC_API uint32_t orc_clump(const int32_t *img, int nrows, int ncols, int32_t ignore_val,
+                           int four_connected, uint32_t clump_id, uint32_t *out)
+{
+    const int MAX_CLUMP_SIZE = 10000;
+    size_t npix = (size_t)nrows * ncols;
+    uint32_t *stack = (uint32_t *)malloc(sizeof(uint32_t) * 2 * (npix ? npix : 1));
+    memset(out, 0, sizeof(uint32_t) * npix);
+    for (int y = 0; y < nrows; y++) {
+        for (int x = 0; x < ncols; x++) {
+            size_t p = (size_t)y * ncols + x;
+            if (img[p] != ignore_val && out[p] == 0) {
+                int32_t val = img[p];
+                int clump_size = 0;
+                size_t sp = 0;
+                stack[0] = (uint32_t)y; stack[1] = (uint32_t)x; sp = 1;
+                out[p] = clump_id;
+                while (sp > 0 && clump_size < MAX_CLUMP_SIZE) {
+                    sp--;
+                    int sy = (int)stack[2 * sp], sx = (int)stack[2 * sp + 1];
+                    int tlx = sx - 1 < 0 ? 0 : sx - 1;
+                    int tly = sy - 1 < 0 ? 0 : sy - 1;
+                    int brx = sx + 1 > ncols - 1 ? ncols - 1 : sx + 1;
+                    int bry = sy + 1 > nrows - 1 ? nrows - 1 : sy + 1;
+                    for (int cx = tlx; cx <= brx; cx++) {
+                        for (int cy = tly; cy <= bry; cy++) {
+                            int connected = !four_connected || (cy == sy || cx == sx);
+                            size_t q = (size_t)cy * ncols + cx;
+                            if (connected && img[q] != ignore_val && out[q] == 0 && img[q] == val) {
+                                out[q] = clump_id;
+                                clump_size++;
+                                stack[2 * sp] = (uint32_t)cy; stack[2 * sp + 1] = (uint32_t)cx;
+                                sp++;
+                            }
+                        }
+                    }
+                }
+                clump_id++;
+            }
+        }
+    }
+    free(stack);
+    return clump_id;
+}
+
+/* makeSegSize: shepseg.py:544-569.  seg_size has max_seg_id+1 entries. */
+ORC_API void orc_make_seg_size(const uint32_t *seg, size_t npix, uint32_t max_seg_id,
+                               uint32_t *seg_size)
+{
+    memset(seg_size, 0, sizeof(uint32_t) * ((size_t)max_seg_id + 1));
+    for (size_t p = 0; p < npix; p++) seg_size[seg[p]]++;
+}
+
+ORC_API uint32_t orc_seg_max(const uint32_t *seg, size_t npix)
+{
+    uint32_t m = 0;
+    for (size_t p = 0; p < npix; p++) if (seg[p] > m) m = seg[p];
+    return m;
+}
+
+/* relabelSegments: shepseg.py:739-777 */
+static void relabel_segments(uint32_t *seg, size_t npix, const uint32_t *seg_size,
+                             size_t nseg /* len(segSize) */, uint32_t min_seg_id)
+{
+    uint32_t *sub = (uint32_t *)calloc(nseg ? nseg : 1, sizeof(uint32_t));
+    for (size_t k = (size_t)min_seg_id + 1; k < nseg; k++) {
+        sub[k] = sub[k - 1];
+        if (seg_size[k - 1] == 0) sub[k]++;
+    }
+    for (size_t p = 0; p < npix; p++) seg[p] -= sub[seg[p]];
+    free(sub);
+}
+
+/* findNearestNeighbourPixel: shepseg.py:677-736 (N2: exact int64; N3: scan order; N4) */
+static int find_nearest_nbr(const void *img, int dtype, int nbands, int nrows, int ncols,
+                            const uint32_t *seg, int i, int j, const uint32_t *seg_size,
+                            int four, int *oi, int *oj)
+{
+    size_t npix = (size_t)nrows * ncols;
+    int64_t min_d = -1;
+    int ii = -1, jj = -1;
+    int i0 = i - 1 < 0 ? 0 : i - 1, i1 = i + 1 > nrows - 1 ? nrows - 1 : i + 1;
+    int j0 = j - 1 < 0 ? 0 : j - 1, j1 = j + 1 > ncols - 1 ? ncols - 1 : j + 1;
+    for (int a = i0; a <= i1; a++)
+        for (int b = j0; b <= j1; b++) {
+            int connected = !four || (a == i || b == j);
+            if (!connected) continue;
+            uint32_t nb = seg[(size_t)a * ncols + b];
+            if (seg_size[nb] > 1) {
+                int64_t d = 0;
+                for (int k = 0; k < nbands; k++) {
+                    int64_t t = px_get(img, dtype, (size_t)k * npix + (size_t)i * ncols + j) -
+                                px_get(img, dtype, (size_t)k * npix + (size_t)a * ncols + b);
+                    d += t * t;
+                }
+                if (min_d < 0 || d < min_d) { min_d = d; ii = a; jj = b; }
+            }
+        }
+    *oi = ii; *oj = jj;
+    return ii >= 0 && jj >= 0;
+}
+
+/* eliminateSinglePixels: shepseg.py:572-615 (+ mergeSinglePixels :618-674).
+ * seg_size has max_seg_id+1 entries and is updated in place (not relabelled,
+ * as in the reference).  Returns total number of pixels merged. */
+ORC_API int64_t orc_eliminate_single_pixels(const void *img, int dtype, int nbands, int nrows,
+                                            int ncols, uint32_t *seg, uint32_t *seg_size,
+                                            uint32_t min_seg_id, uint32_t max_seg_id, int four)
+{
+    size_t npix = (size_t)nrows * ncols;
+    uint32_t *elim = (uint32_t *)malloc(sizeof(uint32_t) * 3 * ((size_t)max_seg_id + 1));
+    int64_t total = 0;
+    for (;;) {
+        size_t n = 0;
+        for (int i = 0; i < nrows; i++)
+            for (int j = 0; j < ncols; j++) {
+                uint32_t s = seg[(size_t)i * ncols + j];
+                if (seg_size[s] == 1) {
+                    int ii, jj;
+                    if (find_nearest_nbr(img, dtype, nbands, nrows, ncols, seg, i, j, seg_size,
+                                         four, &ii, &jj)) {
+                        elim[3 * n] = (uint32_t)i; elim[3 * n + 1] = (uint32_t)j;
+                        elim[3 * n + 2] = seg[(size_t)ii * ncols + jj];
+                        n++;
+                    }
+                }
+            }
+        for (size_t k = 0; k < n; k++) {
+            size_t p = (size_t)elim[3 * k] * ncols + elim[3 * k + 1];
+            uint32_t ns = elim[3 * k + 2], os = seg[p];
+            seg[p] = ns; seg_size[os] = 0; seg_size[ns]++;
+        }
+        if (n == 0) break;
+        total += (int64_t)n;
+    }
+    free(elim);
+    relabel_segments(seg, npix, seg_size, (size_t)max_seg_id + 1, min_seg_id);
+    return total;
+}
+
+/* buildSegmentSpectra: shepseg.py:780-813 (N5: float32, raster order; the
+ * add is evaluated as numba does for the unified type of float32+pixel). */
+static float *build_segment_spectra(const uint32_t *seg, const void *img, int dtype, int nbands,
+                                    size_t npix, uint32_t max_seg_id)
+{
+    float *ss = (float *)calloc(((size_t)max_seg_id + 1) * nbands, sizeof(float));
+    for (size_t p = 0; p < npix; p++) {
+        uint32_t s = seg[p];
+        for (int k = 0; k < nbands; k++) {
+            float *a = &ss[(size_t)s * nbands + k];
+            *a = (float)((double)*a + (double)px_get(img, dtype, (size_t)k * npix + p));
+        }
+    }
+    return ss;
+}
+
+typedef struct { uint32_t n; uint32_t *rc; } seg_loc_t;   /* RowColArray shepseg.py:816-870 */
+
+/* findMergeSegment: shepseg.py:1003-1063 (N6: float32 means / float32 sequential
+ * band sum; N7: first strict minimum in list order, ii outer, jj inner; N8: float64 threshold) */
+static uint32_t find_merge_segment(uint32_t seg_id, const seg_loc_t *loc, const uint32_t *seg,
+                                   const uint32_t *seg_size, const float *ss, int nbands,
+                                   int nrows, int ncols, double max_spectral_diff, int four)
+{
+    uint32_t best = 0;
+    double best_d = 0.0;
+    const uint32_t *rc = loc[seg_id].rc;
+    uint32_t npx = loc[seg_id].n;
+    float spect[64], nbr[64];
+    for (int k = 0; k < nbands; k++) spect[k] = ss[(size_t)seg_id * nbands + k] / (float)npx;
+    for (uint32_t k = 0; k < npx; k++) {
+        int i = (int)rc[2 * k], j = (int)rc[2 * k + 1];
+        int i0 = i - 1 < 0 ? 0 : i - 1, i1 = i + 2 > nrows ? nrows : i + 2;
+        int j0 = j - 1 < 0 ? 0 : j - 1, j1 = j + 2 > ncols ? ncols : j + 2;
+        for (int ii = i0; ii < i1; ii++)
+            for (int jj = j0; jj < j1; jj++) {
+                int connected = !four || (ii == i || jj == j);
+                uint32_t nb = seg[(size_t)ii * ncols + jj];
+                if (connected && nb != seg_id && nb != 0 && seg_size[nb] > seg_size[seg_id]) {
+                    float d = 0.0f;
+                    for (int b = 0; b < nbands; b++) {
+                        nbr[b] = ss[(size_t)nb * nbands + b] / (float)seg_size[nb];
+                        float t = spect[b] - nbr[b];
+                        float t2 = t * t;
+                        d = d + t2;
+                    }
+                    if (best == 0 || (double)d < best_d) { best_d = (double)d; best = nb; }
+                }
+            }
+    }
+    if (best_d > max_spectral_diff * max_spectral_diff) best = 0;
+    return best;
+}
+
+/* doMerge: shepseg.py:1066-1123 */
+static void do_merge(uint32_t s, uint32_t t, uint32_t *seg, uint32_t *seg_size, seg_loc_t *loc,
+                     float *ss, int nbands, int ncols)
+{
+    uint32_t ns = loc[s].n, nt = loc[t].n;
+    uint32_t *m = (uint32_t *)malloc(sizeof(uint32_t) * 2 * ((size_t)ns + nt));
+    memcpy(m, loc[t].rc, sizeof(uint32_t) * 2 * nt);
+    for (uint32_t k = 0; k < ns; k++) {
+        uint32_t r = loc[s].rc[2 * k], c = loc[s].rc[2 * k + 1];
+        seg[(size_t)r * ncols + c] = t;
+        m[2 * (nt + k)] = r; m[2 * (nt + k) + 1] = c;
+    }
+    free(loc[t].rc); free(loc[s].rc);
+    loc[t].rc = m; loc[t].n = ns + nt;
+    loc[s].rc = NULL; loc[s].n = 0;
+    for (int b = 0; b < nbands; b++) {
+        ss[(size_t)t * nbands + b] += ss[(size_t)s * nbands + b];
+        ss[(size_t)s * nbands + b] = 0.0f;
+    }
+    seg_size[t] += seg_size[s];
+    seg_size[s] = 0;
+}
+
+/* eliminateSmallSegments: shepseg.py:918-1000.  Returns number eliminated;
+ * seg relabelled contiguous in place. */
+ORC_API int64_t orc_eliminate_small_segments(uint32_t *seg, const void *img, int dtype, int nbands,
+                                             int nrows, int ncols, uint32_t max_seg_id,
+                                             int min_seg_size, double max_spectral_diff, int four,
+                                             uint32_t min_seg_id)
+{
+    size_t npix = (size_t)nrows * ncols;
+    size_t nseg = (size_t)max_seg_id + 1;
+    if (nbands > 64) return -1;
+    float *ss = build_segment_spectra(seg, img, dtype, nbands, npix, max_seg_id);
+    uint32_t *seg_size = (uint32_t *)malloc(sizeof(uint32_t) * nseg);
+    orc_make_seg_size(seg, npix, max_seg_id, seg_size);
+    /* makeSegmentLocations: shepseg.py:880-915 (raster order) */
+    seg_loc_t *loc = (seg_loc_t *)calloc(nseg, sizeof(seg_loc_t));
+    for (size_t s = 1; s < nseg; s++) {
+        loc[s].rc = (uint32_t *)malloc(sizeof(uint32_t) * 2 * (seg_size[s] ? seg_size[s] : 1));
+        loc[s].n = 0;
+    }
+    for (int r = 0; r < nrows; r++)
+        for (int c = 0; c < ncols; c++) {
+            uint32_t s = seg[(size_t)r * ncols + c];
+            if (s != 0) {
+                loc[s].rc[2 * loc[s].n] = (uint32_t)r;
+                loc[s].rc[2 * loc[s].n + 1] = (uint32_t)c;
+                loc[s].n++;
+            }
+        }
+    uint32_t *merge_seg = (uint32_t *)calloc(nseg, sizeof(uint32_t));
+    int64_t num_elim = 0;
+    for (int target = 1; target < min_seg_size; target++) {
+        int64_t count = 0, prev = -1;
+        for (size_t s = 0; s < nseg; s++) count += (seg_size[s] == (uint32_t)target);
+        int passes = 0;
+        while (count != prev && passes < 10) {
+            prev = count;
+            for (size_t s = min_seg_id; s < nseg; s++)
+                if (seg_size[s] == (uint32_t)target)
+                    merge_seg[s] = find_merge_segment((uint32_t)s, loc, seg, seg_size, ss, nbands,
+                                                      nrows, ncols, max_spectral_diff, four);
+            for (size_t s = min_seg_id; s < nseg; s++)
+                if (merge_seg[s] != 0) {
+                    do_merge((uint32_t)s, merge_seg[s], seg, seg_size, loc, ss, nbands, ncols);
+                    merge_seg[s] = 0;
+                    num_elim++;
+                }
+            count = 0;
+            for (size_t s = 0; s < nseg; s++) count += (seg_size[s] == (uint32_t)target);
+            passes++;
+        }
+    }
+    relabel_segments(seg, npix, seg_size, nseg, min_seg_id);
+    for (size_t s = 0; s < nseg; s++) free(loc[s].rc);
+    free(loc); free(merge_seg); free(seg_size); free(ss);
+    return num_elim;
+}
+
+/* doShepherdSegmentation with a supplied k-means model: shepseg.py:130-249
+ * (stages :206 predict, :212 clump, :219 segSize, :225 single pixels, :235 small).
+ * max_spectral_diff must already be resolved (autoMaxSpectralDiff is host code). */
+ORC_API int orc_segment_tile(const void *img, int dtype, int nbands, int nrows, int ncols,
+                             const double *centres, int k, int has_null, int64_t null_val,
+                             int four, int min_seg_size, double max_spectral_diff,
+                             uint32_t *seg_out, uint32_t *max_seg_id_out,
+                             int64_t *singles_elim_out, int64_t *small_elim_out,
+                             uint32_t *num_clumps_out)
+{
+    size_t npix = (size_t)nrows * ncols;
+    int32_t *clusters = (int32_t *)malloc(sizeof(int32_t) * (npix ? npix : 1));
+    int rc = orc_kmeans_assign(img, dtype, nbands, nrows, ncols, centres, k, has_null, null_val,
+                               clusters);
+    if (rc) { free(clusters); return rc; }
+    uint32_t next = orc_clump(clusters, nrows, ncols, 0, four, 1, seg_out);
+    free(clusters);
+    uint32_t max_seg = next - 1;
+    if (num_clumps_out) *num_clumps_out = max_seg;
+    uint32_t *seg_size = (uint32_t *)malloc(sizeof(uint32_t) * ((size_t)max_seg + 1));
+    orc_make_seg_size(seg_out, npix, max_seg, seg_size);
+    orc_eliminate_single_pixels(img, dtype, nbands, nrows, ncols, seg_out, seg_size, 1, max_seg,
+                                four);
+    free(seg_size);
+    uint32_t new_max = orc_seg_max(seg_out, npix);
+    if (singles_elim_out) *singles_elim_out = (int64_t)max_seg - (int64_t)new_max; /* :226-227 */
+    int64_t ne = orc_eliminate_small_segments(seg_out, img, dtype, nbands, nrows, ncols, new_max,
+                                              min_seg_size, max_spectral_diff, four, 1);
+    if (small_elim_out) *small_elim_out = ne;
+    if (max_seg_id_out) *max_seg_id_out = orc_seg_max(seg_out, npix);
+    return 0;
+}
+
+/* ------------------------------------------------------------------ */
+/* k-means fit: sklearn KMeans(init=<array>, n_init=1).fit restated      */
+/* (call site shepseg.py:305-312).  float64 Lloyd. */
+/* x: nrows*nbands row-major float64 sample.  init: k*nbands.            */
+/* Returns 0; centres_out k*nbands; labels_out may be NULL.              */
+/* ------------------------------------------------------------------ */
+static void lloyd_assign(const double *X, size_t n, int nb, const double *C, int k, int32_t *lab)
+{
+    double *cn = (double *)malloc(sizeof(double) * k);
+    for (int j = 0; j < k; j++) {
+        double s = 0.0;
+        for (int b = 0; b < nb; b++) s = fma(C[j * nb + b], C[j * nb + b], s);
+        cn[j] = s;
+    }
+    for (size_t i = 0; i < n; i++) {
+        int best = 0; double bd = 0.0;
+        for (int j = 0; j < k; j++) {
+            double d = cn[j];
+            for (int b = 0; b < nb; b++) d = fma(X[i * nb + b], -2.0 * C[j * nb + b], d);
+            if (j == 0 || d < bd) { bd = d; best = j; }
+        }
+        lab[i] = best;
+    }
+    free(cn);
+}
+
+ORC_API int orc_kmeans_fit(const double *xin, int64_t nrows, int nbands, int k,
+                           const double *init, int max_iter, double tol_rel,
+                           double *centres_out, int32_t *labels_out, int *n_iter_out)
+{
+    size_t n = (size_t)nrows;
+    int nb = nbands;
+    double *X = (double *)malloc(sizeof(double) * n * nb);
+    double *mu = (double *)calloc(nb, sizeof(double));
+    double *C = (double *)malloc(sizeof(double) * k * nb);
+    double *Cn = (double *)malloc(sizeof(double) * k * nb);
+    double *w = (double *)malloc(sizeof(double) * k);
+    int32_t *lab = (int32_t *)malloc(sizeof(int32_t) * n);
+    int32_t *lab_old = (int32_t *)malloc(sizeof(int32_t) * n);
+    /* centre the data (sklearn _kmeans.py fit: X -= X.mean(axis=0)) */
+    for (int b = 0; b < nb; b++) {
+        double s = 0.0;
+        for (size_t i = 0; i < n; i++) s += xin[i * nb + b];
+        mu[b] = s / (double)n;
+    }
+    for (size_t i = 0; i < n; i++)
+        for (int b = 0; b < nb; b++) X[i * nb + b] = xin[i * nb + b] - mu[b];
+    for (int j = 0; j < k; j++)
+        for (int b = 0; b < nb; b++) C[j * nb + b] = init[j * nb + b] - mu[b];
+    /* tol = mean(var(X, axis=0)) * tol_rel  (_tolerance) */
+    double tol = 0.0;
+    for (int b = 0; b < nb; b++) {
+        double m = 0.0, v = 0.0;
+        for (size_t i = 0; i < n; i++) m += X[i * nb + b];
+        m /= (double)n;
+        for (size_t i = 0; i < n; i++) { double d = X[i * nb + b] - m; v += d * d; }
+        tol += v / (double)n;
+    }
+    tol = tol / nb * tol_rel;
+    int strict = 0, it = 0, have_old = 0;
+    for (it = 1; it <= max_iter; it++) {
+        lloyd_assign(X, n, nb, C, k, lab);
+        memset(Cn, 0, sizeof(double) * k * nb);
+        memset(w, 0, sizeof(double) * k);
+        for (size_t i = 0; i < n; i++) {
+            w[lab[i]] += 1.0;
+            for (int b = 0; b < nb; b++) Cn[lab[i] * nb + b] += X[i * nb + b];
+        }
+        int n_empty = 0;
+        for (int j = 0; j < k; j++) n_empty += (w[j] == 0.0);
+        if (n_empty > 0) {
+            /* _relocate_empty_clusters_dense: farthest samples from their OLD centres */
+            double *dist = (double *)malloc(sizeof(double) * n);
+            double dmax = 0.0;
+            for (size_t i = 0; i < n; i++) {
+                double d = 0.0;
+                for (int b = 0; b < nb; b++) {
+                    double t = X[i * nb + b] - C[lab[i] * nb + b];
+                    d += t * t;
+                }
+                dist[i] = d; if (d > dmax) dmax = d;
+            }
+            if (ORC_RELOCATE_GUARD == 0 || dmax > 0.0) {
+                /* empty_clusters is taken once, ascending (np.where), before any move */
+                int *empties = (int *)malloc(sizeof(int) * n_empty);
+                int ne = 0;
+                for (int j = 0; j < k; j++) if (w[j] == 0.0) empties[ne++] = j;
+                for (int r = 0; r < n_empty; r++) {
+                    /* r-th farthest sample: distance descending, index ascending on ties
+                     * (np.argpartition leaves the order among the n_empty farthest
+                     * implementation-defined; it only permutes cluster indices, N12) */
+                    size_t f = 0; double fd = -1.0;
+                    for (size_t i = 0; i < n; i++) if (dist[i] > fd) { fd = dist[i]; f = i; }
+                    dist[f] = -2.0;
+                    int e = empties[r];
+                    int old = lab[f];
+                    for (int b = 0; b < nb; b++) {
+                        Cn[old * nb + b] -= X[f * nb + b];
+                        Cn[e * nb + b] = X[f * nb + b];
+                    }
+                    w[e] = 1.0; w[old] -= 1.0;
+                }
+                free(empties);
+            }
+            free(dist);
+        }
+        /* _average_centers (sklearn 0.24.2, the pinned oracle stack): centres *= 1/w for
+         * w > 0; a cluster left with w == 0 keeps its residual sum (sklearn >= 1.0
+         * instead copies the biggest cluster's centre: ORC_SKLEARN_GE_1). */
+#if ORC_SKLEARN_GE_1
+        int jmax = 0;
+        for (int j = 1; j < k; j++) if (w[j] > w[jmax]) jmax = j;
+#endif
+        for (int j = 0; j < k; j++) {
+            if (w[j] > 0.0) {
+                double alpha = 1.0 / w[j];
+                for (int b = 0; b < nb; b++) Cn[j * nb + b] *= alpha;
+            }
+#if ORC_SKLEARN_GE_1
+            else for (int b = 0; b < nb; b++) Cn[j * nb + b] = Cn[jmax * nb + b];
+#endif
+        }
+        /* center_shift[j] = euclidean norm (4-way unrolled in sklearn's
+         * _euclidean_dense_dense), center_shift_tot = sum(center_shift**2) */
+        double shift = 0.0;
+        for (int j = 0; j < k; j++) {
+            const double *a = &Cn[j * nb], *c = &C[j * nb];
+            double r = 0.0;
+            int b = 0;
+            for (; b + 4 <= nb; b += 4)
+                r += ((a[b] - c[b]) * (a[b] - c[b]) + (a[b + 1] - c[b + 1]) * (a[b + 1] - c[b + 1]) +
+                      (a[b + 2] - c[b + 2]) * (a[b + 2] - c[b + 2]) +
+                      (a[b + 3] - c[b + 3]) * (a[b + 3] - c[b + 3]));
+            for (; b < nb; b++) r += (a[b] - c[b]) * (a[b] - c[b]);
+            double s = sqrt(r);
+            shift += s * s;
+        }
+        memcpy(C, Cn, sizeof(double) * k * nb);
+        if (have_old && memcmp(lab, lab_old, sizeof(int32_t) * n) == 0) { strict = 1; break; }
+        if (shift <= tol) break;
+        memcpy(lab_old, lab, sizeof(int32_t) * n); have_old = 1;
+    }
+    if (it > max_iter) it = max_iter;
+    if (!strict) lloyd_assign(X, n, nb, C, k, lab);
+    for (int j = 0; j < k; j++)
+        for (int b = 0; b < nb; b++) centres_out[j * nb + b] = C[j * nb + b] + mu[b];
+    if (labels_out) memcpy(labels_out, lab, sizeof(int32_t) * n);
+    if (n_iter_out) *n_iter_out = it;
+    free(X); free(mu); free(C); free(Cn); free(w); free(lab); free(lab_old);
+    return 0;
+}
