@@ -1,0 +1,105 @@
+/*
+ * shepseg_hip.h -- C-ABI of libshepseg_hip.so, the MI355X (gfx950) implementation of the
+ * pyshepseg per-tile segmentation hot path and its tiled driver.
+ *
+ * The reference (ubarsc/pyshepseg v2.0.3) has no native/FFI boundary: its operator API is
+ * three Python call signatures whose arithmetic runs in numba @njit functions and in
+ * sklearn.cluster.KMeans.  Each entry point below replaces the reference function(s)
+ * cited next to it; pyshepseg_amd/{shepseg,tiling,tilingstats}.py bind them with ctypes
+ * under the reference's own Python names (see INTEGRATION.md for the stub).
+ *
+ * Conventions
+ *  - return 0 = OK, negative = error; message via shp_last_error(ctx).
+ *  - the caller owns every host buffer; the library borrows pointers for the call only.
+ *  - all arrays C-contiguous; images are band-planar (nBands, nRows, nCols) like the
+ *    reference's `img` (shepseg.py:140).
+ *  - one shp_ctx per host thread / HIP stream; calls on different contexts are re-entrant
+ *    (the reference calls doShepherdSegmentation from N threads, tiling.py:1560-1595).
+ *  - there is NO CPU fallback: every entry point fails with SHP_ERR_NO_DEVICE when no
+ *    gfx950 device is usable.
+ */
+#ifndef SHEPSEG_HIP_H
+#define SHEPSEG_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct shp_ctx shp_ctx;
+
+/* image dtypes (the integer dtypes the reference accepts for `img`) */
+enum { SHP_U8 = 0, SHP_I16 = 1, SHP_U16 = 2, SHP_I32 = 3, SHP_U32 = 4 };
+
+enum {
+    SHP_OK = 0,
+    SHP_ERR_NO_DEVICE = -1,
+    SHP_ERR_HIP = -2,
+    SHP_ERR_ARG = -3,
+    SHP_ERR_NOMEM = -4,
+    SHP_ERR_STATE = -5
+};
+
+int shp_version(void);
+int shp_device_count(void);                      /* number of usable HIP devices (0 = none) */
+int shp_ctx_create(int device, shp_ctx **out);   /* owns one HIP stream + device workspace */
+void shp_ctx_destroy(shp_ctx *ctx);
+const char *shp_last_error(const shp_ctx *ctx);  /* valid until the next call on ctx */
+/* device-time (HIP events on the ctx stream) of the stages of the last shp_segment_tile /
+ * stage call, milliseconds: [0]=assign [1]=clump [2]=single-pixel [3]=small-segment
+ * [4]=h2d [5]=d2h [6]=total.  out must hold 8 doubles. */
+int shp_last_timings(const shp_ctx *ctx, double *out);
+
+/* ---- k-means ------------------------------------------------------------------------ */
+/* replaces sklearn KMeans(init=<array>, n_init=1).fit as called by
+ * shepseg.fitSpectralClusters (shepseg.py:305-312).  xsample: nrows*nbands float64 rows. */
+int shp_kmeans_fit(shp_ctx *ctx, const double *xsample, int64_t nrows, int nbands, int k,
+                   const double *init_centres, int max_iter, double tol_rel,
+                   double *centres_out, int32_t *labels_out, int *n_iter_out);
+
+/* replaces shepseg.applySpectralClusters (shepseg.py:317-361) + KMeans.predict:
+ * clusters_out[nrows*ncols] int32, 1..k, 0 where any band == null_val. */
+int shp_kmeans_assign(shp_ctx *ctx, const void *img, int dtype, int nbands, int nrows, int ncols,
+                      const double *centres, int k, int has_null, int64_t null_val,
+                      int32_t *clusters_out);
+
+/* ---- per-tile stages (individually callable, like the reference's njit functions) ------ */
+/* replaces shepseg.clump(img, ignoreVal=0, fourConnected, clumpId=1) (shepseg.py:452-541),
+ * including the MAX_CLUMP_SIZE=10000 depth-first cut.  max_seg_id_out = next id - 1. */
+int shp_clump(shp_ctx *ctx, const int32_t *clusters, int nrows, int ncols, int four_connected,
+              uint32_t *seg_out, uint32_t *max_seg_id_out);
+
+/* replaces shepseg.makeSegSize (shepseg.py:544-569): seg_size_out has max_seg_id+1 entries */
+int shp_make_seg_size(shp_ctx *ctx, const uint32_t *seg, int64_t npix, uint32_t max_seg_id,
+                      uint32_t *seg_size_out);
+
+/* replaces shepseg.eliminateSinglePixels (shepseg.py:572-615): seg relabelled in place;
+ * max_seg_id_inout: in = largest id in seg, out = seg.max() after the relabel. */
+int shp_eliminate_single(shp_ctx *ctx, const void *img, int dtype, int nbands, int nrows,
+                         int ncols, int four_connected, uint32_t *seg_inout,
+                         uint32_t *max_seg_id_inout);
+
+/* replaces shepseg.eliminateSmallSegments (shepseg.py:918-1000) */
+int shp_eliminate_small(shp_ctx *ctx, const void *img, int dtype, int nbands, int nrows,
+                        int ncols, int four_connected, int min_seg_size,
+                        double max_spectral_diff, uint32_t *seg_inout,
+                        uint32_t *max_seg_id_inout, int64_t *num_elim_out);
+
+/* replaces shepseg.doShepherdSegmentation with a supplied k-means model
+ * (shepseg.py:130-249, stages :206 :212 :219 :225 :235), fused on the device. */
+int shp_segment_tile(shp_ctx *ctx, const void *img, int dtype, int nbands, int nrows, int ncols,
+                     const double *centres, int k, int has_null, int64_t null_val,
+                     int four_connected, int min_seg_size, double max_spectral_diff,
+                     uint32_t *seg_out, uint32_t *max_seg_id_out, int64_t *singles_elim_out,
+                     int64_t *small_elim_out, uint32_t *num_clumps_out);
+
+/* ---- synthetic imagery (benchmark input; SURVEY.md Appendix B `synthimg v1`) ----------- */
+int shp_synthimg(shp_ctx *ctx, uint64_t seed, int nbands, int64_t y0, int64_t x0, int nrows,
+                 int ncols, uint16_t *out_host);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SHEPSEG_HIP_H */

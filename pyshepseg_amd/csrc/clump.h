@@ -1,0 +1,290 @@
+// clump.h -- connected-component labelling with the reference's size-capped depth-first cut.
+//
+// Replaces shepseg.clump (shepseg.py:452-541).  The reference is a raster scan that grows each
+// clump with an explicit LIFO stack and stops growing after MAX_CLUMP_SIZE pixels were added
+// (SURVEY N9), so a true component of > 10001 pixels is cut into pieces whose membership
+// depends on the visit order.  Design:
+//   1. union-find CCL on the cluster image (labels = smallest linear index of the component);
+//      run heads inside a wavefront are resolved with ballots, vertical links are pruned when
+//      the 2x2 neighbourhood already implies them, the rest goes through atomicMin hooks.
+//   2. component sizes by run-aggregated atomics (one atomic per run per wavefront).
+//   3. every component that can be cut (size >= MAX_CLUMP_SIZE + 2) is replayed exactly by ONE
+//      wavefront: lane 0 runs the depth-first walk with the reference's push order, all 64
+//      lanes search the bounding box for the next unvisited pixel in raster order (next seed).
+//      Components are independent, so the chip runs hundreds of replays concurrently.
+//   4. a piece's id is the raster rank of its seed pixel: flag seeds, exclusive scan, gather.
+// All of it is integer work bound by HBM/L2 latency, not by bandwidth; algorithmic bytes are
+// 2 B (cluster id) in + 4 B (label) out per pixel.
+#pragma once
+#include "common.h"
+#include "scan.h"
+
+struct BigInfo {
+    uint32_t root, size, off, minc, maxc, maxr;
+};
+
+__device__ __forceinline__ uint32_t uf_find(const uint32_t *lab, uint32_t x)
+{
+    uint32_t p = lab[x];
+    while (p != x) { x = p; p = lab[x]; }
+    return x;
+}
+
+__device__ __forceinline__ void uf_merge(uint32_t *lab, uint32_t a, uint32_t b)
+{
+    a = uf_find(lab, a);
+    b = uf_find(lab, b);
+    while (a != b) {
+        if (a < b) { uint32_t t = a; a = b; b = t; }       // a > b: hook a under b
+        const uint32_t old = atomicMin(&lab[a], b);
+        if (old == a) break;                                // a was a root: done
+        a = old;                                            // a was hooked meanwhile: merge old with b
+        a = uf_find(lab, a);
+        b = uf_find(lab, b);
+    }
+}
+
+// lab[p] = first pixel of p's horizontal run inside this wavefront's 64-pixel span
+__global__ __launch_bounds__(256) void k_ccl_init(const uint16_t *__restrict__ clus,
+                                                  uint32_t *__restrict__ lab, uint32_t n,
+                                                  uint32_t ncols)
+{
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    const bool inb = p < n;
+    const unsigned lane = lane_id();
+    const uint32_t c = inb ? clus[p] : 0u;
+    const uint32_t col = p % ncols;
+    const uint32_t cl = __shfl_up(c, 1, 64);
+    const bool leftsame = inb && lane > 0 && col > 0 && c != 0 && cl == c;
+    const unsigned long long heads = __ballot(!leftsame);
+    const unsigned long long m = heads & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
+    const unsigned start = 63u - (unsigned)__clzll(m);
+    if (inb) lab[p] = (c == 0) ? NULL_LAB : p - (lane - start);
+}
+
+__global__ __launch_bounds__(256) void k_ccl_merge(const uint16_t *__restrict__ clus,
+                                                   uint32_t *lab, uint32_t n, uint32_t nrows,
+                                                   uint32_t ncols, int four)
+{
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= n) return;
+    const uint32_t c = clus[p];
+    if (c == 0) return;
+    const uint32_t row = p / ncols, col = p - row * ncols;
+    const bool L = col > 0 && clus[p - 1] == c;
+    const bool U = row > 0 && clus[p - ncols] == c;
+    const bool UL = row > 0 && col > 0 && clus[p - ncols - 1] == c;
+    if (L && lane_id() == 0) uf_merge(lab, p, p - 1);        // runs cut at a wavefront boundary
+    if (U) {
+        if (!(L && UL)) uf_merge(lab, p, p - ncols);
+    } else if (!four) {
+        if (UL && !L) uf_merge(lab, p, p - ncols - 1);
+        const bool UR = row > 0 && col + 1 < ncols && clus[p - ncols + 1] == c;
+        if (UR) uf_merge(lab, p, p - ncols + 1);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_ccl_flatten(uint32_t *lab, uint32_t n)
+{
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= n) return;
+    const uint32_t l = lab[p];
+    if (l == NULL_LAB) return;
+    lab[p] = uf_find(lab, p);
+}
+
+// cnt[key[p]] += 1 for every pixel, one atomic per run of equal keys per wavefront.
+// Pixels whose key == skip are not counted.
+__global__ __launch_bounds__(256) void k_run_count(const uint32_t *__restrict__ key, uint32_t n,
+                                                   uint32_t *cnt, uint32_t skip, int use_skip)
+{
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    const bool inb = p < n;
+    const unsigned lane = lane_id();
+    const uint32_t v = inb ? key[p] : 0u;
+    const uint32_t pv = __shfl_up(v, 1, 64);
+    const bool head = lane == 0 || pv != v || !inb;
+    const unsigned long long heads = __ballot(head);
+    if (head && inb && !(use_skip && v == skip)) {
+        const unsigned long long nxt = (lane == 63) ? 0ull : (heads & ~((2ull << lane) - 1ull));
+        const unsigned nl = nxt ? (unsigned)__builtin_ctzll(nxt) : 64u;
+        atomicAdd(&cnt[v], nl - lane);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_big_list(const uint32_t *__restrict__ lab,
+                                                  uint32_t *csize, uint32_t n, uint32_t ncols,
+                                                  BigInfo *big, uint32_t *counters)
+{
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= n || lab[p] != p) return;
+    const uint32_t s = csize[p];
+    if (s < MAX_CLUMP_SIZE + 2u) return;
+    const uint32_t bi = atomicAdd(&counters[0], 1u);
+    const uint32_t off = atomicAdd(&counters[1], s);
+    BigInfo b;
+    b.root = p; b.size = s; b.off = off; b.minc = ncols; b.maxc = 0; b.maxr = 0;
+    big[bi] = b;
+    csize[p] = VIS_FLAG | bi;
+}
+
+__global__ __launch_bounds__(256) void k_big_bbox(const uint32_t *__restrict__ lab,
+                                                  const uint32_t *__restrict__ csize, uint32_t n,
+                                                  uint32_t ncols, BigInfo *big)
+{
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= n) return;
+    const uint32_t r = lab[p];
+    if (r == NULL_LAB) return;
+    const uint32_t c = csize[r];
+    if (!(c & VIS_FLAG)) return;
+    const uint32_t bi = c & ~VIS_FLAG;
+    const uint32_t row = p / ncols, col = p - row * ncols;
+    const bool headrun = col == 0 || lab[p - 1] != r;
+    const bool tailrun = col == ncols - 1 || lab[p + 1] != r;
+    if (headrun) { atomicMin(&big[bi].minc, col); atomicMax(&big[bi].maxr, row); }
+    if (tailrun) atomicMax(&big[bi].maxc, col);
+}
+
+// One wavefront per cut-able component: exact replay of shepseg.py:490-539 restricted to the
+// component (unvisited member pixels are exactly those with lab == root).
+__global__ __launch_bounds__(64) void k_dfs_split(uint32_t *lab, const BigInfo *__restrict__ big,
+                                                  const uint32_t *__restrict__ counters,
+                                                  uint32_t *stackbuf, uint32_t nrows,
+                                                  uint32_t ncols, int four)
+{
+    const uint32_t bi = blockIdx.x;
+    if (bi >= counters[0]) return;
+    const BigInfo B = big[bi];
+    const uint32_t root = B.root;
+    uint32_t *stack = stackbuf + B.off;
+    const unsigned lane = lane_id();
+    uint32_t cursor = root;
+    for (;;) {
+        // ---- next seed: first unvisited member at or after cursor, raster order ----
+        uint32_t seed = NULL_LAB;
+        const uint32_t crow = cursor / ncols, ccol = cursor - crow * ncols;
+        for (uint32_t row = crow; row <= B.maxr && seed == NULL_LAB; row++) {
+            uint32_t c0 = B.minc;
+            if (row == crow && ccol > c0) c0 = ccol;
+            for (; c0 <= B.maxc; c0 += 64u) {
+                const uint32_t c = c0 + lane;
+                const bool ok = c <= B.maxc && lab[row * ncols + c] == root;
+                const unsigned long long m = __ballot(ok);
+                if (m) { seed = row * ncols + c0 + (uint32_t)__builtin_ctzll(m); break; }
+            }
+        }
+        if (seed == NULL_LAB) break;
+        if (lane == 0) {
+            const uint32_t FL = seed | VIS_FLAG;
+            lab[seed] = FL;
+            uint32_t sp = 0;          // entries in memory (below `top`)
+            uint32_t top = seed;
+            bool have = true;
+            uint32_t cnt = 0;
+            while (have && cnt < MAX_CLUMP_SIZE) {
+                const uint32_t s = top;
+                const uint32_t sy = s / ncols, sx = s - sy * ncols;
+                const bool hl = sx > 0, hr = sx + 1 < ncols, hu = sy > 0, hd = sy + 1 < nrows;
+                // candidate neighbours in the reference's push order (cx outer, cy inner)
+                uint32_t q[8];
+                bool ok[8];
+                int nq = 0;
+                if (four) {
+                    q[0] = s - 1;     ok[0] = hl;
+                    q[1] = s - ncols; ok[1] = hu;
+                    q[2] = s + ncols; ok[2] = hd;
+                    q[3] = s + 1;     ok[3] = hr;
+                    nq = 4;
+                } else {
+                    q[0] = s - ncols - 1; ok[0] = hl && hu;
+                    q[1] = s - 1;         ok[1] = hl;
+                    q[2] = s + ncols - 1; ok[2] = hl && hd;
+                    q[3] = s - ncols;     ok[3] = hu;
+                    q[4] = s + ncols;     ok[4] = hd;
+                    q[5] = s - ncols + 1; ok[5] = hr && hu;
+                    q[6] = s + 1;         ok[6] = hr;
+                    q[7] = s + ncols + 1; ok[7] = hr && hd;
+                    nq = 8;
+                }
+                uint32_t lv[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) lv[i] = (i < nq && ok[i]) ? lab[q[i]] : NULL_LAB;
+                bool pend = false;
+                uint32_t pq = 0;
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    if (i < nq && lv[i] == root) {
+                        lab[q[i]] = FL;
+                        cnt++;
+                        if (pend) stack[sp++] = pq;
+                        pq = q[i];
+                        pend = true;
+                    }
+                }
+                if (pend) top = pq;
+                else if (sp > 0) top = stack[--sp];
+                else have = false;
+            }
+        }
+        __threadfence();
+        cursor = seed + 1;
+        if (cursor >= nrows * ncols) break;
+    }
+}
+
+struct SeedFn {
+    const uint32_t *lab;
+    __device__ __forceinline__ uint32_t operator()(uint32_t p) const
+    {
+        const uint32_t l = lab[p];
+        return (l != NULL_LAB && (l & ~VIS_FLAG) == p) ? 1u : 0u;
+    }
+};
+
+__global__ __launch_bounds__(256) void k_clump_final(const uint32_t *__restrict__ lab,
+                                                     const uint32_t *__restrict__ rank,
+                                                     uint32_t *__restrict__ seg, uint32_t n)
+{
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= n) return;
+    const uint32_t l = lab[p];
+    seg[p] = (l == NULL_LAB) ? 0u : rank[l & ~VIS_FLAG] + 1u;
+}
+
+// d_clus (uint16, 0 = null) -> ctx->seg (uint32 clump ids 1..nclumps, 0 = null).
+// *nclumps_dev: device uint32 receiving the number of clumps.
+static int run_clump(shp_ctx *ctx, const uint16_t *d_clus, uint32_t nrows, uint32_t ncols, int four,
+                     uint32_t *d_seg, uint32_t *nclumps_dev)
+{
+    const uint64_t n64 = (uint64_t)nrows * ncols;
+    if (n64 >= 0x7fffffffull) SHP_FAIL(ctx, SHP_ERR_ARG, "tile too large (%llu px)", (unsigned long long)n64);
+    const uint32_t n = (uint32_t)n64;
+    if (n == 0) { HIPCHK(ctx, hipMemsetAsync(nclumps_dev, 0, 4, ctx->stream)); return 0; }
+    const uint32_t maxbig = n / (MAX_CLUMP_SIZE + 2u) + 1u;
+    CHK(buf_ensure(ctx, ctx->lab, (size_t)n * 4));
+    CHK(buf_ensure(ctx, ctx->aux, (size_t)n * 4));
+    CHK(buf_ensure(ctx, ctx->stack, (size_t)n * 4));
+    CHK(buf_ensure(ctx, ctx->big, (size_t)maxbig * sizeof(BigInfo) + 64));
+    CHK(buf_ensure(ctx, ctx->scan_tmp, scan_tmp_bytes(n)));
+    uint32_t *lab = bp<uint32_t>(ctx->lab), *csize = bp<uint32_t>(ctx->aux);
+    uint32_t *counters = (uint32_t *)((char *)ctx->big.p + (size_t)maxbig * sizeof(BigInfo));
+    BigInfo *big = bp<BigInfo>(ctx->big);
+    const unsigned g = grid_for(n, 256);
+    hipStream_t st = ctx->stream;
+    hipLaunchKernelGGL(k_ccl_init, dim3(g), dim3(256), 0, st, d_clus, lab, n, ncols); KCHK(ctx);
+    hipLaunchKernelGGL(k_ccl_merge, dim3(g), dim3(256), 0, st, d_clus, lab, n, nrows, ncols, four); KCHK(ctx);
+    hipLaunchKernelGGL(k_ccl_flatten, dim3(g), dim3(256), 0, st, lab, n); KCHK(ctx);
+    HIPCHK(ctx, hipMemsetAsync(csize, 0, (size_t)n * 4, st));
+    HIPCHK(ctx, hipMemsetAsync(counters, 0, 16, st));
+    hipLaunchKernelGGL(k_run_count, dim3(g), dim3(256), 0, st, lab, n, csize, NULL_LAB, 1); KCHK(ctx);
+    hipLaunchKernelGGL(k_big_list, dim3(g), dim3(256), 0, st, lab, csize, n, ncols, big, counters); KCHK(ctx);
+    hipLaunchKernelGGL(k_big_bbox, dim3(g), dim3(256), 0, st, lab, csize, n, ncols, big); KCHK(ctx);
+    hipLaunchKernelGGL(k_dfs_split, dim3(maxbig), dim3(64), 0, st, lab, big, counters,
+                       bp<uint32_t>(ctx->stack), nrows, ncols, four); KCHK(ctx);
+    // seed rank -> clump id
+    SeedFn sf{lab};
+    CHK(scan_exclusive(ctx, sf, n, csize, nclumps_dev, bp<uint32_t>(ctx->scan_tmp)));
+    hipLaunchKernelGGL(k_clump_final, dim3(g), dim3(256), 0, st, lab, csize, d_seg, n); KCHK(ctx);
+    return 0;
+}

@@ -1,0 +1,120 @@
+// common.h -- context, device buffers, error handling, small device helpers.
+// Part of libshepseg_hip.so (gfx950 only; wavefront = 64 everywhere).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+#include "../../include/shepseg_hip.h"
+
+#define WAVE 64
+#define NULL_LAB 0xFFFFFFFFu   // CCL label of a null pixel
+#define VIS_FLAG 0x80000000u   // set on labels assigned by the depth-first splitter
+#define MAX_CLUMP_SIZE 10000u  // shepseg.py:481
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+};
+
+struct StageTimer {
+    hipEvent_t a = nullptr, b = nullptr;
+};
+
+struct shp_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    std::vector<DevBuf *> bufs;
+    // named workspace buffers (grow-only)
+    DevBuf img, clus, lab, seg, aux, aux2, stack, scan_tmp, sort_k0, sort_k1, sort_v1, sort_hist,
+        pix, segsz, origsz, off, ssum, chnext, chtail, mergeto, tcount, toff, tfill, tlist, tsorted,
+        small, cen, fit_x, fit_lab, fit_part, big;
+    uint32_t *h_pinned = nullptr;   // 256 x u32 pinned host scratch for small read-backs
+    hipEvent_t ev[16] = {};
+    double timings[8] = {};
+};
+
+#define SHP_FAIL(ctx, code, ...)                                  \
+    do {                                                          \
+        char _b[512];                                             \
+        snprintf(_b, sizeof(_b), __VA_ARGS__);                    \
+        (ctx)->err = _b;                                          \
+        return (code);                                            \
+    } while (0)
+
+#define HIPCHK(ctx, call)                                                                   \
+    do {                                                                                    \
+        hipError_t _e = (call);                                                             \
+        if (_e != hipSuccess)                                                               \
+            SHP_FAIL(ctx, SHP_ERR_HIP, "%s:%d: %s -> %s", __FILE__, __LINE__, #call,        \
+                     hipGetErrorString(_e));                                                \
+    } while (0)
+
+#define CHK(call)                    \
+    do {                             \
+        int _rc = (call);            \
+        if (_rc != 0) return _rc;    \
+    } while (0)
+
+#define KCHK(ctx) HIPCHK(ctx, hipGetLastError())
+
+static inline int buf_ensure(shp_ctx *ctx, DevBuf &b, size_t bytes)
+{
+    if (bytes == 0) bytes = 16;
+    if (b.cap >= bytes) return 0;
+    if (b.p) {
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        HIPCHK(ctx, hipFree(b.p));
+        b.p = nullptr; b.cap = 0;
+    }
+    size_t want = bytes + bytes / 8 + 256;
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) {
+        b.p = nullptr;
+        SHP_FAIL(ctx, SHP_ERR_NOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+    }
+    b.cap = want;
+    return 0;
+}
+
+template <typename T> static inline T *bp(DevBuf &b) { return (T *)b.p; }
+
+static inline unsigned grid_for(size_t n, unsigned block, unsigned cap = 0x7fffffffu)
+{
+    size_t g = (n + block - 1) / block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (unsigned)g;
+}
+
+static inline size_t dtype_size(int dtype)
+{
+    switch (dtype) {
+    case SHP_U8: return 1;
+    case SHP_I16: case SHP_U16: return 2;
+    case SHP_I32: case SHP_U32: return 4;
+    default: return 0;
+    }
+}
+
+// ---- device helpers ---------------------------------------------------------------------
+// Pixel fetch as int64 (uniform branch on dtype; all supported dtypes fit).
+__device__ __forceinline__ long long ld_px(const void *__restrict__ img, int dtype, size_t i)
+{
+    switch (dtype) {
+    case SHP_U8: return ((const uint8_t *)img)[i];
+    case SHP_I16: return ((const int16_t *)img)[i];
+    case SHP_U16: return ((const uint16_t *)img)[i];
+    case SHP_I32: return ((const int32_t *)img)[i];
+    default: return ((const uint32_t *)img)[i];
+    }
+}
+
+__device__ __forceinline__ unsigned lane_id() { return threadIdx.x & 63u; }
+__device__ __forceinline__ unsigned long long lanemask_lt()
+{
+    return (1ull << lane_id()) - 1ull;
+}

@@ -1,0 +1,357 @@
+// kmeans.h -- k-means assign (predict) and Lloyd fit on the device.
+//
+// assign replaces shepseg.applySpectralClusters (shepseg.py:317-361) + sklearn
+// KMeans.predict:  label = argmin_j ( |c_j|^2 - 2 x.c_j ), float64, first minimum wins,
+// evaluated as a band-ordered fma chain (identical to oracle/shepseg_oracle.c so the result
+// is bit-exact by construction; SURVEY N13: any float64 evaluation reproduces sklearn on
+// integer imagery, float32 does not).
+//
+// Roofline: 2*nB*k flop/px in FP64 (720 at 6x60).  gfx950 FP64 vector and matrix peaks are
+// equal (78.6 TFLOP/s), so the contraction runs on v_fma_f64 with the centroid operand in
+// SGPRs (uniform scalar loads); bytes are nB*sizeof(px) in + 2 B (uint16 label) out.
+#pragma once
+#include "common.h"
+
+#define ASSIGN_PPT 4   // pixels per thread (amortises the scalar centroid loads)
+
+template <int NB>
+__global__ __launch_bounds__(256) void k_assign(
+    const void *__restrict__ img, int dtype, size_t npix, int nb_rt,
+    const double *__restrict__ m2c, const double *__restrict__ cnorm, int k, int has_null,
+    long long null_val, uint16_t *__restrict__ clus16, int32_t *__restrict__ clus32)
+{
+    const int nb = (NB > 0) ? NB : nb_rt;
+    const size_t stride = (size_t)gridDim.x * 256u;
+    for (size_t p0 = (size_t)blockIdx.x * 256u + threadIdx.x; p0 < npix; p0 += stride * ASSIGN_PPT) {
+        double x[ASSIGN_PPT][(NB > 0) ? NB : 1];
+        bool isnull[ASSIGN_PPT];
+        double bestd[ASSIGN_PPT];
+        int best[ASSIGN_PPT];
+#pragma unroll
+        for (int q = 0; q < ASSIGN_PPT; q++) {
+            const size_t p = p0 + (size_t)q * stride;
+            isnull[q] = false;
+            best[q] = 0;
+            bestd[q] = 0.0;
+            if (NB > 0) {
+#pragma unroll
+                for (int b = 0; b < NB; b++) {
+                    long long v = (p < npix) ? ld_px(img, dtype, (size_t)b * npix + p) : 0;
+                    if (has_null && v == null_val) isnull[q] = true;
+                    x[q][b] = (double)v;
+                }
+            } else {
+                for (int b = 0; b < nb; b++) {
+                    long long v = (p < npix) ? ld_px(img, dtype, (size_t)b * npix + p) : 0;
+                    if (has_null && v == null_val) isnull[q] = true;
+                }
+            }
+        }
+        for (int j = 0; j < k; j++) {
+            double d[ASSIGN_PPT];
+            const double cn = cnorm[j];
+#pragma unroll
+            for (int q = 0; q < ASSIGN_PPT; q++) d[q] = cn;
+            if (NB > 0) {
+#pragma unroll
+                for (int b = 0; b < NB; b++) {
+                    const double c = m2c[j * NB + b];
+#pragma unroll
+                    for (int q = 0; q < ASSIGN_PPT; q++) d[q] = __builtin_fma(x[q][b], c, d[q]);
+                }
+            } else {
+                for (int b = 0; b < nb; b++) {
+                    const double c = m2c[j * nb + b];
+#pragma unroll
+                    for (int q = 0; q < ASSIGN_PPT; q++) {
+                        const size_t p = p0 + (size_t)q * stride;
+                        const double xv =
+                            (p < npix) ? (double)ld_px(img, dtype, (size_t)b * npix + p) : 0.0;
+                        d[q] = __builtin_fma(xv, c, d[q]);
+                    }
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < ASSIGN_PPT; q++)
+                if (j == 0 || d[q] < bestd[q]) { bestd[q] = d[q]; best[q] = j; }
+        }
+#pragma unroll
+        for (int q = 0; q < ASSIGN_PPT; q++) {
+            const size_t p = p0 + (size_t)q * stride;
+            if (p < npix) {
+                const int c = isnull[q] ? 0 : best[q] + 1;
+                if (clus16) clus16[p] = (uint16_t)c;
+                if (clus32) clus32[p] = c;
+            }
+        }
+    }
+}
+
+// host-side preparation, same arithmetic as oracle orc_kmeans_prepare
+static inline void kmeans_prepare_host(const double *centres, int k, int nb, double *m2c,
+                                       double *cnorm)
+{
+    for (int j = 0; j < k; j++) {
+        double s = 0.0;
+        for (int b = 0; b < nb; b++) {
+            const double c = centres[j * nb + b];
+            s = __builtin_fma(c, c, s);
+            m2c[j * nb + b] = -2.0 * c;
+        }
+        cnorm[j] = s;
+    }
+}
+
+// centres (host) -> ctx->cen (device: m2c[k*nb] then cnorm[k]); launches the assign kernel
+// on the device image `d_img`; writes uint16 labels to d_clus16 and/or int32 to d_clus32.
+static int launch_assign(shp_ctx *ctx, const void *d_img, int dtype, int nb, size_t npix,
+                         const double *centres, int k, int has_null, int64_t null_val,
+                         uint16_t *d_clus16, int32_t *d_clus32)
+{
+    if (k < 1 || k > 65534) SHP_FAIL(ctx, SHP_ERR_ARG, "numClusters %d out of range", k);
+    std::vector<double> h((size_t)k * nb + k);
+    kmeans_prepare_host(centres, k, nb, h.data(), h.data() + (size_t)k * nb);
+    CHK(buf_ensure(ctx, ctx->cen, h.size() * sizeof(double)));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->cen.p, h.data(), h.size() * sizeof(double),
+                               hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // h is a stack-lifetime staging buffer
+    const double *m2c = bp<double>(ctx->cen), *cn = m2c + (size_t)k * nb;
+    const unsigned grid = grid_for((npix + ASSIGN_PPT - 1) / ASSIGN_PPT, 256, 256u * 16u);
+#define LA(NBT)                                                                                  \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_assign<NBT>), dim3(grid), dim3(256), 0, ctx->stream,    \
+                       d_img, dtype, npix, nb, m2c, cn, k, has_null, (long long)null_val,        \
+                       d_clus16, d_clus32)
+    switch (nb) {
+    case 1: LA(1); break;
+    case 2: LA(2); break;
+    case 3: LA(3); break;
+    case 4: LA(4); break;
+    case 5: LA(5); break;
+    case 6: LA(6); break;
+    case 7: LA(7); break;
+    case 8: LA(8); break;
+    case 10: LA(10); break;
+    case 12: LA(12); break;
+    default: LA(0); break;
+    }
+#undef LA
+    KCHK(ctx);
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------
+// Lloyd fit on the device.  Replaces sklearn KMeans(init=<array>, n_init=1).fit as called by
+// shepseg.fitSpectralClusters (shepseg.py:305-312); algorithm restated in SURVEY Appendix D
+// and oracle/shepseg_oracle.c orc_kmeans_fit (sklearn 0.24.2 semantics: centred data,
+// tol = mean(var)*tol_rel, strict-convergence test, empty-cluster relocation, centres *= 1/w).
+// E-step: one thread per sample row, same fma chain as predict.  M-step: deterministic --
+// fixed 4096-row chunks produce per-chunk partial sums (one thread per (cluster, band), rows
+// in index order), then a second kernel adds the chunk partials in chunk order.  No float
+// atomics, so results are bitwise reproducible run to run.
+// ---------------------------------------------------------------------------------------
+#define FIT_CHUNK 4096u
+
+__global__ __launch_bounds__(256) void k_fit_assign(const double *__restrict__ X, uint32_t n, int nb,
+                                                    const double *__restrict__ m2c,
+                                                    const double *__restrict__ cnorm, int k,
+                                                    int32_t *__restrict__ lab,
+                                                    const int32_t *__restrict__ lab_old,
+                                                    uint32_t *ndiff)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    int best = 0;
+    double bestd = 0.0;
+    for (int j = 0; j < k; j++) {
+        double d = cnorm[j];
+        for (int b = 0; b < nb; b++) d = __builtin_fma(X[(size_t)i * nb + b], m2c[j * nb + b], d);
+        if (j == 0 || d < bestd) { bestd = d; best = j; }
+    }
+    lab[i] = best;
+    if (lab_old && lab_old[i] != best) atomicAdd(ndiff, 1u);
+}
+
+// partial[c][j*nb+b] = sum over rows of chunk c with label j of X[row][b]; pcount[c][j]
+__global__ __launch_bounds__(256) void k_fit_partial(const double *__restrict__ X, uint32_t n, int nb,
+                                                     const int32_t *__restrict__ lab, int k,
+                                                     double *__restrict__ partial,
+                                                     uint32_t *__restrict__ pcount)
+{
+    __shared__ int32_t sl[FIT_CHUNK];
+    const uint32_t c = blockIdx.x;
+    const uint32_t r0 = c * FIT_CHUNK;
+    const uint32_t cnt = (n - r0 < FIT_CHUNK) ? (n - r0) : FIT_CHUNK;
+    for (uint32_t i = threadIdx.x; i < cnt; i += 256u) sl[i] = lab[r0 + i];
+    __syncthreads();
+    const int kn = k * nb;
+    for (int t = threadIdx.x; t < kn; t += 256) {
+        const int j = t / nb, b = t - j * nb;
+        double acc = 0.0;
+        uint32_t w = 0;
+        for (uint32_t i = 0; i < cnt; i++)
+            if (sl[i] == j) { acc += X[(size_t)(r0 + i) * nb + b]; w++; }
+        partial[(size_t)c * kn + t] = acc;
+        if (b == 0) pcount[(size_t)c * k + j] = w;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_fit_reduce(const double *__restrict__ partial,
+                                                    const uint32_t *__restrict__ pcount,
+                                                    uint32_t nchunks, int k, int nb,
+                                                    double *__restrict__ S, double *__restrict__ w)
+{
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const int kn = k * nb;
+    if (t >= kn) return;
+    const int j = t / nb, b = t - j * nb;
+    double acc = 0.0;
+    for (uint32_t c = 0; c < nchunks; c++) acc += partial[(size_t)c * kn + t];
+    S[t] = acc;
+    if (b == 0) {
+        uint32_t ww = 0;
+        for (uint32_t c = 0; c < nchunks; c++) ww += pcount[(size_t)c * k + j];
+        w[j] = (double)ww;
+    }
+}
+
+// dist[i] = |X_i - C[lab_i]|^2 (for empty-cluster relocation, rare)
+__global__ __launch_bounds__(256) void k_fit_dist(const double *__restrict__ X, uint32_t n, int nb,
+                                                  const int32_t *__restrict__ lab,
+                                                  const double *__restrict__ C,
+                                                  double *__restrict__ dist)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const int j = lab[i];
+    double d = 0.0;
+    for (int b = 0; b < nb; b++) {
+        const double t = X[(size_t)i * nb + b] - C[j * nb + b];
+        d += t * t;
+    }
+    dist[i] = d;
+}
+
+static int run_kmeans_fit(shp_ctx *ctx, const double *xin, int64_t nrows, int nb, int k,
+                          const double *init, int max_iter, double tol_rel, double *centres_out,
+                          int32_t *labels_out, int *n_iter_out)
+{
+    if (nrows < 1 || nrows > 0x7fffffffll || nb < 1 || k < 1)
+        SHP_FAIL(ctx, SHP_ERR_ARG, "kmeans_fit: bad shape");
+    if (nrows < k) SHP_FAIL(ctx, SHP_ERR_ARG, "n_samples=%lld should be >= n_clusters=%d",
+                            (long long)nrows, k);
+    const uint32_t n = (uint32_t)nrows;
+    const int kn = k * nb;
+    // centre the data on the host (one pass; sklearn: X -= X.mean(axis=0))
+    std::vector<double> mu(nb, 0.0), X((size_t)n * nb);
+    for (int b = 0; b < nb; b++) {
+        double s = 0.0;
+        for (uint32_t i = 0; i < n; i++) s += xin[(size_t)i * nb + b];
+        mu[b] = s / (double)n;
+    }
+    double tol = 0.0;
+    for (int b = 0; b < nb; b++) {
+        double m = 0.0, v = 0.0;
+        for (uint32_t i = 0; i < n; i++) { X[(size_t)i * nb + b] = xin[(size_t)i * nb + b] - mu[b]; m += X[(size_t)i * nb + b]; }
+        m /= (double)n;
+        for (uint32_t i = 0; i < n; i++) { const double d = X[(size_t)i * nb + b] - m; v += d * d; }
+        tol += v / (double)n;
+    }
+    tol = tol / nb * tol_rel;
+    std::vector<double> C(kn), Cn(kn), w(k), hm((size_t)kn + k);
+    for (int t = 0; t < kn; t++) C[t] = init[t] - mu[t % nb];
+
+    const uint32_t nchunks = (n + FIT_CHUNK - 1) / FIT_CHUNK;
+    CHK(buf_ensure(ctx, ctx->fit_x, (size_t)n * nb * 8 + (size_t)n * 8));
+    CHK(buf_ensure(ctx, ctx->fit_lab, (size_t)n * 4 * 2 + 64));
+    CHK(buf_ensure(ctx, ctx->fit_part, (size_t)nchunks * kn * 8 + (size_t)nchunks * k * 4 + (size_t)(kn + k) * 8 * 2 + 256));
+    CHK(buf_ensure(ctx, ctx->cen, (size_t)(kn + k) * 8 * 2));
+    double *dX = bp<double>(ctx->fit_x), *ddist = dX + (size_t)n * nb;
+    int32_t *dlab = bp<int32_t>(ctx->fit_lab), *dlab_old = dlab + n;
+    uint32_t *ndiff = (uint32_t *)(dlab_old + n);
+    double *dpart = bp<double>(ctx->fit_part);
+    double *dS = dpart + (size_t)nchunks * kn, *dw = dS + kn;
+    uint32_t *dpc = (uint32_t *)(dw + k + 2);
+    double *dm2c = bp<double>(ctx->cen), *dcn = dm2c + kn, *dC = dcn + k;
+    hipStream_t st = ctx->stream;
+    HIPCHK(ctx, hipMemcpyAsync(dX, X.data(), (size_t)n * nb * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemsetAsync(dlab_old, 0xff, (size_t)n * 4, st));     // labels_old = -1
+    const unsigned g = grid_for(n, 256);
+    auto upload_centres = [&](const std::vector<double> &cc) -> int {
+        kmeans_prepare_host(cc.data(), k, nb, hm.data(), hm.data() + kn);
+        HIPCHK(ctx, hipMemcpyAsync(dm2c, hm.data(), (size_t)(kn + k) * 8, hipMemcpyHostToDevice, st));
+        HIPCHK(ctx, hipMemcpyAsync(dC, cc.data(), (size_t)kn * 8, hipMemcpyHostToDevice, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        return 0;
+    };
+    bool strict = false;
+    int it = 0;
+    std::vector<double> hS(kn + k);
+    for (it = 1; it <= max_iter; it++) {
+        CHK(upload_centres(C));
+        HIPCHK(ctx, hipMemsetAsync(ndiff, 0, 4, st));
+        hipLaunchKernelGGL(k_fit_assign, dim3(g), dim3(256), 0, st, dX, n, nb, dm2c, dcn, k, dlab,
+                           dlab_old, ndiff); KCHK(ctx);
+        hipLaunchKernelGGL(k_fit_partial, dim3(nchunks), dim3(256), 0, st, dX, n, nb, dlab, k, dpart,
+                           dpc); KCHK(ctx);
+        hipLaunchKernelGGL(k_fit_reduce, dim3(grid_for(kn, 256)), dim3(256), 0, st, dpart, dpc,
+                           nchunks, k, nb, dS, dw); KCHK(ctx);
+        HIPCHK(ctx, hipMemcpyAsync(hS.data(), dS, (size_t)(kn + k) * 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_pinned, ndiff, 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        for (int t = 0; t < kn; t++) Cn[t] = hS[t];
+        for (int j = 0; j < k; j++) w[j] = hS[kn + j];
+        const uint32_t nd = ctx->h_pinned[0];
+        int n_empty = 0;
+        for (int j = 0; j < k; j++) n_empty += (w[j] == 0.0);
+        if (n_empty > 0) {
+            // _relocate_empty_clusters_dense: farthest samples from their OLD centres
+            hipLaunchKernelGGL(k_fit_dist, dim3(g), dim3(256), 0, st, dX, n, nb, dlab, dC, ddist); KCHK(ctx);
+            std::vector<double> dist(n);
+            std::vector<int32_t> hl(n);
+            HIPCHK(ctx, hipMemcpyAsync(dist.data(), ddist, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+            HIPCHK(ctx, hipMemcpyAsync(hl.data(), dlab, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+            HIPCHK(ctx, hipStreamSynchronize(st));
+            std::vector<int> empties;
+            for (int j = 0; j < k; j++) if (w[j] == 0.0) empties.push_back(j);
+            for (int r = 0; r < n_empty; r++) {
+                uint32_t f = 0; double fd = -1.0;
+                for (uint32_t i = 0; i < n; i++) if (dist[i] > fd) { fd = dist[i]; f = i; }
+                dist[f] = -2.0;
+                const int e = empties[r], old = hl[f];
+                for (int b = 0; b < nb; b++) {
+                    Cn[old * nb + b] -= X[(size_t)f * nb + b];
+                    Cn[e * nb + b] = X[(size_t)f * nb + b];
+                }
+                w[e] = 1.0; w[old] -= 1.0;
+            }
+        }
+        for (int j = 0; j < k; j++)
+            if (w[j] > 0.0) { const double alpha = 1.0 / w[j]; for (int b = 0; b < nb; b++) Cn[j * nb + b] *= alpha; }
+        double shift = 0.0;
+        for (int j = 0; j < k; j++) {
+            const double *a = &Cn[j * nb], *c = &C[j * nb];
+            double r = 0.0; int b = 0;
+            for (; b + 4 <= nb; b += 4)
+                r += ((a[b] - c[b]) * (a[b] - c[b]) + (a[b + 1] - c[b + 1]) * (a[b + 1] - c[b + 1]) +
+                      (a[b + 2] - c[b + 2]) * (a[b + 2] - c[b + 2]) + (a[b + 3] - c[b + 3]) * (a[b + 3] - c[b + 3]));
+            for (; b < nb; b++) r += (a[b] - c[b]) * (a[b] - c[b]);
+            const double s = __builtin_sqrt(r);
+            shift += s * s;
+        }
+        C = Cn;
+        if (nd == 0) { strict = true; break; }
+        if (shift <= tol) break;
+        HIPCHK(ctx, hipMemcpyAsync(dlab_old, dlab, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
+    }
+    if (it > max_iter) it = max_iter;
+    if (!strict) {
+        CHK(upload_centres(C));
+        hipLaunchKernelGGL(k_fit_assign, dim3(g), dim3(256), 0, st, dX, n, nb, dm2c, dcn, k, dlab,
+                           (const int32_t *)nullptr, ndiff); KCHK(ctx);
+    }
+    if (labels_out) HIPCHK(ctx, hipMemcpyAsync(labels_out, dlab, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    for (int t = 0; t < kn; t++) centres_out[t] = C[t] + mu[t % nb];
+    if (n_iter_out) *n_iter_out = it;
+    return 0;
+}

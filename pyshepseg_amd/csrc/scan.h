@@ -1,0 +1,91 @@
+// scan.h -- exclusive prefix sum of uint32 values produced by a device functor.
+// Three-phase (block-local scan, recursive scan of block totals, add-back); 1024 items per
+// 256-thread workgroup.  HBM-bound: 4 B read (whatever the functor reads) + 4 B written/item.
+#pragma once
+#include "common.h"
+
+#define SCAN_ITEMS 1024u
+
+template <class F>
+__global__ __launch_bounds__(256) void k_scan_local(F f, uint32_t n, uint32_t *__restrict__ out,
+                                                    uint32_t *__restrict__ bsum)
+{
+    __shared__ uint32_t wsum[4];
+    const uint32_t base = blockIdx.x * SCAN_ITEMS + threadIdx.x * 4u;
+    uint32_t v[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) v[i] = (base + i < n) ? f(base + i) : 0u;
+    const uint32_t tsum = v[0] + v[1] + v[2] + v[3];
+    uint32_t incl = tsum;
+    const unsigned lane = lane_id();
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        uint32_t t = __shfl_up(incl, d, 64);
+        if (lane >= (unsigned)d) incl += t;
+    }
+    const unsigned w = threadIdx.x >> 6;
+    if (lane == 63) wsum[w] = incl;
+    __syncthreads();
+    uint32_t woff = 0;
+    for (unsigned i = 0; i < w; i++) woff += wsum[i];
+    uint32_t run = woff + incl - tsum;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        if (base + i < n) out[base + i] = run;
+        run += v[i];
+    }
+    if (threadIdx.x == 255) bsum[blockIdx.x] = woff + incl;
+}
+
+__global__ __launch_bounds__(256) void k_scan_add(uint32_t *__restrict__ out, uint32_t n,
+                                                  const uint32_t *__restrict__ boff)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n) out[i] += boff[i / SCAN_ITEMS];
+}
+
+struct ArrFn {
+    const uint32_t *a;
+    __device__ __forceinline__ uint32_t operator()(uint32_t i) const { return a[i]; }
+};
+
+// bytes of scratch needed for scanning n items
+static inline size_t scan_tmp_bytes(size_t n)
+{
+    size_t tot = 0;
+    while (true) {
+        size_t nb = (n + SCAN_ITEMS - 1) / SCAN_ITEMS;
+        tot += 2 * nb + 2;
+        if (nb <= 1) break;
+        n = nb;
+    }
+    return (tot + 16) * sizeof(uint32_t);
+}
+
+// out[i] = sum_{j<i} f(j); *total_dev (optional, device pointer) = sum of all.
+// tmp: device scratch of scan_tmp_bytes(n).
+template <class F>
+static int scan_exclusive(shp_ctx *ctx, F f, uint32_t n, uint32_t *out, uint32_t *total_dev,
+                          uint32_t *tmp)
+{
+    if (n == 0) {
+        if (total_dev) HIPCHK(ctx, hipMemsetAsync(total_dev, 0, 4, ctx->stream));
+        return 0;
+    }
+    const uint32_t nb = (n + SCAN_ITEMS - 1) / SCAN_ITEMS;
+    uint32_t *bsum = tmp;
+    uint32_t *boff = tmp + nb + 1;
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_local<F>), dim3(nb), dim3(256), 0, ctx->stream, f, n,
+                       out, bsum);
+    KCHK(ctx);
+    if (nb == 1) {
+        if (total_dev)
+            HIPCHK(ctx, hipMemcpyAsync(total_dev, bsum, 4, hipMemcpyDeviceToDevice, ctx->stream));
+        return 0;
+    }
+    ArrFn g{bsum};
+    CHK(scan_exclusive(ctx, g, nb, boff, total_dev, tmp + 2 * (size_t)nb + 2));
+    hipLaunchKernelGGL(k_scan_add, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, out, n, boff);
+    KCHK(ctx);
+    return 0;
+}

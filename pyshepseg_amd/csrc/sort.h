@@ -1,0 +1,138 @@
+// sort.h -- stable LSD radix sort of (uint32 key, uint32 value) pairs, 8-bit digits.
+// Wave-level multi-split: for each 64-item row the lanes that share a digit are found with
+// 8 ballots (match-any), ranked with popcount, and placed after the running per-wave digit
+// offset, so the sort is stable without any per-thread counters.  2048 items per workgroup.
+// Per pass: histogram kernel, exclusive scan of the (digit-major) block histograms, scatter.
+#pragma once
+#include "common.h"
+#include "scan.h"
+
+#define SORT_ROWS 8u
+#define SORT_TILE (4u * SORT_ROWS * 64u)   // items per 256-thread workgroup
+
+__global__ __launch_bounds__(256) void k_sort_hist(const uint32_t *__restrict__ keys, uint32_t n,
+                                                   int shift, uint32_t *__restrict__ hist,
+                                                   uint32_t nblk)
+{
+    __shared__ uint32_t h[256];
+    h[threadIdx.x] = 0;
+    __syncthreads();
+    const unsigned w = threadIdx.x >> 6, lane = lane_id();
+    const uint32_t base = blockIdx.x * SORT_TILE + w * SORT_ROWS * 64u + lane;
+#pragma unroll
+    for (unsigned r = 0; r < SORT_ROWS; r++) {
+        const uint32_t idx = base + r * 64u;
+        if (idx < n) atomicAdd(&h[(keys[idx] >> shift) & 255u], 1u);
+    }
+    __syncthreads();
+    hist[(size_t)threadIdx.x * nblk + blockIdx.x] = h[threadIdx.x];
+}
+
+__device__ __forceinline__ unsigned long long match_digit(uint32_t d, bool valid)
+{
+    unsigned long long peers = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+        const bool bit = (d >> b) & 1u;
+        const unsigned long long m = __ballot(bit);
+        peers &= bit ? m : ~m;
+    }
+    return peers;
+}
+
+__global__ __launch_bounds__(256) void k_sort_scatter(
+    const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
+    uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, uint32_t n, int shift,
+    const uint32_t *__restrict__ histscan, uint32_t nblk)
+{
+    __shared__ uint32_t wcount[4][256];
+    const unsigned w = threadIdx.x >> 6, lane = lane_id();
+    const uint32_t base = blockIdx.x * SORT_TILE + w * SORT_ROWS * 64u + lane;
+    uint32_t k[SORT_ROWS], v[SORT_ROWS];
+#pragma unroll
+    for (unsigned r = 0; r < SORT_ROWS; r++) {
+        const uint32_t idx = base + r * 64u;
+        k[r] = (idx < n) ? keys_in[idx] : 0u;
+        v[r] = (idx < n) ? (vals_in ? vals_in[idx] : idx) : 0u;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) wcount[i][threadIdx.x] = 0;
+    __syncthreads();
+    const unsigned long long lt = lanemask_lt();
+#pragma unroll
+    for (unsigned r = 0; r < SORT_ROWS; r++) {
+        const bool valid = (base + r * 64u) < n;
+        const uint32_t d = (k[r] >> shift) & 255u;
+        const unsigned long long peers = match_digit(d, valid);
+        if (valid && (peers & lt) == 0ull) wcount[w][d] += (uint32_t)__popcll(peers);
+    }
+    __syncthreads();
+    {
+        uint32_t run = histscan[(size_t)threadIdx.x * nblk + blockIdx.x];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const uint32_t c = wcount[i][threadIdx.x];
+            wcount[i][threadIdx.x] = run;
+            run += c;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (unsigned r = 0; r < SORT_ROWS; r++) {
+        const bool valid = (base + r * 64u) < n;
+        const uint32_t d = (k[r] >> shift) & 255u;
+        const unsigned long long peers = match_digit(d, valid);
+        uint32_t off = 0;
+        if (valid) off = wcount[w][d];
+        __builtin_amdgcn_wave_barrier();
+        if (valid) {
+            const uint32_t pos = off + (uint32_t)__popcll(peers & lt);
+            keys_out[pos] = k[r];
+            vals_out[pos] = v[r];
+            if ((peers & lt) == 0ull) wcount[w][d] = off + (uint32_t)__popcll(peers);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// Sort n pairs by the low `bits` bits of the key.  vals_in == nullptr means value = index.
+// Uses ctx->sort_k0/sort_k1/sort_v1/pix as ping-pong storage and ctx->sort_hist/scan_tmp as
+// scratch.  On return *keys_sorted / *vals_sorted point at the buffers holding the result
+// (vals always end up in ctx->pix or ctx->sort_v1).
+static int sort_pairs(shp_ctx *ctx, const uint32_t *keys_in, const uint32_t *vals_in, uint32_t n,
+                      int bits, uint32_t **keys_sorted, uint32_t **vals_sorted)
+{
+    const uint32_t nblk = (n + SORT_TILE - 1) / SORT_TILE;
+    int passes = (bits + 7) / 8;
+    if (passes < 1) passes = 1;
+    CHK(buf_ensure(ctx, ctx->sort_k0, (size_t)n * 4));
+    CHK(buf_ensure(ctx, ctx->sort_k1, (size_t)n * 4));
+    CHK(buf_ensure(ctx, ctx->sort_v1, (size_t)n * 4));
+    CHK(buf_ensure(ctx, ctx->pix, (size_t)n * 4));
+    const size_t nh = (size_t)256 * (nblk ? nblk : 1);
+    CHK(buf_ensure(ctx, ctx->sort_hist, 2 * nh * 4));
+    CHK(buf_ensure(ctx, ctx->scan_tmp, scan_tmp_bytes(nh)));
+    uint32_t *hist = bp<uint32_t>(ctx->sort_hist), *hscan = hist + nh;
+    // choose ping-pong so the values finish in ctx->pix
+    uint32_t *kbuf[2] = {bp<uint32_t>(ctx->sort_k0), bp<uint32_t>(ctx->sort_k1)};
+    uint32_t *vbuf[2];
+    if (passes & 1) { vbuf[0] = bp<uint32_t>(ctx->pix); vbuf[1] = bp<uint32_t>(ctx->sort_v1); }
+    else            { vbuf[0] = bp<uint32_t>(ctx->sort_v1); vbuf[1] = bp<uint32_t>(ctx->pix); }
+    const uint32_t *kin = keys_in, *vin = vals_in;
+    if (n == 0) { *keys_sorted = kbuf[0]; *vals_sorted = bp<uint32_t>(ctx->pix); return 0; }
+    for (int p = 0; p < passes; p++) {
+        uint32_t *kout = kbuf[p & 1], *vout = vbuf[p & 1];
+        hipLaunchKernelGGL(k_sort_hist, dim3(nblk), dim3(256), 0, ctx->stream, kin, n, p * 8, hist,
+                           nblk);
+        KCHK(ctx);
+        ArrFn f{hist};
+        CHK(scan_exclusive(ctx, f, (uint32_t)nh, hscan, nullptr, bp<uint32_t>(ctx->scan_tmp)));
+        hipLaunchKernelGGL(k_sort_scatter, dim3(nblk), dim3(256), 0, ctx->stream, kin, vin, kout,
+                           vout, n, p * 8, hscan, nblk);
+        KCHK(ctx);
+        kin = kout; vin = vout;
+    }
+    *keys_sorted = (uint32_t *)kin;
+    *vals_sorted = (uint32_t *)vin;
+    return 0;
+}

@@ -1,0 +1,153 @@
+"""GPU parity tests of the per-tile hot path: HIP (through the C-ABI, via the drop-in Python
+API) against the golden vectors of the reference and against the C oracle on seeded inputs.
+Bar: bit-exact for every label image and count."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+pytestmark = pytest.mark.gpu
+
+TILE_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, 'tile_*.npz')))
+CLUMP_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, 'clump_*.npz')))
+
+
+@pytest.fixture(scope='module')
+def shepseg():
+    from pyshepseg_amd import shepseg as m
+    from pyshepseg_amd import _lib
+    assert _lib.lib().shp_device_count() > 0, 'no GPU: the HIP path cannot run'
+    return m
+
+
+def _null(g):
+    return int(g['null_val']) if int(g['has_null']) else None
+
+
+@pytest.mark.parametrize('name', TILE_CASES)
+def test_golden_stages(name, golden, shepseg):
+    g = golden(name)
+    img, four, null = g['img'], bool(g['four']), _null(g)
+    km = shepseg.KMeansModel(g['centres'])
+    cl = shepseg.applySpectralClusters(km, img, null)
+    assert cl.dtype == np.int32 and np.array_equal(cl, g['clusters'])
+    seg, nxt = shepseg.clump(g['clusters'], shepseg.SEGNULLVAL, fourConnected=four,
+                             clumpId=shepseg.MINSEGID)
+    assert seg.dtype == np.uint32
+    assert np.array_equal(seg, g['clump']) and nxt - 1 == int(g['num_clumps'])
+    assert np.array_equal(shepseg.makeSegSize(g['clump']), np.bincount(g['clump'].ravel()))
+    seg1 = g['clump'].copy()
+    shepseg.eliminateSinglePixels(img, seg1, shepseg.makeSegSize(seg1), shepseg.MINSEGID,
+                                  int(g['num_clumps']), four)
+    assert np.array_equal(seg1, g['seg_single'])
+    seg2 = g['seg_single'].copy()
+    ne = shepseg.eliminateSmallSegments(seg2, img, int(seg2.max()), int(g['min_seg']),
+                                        float(g['msd']), four, shepseg.MINSEGID)
+    assert np.array_equal(seg2, g['seg_final']) and ne == int(g['num_small'])
+
+
+@pytest.mark.parametrize('name', TILE_CASES)
+def test_golden_fused(name, golden, shepseg):
+    g = golden(name)
+    km = shepseg.KMeansModel(g['centres'])
+    r = shepseg.doShepherdSegmentation(g['img'], numClusters=int(g['k']),
+                                       minSegmentSize=int(g['min_seg']), imgNullVal=_null(g),
+                                       fourConnected=bool(g['four']), kmeansObj=km)
+    assert np.array_equal(r.segimg, g['seg_final'])
+    assert r.maxSpectralDiff == g['msd']
+    assert r.singlePixelsEliminated == int(g['num_single'])
+    assert r.smallSegmentsEliminated == int(g['num_small'])
+
+
+@pytest.mark.parametrize('name', CLUMP_CASES)
+def test_golden_clump(name, golden, shepseg):
+    g = golden(name)
+    seg, nxt = shepseg.clump(g['clusters'].astype(np.int32), 0, fourConnected=bool(g['four']))
+    assert np.array_equal(seg, g['clump']) and nxt == int(g['next_id'])
+
+
+def test_synthimg_device_matches_oracle(shepseg, oracle):
+    import ctypes
+    from pyshepseg_amd import _lib
+    c = _lib.ctx()
+    out = np.empty((3, 70, 90), dtype=np.uint16)
+    c.check(c._L.shp_synthimg(c.handle, 5, 3, 1000, 37, 70, 90, _lib.ptr(out)))
+    assert np.array_equal(out, oracle.synthimg(5, 3, 70, 90, y0=1000, x0=37))
+
+
+@pytest.mark.parametrize('seed,nb,size,k,minseg,four', [
+    (1, 3, 512, 10, 20, True),
+    (3, 6, 512, 60, 50, True),
+    (4, 6, 384, 60, 50, False),
+    (1, 3, 1024, 10, 20, True),        # BASELINE config[0] (C1) size
+])
+def test_oracle_parity_seeded(seed, nb, size, k, minseg, four, shepseg, oracle):
+    img = oracle.synthimg(seed, nb, size, size)
+    xs = shepseg._sample_rows(img, 1, None)
+    init = shepseg.diagonalClusterCentres(xs, k).astype(np.float64)
+    centres, _lab, _nit = oracle.kmeans_fit(xs.astype(np.float64), init)
+    km = shepseg.KMeansModel(centres)
+    msd = float(shepseg.autoMaxSpectralDiff(km, 'auto', 50))
+    want = oracle.segment_tile(img, centres, minseg, msd, None, four)
+    got = shepseg.doShepherdSegmentation(img, numClusters=k, minSegmentSize=minseg,
+                                         fourConnected=four, kmeansObj=km)
+    assert np.array_equal(got.segimg, want['segimg'])
+    assert got.singlePixelsEliminated == want['singlePixelsEliminated']
+    assert got.smallSegmentsEliminated == want['smallSegmentsEliminated']
+    # stage-wise at this size too (clump includes cut components)
+    cl = shepseg.applySpectralClusters(km, img, None)
+    assert np.array_equal(cl, oracle.kmeans_assign(img, centres, None))
+    seg, nxt = shepseg.clump(cl, 0, fourConnected=four)
+    oseg, onxt = oracle.clump(cl, 0, four, 1)
+    assert nxt == onxt and np.array_equal(seg, oseg)
+
+
+def test_c1_known_counts(shepseg, oracle):
+    """BASELINE config[0]: synthimg(1,3,1024,1024), k=10, minSeg=20, fixed init, 1 % sample.
+    SURVEY 8(d): 32318 clumps -> 10297 after singles -> 1603 final (reference run)."""
+    img = oracle.synthimg(1, 3, 1024, 1024)
+    xs = shepseg._sample_rows(img, 1, None)
+    centres, _l, _n = oracle.kmeans_fit(xs.astype(np.float64),
+                                        shepseg.diagonalClusterCentres(xs, 10).astype(np.float64))
+    r = shepseg.doShepherdSegmentation(img, numClusters=10, minSegmentSize=20,
+                                       kmeansObj=shepseg.KMeansModel(centres))
+    assert int(r.segimg.max()) == 1603
+    assert r.singlePixelsEliminated == 32318 - 10297
+    assert abs(float(r.maxSpectralDiff) - 809.8255004882812) < 1e-9
+
+
+def test_kmeans_fit_device(golden, shepseg, oracle):
+    g = golden('kmeans_fit_synth512')
+    km = shepseg._fit(g['sample'], g['init'])
+    assert km.n_iter_ == int(g['n_iter'])
+    pairs = set(zip(km.labels_.tolist(), g['labels'].tolist()))
+    assert len(pairs) == len(set(km.labels_.tolist())) == len(set(g['labels'].tolist()))
+    a = km.cluster_centers_[np.lexsort(km.cluster_centers_.T[::-1])]
+    b = g['centres'][np.lexsort(g['centres'].T[::-1])]
+    assert np.allclose(a, b, rtol=0, atol=1e-8)
+    # run-to-run determinism of the device reduction
+    km2 = shepseg._fit(g['sample'], g['init'])
+    assert np.array_equal(km.cluster_centers_, km2.cluster_centers_)
+
+
+def test_edge_shapes(shepseg, oracle):
+    km = shepseg.KMeansModel(np.array([[10., 10.], [200., 200.]]))
+    # all-null image
+    img = np.full((2, 9, 11), 255, dtype=np.uint8)
+    r = shepseg.doShepherdSegmentation(img, imgNullVal=255, kmeansObj=km, minSegmentSize=5)
+    assert r.segimg.shape == (9, 11) and not r.segimg.any()
+    # 1x1
+    img = np.array([[[7]], [[9]]], dtype=np.uint8)
+    r = shepseg.doShepherdSegmentation(img, kmeansObj=km, minSegmentSize=5)
+    assert r.segimg.tolist() == [[1]]
+    # properties on a larger random image: ids contiguous, 4-connected segments, idempotent sizes
+    rng = np.random.RandomState(5)
+    img = rng.randint(0, 255, size=(2, 200, 300)).astype(np.uint8)
+    r = shepseg.doShepherdSegmentation(img, kmeansObj=km, minSegmentSize=10)
+    want = oracle.segment_tile(img, km.cluster_centers_, 10, float(r.maxSpectralDiff), None, True)
+    assert np.array_equal(r.segimg, want['segimg'])
+    ids = np.unique(r.segimg)
+    assert ids[0] >= 1 and np.array_equal(ids, np.arange(ids[0], ids[-1] + 1))

@@ -1,0 +1,107 @@
+"""CPU: the C oracle (oracle/shepseg_oracle.c) against the golden vectors produced by the
+unmodified reference (oracle/refgen/gen_golden.py), plus product host code that needs no GPU."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN
+
+TILE_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, 'tile_*.npz')))
+CLUMP_CASES = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, 'clump_*.npz')))
+
+
+def _null(g):
+    return int(g['null_val']) if int(g['has_null']) else None
+
+
+@pytest.mark.parametrize('name', TILE_CASES)
+def test_oracle_tile_stages(name, golden, oracle):
+    g = golden(name)
+    img, four, null = g['img'], bool(g['four']), _null(g)
+    cl = oracle.kmeans_assign(img, g['centres'], null)
+    assert np.array_equal(cl, g['clusters'])
+    seg, nxt = oracle.clump(g['clusters'], 0, four, 1)
+    assert np.array_equal(seg, g['clump']) and nxt - 1 == int(g['num_clumps'])
+    seg1 = g['clump'].copy()
+    ss = oracle.make_seg_size(seg1)
+    oracle.eliminate_single_pixels(img, seg1, ss, 1, int(g['num_clumps']), four)
+    assert np.array_equal(seg1, g['seg_single'])
+    seg2 = g['seg_single'].copy()
+    ne = oracle.eliminate_small_segments(seg2, img, int(seg2.max()), int(g['min_seg']),
+                                         float(g['msd']), four)
+    assert np.array_equal(seg2, g['seg_final']) and ne == int(g['num_small'])
+
+
+@pytest.mark.parametrize('name', TILE_CASES)
+def test_oracle_tile_fused(name, golden, oracle):
+    g = golden(name)
+    r = oracle.segment_tile(g['img'], g['centres'], int(g['min_seg']), float(g['msd']), _null(g),
+                            bool(g['four']))
+    assert np.array_equal(r['segimg'], g['seg_final'])
+    assert r['singlePixelsEliminated'] == int(g['num_single'])
+    assert r['smallSegmentsEliminated'] == int(g['num_small'])
+    assert r['numClumps'] == int(g['num_clumps'])
+
+
+@pytest.mark.parametrize('name', CLUMP_CASES)
+def test_oracle_clump(name, golden, oracle):
+    g = golden(name)
+    seg, nxt = oracle.clump(g['clusters'].astype(np.int32), 0, bool(g['four']), 1)
+    assert np.array_equal(seg, g['clump']) and nxt == int(g['next_id'])
+
+
+def test_clump_split_fixture_really_splits(golden):
+    """the fixtures must exercise the MAX_CLUMP_SIZE cut"""
+    g = golden('clump_uniform150_4conn')
+    assert np.bincount(g['clump'].ravel())[1:].tolist() == [10001, 10002, 2497]
+    g = golden('clump_synth256_4conn')
+    sizes = np.bincount(g['clump'].ravel())[1:]
+    assert (sizes > 10000).sum() >= 1
+
+
+def test_oracle_kmeans_fit(golden, oracle):
+    g = golden('kmeans_fit_synth512')
+    centres, labels, nit = oracle.kmeans_fit(g['sample'].astype(np.float64),
+                                             g['init'].astype(np.float64))
+    assert nit == int(g['n_iter'])
+    pairs = set(zip(labels.tolist(), g['labels'].tolist()))     # same partition (N12)
+    assert len(pairs) == len(set(labels.tolist())) == len(set(g['labels'].tolist()))
+    a = centres[np.lexsort(centres.T[::-1])]
+    b = g['centres'][np.lexsort(g['centres'].T[::-1])]
+    assert np.allclose(a, b, rtol=0, atol=1e-8)
+
+
+def test_synthimg_checksums(oracle):
+    a = oracle.synthimg(1, 3, 64, 64)
+    assert (int(a.min()), int(a.max()), int(a.sum(dtype=np.int64))) == (2196, 4157, 38984854)
+    w = oracle.synthimg(1, 3, 16, 20, y0=40, x0=30)
+    assert np.array_equal(w, a[:, 40:56, 30:50])
+
+
+def test_host_auto_max_spectral_diff(golden):
+    from pyshepseg_amd import shepseg
+    g = golden('auto_msd')
+    km = shepseg.KMeansModel(g['centres'])
+    for key, pct in (('p50', 50), ('p25', 25), ('p90', 90)):
+        v = shepseg.autoMaxSpectralDiff(km, 'auto', pct)
+        assert isinstance(v, np.float64) and v == g[key]
+    assert np.float64(shepseg.autoMaxSpectralDiff(km, None, 50)) == g['none']
+    assert shepseg.autoMaxSpectralDiff(km, 123.5, 50) == 123.5
+
+
+def test_host_sample_and_diagonal_init(golden):
+    from pyshepseg_amd import shepseg
+    g = golden('kmeans_fit_synth512')
+    from oracle import oracle
+    img = oracle.synthimg(2, 6, 512, 512)
+    xs = shepseg._sample_rows(img, 1, None)
+    assert np.array_equal(xs, g['sample'])
+    assert np.array_equal(shepseg.diagonalClusterCentres(xs, 60), g['init'])
+    # null handling: rows with any null band dropped before the stride
+    img2 = img.copy()
+    img2[3, 0, :7] = 65535
+    xs2 = shepseg._sample_rows(img2, 1, 65535)
+    full = np.transpose(img2, (1, 2, 0)).reshape(-1, 6)
+    assert np.array_equal(xs2, full[(full != 65535).all(axis=1)][::100])
