@@ -51,6 +51,10 @@ const char *shp_last_error(const shp_ctx *ctx);  /* valid until the next call on
  * stage call, milliseconds: [0]=assign [1]=clump [2]=single-pixel [3]=small-segment
  * [4]=h2d [5]=d2h [6]=total.  out must hold 8 doubles. */
 int shp_last_timings(const shp_ctx *ctx, double *out);
+/* accumulated device time (ms, HIP events on the ctx stream) and launch count of the
+ * instrumented kernels: ids 0 assign, 1 ccl, 2 dfs_split, 3 radix sort, 4 spectra,
+ * 5 small-segment pass loop, 7 seed scan + final labels.  reset != 0 clears the counters. */
+int shp_prof_get(shp_ctx *ctx, double *ms_out, uint64_t *count_out, int n, int reset);
 
 /* ---- k-means ------------------------------------------------------------------------ */
 /* replaces sklearn KMeans(init=<array>, n_init=1).fit as called by
@@ -98,6 +102,56 @@ int shp_segment_tile(shp_ctx *ctx, const void *img, int dtype, int nbands, int n
 /* ---- synthetic imagery (benchmark input; SURVEY.md Appendix B `synthimg v1`) ----------- */
 int shp_synthimg(shp_ctx *ctx, uint64_t seed, int nbands, int64_t y0, int64_t x0, int nrows,
                  int ncols, uint16_t *out_host);
+
+/* ---- device-resident rasters: tiled driver + cross-tile stitch --------------------------------
+ * Device pointers cross the boundary as plain void* / uint32_t* (they come from shp_dev_alloc).
+ * These replace the per-tile loop and the stitch of tiling.doTiledShepherdSegmentation:
+ *   SegNoConcurrencyMgr.segmentAllTiles / SegThreadsMgr.worker (tiling.py:1413-1469, :1560-1600)
+ *   stitchTiles / recodeTile / recodeSharedSegments / relabelSegments (tiling.py:950-1306)
+ *   HistogramAccumulator (tiling.py:1915-1963), readSubsampledImageBand (tiling.py:259-314). */
+int shp_dev_alloc(shp_ctx *ctx, size_t bytes, void **dptr);
+int shp_dev_free(shp_ctx *ctx, void *dptr);
+int shp_dev_upload(shp_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
+int shp_dev_download(shp_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
+int shp_dev_memset(shp_ctx *ctx, void *dst_dev, int value, size_t bytes);
+int shp_sync(shp_ctx *ctx);
+/* synthimg v1 window written straight into device memory (band-planar uint16) */
+int shp_dev_synthimg(shp_ctx *ctx, uint64_t seed, int nbands, int64_t y0, int64_t x0, int nrows,
+                     int ncols, void *d_out);
+/* out_host[b][i][j] = img[b][row_idx[i]][col_idx[j]] of a device raster (k-means subsample) */
+int shp_dev_subsample(shp_ctx *ctx, const void *d_img, int dtype, int nbands, int nrows, int ncols,
+                      const uint32_t *row_idx, int ny, const uint32_t *col_idx, int nx,
+                      void *out_host);
+/* doShepherdSegmentation on window (x, y, xs, ys) of a device raster; labels (ys*xs uint32,
+ * local ids) are written to device memory d_seg_out.  Synchronous on return. */
+int shp_segment_window_dev(shp_ctx *ctx, const void *d_img, int dtype, int nbands, int img_rows,
+                           int img_cols, int x, int y, int xs, int ys, const double *centres, int k,
+                           int has_null, int64_t null_val, int four_connected, int min_seg_size,
+                           double max_spectral_diff, uint32_t *d_seg_out, uint32_t *max_seg_id_out,
+                           int64_t *singles_elim_out, int64_t *small_elim_out,
+                           uint32_t *num_clumps_out);
+/* same with the tile image handed over as a host buffer (read -> H2D -> segment) */
+int shp_segment_tile_to_dev(shp_ctx *ctx, const void *img, int dtype, int nbands, int nrows,
+                            int ncols, const double *centres, int k, int has_null, int64_t null_val,
+                            int four_connected, int min_seg_size, double max_spectral_diff,
+                            uint32_t *d_seg_out, uint32_t *max_seg_id_out,
+                            int64_t *singles_elim_out, int64_t *small_elim_out,
+                            uint32_t *num_clumps_out);
+/* one tile of stitchTiles, asynchronous on the ctx stream (call shp_sync to wait):
+ * d_tile (ys*xs local ids) is recoded in place against the already-recoded strips of the tile
+ * above (d_top_b: first row of its last `overlap` rows, row pitch top_pitch elements) and of the
+ * tile to the left (d_left_b: first of its last `overlap` columns, pitch left_pitch); NULL where
+ * there is no such neighbour.  The trimmed window [top,bottom) x [left,right) is written to
+ * d_out at (yout, xout) (row pitch out_pitch) and *d_max_seg_id (device scalar) advances to the
+ * largest id in it.  max_local = largest local id in d_tile. */
+int shp_stitch_tile_dev(shp_ctx *ctx, uint32_t *d_tile, int ys, int xs, int overlap,
+                        const uint32_t *d_top_b, int64_t top_pitch, const uint32_t *d_left_b,
+                        int64_t left_pitch, uint32_t max_local, int simple_recode,
+                        uint32_t *d_max_seg_id, int top, int bottom, int left, int right,
+                        uint32_t *d_out, int64_t out_pitch, int xout, int yout);
+/* histogram of a device label raster, hist_out_host[0..max_seg_id], entry 0 zeroed */
+int shp_histogram_dev(shp_ctx *ctx, const uint32_t *d_raster, int64_t npix, uint32_t max_seg_id,
+                      uint32_t *hist_out_host);
 
 #ifdef __cplusplus
 }

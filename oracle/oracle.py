@@ -38,6 +38,7 @@ def lib():
         _lib.orc_seg_max.restype = ctypes.c_uint32
         _lib.orc_eliminate_single_pixels.restype = ctypes.c_int64
         _lib.orc_eliminate_small_segments.restype = ctypes.c_int64
+        _lib.orc_recode_tile.restype = ctypes.c_uint32
     return _lib
 
 
@@ -143,3 +144,84 @@ def kmeans_fit(xsample, init, max_iter=300, tol=1e-4):
                               ctypes.c_double(tol), _p(centres), _p(labels), ctypes.byref(nit))
     assert rc == 0
     return centres, labels, nit.value
+
+
+def recode_tile(tile, overlap, top_b, left_b, max_seg_id, top, bottom, left, right):
+    """tiling.recodeTile for one tile: returns the recoded copy.  top_b / left_b: the saved
+    (recoded) bottom strip of the tile above / right strip of the tile to the left, or None."""
+    tile = np.ascontiguousarray(tile, dtype=np.uint32)
+    ys, xs = tile.shape
+    out = np.empty_like(tile)
+    tb = lb = None
+    tp = lp = 0
+    if top_b is not None:
+        tb = np.ascontiguousarray(top_b, dtype=np.uint32); tp = tb.shape[1]
+    if left_b is not None:
+        lb = np.ascontiguousarray(left_b, dtype=np.uint32); lp = lb.shape[1]
+    lib().orc_recode_tile(_p(tile), ys, xs, int(overlap),
+                          _p(tb) if tb is not None else None, ctypes.c_size_t(tp),
+                          _p(lb) if lb is not None else None, ctypes.c_size_t(lp),
+                          ctypes.c_uint32(int(max_seg_id)), int(top), int(bottom), int(left),
+                          int(right), _p(out))
+    return out
+
+
+def get_tiles(nrows, ncols, tile_size, overlap):
+    """tiling.getTilesForFile (tiling.py:376-443): dict (col,row) -> (xpos, ypos, xsize, ysize)."""
+    tiles = {}
+    ypos = 0; ytile = 0; xtile = 0; ydone = False
+    while not ydone:
+        xdone = False; xpos = 0; xtile = 0; ysize = tile_size
+        if ypos + ysize * 2 > nrows:
+            ysize = nrows - ypos; ydone = True
+            if ysize == 0:
+                break
+        while not xdone:
+            xsize = tile_size
+            if xpos + xsize * 2 > ncols:
+                xsize = ncols - xpos; xdone = True
+                if xsize == 0:
+                    break
+            tiles[(xtile, ytile)] = (xpos, ypos, xsize, ysize)
+            xpos += tile_size - overlap; xtile += 1
+        ypos += tile_size - overlap; ytile += 1
+    return tiles, xtile, ytile
+
+
+def stitch_tiles(tile_segs, tiles, ntcols, ntrows, nrows, ncols, overlap, simple=False):
+    """tiling.stitchTiles (tiling.py:950-1064) on in-memory tiles.  tile_segs: dict
+    (col,row) -> local label array.  Returns (mosaic, maxSegId, hist)."""
+    margin = int(overlap / 2)
+    out = np.zeros((nrows, ncols), dtype=np.uint32)
+    cache = {}
+    max_seg = 0
+    for row in range(ntrows):
+        for col in range(ntcols):
+            xpos, ypos, xsize, ysize = tiles[(col, row)]
+            t = tile_segs[(col, row)]
+            top, bottom, left, right = margin, ysize - margin, margin, xsize - margin
+            xout, yout = xpos + margin, ypos + margin
+            if row == 0:
+                top = 0; yout = ypos
+            if row == ntrows - 1:
+                bottom = ysize
+            if col == 0:
+                left = 0; xout = xpos
+            if col == ntcols - 1:
+                right = xsize
+            if simple:
+                t = np.where(t == 0, 0, t + np.uint32(max_seg)).astype(np.uint32)
+            else:
+                t = recode_tile(t, overlap, cache.get(('b', col, row - 1)) if row > 0 else None,
+                                cache.get(('r', col - 1, row)) if col > 0 else None, max_seg,
+                                top, bottom, left, right)
+            trimmed = t[top:bottom, left:right]
+            out[yout:yout + trimmed.shape[0], xout:xout + trimmed.shape[1]] = trimmed
+            if col != ntcols - 1:
+                cache[('r', col, row)] = t[:, -overlap:].copy()
+            if row != ntrows - 1:
+                cache[('b', col, row)] = t[-overlap:, :].copy()
+            max_seg = max(max_seg, int(trimmed.max()))
+    hist = np.bincount(out.ravel(), minlength=max_seg + 1).astype(np.uint32)
+    hist[0] = 0
+    return out, max_seg, hist

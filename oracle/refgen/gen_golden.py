@@ -109,6 +109,86 @@ def main():
          p25=np.float64(shepseg.autoMaxSpectralDiff(km, 'auto', 25)),
          p90=np.float64(shepseg.autoMaxSpectralDiff(km, 'auto', 90)),
          none=np.float64(shepseg.autoMaxSpectralDiff(km, None, 50)))
+    stitch_cases()
+
+
+def stitch_case(name, img, tile_size, overlap, k, min_seg, null_val, four):
+    """tiling.stitchTiles loop (tiling.py:979-1043) driven through the reference's own
+    recodeTile / recodeSharedSegments / relabelSegments / crossesMidline, in memory."""
+    from pyshepseg import tiling
+
+    class FakeDs(object):
+        RasterXSize = img.shape[2]
+        RasterYSize = img.shape[1]
+
+    class FakeMgr(object):
+        pass
+    ti = tiling.getTilesForFile(FakeDs(), tile_size, overlap)
+    km = shepseg.fitSpectralClusters(img, k, 5, null_val, True)
+    cache = {}
+    mgr = FakeMgr()
+    mgr.overlapSize = overlap
+    mgr.overlapCacheKey = lambda col, row, edge: '{}_{}_{}'.format(edge, col, row)
+    mgr.loadOverlap = lambda key: cache[key]
+    mgr.recodeSharedSegments = tiling.SegmentationConcurrencyMgr.recodeSharedSegments
+    mgr.relabelSegments = tiling.SegmentationConcurrencyMgr.relabelSegments
+    margin = int(overlap / 2)
+    out = np.zeros(img.shape[1:], dtype=np.uint32)
+    hist = tiling.HistogramAccumulator()
+    max_seg = 0
+    arrs = {}
+    msd = None
+    for (col, row) in sorted(ti.tiles.keys(), key=lambda x: (x[1], x[0])):
+        (xpos, ypos, xsize, ysize) = ti.getTile(col, row)
+        sub = np.ascontiguousarray(img[:, ypos:ypos + ysize, xpos:xpos + xsize])
+        r = shepseg.doShepherdSegmentation(sub, minSegmentSize=min_seg, imgNullVal=null_val,
+                                           fourConnected=four, kmeansObj=km)
+        msd = r.maxSpectralDiff
+        tileData = r.segimg
+        arrs['local_%d_%d' % (col, row)] = tileData.copy()
+        top, bottom, left, right = margin, ysize - margin, margin, xsize - margin
+        xout, yout = xpos + margin, ypos + margin
+        rightName = mgr.overlapCacheKey(col, row, tiling.RIGHT_OVERLAP)
+        bottomName = mgr.overlapCacheKey(col, row, tiling.BOTTOM_OVERLAP)
+        if row == 0:
+            top = 0; yout = ypos
+        if row == ti.nrows - 1:
+            bottom = ysize; bottomName = None
+        if col == 0:
+            left = 0; xout = xpos
+        if col == ti.ncols - 1:
+            right = xsize; rightName = None
+        tileData = tiling.SegmentationConcurrencyMgr.recodeTile(mgr, tileData, max_seg, row, col,
+                                                                top, bottom, left, right)
+        arrs['recoded_%d_%d' % (col, row)] = tileData.copy()
+        trimmed = tileData[top:bottom, left:right]
+        out[yout:yout + trimmed.shape[0], xout:xout + trimmed.shape[1]] = trimmed
+        hist.doHistAccum(trimmed)
+        if rightName is not None:
+            cache[rightName] = tileData[:, -overlap:].copy()
+        if bottomName is not None:
+            cache[bottomName] = tileData[-overlap:, :].copy()
+        max_seg = max(max_seg, trimmed.max())
+    save(name, img=img, tile_size=np.int64(tile_size), overlap=np.int64(overlap), k=np.int64(k),
+         min_seg=np.int64(min_seg), null_val=np.int64(-1 if null_val is None else null_val),
+         has_null=np.int64(null_val is not None), four=np.int64(four),
+         centres=np.asarray(km.cluster_centers_, dtype=np.float64), msd=np.float64(msd),
+         ntcols=np.int64(ti.ncols), ntrows=np.int64(ti.nrows), mosaic=out,
+         max_seg_id=np.int64(max_seg), hist=hist.hist.astype(np.uint32), **arrs)
+    print('   tiles %dx%d maxSegId %d empty ids %d' % (ti.ncols, ti.nrows, max_seg,
+                                                        int((hist.hist[1:] == 0).sum())))
+
+
+def stitch_cases():
+    img = oracle.synthimg(21, 3, 200, 200)
+    stitch_case('stitch_2x2', img, 96, 32, 8, 12, None, True)
+    img = oracle.synthimg(22, 3, 300, 280, 50, 70)
+    img[:, :6, :] = 65535
+    img[:, :, -5:] = 65535
+    img[1, 140:170, 100:160] = 65535
+    stitch_case('stitch_3x3_null', img, 96, 32, 8, 15, 65535, True)
+    img = oracle.synthimg(23, 3, 260, 330)
+    stitch_case('stitch_3x4_8conn', img, 80, 24, 6, 10, None, False)
 
 
 if __name__ == '__main__':

@@ -610,3 +610,105 @@ ORC_API int orc_kmeans_fit(const double *xin, int64_t nrows, int nbands, int k,
     free(X); free(mu); free(C); free(Cn); free(w); free(lab); free(lab_old);
     return 0;
 }
+
+/* ------------------------------------------------------------------ */
+/* Stitch: tiling.py:1066-1306 recodeTile / recodeSharedSegments /       */
+/* crossesMidline / relabelSegments, for ONE tile.                       */
+/*  tile      ys*xs local segment ids (0 = null), not modified           */
+/*  top_b     the saved (already recoded) bottom strip of the tile above */
+/*            (ovr rows x xs, row pitch top_pitch) or NULL (tile row 0)  */
+/*  left_b    saved right strip of the tile to the left (ys x ovc cols,  */
+/*            row pitch left_pitch) or NULL (tile col 0)                 */
+/*  overlap   overlapSize; the A strips are tile[:overlap,:] and         */
+/*            tile[:, :overlap] (clipped to the tile)                    */
+/*  out       ys*xs recoded copy (unlisted ids -> 0).  Returns newSegId. */
+/* ------------------------------------------------------------------ */
+static void recode_shared(const uint32_t *tile, int ys, int xs, int an_rows, int an_cols,
+                          const uint32_t *b, size_t b_pitch, int horizontal, uint32_t max_local,
+                          uint8_t *in_dict, uint32_t *recode)
+{
+    /* crossesMidline tiling.py:1271-1306: minN < mid && maxN >= mid along the short axis */
+    (void)ys;
+    int mid = horizontal ? an_rows / 2 : an_cols / 2;
+    int *mn = (int *)malloc(sizeof(int) * ((size_t)max_local + 1));
+    int *mx = (int *)malloc(sizeof(int) * ((size_t)max_local + 1));
+    for (size_t s = 0; s <= max_local; s++) { mn[s] = 0x7fffffff; mx[s] = -1; }
+    for (int r = 0; r < an_rows; r++)
+        for (int c = 0; c < an_cols; c++) {
+            uint32_t s = tile[(size_t)r * xs + c];
+            int v = horizontal ? r : c;
+            if (v < mn[s]) mn[s] = v;
+            if (v > mx[s]) mx[s] = v;
+        }
+    /* per crossing segment: scipy.stats.mode of B under the segment's A pixels
+     * (most frequent value, smallest on ties; may be 0)  tiling.py:1194-1203 */
+    size_t npx = (size_t)an_rows * an_cols;
+    uint32_t *cnt_seg = (uint32_t *)calloc((size_t)max_local + 2, sizeof(uint32_t));
+    for (int r = 0; r < an_rows; r++)
+        for (int c = 0; c < an_cols; c++) cnt_seg[tile[(size_t)r * xs + c] + 1]++;
+    for (size_t s = 1; s <= (size_t)max_local + 1; s++) cnt_seg[s] += cnt_seg[s - 1];
+    uint32_t *vals = (uint32_t *)malloc(sizeof(uint32_t) * (npx ? npx : 1));
+    uint32_t *fill = (uint32_t *)calloc((size_t)max_local + 1, sizeof(uint32_t));
+    for (int r = 0; r < an_rows; r++)
+        for (int c = 0; c < an_cols; c++) {
+            uint32_t s = tile[(size_t)r * xs + c];
+            vals[cnt_seg[s] + fill[s]++] = b[(size_t)r * b_pitch + c];
+        }
+    for (size_t s = 1; s <= max_local; s++) {
+        if (mx[s] < 0) continue;                       /* not in the strip */
+        if (!(mn[s] < mid && mx[s] >= mid)) continue;
+        uint32_t *v = vals + cnt_seg[s];
+        uint32_t n = cnt_seg[s + 1] - cnt_seg[s];
+        /* insertion-free mode: sort the small list */
+        for (uint32_t i = 1; i < n; i++) {             /* simple insertion sort (test sizes) */
+            uint32_t x = v[i]; uint32_t j = i;
+            while (j > 0 && v[j - 1] > x) { v[j] = v[j - 1]; j--; }
+            v[j] = x;
+        }
+        uint32_t best = 0, bestc = 0;
+        for (uint32_t i = 0; i < n;) {
+            uint32_t j = i;
+            while (j < n && v[j] == v[i]) j++;
+            if (j - i > bestc) { bestc = j - i; best = v[i]; }
+            i = j;
+        }
+        in_dict[s] = 1; recode[s] = best;
+    }
+    free(mn); free(mx); free(cnt_seg); free(vals); free(fill);
+}
+
+ORC_API uint32_t orc_recode_tile(const uint32_t *tile, int ys, int xs, int overlap,
+                                 const uint32_t *top_b, size_t top_pitch,
+                                 const uint32_t *left_b, size_t left_pitch,
+                                 uint32_t max_seg_id, int top, int bottom, int left, int right,
+                                 uint32_t *out)
+{
+    size_t npix = (size_t)ys * xs;
+    uint32_t max_local = 0;
+    for (size_t p = 0; p < npix; p++) if (tile[p] > max_local) max_local = tile[p];
+    uint8_t *in_dict = (uint8_t *)calloc((size_t)max_local + 1, 1);
+    uint32_t *recode = (uint32_t *)calloc((size_t)max_local + 1, sizeof(uint32_t));
+    int an_rows = overlap < ys ? overlap : ys, an_cols = overlap < xs ? overlap : xs;
+    if (top_b) recode_shared(tile, ys, xs, an_rows, xs, top_b, top_pitch, 1, max_local, in_dict, recode);
+    if (left_b) recode_shared(tile, ys, xs, ys, an_cols, left_b, left_pitch, 0, max_local, in_dict, recode);
+    /* relabelSegments tiling.py:1205-1269 */
+    int *seg_top = (int *)malloc(sizeof(int) * ((size_t)max_local + 1));
+    int *seg_left = (int *)malloc(sizeof(int) * ((size_t)max_local + 1));
+    for (size_t s = 0; s <= max_local; s++) { seg_top[s] = 0x7fffffff; seg_left[s] = 0x7fffffff; }
+    for (int r = 0; r < ys; r++)
+        for (int c = 0; c < xs; c++) {
+            uint32_t s = tile[(size_t)r * xs + c];
+            if (r < seg_top[s]) seg_top[s] = r;
+            if (c < seg_left[s]) seg_left[s] = c;
+        }
+    uint32_t *lut = (uint32_t *)calloc((size_t)max_local + 1, sizeof(uint32_t));
+    uint32_t new_id = max_seg_id;
+    for (size_t s = 1; s <= max_local; s++) {
+        if (in_dict[s]) lut[s] = recode[s];
+        else if (seg_left[s] >= left && seg_top[s] >= top && seg_left[s] < right && seg_top[s] < bottom)
+            lut[s] = ++new_id;
+    }
+    for (size_t p = 0; p < npix; p++) out[p] = lut[tile[p]];
+    free(in_dict); free(recode); free(seg_top); free(seg_left); free(lut);
+    return new_id;
+}

@@ -33,6 +33,7 @@ _SIGS = {
     'shp_ctx_destroy': (None, [_vp]),
     'shp_last_error': (_c.c_char_p, [_vp]),
     'shp_last_timings': (_c.c_int, [_vp, _vp]),
+    'shp_prof_get': (_c.c_int, [_vp, _vp, _vp, _c.c_int, _c.c_int]),
     'shp_kmeans_fit': (_c.c_int, [_vp, _vp, _c.c_int64, _c.c_int, _c.c_int, _vp, _c.c_int,
                                   _c.c_double, _vp, _vp, _c.POINTER(_c.c_int)]),
     'shp_kmeans_assign': (_c.c_int, [_vp, _vp, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _vp,
@@ -52,6 +53,31 @@ _SIGS = {
                                     _c.POINTER(_c.c_uint32)]),
     'shp_synthimg': (_c.c_int, [_vp, _c.c_uint64, _c.c_int, _c.c_int64, _c.c_int64, _c.c_int,
                                 _c.c_int, _vp]),
+    'shp_dev_alloc': (_c.c_int, [_vp, _c.c_size_t, _c.POINTER(_vp)]),
+    'shp_dev_free': (_c.c_int, [_vp, _vp]),
+    'shp_dev_upload': (_c.c_int, [_vp, _vp, _vp, _c.c_size_t]),
+    'shp_dev_download': (_c.c_int, [_vp, _vp, _vp, _c.c_size_t]),
+    'shp_dev_memset': (_c.c_int, [_vp, _vp, _c.c_int, _c.c_size_t]),
+    'shp_sync': (_c.c_int, [_vp]),
+    'shp_dev_synthimg': (_c.c_int, [_vp, _c.c_uint64, _c.c_int, _c.c_int64, _c.c_int64, _c.c_int,
+                                    _c.c_int, _vp]),
+    'shp_dev_subsample': (_c.c_int, [_vp, _vp, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _vp,
+                                     _c.c_int, _vp, _c.c_int, _vp]),
+    'shp_segment_window_dev': (_c.c_int, [_vp, _vp, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
+                                          _c.c_int, _c.c_int, _c.c_int, _c.c_int, _vp, _c.c_int,
+                                          _c.c_int, _c.c_int64, _c.c_int, _c.c_int, _c.c_double,
+                                          _vp, _c.POINTER(_c.c_uint32), _c.POINTER(_c.c_int64),
+                                          _c.POINTER(_c.c_int64), _c.POINTER(_c.c_uint32)]),
+    'shp_segment_tile_to_dev': (_c.c_int, [_vp, _vp, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _vp,
+                                           _c.c_int, _c.c_int, _c.c_int64, _c.c_int, _c.c_int,
+                                           _c.c_double, _vp, _c.POINTER(_c.c_uint32),
+                                           _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int64),
+                                           _c.POINTER(_c.c_uint32)]),
+    'shp_stitch_tile_dev': (_c.c_int, [_vp, _vp, _c.c_int, _c.c_int, _c.c_int, _vp, _c.c_int64,
+                                       _vp, _c.c_int64, _c.c_uint32, _c.c_int, _vp, _c.c_int,
+                                       _c.c_int, _c.c_int, _c.c_int, _vp, _c.c_int64, _c.c_int,
+                                       _c.c_int]),
+    'shp_histogram_dev': (_c.c_int, [_vp, _vp, _c.c_int64, _c.c_uint32, _vp]),
 }
 
 _lib = None

@@ -8,6 +8,7 @@
 #include "elim_single.h"
 #include "elim_small.h"
 #include "synth.h"
+#include "stitch.h"
 
 #define API extern "C" __attribute__((visibility("default")))
 
@@ -61,6 +62,9 @@ API void shp_ctx_destroy(shp_ctx *ctx)
         if (b->p) hipFree(b->p);
     for (int i = 0; i < 16; i++)
         if (ctx->ev[i]) hipEventDestroy(ctx->ev[i]);
+    for (int i = 0; i < PROF_POOL; i++)
+        for (int j = 0; j < 2; j++)
+            if (ctx->prof_ev[i][j]) hipEventDestroy(ctx->prof_ev[i][j]);
     if (ctx->h_pinned) hipHostFree(ctx->h_pinned);
     hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -80,6 +84,10 @@ static int enter(shp_ctx *ctx)
     if (!ctx) return SHP_ERR_ARG;
     ctx->err.clear();
     HIPCHK(ctx, hipSetDevice(ctx->device));
+    if (ctx->prof_used) {                       // events of an earlier (synchronised) call
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        prof_collect(ctx);
+    }
     return 0;
 }
 
@@ -109,6 +117,7 @@ static int read_u32(shp_ctx *ctx, const uint32_t *d, uint32_t *h)
     return 0;
 }
 
+static void collect_timings(shp_ctx *ctx);
 static float ev_ms(shp_ctx *ctx, int a, int b)
 {
     float ms = 0.f;
@@ -259,19 +268,18 @@ API int shp_eliminate_small(shp_ctx *ctx, const void *img, int dtype, int nbands
 }
 
 // Device-resident fused pipeline on ctx->img -> ctx->seg.  Records stage events 1..5.
-static int segment_device(shp_ctx *ctx, int dtype, int nb, uint32_t nrows, uint32_t ncols,
+static int segment_device(shp_ctx *ctx, const void *d_img, uint32_t *d_seg, int dtype, int nb,
+                          uint32_t nrows, uint32_t ncols,
                           const double *centres, int k, int has_null, int64_t null_val, int four,
                           int min_seg_size, double msd, uint32_t *max_seg_id, int64_t *singles,
                           int64_t *small, uint32_t *nclumps_out)
 {
     const uint32_t n = nrows * ncols;
     CHK(buf_ensure(ctx, ctx->clus, (size_t)n * 2));
-    CHK(buf_ensure(ctx, ctx->seg, (size_t)n * 4));
     CHK(buf_ensure(ctx, ctx->small, 4096));
-    uint32_t *d_seg = bp<uint32_t>(ctx->seg);
     uint32_t *scal = bp<uint32_t>(ctx->small);
     hipEventRecord(ctx->ev[1], ctx->stream);
-    CHK(launch_assign(ctx, ctx->img.p, dtype, nb, n, centres, k, has_null, null_val,
+    CHK(launch_assign(ctx, d_img, dtype, nb, n, centres, k, has_null, null_val,
                       bp<uint16_t>(ctx->clus), nullptr));
     hipEventRecord(ctx->ev[2], ctx->stream);
     CHK(run_clump(ctx, bp<uint16_t>(ctx->clus), nrows, ncols, four, d_seg, scal + 2));
@@ -279,11 +287,11 @@ static int segment_device(shp_ctx *ctx, int dtype, int nb, uint32_t nrows, uint3
     CHK(read_u32(ctx, scal + 2, &nclumps));
     hipEventRecord(ctx->ev[3], ctx->stream);
     uint32_t max_id = nclumps;
-    CHK(run_eliminate_single(ctx, ctx->img.p, dtype, nb, nrows, ncols, four, d_seg, &max_id));
+    CHK(run_eliminate_single(ctx, d_img, dtype, nb, nrows, ncols, four, d_seg, &max_id));
     hipEventRecord(ctx->ev[4], ctx->stream);
     if (singles) *singles = (int64_t)nclumps - (int64_t)max_id;        // shepseg.py:226-227
     int64_t ne = 0;
-    CHK(run_eliminate_small(ctx, ctx->img.p, dtype, nb, nrows, ncols, four, min_seg_size, msd, d_seg,
+    CHK(run_eliminate_small(ctx, d_img, dtype, nb, nrows, ncols, four, min_seg_size, msd, d_seg,
                             &max_id, &ne));
     hipEventRecord(ctx->ev[5], ctx->stream);
     if (small) *small = ne;
@@ -309,19 +317,14 @@ API int shp_segment_tile(shp_ctx *ctx, const void *img, int dtype, int nbands, i
     if (n == 0) return 0;
     hipEventRecord(ctx->ev[0], ctx->stream);
     CHK(upload_img(ctx, img, dtype, nbands, n));
-    CHK(segment_device(ctx, dtype, nbands, nrows, ncols, centres, k, has_null, null_val,
+    CHK(buf_ensure(ctx, ctx->seg, (size_t)n * 4));
+    CHK(segment_device(ctx, ctx->img.p, bp<uint32_t>(ctx->seg), dtype, nbands, nrows, ncols, centres, k, has_null, null_val,
                        four_connected, min_seg_size, max_spectral_diff, max_seg_id_out,
                        singles_elim_out, small_elim_out, num_clumps_out));
     HIPCHK(ctx, hipMemcpyAsync(seg_out, ctx->seg.p, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
     hipEventRecord(ctx->ev[6], ctx->stream);
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->timings[0] = ev_ms(ctx, 1, 2);
-    ctx->timings[1] = ev_ms(ctx, 2, 3);
-    ctx->timings[2] = ev_ms(ctx, 3, 4);
-    ctx->timings[3] = ev_ms(ctx, 4, 5);
-    ctx->timings[4] = ev_ms(ctx, 0, 1);
-    ctx->timings[5] = ev_ms(ctx, 5, 6);
-    ctx->timings[6] = ev_ms(ctx, 0, 6);
+    collect_timings(ctx);
     return 0;
 }
 
@@ -339,5 +342,258 @@ API int shp_synthimg(shp_ctx *ctx, uint64_t seed, int nbands, int64_t y0, int64_
     KCHK(ctx);
     HIPCHK(ctx, hipMemcpyAsync(out_host, ctx->img.p, total * 2, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+static void collect_timings(shp_ctx *ctx)
+{
+    prof_collect(ctx);
+    ctx->timings[0] = ev_ms(ctx, 1, 2);
+    ctx->timings[1] = ev_ms(ctx, 2, 3);
+    ctx->timings[2] = ev_ms(ctx, 3, 4);
+    ctx->timings[3] = ev_ms(ctx, 4, 5);
+    ctx->timings[4] = ev_ms(ctx, 0, 1);
+    ctx->timings[5] = ev_ms(ctx, 5, 6);
+    ctx->timings[6] = ev_ms(ctx, 0, 6);
+}
+
+// ---- device-resident rasters (tiled driver, benchmark) ----------------------------------------
+API int shp_dev_alloc(shp_ctx *ctx, size_t bytes, void **dptr)
+{
+    CHK(enter(ctx));
+    if (!dptr) SHP_FAIL(ctx, SHP_ERR_ARG, "NULL argument");
+    *dptr = nullptr;
+    hipError_t e = hipMalloc(dptr, bytes ? bytes : 16);
+    if (e != hipSuccess) SHP_FAIL(ctx, SHP_ERR_NOMEM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e));
+    return 0;
+}
+
+API int shp_dev_free(shp_ctx *ctx, void *dptr)
+{
+    CHK(enter(ctx));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (dptr) HIPCHK(ctx, hipFree(dptr));
+    return 0;
+}
+
+API int shp_dev_upload(shp_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes)
+{
+    CHK(enter(ctx));
+    if (bytes) HIPCHK(ctx, hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+API int shp_dev_download(shp_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes)
+{
+    CHK(enter(ctx));
+    if (bytes) HIPCHK(ctx, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+API int shp_dev_memset(shp_ctx *ctx, void *dst_dev, int value, size_t bytes)
+{
+    CHK(enter(ctx));
+    if (bytes) HIPCHK(ctx, hipMemsetAsync(dst_dev, value, bytes, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+API int shp_dev_synthimg(shp_ctx *ctx, uint64_t seed, int nbands, int64_t y0, int64_t x0, int nrows,
+                         int ncols, void *d_out)
+{
+    CHK(enter(ctx));
+    if (!d_out || nbands < 1 || nrows < 0 || ncols < 0) SHP_FAIL(ctx, SHP_ERR_ARG, "bad argument");
+    const size_t total = (size_t)nbands * nrows * ncols;
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(k_synthimg, dim3(grid_for(total, 256, 65535u * 8u)), dim3(256), 0, ctx->stream,
+                       seed, nbands, y0, x0, (uint32_t)nrows, (uint32_t)ncols, (uint16_t *)d_out);
+    KCHK(ctx);
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+// gather rows y0,y0+ystep.. / cols likewise of every band of a device raster into a host array
+__global__ __launch_bounds__(256) void k_subsample(const void *__restrict__ img, int dtype, int nb,
+                                                   uint32_t rows, uint32_t cols,
+                                                   const uint32_t *__restrict__ ry,
+                                                   const uint32_t *__restrict__ rx, uint32_t ny,
+                                                   uint32_t nx, void *__restrict__ out)
+{
+    const size_t total = (size_t)nb * ny * nx;
+    const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= total) return;
+    const size_t b = i / ((size_t)ny * nx), r = (i / nx) % ny, c = i % nx;
+    const size_t src = b * (size_t)rows * cols + (size_t)ry[r] * cols + rx[c];
+    switch (dtype) {
+    case SHP_U8: ((uint8_t *)out)[i] = ((const uint8_t *)img)[src]; break;
+    case SHP_I16: case SHP_U16: ((uint16_t *)out)[i] = ((const uint16_t *)img)[src]; break;
+    default: ((uint32_t *)out)[i] = ((const uint32_t *)img)[src]; break;
+    }
+}
+
+API int shp_dev_subsample(shp_ctx *ctx, const void *d_img, int dtype, int nbands, int nrows, int ncols,
+                          const uint32_t *row_idx, int ny, const uint32_t *col_idx, int nx,
+                          void *out_host)
+{
+    CHK(enter(ctx));
+    if (!d_img || !row_idx || !col_idx || !out_host || dtype_size(dtype) == 0)
+        SHP_FAIL(ctx, SHP_ERR_ARG, "bad argument");
+    const size_t total = (size_t)nbands * ny * nx;
+    if (total == 0) return 0;
+    CHK(buf_ensure(ctx, ctx->aux, total * dtype_size(dtype)));
+    CHK(buf_ensure(ctx, ctx->aux2, ((size_t)ny + nx) * 4));
+    uint32_t *ry = bp<uint32_t>(ctx->aux2), *rx = ry + ny;
+    HIPCHK(ctx, hipMemcpyAsync(ry, row_idx, (size_t)ny * 4, hipMemcpyHostToDevice, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(rx, col_idx, (size_t)nx * 4, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_subsample, dim3(grid_for(total, 256)), dim3(256), 0, ctx->stream, d_img, dtype,
+                       nbands, (uint32_t)nrows, (uint32_t)ncols, ry, rx, (uint32_t)ny, (uint32_t)nx,
+                       ctx->aux.p);
+    KCHK(ctx);
+    HIPCHK(ctx, hipMemcpyAsync(out_host, ctx->aux.p, total * dtype_size(dtype), hipMemcpyDeviceToHost,
+                               ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+// copy window (x, y, xs, ys) of every band of a device raster into a contiguous tile image
+__global__ __launch_bounds__(256) void k_window(const void *__restrict__ img, int esize, int nb,
+                                                uint32_t rows, uint32_t cols, uint32_t x, uint32_t y,
+                                                uint32_t xs, uint32_t ys, void *__restrict__ out)
+{
+    const size_t total = (size_t)nb * ys * xs;
+    for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < total; i += (size_t)gridDim.x * 256u) {
+        const size_t b = i / ((size_t)ys * xs), r = (i / xs) % ys, c = i % xs;
+        const size_t src = b * (size_t)rows * cols + (size_t)(y + r) * cols + (x + c);
+        if (esize == 1) ((uint8_t *)out)[i] = ((const uint8_t *)img)[src];
+        else if (esize == 2) ((uint16_t *)out)[i] = ((const uint16_t *)img)[src];
+        else ((uint32_t *)out)[i] = ((const uint32_t *)img)[src];
+    }
+}
+
+API int shp_segment_window_dev(shp_ctx *ctx, const void *d_img, int dtype, int nbands, int img_rows,
+                               int img_cols, int x, int y, int xs, int ys, const double *centres, int k,
+                               int has_null, int64_t null_val, int four_connected, int min_seg_size,
+                               double max_spectral_diff, uint32_t *d_seg_out, uint32_t *max_seg_id_out,
+                               int64_t *singles_elim_out, int64_t *small_elim_out,
+                               uint32_t *num_clumps_out)
+{
+    CHK(enter(ctx));
+    if (!d_img || !centres || !d_seg_out || dtype_size(dtype) == 0 || nbands < 1)
+        SHP_FAIL(ctx, SHP_ERR_ARG, "bad argument");
+    if (x < 0 || y < 0 || xs < 0 || ys < 0 || (int64_t)x + xs > img_cols || (int64_t)y + ys > img_rows)
+        SHP_FAIL(ctx, SHP_ERR_ARG, "window (%d,%d,%d,%d) outside the %d x %d raster", x, y, xs, ys, img_rows, img_cols);
+    if ((uint64_t)xs * (uint64_t)ys >= 0x7fffffffull) SHP_FAIL(ctx, SHP_ERR_ARG, "tile too large");
+    const uint32_t n = (uint32_t)xs * (uint32_t)ys;
+    if (max_seg_id_out) *max_seg_id_out = 0;
+    if (singles_elim_out) *singles_elim_out = 0;
+    if (small_elim_out) *small_elim_out = 0;
+    if (num_clumps_out) *num_clumps_out = 0;
+    if (n == 0) return 0;
+    hipEventRecord(ctx->ev[0], ctx->stream);
+    const void *tile_img = d_img;
+    if (!(x == 0 && y == 0 && xs == img_cols && ys == img_rows)) {
+        const size_t total = (size_t)nbands * n;
+        CHK(buf_ensure(ctx, ctx->img, total * dtype_size(dtype)));
+        hipLaunchKernelGGL(k_window, dim3(grid_for(total, 256, 256u * 32u)), dim3(256), 0, ctx->stream, d_img,
+                           (int)dtype_size(dtype), nbands, (uint32_t)img_rows, (uint32_t)img_cols, (uint32_t)x,
+                           (uint32_t)y, (uint32_t)xs, (uint32_t)ys, ctx->img.p);
+        KCHK(ctx);
+        tile_img = ctx->img.p;
+    }
+    CHK(segment_device(ctx, tile_img, d_seg_out, dtype, nbands, ys, xs, centres, k, has_null, null_val,
+                       four_connected, min_seg_size, max_spectral_diff, max_seg_id_out,
+                       singles_elim_out, small_elim_out, num_clumps_out));
+    hipEventRecord(ctx->ev[6], ctx->stream);
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    collect_timings(ctx);
+    return 0;
+}
+
+// host tile in, device labels out (file-based tiled driver: read -> H2D -> segment, labels stay in HBM)
+API int shp_segment_tile_to_dev(shp_ctx *ctx, const void *img, int dtype, int nbands, int nrows,
+                                int ncols, const double *centres, int k, int has_null, int64_t null_val,
+                                int four_connected, int min_seg_size, double max_spectral_diff,
+                                uint32_t *d_seg_out, uint32_t *max_seg_id_out,
+                                int64_t *singles_elim_out, int64_t *small_elim_out,
+                                uint32_t *num_clumps_out)
+{
+    CHK(enter(ctx));
+    CHK(check_img_args(ctx, img, dtype, nbands, nrows, ncols));
+    if (!centres || !d_seg_out) SHP_FAIL(ctx, SHP_ERR_ARG, "NULL argument");
+    const uint32_t n = (uint32_t)nrows * (uint32_t)ncols;
+    if (max_seg_id_out) *max_seg_id_out = 0;
+    if (singles_elim_out) *singles_elim_out = 0;
+    if (small_elim_out) *small_elim_out = 0;
+    if (num_clumps_out) *num_clumps_out = 0;
+    if (n == 0) return 0;
+    hipEventRecord(ctx->ev[0], ctx->stream);
+    CHK(upload_img(ctx, img, dtype, nbands, n));
+    CHK(segment_device(ctx, ctx->img.p, d_seg_out, dtype, nbands, nrows, ncols, centres, k, has_null,
+                       null_val, four_connected, min_seg_size, max_spectral_diff, max_seg_id_out,
+                       singles_elim_out, small_elim_out, num_clumps_out));
+    hipEventRecord(ctx->ev[6], ctx->stream);
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    collect_timings(ctx);
+    return 0;
+}
+
+API int shp_stitch_tile_dev(shp_ctx *ctx, uint32_t *d_tile, int ys, int xs, int overlap,
+                            const uint32_t *d_top_b, int64_t top_pitch, const uint32_t *d_left_b,
+                            int64_t left_pitch, uint32_t max_local, int simple_recode,
+                            uint32_t *d_max_seg_id, int top, int bottom, int left, int right,
+                            uint32_t *d_out, int64_t out_pitch, int xout, int yout)
+{
+    CHK(enter(ctx));
+    if (!d_tile || !d_max_seg_id || !d_out || ys < 0 || xs < 0 || overlap < 0)
+        SHP_FAIL(ctx, SHP_ERR_ARG, "bad argument");
+    if (top < 0 || left < 0 || bottom > ys || right > xs || top > bottom || left > right)
+        SHP_FAIL(ctx, SHP_ERR_ARG, "bad trimmed window");
+    return run_stitch_tile(ctx, d_tile, (uint32_t)ys, (uint32_t)xs, (uint32_t)overlap, d_top_b,
+                           (size_t)top_pitch, d_left_b, (size_t)left_pitch, max_local, simple_recode,
+                           d_max_seg_id, (uint32_t)top, (uint32_t)bottom, (uint32_t)left,
+                           (uint32_t)right, d_out, (size_t)out_pitch, (uint32_t)xout, (uint32_t)yout);
+}
+
+API int shp_sync(shp_ctx *ctx)
+{
+    CHK(enter(ctx));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+// histogram of a device label raster: hist_out[0..max_seg_id], hist_out[0] = 0 (tiling.py:1915-1963)
+API int shp_histogram_dev(shp_ctx *ctx, const uint32_t *d_raster, int64_t npix, uint32_t max_seg_id,
+                          uint32_t *hist_out_host)
+{
+    CHK(enter(ctx));
+    if (!d_raster || !hist_out_host || npix < 0) SHP_FAIL(ctx, SHP_ERR_ARG, "bad argument");
+    CHK(buf_ensure(ctx, ctx->segsz, ((size_t)max_seg_id + 2) * 4));
+    uint32_t *h = bp<uint32_t>(ctx->segsz);
+    HIPCHK(ctx, hipMemsetAsync(h, 0, ((size_t)max_seg_id + 1) * 4, ctx->stream));
+    const int64_t CH = 1ll << 30;
+    for (int64_t o = 0; o < npix; o += CH) {
+        const uint32_t m = (uint32_t)((npix - o < CH) ? (npix - o) : CH);
+        hipLaunchKernelGGL(k_run_count, dim3(grid_for(m, 256)), dim3(256), 0, ctx->stream, d_raster + o, m,
+                           h, 0u, 1);
+        KCHK(ctx);
+    }
+    HIPCHK(ctx, hipMemcpyAsync(hist_out_host, h, ((size_t)max_seg_id + 1) * 4, hipMemcpyDeviceToHost,
+                               ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    hist_out_host[0] = 0;
+    return 0;
+}
+
+// accumulated device time (ms) and launch count of the instrumented kernels of this context:
+// ids: 0 assign, 1 ccl (init+merge+flatten), 2 dfs_split, 3 radix sort, 4 spectra,
+//      5 small-segment pass loop, 6 (unused), 7 seed scan + final labels.  reset != 0 clears.
+API int shp_prof_get(shp_ctx *ctx, double *ms_out, uint64_t *count_out, int n, int reset)
+{
+    if (!ctx || !ms_out || !count_out) return SHP_ERR_ARG;
+    prof_collect(ctx);
+    for (int i = 0; i < n && i < PROF_N; i++) { ms_out[i] = ctx->prof_ms[i]; count_out[i] = ctx->prof_cnt[i]; }
+    if (reset) for (int i = 0; i < PROF_N; i++) { ctx->prof_ms[i] = 0; ctx->prof_cnt[i] = 0; }
     return 0;
 }

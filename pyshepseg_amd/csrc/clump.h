@@ -272,19 +272,25 @@ static int run_clump(shp_ctx *ctx, const uint16_t *d_clus, uint32_t nrows, uint3
     BigInfo *big = bp<BigInfo>(ctx->big);
     const unsigned g = grid_for(n, 256);
     hipStream_t st = ctx->stream;
+    int ps = prof_begin(ctx, PROF_CCL);
     hipLaunchKernelGGL(k_ccl_init, dim3(g), dim3(256), 0, st, d_clus, lab, n, ncols); KCHK(ctx);
     hipLaunchKernelGGL(k_ccl_merge, dim3(g), dim3(256), 0, st, d_clus, lab, n, nrows, ncols, four); KCHK(ctx);
     hipLaunchKernelGGL(k_ccl_flatten, dim3(g), dim3(256), 0, st, lab, n); KCHK(ctx);
+    prof_end(ctx, ps);
     HIPCHK(ctx, hipMemsetAsync(csize, 0, (size_t)n * 4, st));
     HIPCHK(ctx, hipMemsetAsync(counters, 0, 16, st));
     hipLaunchKernelGGL(k_run_count, dim3(g), dim3(256), 0, st, lab, n, csize, NULL_LAB, 1); KCHK(ctx);
     hipLaunchKernelGGL(k_big_list, dim3(g), dim3(256), 0, st, lab, csize, n, ncols, big, counters); KCHK(ctx);
     hipLaunchKernelGGL(k_big_bbox, dim3(g), dim3(256), 0, st, lab, csize, n, ncols, big); KCHK(ctx);
+    ps = prof_begin(ctx, PROF_DFS);
     hipLaunchKernelGGL(k_dfs_split, dim3(maxbig), dim3(64), 0, st, lab, big, counters,
                        bp<uint32_t>(ctx->stack), nrows, ncols, four); KCHK(ctx);
+    prof_end(ctx, ps);
+    ps = prof_begin(ctx, PROF_LABEL);
     // seed rank -> clump id
     SeedFn sf{lab};
     CHK(scan_exclusive(ctx, sf, n, csize, nclumps_dev, bp<uint32_t>(ctx->scan_tmp)));
     hipLaunchKernelGGL(k_clump_final, dim3(g), dim3(256), 0, st, lab, csize, d_seg, n); KCHK(ctx);
+    prof_end(ctx, ps);
     return 0;
 }

@@ -13,6 +13,8 @@
 #define NULL_LAB 0xFFFFFFFFu   // CCL label of a null pixel
 #define VIS_FLAG 0x80000000u   // set on labels assigned by the depth-first splitter
 #define MAX_CLUMP_SIZE 10000u  // shepseg.py:481
+#define PROF_N 16
+#define PROF_POOL 32
 
 struct DevBuf {
     void *p = nullptr;
@@ -35,7 +37,43 @@ struct shp_ctx {
     uint32_t *h_pinned = nullptr;   // 256 x u32 pinned host scratch for small read-backs
     hipEvent_t ev[16] = {};
     double timings[8] = {};
+    // per-kernel device-time accounting (HIP events on this stream), see PROF_* below
+    double prof_ms[PROF_N] = {};
+    uint64_t prof_cnt[PROF_N] = {};
+    hipEvent_t prof_ev[PROF_POOL][2] = {};
+    int prof_id[PROF_POOL] = {};
+    int prof_used = 0;
 };
+
+// kernels whose launch durations bench.py reports against the roofline
+enum { PROF_ASSIGN = 0, PROF_CCL = 1, PROF_DFS = 2, PROF_SORT = 3, PROF_SPECTRA = 4,
+       PROF_SMALL_LOOP = 5, PROF_SINGLE = 6, PROF_LABEL = 7 };
+
+static inline int prof_begin(shp_ctx *ctx, int id)
+{
+    if (ctx->prof_used >= PROF_POOL) return -1;
+    const int slot = ctx->prof_used++;
+    if (!ctx->prof_ev[slot][0]) { hipEventCreate(&ctx->prof_ev[slot][0]); hipEventCreate(&ctx->prof_ev[slot][1]); }
+    ctx->prof_id[slot] = id;
+    hipEventRecord(ctx->prof_ev[slot][0], ctx->stream);
+    return slot;
+}
+static inline void prof_end(shp_ctx *ctx, int slot)
+{
+    if (slot >= 0) hipEventRecord(ctx->prof_ev[slot][1], ctx->stream);
+}
+// call after the stream has been synchronised
+static inline void prof_collect(shp_ctx *ctx)
+{
+    for (int i = 0; i < ctx->prof_used; i++) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ctx->prof_ev[i][0], ctx->prof_ev[i][1]) == hipSuccess) {
+            ctx->prof_ms[ctx->prof_id[i]] += ms;
+            ctx->prof_cnt[ctx->prof_id[i]] += 1;
+        }
+    }
+    ctx->prof_used = 0;
+}
 
 #define SHP_FAIL(ctx, code, ...)                                  \
     do {                                                          \

@@ -291,7 +291,9 @@ static int run_eliminate_small(shp_ctx *ctx, const void *d_img, int dtype, int n
     if (n == 0 || S == 0) return 0;
     // CSR: pixels grouped by segment id, raster order inside (stable sort of (seg, index))
     uint32_t *ksorted = nullptr, *pix = nullptr;
+    int ps = prof_begin(ctx, PROF_SORT);
     CHK(sort_pairs(ctx, d_seg, nullptr, n, bits_for(S), &ksorted, &pix));
+    prof_end(ctx, ps);
     uint32_t *stmp = bp<uint32_t>(ctx->scan_tmp);      // (fetched after sort_pairs: it may regrow)
     ArrFn szf{segsz};
     CHK(scan_exclusive(ctx, szf, S + 1u, off, nullptr, stmp));
@@ -299,10 +301,13 @@ static int run_eliminate_small(shp_ctx *ctx, const void *d_img, int dtype, int n
     HIPCHK(ctx, hipMemsetAsync(hist, 0, ((size_t)min_seg + 2) * 4, st));
     hipLaunchKernelGGL(k_small_init, dim3(gs), dim3(256), 0, st, segsz, origsz, chnext, chtail,
                        mergeto, tcount, tfill, hist, S, min_seg); KCHK(ctx);
+    ps = prof_begin(ctx, PROF_SPECTRA);
     hipLaunchKernelGGL(k_spectra_small, dim3(gs), dim3(256), 0, st, d_img, dtype, nb, n, pix, off,
                        segsz, ssum, S); KCHK(ctx);
     hipLaunchKernelGGL(k_spectra_big, dim3(grid_for((size_t)S * 64, 256)), dim3(256), 0, st, d_img,
                        dtype, nb, n, pix, off, segsz, ssum, S); KCHK(ctx);
+    prof_end(ctx, ps);
+    ps = prof_begin(ctx, PROF_SMALL_LOOP);
 
     const double thr2 = max_spectral_diff * max_spectral_diff;       // float64 square (N8)
     std::vector<uint32_t> hhist((size_t)min_seg + 2, 0);
@@ -339,6 +344,7 @@ static int run_eliminate_small(shp_ctx *ctx, const void *d_img, int dtype, int n
             passes++;
         }
     }
+    prof_end(ctx, ps);
     *num_elim = (int64_t)hhist[min_seg + 1];
     uint32_t new_max = 0;
     CHK(run_relabel(ctx, d_seg, n, segsz, S, &new_max));

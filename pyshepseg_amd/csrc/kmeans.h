@@ -121,6 +121,7 @@ static int launch_assign(shp_ctx *ctx, const void *d_img, int dtype, int nb, siz
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_assign<NBT>), dim3(grid), dim3(256), 0, ctx->stream,    \
                        d_img, dtype, npix, nb, m2c, cn, k, has_null, (long long)null_val,        \
                        d_clus16, d_clus32)
+    const int ps = prof_begin(ctx, PROF_ASSIGN);
     switch (nb) {
     case 1: LA(1); break;
     case 2: LA(2); break;
@@ -135,6 +136,7 @@ static int launch_assign(shp_ctx *ctx, const void *d_img, int dtype, int nb, siz
     default: LA(0); break;
     }
 #undef LA
+    prof_end(ctx, ps);
     KCHK(ctx);
     return 0;
 }

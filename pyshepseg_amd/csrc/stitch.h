@@ -1,0 +1,253 @@
+// stitch.h -- cross-tile segment-id stitch for one tile, entirely on the device.
+//
+// Replaces tiling.recodeTile / recodeSharedSegments / crossesMidline / relabelSegments
+// (tiling.py:1066-1306) and the per-tile part of stitchTiles (tiling.py:1029-1043).
+//   * a local segment "crosses the midline" of the top (left) overlap strip when its pixels in
+//     the strip span rows (cols) min < mid <= max            -> two integer atomics per pixel
+//   * it is recoded to scipy.stats.mode of the neighbour tile's already-recoded labels under
+//     its strip pixels (most frequent, smallest on ties, may be 0): exact (label, value) pair
+//     counts in an open-addressing hash table (64-bit CAS, run-aggregated adds), then a
+//     64-bit atomicMax of (count << 32 | ~value) per segment; top strip first, left overwrites
+//   * every other segment whose bounding-box corner lies in the trimmed window gets the next
+//     new id in ascending local-id order (flag + exclusive scan); the rest become 0
+//   * the LUT is applied in place, the trimmed window is written to the output raster and
+//     maxSegId advances to the largest id present in the trimmed window (device scalar).
+// No host synchronisation: the whole tile is a chain of launches on the context's stream.
+#pragma once
+#include "common.h"
+#include "scan.h"
+
+__device__ __forceinline__ uint32_t hash64(unsigned long long k)
+{
+    k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
+    return (uint32_t)k;
+}
+
+// strip geometry: pixel i of the strip -> (r, c) of the tile, r < srows, c < scols
+__global__ __launch_bounds__(256) void k_strip_minmax(const uint32_t *__restrict__ tile, uint32_t xs,
+                                                      uint32_t srows, uint32_t scols, int horizontal,
+                                                      uint32_t *mn, uint32_t *mx)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= srows * scols) return;
+    const uint32_t r = i / scols, c = i - r * scols;
+    const uint32_t s = tile[r * xs + c];
+    if (s == 0) return;
+    const uint32_t v = horizontal ? r : c;
+    // cheap pruning: only extremal candidates need to touch memory
+    if (v < mn[s]) atomicMin(&mn[s], v);
+    if (v + 1u > mx[s]) atomicMax(&mx[s], v + 1u);     // mx holds max+1 (0 = absent)
+}
+
+__global__ __launch_bounds__(256) void k_pair_count(
+    const uint32_t *__restrict__ tile, uint32_t xs, uint32_t srows, uint32_t scols,
+    const uint32_t *__restrict__ B, size_t bpitch, const uint32_t *__restrict__ mn,
+    const uint32_t *__restrict__ mx, uint32_t mid, unsigned long long *keys, uint32_t *cnts,
+    uint32_t hmask)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const bool inb = i < srows * scols;
+    unsigned long long key = 0;
+    if (inb) {
+        const uint32_t r = i / scols, c = i - r * scols;
+        const uint32_t s = tile[r * xs + c];
+        if (s != 0 && mn[s] < mid && mx[s] >= mid + 1u)
+            key = ((unsigned long long)s << 32) | (unsigned long long)B[(size_t)r * bpitch + c];
+    }
+    // aggregate runs of equal keys inside the wavefront
+    const unsigned lane = lane_id();
+    const unsigned long long pk = __shfl_up(key, 1, 64);
+    const bool head = lane == 0 || pk != key;
+    const unsigned long long heads = __ballot(head);
+    if (head && key != 0) {
+        const unsigned long long nxt = (lane == 63) ? 0ull : (heads & ~((2ull << lane) - 1ull));
+        const uint32_t len = (nxt ? (unsigned)__builtin_ctzll(nxt) : 64u) - lane;
+        uint32_t h = hash64(key) & hmask;
+        for (;;) {
+            const unsigned long long old = atomicCAS(&keys[h], 0ull, key);
+            if (old == 0ull || old == key) { atomicAdd(&cnts[h], len); break; }
+            h = (h + 1u) & hmask;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_pair_best(const unsigned long long *__restrict__ keys,
+                                                   const uint32_t *__restrict__ cnts, uint32_t hsize,
+                                                   unsigned long long *best)
+{
+    const uint32_t h = blockIdx.x * 256u + threadIdx.x;
+    if (h >= hsize) return;
+    const unsigned long long key = keys[h];
+    if (key == 0ull) return;
+    const uint32_t s = (uint32_t)(key >> 32), b = (uint32_t)key;
+    atomicMax(&best[s], ((unsigned long long)cnts[h] << 32) | (unsigned long long)(~b));
+}
+
+__global__ __launch_bounds__(256) void k_best_to_dict(const unsigned long long *__restrict__ best,
+                                                      uint32_t nseg, uint32_t *in_dict,
+                                                      uint32_t *recode)
+{
+    const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+    if (s >= nseg) return;
+    const unsigned long long b = best[s];
+    if (b != 0ull) { in_dict[s] = 1u; recode[s] = ~(uint32_t)b; }
+}
+
+__global__ __launch_bounds__(256) void k_seg_topleft(const uint32_t *__restrict__ tile, uint32_t ys,
+                                                     uint32_t xs, uint32_t *segtop, uint32_t *segleft)
+{
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= ys * xs) return;
+    const uint32_t s = tile[p];
+    if (s == 0) return;
+    const uint32_t r = p / xs, c = p - r * xs;
+    if ((r == 0 || tile[p - xs] != s) && r < segtop[s]) atomicMin(&segtop[s], r);
+    if ((c == 0 || tile[p - 1] != s) && c < segleft[s]) atomicMin(&segleft[s], c);
+}
+
+struct OwnFn {
+    const uint32_t *in_dict, *segtop, *segleft;
+    uint32_t top, bottom, left, right;
+    __device__ __forceinline__ uint32_t operator()(uint32_t s) const
+    {
+        if (s == 0 || in_dict[s]) return 0u;
+        const uint32_t t = segtop[s], l = segleft[s];
+        return (l >= left && t >= top && l < right && t < bottom) ? 1u : 0u;
+    }
+};
+
+__global__ __launch_bounds__(256) void k_build_lut(OwnFn own, const uint32_t *__restrict__ rank,
+                                                   const uint32_t *__restrict__ recode,
+                                                   const uint32_t *__restrict__ max_seg_id,
+                                                   uint32_t nseg, uint32_t *__restrict__ lut)
+{
+    const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+    if (s >= nseg) return;
+    uint32_t v = 0;
+    if (s != 0) {
+        if (own.in_dict[s]) v = recode[s];
+        else if (own(s)) v = *max_seg_id + rank[s] + 1u;
+    }
+    lut[s] = v;
+}
+
+__global__ __launch_bounds__(256) void k_simple_recode(uint32_t *tile, uint32_t n,
+                                                       const uint32_t *__restrict__ max_seg_id)
+{
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= n) return;
+    const uint32_t s = tile[p];
+    if (s != 0) tile[p] = s + *max_seg_id;          // tiling.py:1024-1027
+}
+
+// tile[p] = lut[tile[p]] (lut == nullptr: keep); trimmed window -> output raster; tmax = max id
+__global__ __launch_bounds__(256) void k_apply_lut(uint32_t *tile, uint32_t ys, uint32_t xs,
+                                                   const uint32_t *__restrict__ lut, uint32_t top,
+                                                   uint32_t bottom, uint32_t left, uint32_t right,
+                                                   uint32_t *__restrict__ out, size_t opitch,
+                                                   uint32_t xout, uint32_t yout, uint32_t *tmax)
+{
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    uint32_t m = 0;
+    if (p < ys * xs) {
+        const uint32_t r = p / xs, c = p - r * xs;
+        const uint32_t v = lut ? lut[tile[p]] : tile[p];
+        if (lut) tile[p] = v;
+        if (r >= top && r < bottom && c >= left && c < right) {
+            out[(size_t)(yout + r - top) * opitch + (xout + c - left)] = v;
+            m = v;
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t o = __shfl_xor(m, d, 64);
+        m = o > m ? o : m;
+    }
+    if (lane_id() == 0 && m != 0) atomicMax(tmax, m);
+}
+
+__global__ void k_max_merge(uint32_t *max_seg_id, const uint32_t *tmax)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0 && *tmax > *max_seg_id) *max_seg_id = *tmax;
+}
+
+static int stitch_strip(shp_ctx *ctx, const uint32_t *tile, uint32_t xs, uint32_t srows,
+                        uint32_t scols, int horizontal, const uint32_t *B, size_t bpitch,
+                        uint32_t nseg, uint32_t *mn, uint32_t *mx, unsigned long long *best,
+                        unsigned long long *keys, uint32_t *cnts, uint32_t hsize, uint32_t *in_dict,
+                        uint32_t *recode)
+{
+    hipStream_t st = ctx->stream;
+    const uint32_t npx = srows * scols;
+    if (npx == 0) return 0;
+    const uint32_t mid = (horizontal ? srows : scols) / 2u;          // int(n / 2), tiling.py:1296
+    HIPCHK(ctx, hipMemsetAsync(mn, 0xff, (size_t)nseg * 4, st));
+    HIPCHK(ctx, hipMemsetAsync(mx, 0, (size_t)nseg * 4, st));
+    HIPCHK(ctx, hipMemsetAsync(best, 0, (size_t)nseg * 8, st));
+    HIPCHK(ctx, hipMemsetAsync(keys, 0, (size_t)hsize * 8, st));
+    HIPCHK(ctx, hipMemsetAsync(cnts, 0, (size_t)hsize * 4, st));
+    const unsigned g = grid_for(npx, 256);
+    hipLaunchKernelGGL(k_strip_minmax, dim3(g), dim3(256), 0, st, tile, xs, srows, scols, horizontal, mn, mx); KCHK(ctx);
+    hipLaunchKernelGGL(k_pair_count, dim3(g), dim3(256), 0, st, tile, xs, srows, scols, B, bpitch, mn, mx,
+                       mid, keys, cnts, hsize - 1u); KCHK(ctx);
+    hipLaunchKernelGGL(k_pair_best, dim3(grid_for(hsize, 256)), dim3(256), 0, st, keys, cnts, hsize, best); KCHK(ctx);
+    hipLaunchKernelGGL(k_best_to_dict, dim3(grid_for(nseg, 256)), dim3(256), 0, st, best, nseg, in_dict, recode); KCHK(ctx);
+    return 0;
+}
+
+// One tile of stitchTiles.  d_tile: ys*xs local ids, recoded in place.
+static int run_stitch_tile(shp_ctx *ctx, uint32_t *d_tile, uint32_t ys, uint32_t xs, uint32_t overlap,
+                           const uint32_t *d_top_b, size_t top_pitch, const uint32_t *d_left_b,
+                           size_t left_pitch, uint32_t max_local, int simple, uint32_t *d_max_seg_id,
+                           uint32_t top, uint32_t bottom, uint32_t left, uint32_t right,
+                           uint32_t *d_out, size_t out_pitch, uint32_t xout, uint32_t yout)
+{
+    hipStream_t st = ctx->stream;
+    const uint32_t n = ys * xs;
+    if (n == 0) return 0;
+    const uint32_t nseg = max_local + 1u;
+    const uint32_t an_rows = overlap < ys ? overlap : ys, an_cols = overlap < xs ? overlap : xs;
+    uint32_t maxstrip = 0;
+    if (d_top_b) maxstrip = an_rows * xs;
+    if (d_left_b && ys * an_cols > maxstrip) maxstrip = ys * an_cols;
+    uint32_t hsize = 1024;
+    while (hsize < 2u * maxstrip) hsize <<= 1;
+    // workspace carve-up (aux: per-segment tables, aux2: hash table)
+    CHK(buf_ensure(ctx, ctx->aux, (size_t)nseg * 4 * 10 + 256));
+    CHK(buf_ensure(ctx, ctx->aux2, (size_t)hsize * 12 + 256));
+    CHK(buf_ensure(ctx, ctx->scan_tmp, scan_tmp_bytes(nseg)));
+    CHK(buf_ensure(ctx, ctx->small, 4096));
+    uint32_t *w = bp<uint32_t>(ctx->aux);
+    uint32_t *in_dict = w, *recode = w + nseg, *mn = w + 2 * (size_t)nseg, *mx = w + 3 * (size_t)nseg;
+    uint32_t *segtop = w + 4 * (size_t)nseg, *segleft = w + 5 * (size_t)nseg;
+    uint32_t *rank = w + 6 * (size_t)nseg, *lut = w + 7 * (size_t)nseg;
+    unsigned long long *best = (unsigned long long *)(w + 8 * (size_t)nseg);   // 32*nseg B: 8-aligned
+    unsigned long long *keys = bp<unsigned long long>(ctx->aux2);
+    uint32_t *cnts = (uint32_t *)(keys + hsize);
+    uint32_t *tmax = bp<uint32_t>(ctx->small) + 32;
+    HIPCHK(ctx, hipMemsetAsync(tmax, 0, 4, st));
+    const unsigned g = grid_for(n, 256);
+    if (simple) {
+        hipLaunchKernelGGL(k_simple_recode, dim3(g), dim3(256), 0, st, d_tile, n, d_max_seg_id); KCHK(ctx);
+        hipLaunchKernelGGL(k_apply_lut, dim3(g), dim3(256), 0, st, d_tile, ys, xs, (const uint32_t *)nullptr,
+                           top, bottom, left, right, d_out, out_pitch, xout, yout, tmax); KCHK(ctx);
+    } else {
+        HIPCHK(ctx, hipMemsetAsync(in_dict, 0, (size_t)nseg * 4, st));
+        if (d_top_b)
+            CHK(stitch_strip(ctx, d_tile, xs, an_rows, xs, 1, d_top_b, top_pitch, nseg, mn, mx, best, keys,
+                             cnts, hsize, in_dict, recode));
+        if (d_left_b)
+            CHK(stitch_strip(ctx, d_tile, xs, ys, an_cols, 0, d_left_b, left_pitch, nseg, mn, mx, best, keys,
+                             cnts, hsize, in_dict, recode));
+        HIPCHK(ctx, hipMemsetAsync(segtop, 0xff, (size_t)nseg * 8, st));      // segtop + segleft
+        hipLaunchKernelGGL(k_seg_topleft, dim3(g), dim3(256), 0, st, d_tile, ys, xs, segtop, segleft); KCHK(ctx);
+        OwnFn own{in_dict, segtop, segleft, top, bottom, left, right};
+        CHK(scan_exclusive(ctx, own, nseg, rank, nullptr, bp<uint32_t>(ctx->scan_tmp)));
+        hipLaunchKernelGGL(k_build_lut, dim3(grid_for(nseg, 256)), dim3(256), 0, st, own, rank, recode,
+                           d_max_seg_id, nseg, lut); KCHK(ctx);
+        hipLaunchKernelGGL(k_apply_lut, dim3(g), dim3(256), 0, st, d_tile, ys, xs, lut, top, bottom, left,
+                           right, d_out, out_pitch, xout, yout, tmax); KCHK(ctx);
+    }
+    hipLaunchKernelGGL(k_max_merge, dim3(1), dim3(64), 0, st, d_max_seg_id, tmax); KCHK(ctx);
+    return 0;
+}

@@ -1,0 +1,631 @@
+"""Drop-in for the segmentation side of ``pyshepseg.tiling``: tiled Shepherd segmentation of a
+large raster with the per-tile work and the cross-tile stitch on the GPU.
+
+Same entry point and arguments as the reference (``doTiledShepherdSegmentation``,
+tiling.py:446-571), same tile grid (``getTilesForFile``, :376-443), same global k-means
+subsample (``fitSpectralClustersWholeFile`` / ``readSubsampledImageBand``, :154-314) and the
+same sequential stitch semantics (``stitchTiles``, :950-1064) -- but tiles are segmented by
+HIP worker contexts (one stream each) and their labels never leave HBM until the stitched
+raster is complete.  What is NOT here, on purpose: the CPU worker farms / AWS Fargate /
+network channel (tiling.py:590-697, :1531-1912), overviews and colour tables.
+
+Rasters.  GDAL is optional (imported lazily).  ``infile`` may be
+  * a ``(nBands, nRows, nCols)`` numpy array or a ``.npy`` path (memory-mapped),
+  * a :class:`DeviceRaster` (already resident in HBM, e.g. synthetic benchmark imagery),
+  * anything GDAL opens, when ``osgeo`` is importable.
+``outfile`` may be ``None`` (labels returned in ``result.segimg``), a ``.npy`` path, or a GDAL
+path when ``osgeo`` is importable.
+"""
+import ctypes
+import os
+import queue
+import sys
+import threading
+import time
+
+import numpy
+
+from . import _lib
+from . import shepseg
+
+TILESIZE = 1024                 # block size of the subsample reader (reference tiling.py:93)
+DFLT_TILESIZE = 4096
+DFLT_OVERLAPSIZE = 1024
+DFLT_CHUNKSIZE = 100000
+
+CONC_NONE = "CONC_NONE"
+CONC_THREADS = "CONC_THREADS"
+CONC_FARGATE = "CONC_FARGATE"
+CONC_SUBPROC = "CONC_SUBPROC"
+
+
+class PyShepSegTilingError(Exception):
+    pass
+
+
+class TiledSegmentationResult(object):
+    """Result of tiled segmentation (reference tiling.py:112-151).  ``segimg`` (the stitched
+    label array) and ``hist`` are additions for the in-memory / .npy path."""
+    def __init__(self):
+        self.maxSegId = None
+        self.numTileRows = None
+        self.numTileCols = None
+        self.subsamplePcnt = None
+        self.maxSpectralDiff = None
+        self.kmeans = None
+        self.hasEmptySegments = None
+        self.timings = None
+        self.outDs = None
+        self.segimg = None
+        self.hist = None
+
+
+class SegmentationConcurrencyConfig(object):
+    """Accepted for API compatibility (reference tiling.py:590-634).  Only ``numWorkers``
+    matters here: it is the number of HIP worker contexts (streams) segmenting tiles
+    concurrently on the GPU.  CONC_NONE means one worker; the CPU farm types
+    (CONC_SUBPROC / CONC_FARGATE) are out of scope and are run as CONC_THREADS."""
+    def __init__(self, concurrencyType=CONC_NONE, numWorkers=0, maxConcurrentReads=20,
+                 tileCompletionTimeout=60, barrierTimeout=60, fargateCfg=None):
+        if concurrencyType not in (CONC_NONE, CONC_THREADS, CONC_FARGATE, CONC_SUBPROC):
+            raise ValueError("Unknown concurrencyType '{}'".format(concurrencyType))
+        self.concurrencyType = concurrencyType
+        self.numWorkers = numWorkers
+        self.maxConcurrentReads = maxConcurrentReads
+        self.tileCompletionTimeout = tileCompletionTimeout
+        self.barrierTimeout = barrierTimeout
+        self.fargateCfg = fargateCfg
+
+
+class Timers(object):
+    """Named interval timers, same interval names as the reference (timinghooks.py:18-160)."""
+    def __init__(self):
+        self.pairs = {}
+        self.lock = threading.Lock()
+
+    class _Interval(object):
+        def __init__(self, timers, name):
+            self.timers, self.name = timers, name
+
+        def __enter__(self):
+            self.t0 = time.time()
+
+        def __exit__(self, *args):
+            t1 = time.time()
+            with self.timers.lock:
+                self.timers.pairs.setdefault(self.name, []).append((self.t0, t1))
+
+    def interval(self, name):
+        return Timers._Interval(self, name)
+
+    def makeSummaryDict(self):
+        d = {}
+        for name, pairs in self.pairs.items():
+            iv = numpy.array([b - a for (a, b) in pairs])
+            d[name] = {'total': float(iv.sum()), 'min': float(iv.min()), 'max': float(iv.max()),
+                       'count': len(pairs)}
+        return d
+
+
+# ------------------------------------------------------------------------------------------
+# raster sources
+# ------------------------------------------------------------------------------------------
+class DeviceRaster(object):
+    """A band-planar raster resident in HBM (device 0 of the calling thread's context)."""
+    def __init__(self, nBands, nRows, nCols, dtype=numpy.uint16, nullVal=None):
+        self.dtype = numpy.dtype(dtype)
+        self.shape = (int(nBands), int(nRows), int(nCols))
+        self.nullVal = nullVal
+        self.RasterXSize, self.RasterYSize = self.shape[2], self.shape[1]
+        self.nbytes = int(nBands) * int(nRows) * int(nCols) * self.dtype.itemsize
+        c = _lib.ctx()
+        p = ctypes.c_void_p()
+        c.check(c._L.shp_dev_alloc(c.handle, self.nbytes, ctypes.byref(p)))
+        self.ptr = p.value
+        self.device = c.device
+
+    @classmethod
+    def synth(cls, seed, nBands, nRows, nCols, y0=0, x0=0):
+        """`synthimg v1` generated on the device."""
+        r = cls(nBands, nRows, nCols, numpy.uint16)
+        c = _lib.ctx()
+        c.check(c._L.shp_dev_synthimg(c.handle, seed, nBands, y0, x0, nRows, nCols,
+                                      ctypes.c_void_p(r.ptr)))
+        return r
+
+    @classmethod
+    def fromArray(cls, img, nullVal=None):
+        img, _dt = _lib.as_image(img)
+        r = cls(img.shape[0], img.shape[1], img.shape[2], img.dtype, nullVal)
+        c = _lib.ctx()
+        c.check(c._L.shp_dev_upload(c.handle, ctypes.c_void_p(r.ptr), _lib.ptr(img), r.nbytes))
+        return r
+
+    def toArray(self):
+        out = numpy.empty(self.shape, dtype=self.dtype)
+        c = _lib.ctx()
+        c.check(c._L.shp_dev_download(c.handle, _lib.ptr(out), ctypes.c_void_p(self.ptr),
+                                      self.nbytes))
+        return out
+
+    def free(self):
+        if self.ptr:
+            c = _lib.ctx()
+            c.check(c._L.shp_dev_free(c.handle, ctypes.c_void_p(self.ptr)))
+            self.ptr = None
+
+
+class _ArraySource(object):
+    """Host ndarray / memmap source with the reader interface the driver needs."""
+    def __init__(self, arr, nullVal=None):
+        if arr.ndim != 3:
+            raise PyShepSegTilingError("raster array must have shape (nBands, nRows, nCols)")
+        self.arr = arr
+        self.shape = arr.shape
+        self.dtype = arr.dtype
+        self.nullVal = nullVal
+        self.RasterXSize, self.RasterYSize = arr.shape[2], arr.shape[1]
+
+    def read(self, bands, xpos, ypos, xsize, ysize):
+        return numpy.ascontiguousarray(self.arr[bands, ypos:ypos + ysize, xpos:xpos + xsize])
+
+
+class _GdalSource(object):
+    def __init__(self, path):
+        from osgeo import gdal
+        gdal.UseExceptions()
+        self.ds = gdal.Open(path)
+        self.path = path
+        self.RasterXSize, self.RasterYSize = self.ds.RasterXSize, self.ds.RasterYSize
+        self.shape = (self.ds.RasterCount, self.RasterYSize, self.RasterXSize)
+        self.nullVal = None
+        self.local = threading.local()
+
+    def bandNull(self, bandNumbers):
+        arr = numpy.array([self.ds.GetRasterBand(i).GetNoDataValue() for i in bandNumbers])
+        if (arr != arr[0]).any():
+            raise PyShepSegTilingError("Different null values in some bands")
+        return arr[0]
+
+    def read(self, bands, xpos, ypos, xsize, ysize):
+        from osgeo import gdal
+        ds = getattr(self.local, 'ds', None)
+        if ds is None:
+            ds = self.local.ds = gdal.Open(self.path)      # per-thread dataset (tiling.py:1565)
+        return numpy.array([ds.GetRasterBand(int(b) + 1).ReadAsArray(xpos, ypos, xsize, ysize)
+                            for b in bands])
+
+
+def _open_source(infile):
+    if isinstance(infile, DeviceRaster):
+        return infile
+    if isinstance(infile, numpy.ndarray):
+        return _ArraySource(infile)
+    if isinstance(infile, str) and infile.endswith('.npy'):
+        return _ArraySource(numpy.load(infile, mmap_mode='r'))
+    try:
+        import osgeo  # noqa: F401
+    except ImportError:
+        raise PyShepSegTilingError("cannot open %r: GDAL (osgeo) is not importable here; pass a "
+                                   "numpy array, a .npy path or a DeviceRaster" % (infile,))
+    return _GdalSource(infile)
+
+
+# ------------------------------------------------------------------------------------------
+# tile grid (reference tiling.py:317-443)
+# ------------------------------------------------------------------------------------------
+class TileInfo(object):
+    """Pixel coordinates of the tiles within an image (reference tiling.py:317-374)."""
+    def __init__(self):
+        self.tiles = {}
+        self.ncols = None
+        self.nrows = None
+
+    def addTile(self, xpos, ypos, xsize, ysize, col, row):
+        self.tiles[(col, row)] = (xpos, ypos, xsize, ysize)
+
+    def getNumTiles(self):
+        return len(self.tiles)
+
+    def getTile(self, col, row):
+        return self.tiles[(col, row)]
+
+
+def getTilesForFile(ds, tileSize, overlapSize):
+    """TileInfo for a raster (anything with RasterXSize / RasterYSize).  Tile origins every
+    tileSize-overlapSize; a tile grows to the image edge when another whole tile would not fit
+    (reference tiling.py:376-443)."""
+    tileSize = int(tileSize)
+    overlapSize = int(overlapSize)
+    tileInfo = TileInfo()
+    yDone = False
+    ypos = 0
+    xtile = 0
+    ytile = 0
+    while not yDone:
+        xDone = False
+        xpos = 0
+        xtile = 0
+        ysize = tileSize
+        if (ypos + ysize * 2) > ds.RasterYSize:
+            ysize = ds.RasterYSize - ypos
+            yDone = True
+            if ysize == 0:
+                break
+        while not xDone:
+            xsize = tileSize
+            if (xpos + xsize * 2) > ds.RasterXSize:
+                xsize = ds.RasterXSize - xpos
+                xDone = True
+                if xsize == 0:
+                    break
+            tileInfo.addTile(xpos, ypos, xsize, ysize, xtile, ytile)
+            xpos += (tileSize - overlapSize)
+            xtile += 1
+        ypos += (tileSize - overlapSize)
+        ytile += 1
+    tileInfo.ncols = xtile
+    tileInfo.nrows = ytile
+    return tileInfo
+
+
+# ------------------------------------------------------------------------------------------
+# whole-image k-means (reference tiling.py:154-314)
+# ------------------------------------------------------------------------------------------
+def _subsample_indices(n, skip, tileSize=TILESIZE):
+    """Indices kept by readSubsampledImageBand along one axis: [::skip] restarted inside every
+    1024-pixel block (reference tiling.py:287-311)."""
+    idx = []
+    for start in range(0, n, tileSize):
+        size = min(tileSize, n - start)
+        idx.extend(range(start, start + size, skip))
+    return numpy.array(idx, dtype=numpy.uint32)
+
+
+def readSubsampledImage(src, bandNumbers, subsampleProp):
+    """Sub-sampled copy of the selected bands: (nBands, nRowsSub, nColsSub)."""
+    skip = int(round(1. / subsampleProp))
+    (nb, nlines, npix) = src.shape
+    ry = _subsample_indices(nlines, skip)
+    rx = _subsample_indices(npix, skip)
+    bands = [b - 1 for b in bandNumbers]
+    if isinstance(src, DeviceRaster):
+        out = numpy.empty((nb, len(ry), len(rx)), dtype=src.dtype)
+        c = _lib.ctx()
+        c.check(c._L.shp_dev_subsample(c.handle, ctypes.c_void_p(src.ptr),
+                                       _lib.SHP_DTYPES[src.dtype], nb, nlines, npix,
+                                       _lib.ptr(ry), len(ry), _lib.ptr(rx), len(rx), _lib.ptr(out)))
+        return numpy.ascontiguousarray(out[bands])
+    rows = []
+    for ypos in range(0, nlines, TILESIZE):
+        ysize = min(TILESIZE, nlines - ypos)
+        cols = []
+        for xpos in range(0, npix, TILESIZE):
+            xsize = min(TILESIZE, npix - xpos)
+            t = src.read(bands, xpos, ypos, xsize, ysize)
+            cols.append(t[:, ::skip, ::skip])
+        rows.append(numpy.concatenate(cols, axis=2))
+    return numpy.ascontiguousarray(numpy.concatenate(rows, axis=1))
+
+
+def fitSpectralClustersWholeFile(inDs, bandNumbers, numClusters=60, subsamplePcnt=None,
+        imgNullVal=None, fixedKMeansInit=False):
+    """Read a sub-sample of the whole raster and fit the spectral clusters on it
+    (reference tiling.py:154-226).  Returns (kmeansObj, subsamplePcnt, imgNullVal)."""
+    if subsamplePcnt is None:
+        dfltTotalPixels = 1000000
+        totalImagePixels = inDs.RasterXSize * inDs.RasterYSize
+        subsampleProp = numpy.sqrt(dfltTotalPixels / totalImagePixels)
+        subsampleProp = min(1, subsampleProp)
+        subsamplePcnt = 100 * subsampleProp**2
+    else:
+        subsampleProp = numpy.sqrt(subsamplePcnt / 100.0)
+    if imgNullVal is None:
+        if isinstance(inDs, _GdalSource):
+            imgNullVal = inDs.bandNull(bandNumbers)
+        else:
+            imgNullVal = inDs.nullVal
+    img = readSubsampledImage(inDs, bandNumbers, subsampleProp)
+    kmeansObj = shepseg.fitSpectralClusters(img, numClusters=numClusters, subsamplePcnt=100,
+                                            imgNullVal=imgNullVal, fixedKMeansInit=fixedKMeansInit)
+    return (kmeansObj, subsamplePcnt, imgNullVal)
+
+
+# ------------------------------------------------------------------------------------------
+# the tiled driver
+# ------------------------------------------------------------------------------------------
+class _TileJob(object):
+    __slots__ = ('col', 'row', 'xpos', 'ypos', 'xsize', 'ysize', 'offset', 'maxLocal', 'done',
+                 'error')
+
+
+def doTiledShepherdSegmentation(infile, outfile, tileSize=DFLT_TILESIZE,
+        overlapSize=DFLT_OVERLAPSIZE, minSegmentSize=50, numClusters=60,
+        bandNumbers=None, subsamplePcnt=None, maxSpectralDiff='auto',
+        imgNullVal=None, fixedKMeansInit=False, fourConnected=True, verbose=False,
+        simpleTileRecode=False, outputDriver='KEA', creationOptions=[],
+        spectDistPcntile=50, kmeansObj=None, tempfilesDriver='KEA',
+        tempfilesExt='kea', tempfilesCreationOptions=[], writeHistogram=True,
+        returnGDALDS=False, concurrencyCfg=None):
+    """
+    Run the Shepherd segmentation algorithm in a memory-efficient manner suitable for large
+    rasters: one global k-means, overlapping tiles segmented independently, tiles stitched by
+    matching segments across the overlap midline.  Arguments as the reference
+    (tiling.py:446-571); the temp-file arguments are accepted and ignored (tile labels stay in
+    GPU memory).  Returns a :class:`TiledSegmentationResult`.
+    """
+    if concurrencyCfg is None:
+        concurrencyCfg = SegmentationConcurrencyConfig()
+    if (overlapSize % 2) != 0:
+        raise PyShepSegTilingError("Overlap size must be an even number")     # tiling.py:746
+    timings = Timers()
+    with timings.interval('walltime'):
+        src = _open_source(infile)
+        nBandsAll = src.shape[0]
+        if bandNumbers is None:
+            bandNumbers = list(range(1, nBandsAll + 1))
+        bands = [b - 1 for b in bandNumbers]
+        (inYsize, inXsize) = (src.RasterYSize, src.RasterXSize)
+
+        with timings.interval('spectralclusters'):
+            if kmeansObj is None:
+                (kmeansObj, subsamplePcnt, imgNullVal) = fitSpectralClustersWholeFile(
+                    src, bandNumbers, numClusters, subsamplePcnt, imgNullVal, fixedKMeansInit)
+            elif imgNullVal is None:
+                imgNullVal = (src.bandNull(bandNumbers) if isinstance(src, _GdalSource)
+                              else src.nullVal)
+        centres = numpy.ascontiguousarray(kmeansObj.cluster_centers_, dtype=numpy.float64)
+        msd = shepseg.autoMaxSpectralDiff(kmeansObj, maxSpectralDiff, spectDistPcntile)
+        if verbose:
+            print("KMeans of whole raster", kmeansObj.n_clusters, "clusters; maxSpectralDiff", msd)
+
+        tileInfo = getTilesForFile(src, tileSize, overlapSize)
+        if verbose:
+            print("Found {} tiles, with {} rows and {} cols".format(
+                tileInfo.getNumTiles(), tileInfo.nrows, tileInfo.ncols))
+
+        main = _lib.ctx()
+        L = main._L
+        # one device block for every tile's labels, one for the stitched raster
+        jobs = []
+        total = 0
+        for (col, row) in sorted(tileInfo.tiles.keys(), key=lambda x: (x[1], x[0])):
+            j = _TileJob()
+            (j.col, j.row) = (col, row)
+            (j.xpos, j.ypos, j.xsize, j.ysize) = tileInfo.getTile(col, row)
+            j.offset = total
+            j.maxLocal = 0
+            j.done = threading.Event()
+            j.error = None
+            total += j.xsize * j.ysize
+            jobs.append(j)
+        jobmap = {(j.col, j.row): j for j in jobs}
+        d_tiles = ctypes.c_void_p()
+        d_out = ctypes.c_void_p()
+        d_scal = ctypes.c_void_p()
+        main.check(L.shp_dev_alloc(main.handle, max(total, 1) * 4, ctypes.byref(d_tiles)))
+        main.check(L.shp_dev_alloc(main.handle, max(inYsize * inXsize, 1) * 4, ctypes.byref(d_out)))
+        main.check(L.shp_dev_alloc(main.handle, 256, ctypes.byref(d_scal)))
+        main.check(L.shp_dev_memset(main.handle, d_scal, 0, 256))
+        try:
+            nullFlag = int(imgNullVal is not None)
+            nullV = 0 if imgNullVal is None else int(imgNullVal)
+            onDevice = isinstance(src, DeviceRaster)
+            if onDevice and bands != list(range(nBandsAll)):
+                raise PyShepSegTilingError("band selection on a DeviceRaster is not supported")
+            dtcode = _lib.SHP_DTYPES[numpy.dtype(src.dtype)] if onDevice else None
+            readSem = threading.BoundedSemaphore(max(1, concurrencyCfg.maxConcurrentReads))
+            inQue = queue.Queue()
+            for j in jobs:
+                inQue.put(j)
+            forceExit = threading.Event()
+
+            def worker():
+                try:
+                    c = _lib.ctx()
+                except Exception as e:          # no GPU, library missing ...
+                    forceExit.set()
+                    for jj in jobs:
+                        if jj.error is None:
+                            jj.error = e
+                        jj.done.set()
+                    return
+                while not forceExit.is_set():
+                    try:
+                        j = inQue.get_nowait()
+                    except queue.Empty:
+                        break
+                    try:
+                        mx = ctypes.c_uint32(0)
+                        s1 = ctypes.c_int64(0)
+                        s2 = ctypes.c_int64(0)
+                        ncl = ctypes.c_uint32(0)
+                        dseg = ctypes.c_void_p(d_tiles.value + 4 * j.offset)
+                        if onDevice:
+                            with timings.interval('segmentation'):
+                                c.check(L.shp_segment_window_dev(
+                                    c.handle, ctypes.c_void_p(src.ptr), dtcode, nBandsAll, inYsize,
+                                    inXsize, j.xpos, j.ypos, j.xsize, j.ysize, _lib.ptr(centres),
+                                    centres.shape[0], nullFlag, nullV, int(bool(fourConnected)),
+                                    int(minSegmentSize), float(msd), dseg, ctypes.byref(mx),
+                                    ctypes.byref(s1), ctypes.byref(s2), ctypes.byref(ncl)))
+                        else:
+                            with timings.interval('reading'):
+                                with readSem:
+                                    img = src.read(bands, j.xpos, j.ypos, j.xsize, j.ysize)
+                            img, dt = _lib.as_image(img)
+                            with timings.interval('segmentation'):
+                                c.check(L.shp_segment_tile_to_dev(
+                                    c.handle, _lib.ptr(img), dt, img.shape[0], j.ysize, j.xsize,
+                                    _lib.ptr(centres), centres.shape[0], nullFlag, nullV,
+                                    int(bool(fourConnected)), int(minSegmentSize), float(msd), dseg,
+                                    ctypes.byref(mx), ctypes.byref(s1), ctypes.byref(s2),
+                                    ctypes.byref(ncl)))
+                        j.maxLocal = mx.value
+                        if verbose:
+                            print("Tile ({}, {}): {} segments".format(j.col, j.row, mx.value))
+                    except Exception as e:
+                        j.error = e
+                        forceExit.set()
+                    j.done.set()
+
+            numWorkers = 1
+            if concurrencyCfg.concurrencyType != CONC_NONE:
+                numWorkers = max(1, int(concurrencyCfg.numWorkers))
+            with timings.interval('startworkers'):
+                threads = [threading.Thread(target=worker, daemon=True) for _ in range(numWorkers)]
+                for t in threads:
+                    t.start()
+
+            # ---- stitchTiles (tiling.py:950-1064): sequential, concurrent with the workers ----
+            marginSize = int(overlapSize / 2)
+            with timings.interval('stitchtiles'):
+                for j in jobs:
+                    timeout = concurrencyCfg.tileCompletionTimeout
+                    while not j.done.wait(timeout=max(timeout, 1)):
+                        if forceExit.is_set():
+                            break
+                        if not any(t.is_alive() for t in threads):
+                            break
+                    if j.error is not None or not j.done.is_set():
+                        forceExit.set()
+                        err = j.error
+                        for jj in jobs:
+                            err = err or jj.error
+                        if isinstance(err, _lib.ShepsegHipError):
+                            raise err
+                        raise PyShepSegTilingError("Tile ({}, {}) failed: {}".format(j.col, j.row, err))
+                    (top, bottom, left, right) = (marginSize, j.ysize - marginSize, marginSize,
+                                                  j.xsize - marginSize)
+                    (xout, yout) = (j.xpos + marginSize, j.ypos + marginSize)
+                    if j.row == 0:
+                        top = 0
+                        yout = j.ypos
+                    if j.row == tileInfo.nrows - 1:
+                        bottom = j.ysize
+                    if j.col == 0:
+                        left = 0
+                        xout = j.xpos
+                    if j.col == tileInfo.ncols - 1:
+                        right = j.xsize
+                    topB = leftB = None
+                    (topPitch, leftPitch) = (0, 0)
+                    if not simpleTileRecode:
+                        if j.row > 0:
+                            a = jobmap[(j.col, j.row - 1)]
+                            topB = ctypes.c_void_p(d_tiles.value + 4 * (a.offset + (a.ysize - overlapSize) * a.xsize))
+                            topPitch = a.xsize
+                        if j.col > 0:
+                            a = jobmap[(j.col - 1, j.row)]
+                            leftB = ctypes.c_void_p(d_tiles.value + 4 * (a.offset + (a.xsize - overlapSize)))
+                            leftPitch = a.xsize
+                    main.check(L.shp_stitch_tile_dev(
+                        main.handle, ctypes.c_void_p(d_tiles.value + 4 * j.offset), j.ysize, j.xsize,
+                        overlapSize, topB, topPitch, leftB, leftPitch, j.maxLocal,
+                        int(bool(simpleTileRecode)), d_scal, top, bottom, left, right, d_out,
+                        inXsize, xout - 0, yout - 0))
+                main.check(L.shp_sync(main.handle))
+            for t in threads:
+                t.join()
+
+            scal = numpy.zeros(1, dtype=numpy.uint32)
+            main.check(L.shp_dev_download(main.handle, _lib.ptr(scal), d_scal, 4))
+            maxSegId = int(scal[0])
+            hist = numpy.zeros(maxSegId + 1, dtype=numpy.uint32)
+            main.check(L.shp_histogram_dev(main.handle, d_out, inYsize * inXsize, maxSegId,
+                                           _lib.ptr(hist)))
+            hasEmpty = bool((hist[1:] == 0).any())
+            if hasEmpty:
+                _warnEmptySegments(hist, overlapSize)
+
+            result = TiledSegmentationResult()
+            if outfile is _KEEP_ON_DEVICE:
+                result.outDev = (d_out.value, inYsize, inXsize)
+                d_out = ctypes.c_void_p()           # ownership moves to the caller
+            else:
+                segimg = numpy.empty((inYsize, inXsize), dtype=shepseg.SegIdType)
+                main.check(L.shp_dev_download(main.handle, _lib.ptr(segimg), d_out, segimg.nbytes))
+                if outfile is None:
+                    result.segimg = segimg
+                elif isinstance(outfile, str) and outfile.endswith('.npy'):
+                    numpy.save(outfile, segimg)
+                    if writeHistogram:
+                        numpy.save(outfile[:-4] + '_hist.npy', hist)
+                else:
+                    _writeGdal(outfile, segimg, hist, infile, outputDriver, creationOptions,
+                               writeHistogram)
+        finally:
+            forceExit_ = locals().get('forceExit')
+            if forceExit_ is not None:
+                forceExit_.set()
+            for p in (d_tiles, d_out, d_scal):
+                if p.value:
+                    L.shp_dev_free(main.handle, p)
+
+    result.maxSegId = maxSegId
+    result.numTileRows = tileInfo.nrows
+    result.numTileCols = tileInfo.ncols
+    result.subsamplePcnt = subsamplePcnt
+    result.maxSpectralDiff = msd
+    result.kmeans = kmeansObj
+    result.hasEmptySegments = hasEmpty
+    result.hist = hist
+    result.timings = timings
+    return result
+
+
+_KEEP_ON_DEVICE = object()      # outfile sentinel used by bench.py: labels stay in HBM
+
+
+def freeDeviceOutput(result):
+    """Release the device raster kept by outfile=_KEEP_ON_DEVICE."""
+    od = getattr(result, 'outDev', None)
+    if od and od[0]:
+        c = _lib.ctx()
+        c.check(c._L.shp_dev_free(c.handle, ctypes.c_void_p(od[0])))
+        result.outDev = None
+
+
+def _warnEmptySegments(hist, overlapSize):
+    """Same warning as reference checkForEmptySegments (tiling.py:1308-1341).  NB the reference
+    method has no return statement, so its hasEmptySegments is always None; here the flag is the
+    real boolean (a knowing fix)."""
+    emptySegIds = numpy.where(hist[1:] == 0)[0] + 1
+    msg = [
+        "",
+        "WARNING: Found {} segments with zero pixels".format(len(emptySegIds)),
+        "    Segment IDs: {}".format(emptySegIds),
+        "    This is caused by inconsistent joining of segmentation",
+        "    tiles, and will probably cause trouble later on.",
+        "    It is highly recommended to re-run with a larger overlap",
+        "    size (currently {}), and if necessary a larger tile size".format(overlapSize),
+        ""
+    ]
+    print('\n'.join(msg), file=sys.stderr)
+
+
+def _writeGdal(outfile, segimg, hist, infile, outputDriver, creationOptions, writeHistogram):
+    try:
+        from osgeo import gdal
+    except ImportError:
+        raise PyShepSegTilingError("cannot write %r: GDAL (osgeo) is not importable here; use "
+                                   "outfile=None or a .npy path" % (outfile,))
+    drvr = gdal.GetDriverByName(outputDriver)
+    if drvr is None:
+        raise PyShepSegTilingError("This GDAL does not support driver '{}'".format(outputDriver))
+    (ys, xs) = segimg.shape
+    ds = drvr.Create(outfile, xs, ys, 1, gdal.GDT_UInt32, creationOptions)
+    if isinstance(infile, str):
+        inDs = gdal.Open(infile)
+        ds.SetProjection(inDs.GetProjection())
+        ds.SetGeoTransform(inDs.GetGeoTransform())
+    band = ds.GetRasterBand(1)
+    band.SetMetadataItem('LAYER_TYPE', 'thematic')
+    band.SetNoDataValue(shepseg.SEGNULLVAL)
+    band.WriteArray(segimg)
+    if writeHistogram:
+        rat = band.GetDefaultRAT()
+        rat.SetRowCount(len(hist))
+        rat.CreateColumn('Histogram', gdal.GFT_Real, gdal.GFU_PixelCount)
+        rat.WriteArray(hist.astype(numpy.float64), rat.GetColumnCount() - 1)
+    ds.FlushCache()
