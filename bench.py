@@ -104,15 +104,6 @@ def main():
     cfg = tiling.SegmentationConcurrencyConfig(concurrencyType=tiling.CONC_THREADS,
                                                numWorkers=args.workers)
 
-    # keep handles on the worker contexts so their per-kernel timers can be read
-    contexts = []
-    orig_ctx = _lib.Context.__init__
-
-    def tracking_init(self, *a, **k):
-        orig_ctx(self, *a, **k)
-        contexts.append(self)
-    _lib.Context.__init__ = tracking_init
-
     def step():
         r = tiling.doTiledShepherdSegmentation(
             ras, tiling._KEEP_ON_DEVICE, tileSize=args.tile, overlapSize=args.overlap,
@@ -122,7 +113,7 @@ def main():
 
     for _ in range(args.warmup):
         r = step()
-    prof_totals(contexts)                       # reset the per-kernel timers
+    prof_totals(_lib.pool_contexts())           # reset the per-kernel timers
     c = _lib.ctx()
     c.check(c._L.shp_sync(c.handle))
     t0 = time.time()
@@ -130,7 +121,7 @@ def main():
         r = step()
     c.check(c._L.shp_sync(c.handle))
     dt = (time.time() - t0) / max(args.steps, 1)
-    prof = prof_totals(contexts)
+    prof = prof_totals(_lib.pool_contexts())
 
     npix = args.size * args.size
     value = npix / dt / 1e6
@@ -168,6 +159,8 @@ def main():
                      "device_ms_by_kernel": {names[i]: round(prof.get(i, (0, 0))[0] / max(args.steps, 1), 1)
                                              for i in names}},
     }
+    out["config"]["host_timers_s"] = {k: round(v['total'], 3)
+                                       for k, v in r.timings.makeSummaryDict().items()}
     if args.cpu_sample > 0:
         out["cpu_baseline"] = cpu_baseline(ras, args, r.kmeans.cluster_centers_,
                                            float(r.maxSpectralDiff))

@@ -8,6 +8,10 @@ import ctypes
 import os
 import threading
 
+# more hardware queues than ROCm's default of 4, so that the per-tile worker streams do not
+# queue behind each other's long-running kernels (must be set before the HIP runtime starts)
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '16')
+
 import numpy
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -155,6 +159,30 @@ def ctx():
         c = Context()
         _tls.ctx = c
     return c
+
+
+_pool = []
+_pool_lock = threading.Lock()
+
+
+class pooled_ctx(object):
+    """Borrow a worker context (stream + grown device workspace) from a process-wide pool, so
+    that worker threads of successive tiled runs reuse the same HIP allocations."""
+    def __enter__(self):
+        with _pool_lock:
+            self.c = _pool.pop() if _pool else None
+        if self.c is None:
+            self.c = Context()
+        return self.c
+
+    def __exit__(self, *args):
+        with _pool_lock:
+            _pool.append(self.c)
+
+
+def pool_contexts():
+    with _pool_lock:
+        return list(_pool)
 
 
 def ptr(a):

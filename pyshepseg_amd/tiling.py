@@ -422,14 +422,16 @@ def doTiledShepherdSegmentation(infile, outfile, tileSize=DFLT_TILESIZE,
 
             def worker():
                 try:
-                    c = _lib.ctx()
+                    with _lib.pooled_ctx() as c:
+                        worker_loop(c)
                 except Exception as e:          # no GPU, library missing ...
                     forceExit.set()
                     for jj in jobs:
-                        if jj.error is None:
+                        if jj.error is None and not jj.done.is_set():
                             jj.error = e
                         jj.done.set()
-                    return
+
+            def worker_loop(c):
                 while not forceExit.is_set():
                     try:
                         j = inQue.get_nowait()
