@@ -37,7 +37,7 @@ API int shp_ctx_create(int device, shp_ctx **out)
         delete ctx;
         return SHP_ERR_HIP;
     }
-    if (hipHostMalloc((void **)&ctx->h_pinned, 4096, hipHostMallocDefault) != hipSuccess) {
+    if (hipHostMalloc((void **)&ctx->h_pinned, SHP_PINNED_BYTES, hipHostMallocDefault) != hipSuccess) {
         hipStreamDestroy(ctx->stream);
         delete ctx;
         return SHP_ERR_HIP;
@@ -48,7 +48,7 @@ API int shp_ctx_create(int device, shp_ctx **out)
                  &ctx->pix, &ctx->segsz, &ctx->origsz, &ctx->off, &ctx->ssum, &ctx->chnext,
                  &ctx->chtail, &ctx->mergeto, &ctx->tcount, &ctx->toff, &ctx->tfill, &ctx->tlist,
                  &ctx->tsorted, &ctx->small, &ctx->cen, &ctx->fit_x, &ctx->fit_lab, &ctx->fit_part,
-                 &ctx->big};
+                 &ctx->big, &ctx->srclist, &ctx->tgtlist};
     *out = ctx;
     return SHP_OK;
 }

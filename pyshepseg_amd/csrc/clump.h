@@ -148,17 +148,36 @@ __global__ __launch_bounds__(256) void k_big_bbox(const uint32_t *__restrict__ l
 
 // One wavefront per cut-able component: exact replay of shepseg.py:490-539 restricted to the
 // component (unvisited member pixels are exactly those with lab == root).
-__global__ __launch_bounds__(64) void k_dfs_split(uint32_t *lab, const BigInfo *__restrict__ big,
-                                                  const uint32_t *__restrict__ counters,
-                                                  uint32_t *stackbuf, uint32_t nrows,
-                                                  uint32_t ncols, int four)
+//   * the explicit LIFO stack lives in an LDS window (oldest half spilled to / refilled from
+//     a per-component slice of a global scratch array), entries are packed (row << 16 | col)
+//     so that no integer division sits on the dependent path;
+//   * lanes 0..3 (0..7 for 8-connectivity) each own one neighbour in the reference's push
+//     order (cx outer, cy inner): one ballot decides which are unvisited members, they are
+//     labelled together and pushed in lane order, the last one becoming the next pop;
+//   * all 64 lanes scan the bounding box for the next seed in raster order.
+#define DFS_SWN 4096u        // stack window entries in LDS (16 KiB)
+__device__ __forceinline__ bool dfs_fits_lds(const BigInfo &B, uint32_t ncols);
+
+__device__ __forceinline__ void dfs_split_global(uint32_t *lab, const BigInfo &B, uint32_t *sw,
+                                                 uint32_t *stackbuf, uint32_t nrows, uint32_t ncols,
+                                                 int four)
 {
-    const uint32_t bi = blockIdx.x;
-    if (bi >= counters[0]) return;
-    const BigInfo B = big[bi];
     const uint32_t root = B.root;
-    uint32_t *stack = stackbuf + B.off;
+    uint32_t *gstack = stackbuf + B.off;
     const unsigned lane = lane_id();
+    const unsigned long long lt = lanemask_lt();
+    // this lane's neighbour offset in push order
+    int dy = 0, dx = 0;
+    const unsigned nq = four ? 4u : 8u;
+    if (four) {
+        dy = (lane == 1) ? -1 : (lane == 2) ? 1 : 0;
+        dx = (lane == 0) ? -1 : (lane == 3) ? 1 : 0;
+    } else {
+        const int t8y[8] = {-1, 0, 1, -1, 1, -1, 0, 1};
+        const int t8x[8] = {-1, -1, -1, 0, 0, 1, 1, 1};
+        dy = t8y[lane & 7u];
+        dx = t8x[lane & 7u];
+    }
     uint32_t cursor = root;
     for (;;) {
         // ---- next seed: first unvisited member at or after cursor, raster order ----
@@ -175,62 +194,209 @@ __global__ __launch_bounds__(64) void k_dfs_split(uint32_t *lab, const BigInfo *
             }
         }
         if (seed == NULL_LAB) break;
-        if (lane == 0) {
-            const uint32_t FL = seed | VIS_FLAG;
-            lab[seed] = FL;
-            uint32_t sp = 0;          // entries in memory (below `top`)
-            uint32_t top = seed;
-            bool have = true;
-            uint32_t cnt = 0;
-            while (have && cnt < MAX_CLUMP_SIZE) {
-                const uint32_t s = top;
-                const uint32_t sy = s / ncols, sx = s - sy * ncols;
-                const bool hl = sx > 0, hr = sx + 1 < ncols, hu = sy > 0, hd = sy + 1 < nrows;
-                // candidate neighbours in the reference's push order (cx outer, cy inner)
-                uint32_t q[8];
-                bool ok[8];
-                int nq = 0;
-                if (four) {
-                    q[0] = s - 1;     ok[0] = hl;
-                    q[1] = s - ncols; ok[1] = hu;
-                    q[2] = s + ncols; ok[2] = hd;
-                    q[3] = s + 1;     ok[3] = hr;
-                    nq = 4;
+        const uint32_t FL = seed | VIS_FLAG;
+        if (lane == 0) lab[seed] = FL;
+        uint32_t sp_l = 0, sp_g = 0;            // entries in the LDS window / spilled to global
+        uint32_t ty = seed / ncols, tx = seed - ty * ncols;    // current pop (uniform)
+        bool have = true;
+        uint32_t cnt = 0;
+        while (have && cnt < MAX_CLUMP_SIZE) {
+            const int ny = (int)ty + dy, nx = (int)tx + dx;
+            const bool valid = lane < nq && ny >= 0 && nx >= 0 && ny < (int)nrows && nx < (int)ncols;
+            const uint32_t q = (uint32_t)ny * ncols + (uint32_t)nx;
+            const bool avail = valid && lab[q] == root;
+            const unsigned long long m = __ballot(avail);
+            if (avail) lab[q] = FL;
+            const uint32_t npush = (uint32_t)__popcll(m);
+            if (npush == 0) {
+                if (sp_l == 0 && sp_g > 0) {            // refill the window from the spill area
+                    const uint32_t k = sp_g < DFS_SWN / 2u ? sp_g : DFS_SWN / 2u;
+                    for (uint32_t i = lane; i < k; i += 64u) sw[i] = gstack[sp_g - k + i];
+                    sp_g -= k;
+                    sp_l = k;
+                    __builtin_amdgcn_wave_barrier();
+                }
+                if (sp_l > 0) {
+                    const uint32_t e = sw[--sp_l];
+                    ty = e >> 16; tx = e & 0xffffu;
                 } else {
-                    q[0] = s - ncols - 1; ok[0] = hl && hu;
-                    q[1] = s - 1;         ok[1] = hl;
-                    q[2] = s + ncols - 1; ok[2] = hl && hd;
-                    q[3] = s - ncols;     ok[3] = hu;
-                    q[4] = s + ncols;     ok[4] = hd;
-                    q[5] = s - ncols + 1; ok[5] = hr && hu;
-                    q[6] = s + 1;         ok[6] = hr;
-                    q[7] = s + ncols + 1; ok[7] = hr && hd;
-                    nq = 8;
+                    have = false;
                 }
-                uint32_t lv[8];
-#pragma unroll
-                for (int i = 0; i < 8; i++) lv[i] = (i < nq && ok[i]) ? lab[q[i]] : NULL_LAB;
-                bool pend = false;
-                uint32_t pq = 0;
-#pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    if (i < nq && lv[i] == root) {
-                        lab[q[i]] = FL;
-                        cnt++;
-                        if (pend) stack[sp++] = pq;
-                        pq = q[i];
-                        pend = true;
+            } else {
+                if (sp_l + 8u > DFS_SWN) {              // spill the oldest half of the window
+                    for (uint32_t i = lane; i < DFS_SWN / 2u; i += 64u) gstack[sp_g + i] = sw[i];
+                    __builtin_amdgcn_wave_barrier();
+                    for (uint32_t i0 = 0; i0 + DFS_SWN / 2u < sp_l; i0 += 64u) {
+                        const uint32_t i = i0 + lane;
+                        uint32_t v = 0;
+                        if (i + DFS_SWN / 2u < sp_l) v = sw[i + DFS_SWN / 2u];
+                        __builtin_amdgcn_wave_barrier();
+                        if (i + DFS_SWN / 2u < sp_l) sw[i] = v;
                     }
+                    sp_g += DFS_SWN / 2u;
+                    sp_l -= DFS_SWN / 2u;
+                    __builtin_amdgcn_wave_barrier();
                 }
-                if (pend) top = pq;
-                else if (sp > 0) top = stack[--sp];
-                else have = false;
+                const unsigned last = 63u - (unsigned)__clzll(m);
+                const uint32_t packed = ((uint32_t)ny << 16) | (uint32_t)nx;
+                if (avail && lane != last) sw[sp_l + (uint32_t)__popcll(m & lt)] = packed;
+                sp_l += npush - 1u;
+                const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)packed, (int)last);
+                ty = e >> 16; tx = e & 0xffffu;
+                cnt += npush;
+                __builtin_amdgcn_wave_barrier();
             }
         }
         __threadfence();
         cursor = seed + 1;
         if (cursor >= nrows * ncols) break;
     }
+}
+
+// LDS variant of the replay for components whose bounding box fits the LDS bitmap (all of
+// them on the benchmark imagery): membership/unvisited state is one bit per bounding-box pixel
+// in LDS (64 KiB), so a pop costs one LDS round trip instead of a dependent HBM/L2 access, and the walk
+// no longer suffers when other streams pollute L2.  Labels are still written to `lab` with
+// fire-and-forget stores.  Components that do not fit take dfs_split_global.
+#define DFS_BMW 16384u       // bitmap words (524288 bounding-box pixels, 64 KiB)
+
+__device__ __forceinline__ bool dfs_fits_lds(const BigInfo &B, uint32_t ncols)
+{
+    const uint32_t minr = B.root / ncols;
+    const uint32_t H = B.maxr - minr + 1u, W = B.maxc - B.minc + 1u;
+    return (unsigned long long)H * ((W + 31u) >> 5) <= DFS_BMW;
+}
+
+__device__ __forceinline__ void dfs_split_lds(uint32_t *lab, const BigInfo &B, uint32_t *bm,
+                                              uint32_t *sw, uint32_t *stackbuf, uint32_t ncols,
+                                              int four)
+{
+    const uint32_t root = B.root;
+    uint32_t *gstack = stackbuf + B.off;
+    const unsigned lane = lane_id();
+    const unsigned long long lt = lanemask_lt();
+    const uint32_t minr = root / ncols, minc = B.minc;
+    const uint32_t H = B.maxr - minr + 1u, W = B.maxc - minc + 1u, wpr = (W + 31u) >> 5;
+    const uint32_t nwords = H * wpr;
+    // ---- build the member bitmap from the flattened CCL labels ----
+    for (uint32_t r = 0; r < H; r++) {
+        const uint32_t rowbase = (minr + r) * ncols + minc;
+        for (uint32_t c0 = 0; c0 < W; c0 += 64u) {
+            const uint32_t c = c0 + lane;
+            const bool mem = c < W && lab[rowbase + c] == root;
+            const unsigned long long m = __ballot(mem);
+            if (lane == 0) {
+                bm[r * wpr + (c0 >> 5)] = (uint32_t)m;
+                if ((c0 >> 5) + 1u < wpr) bm[r * wpr + (c0 >> 5) + 1u] = (uint32_t)(m >> 32);
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    int dy = 0, dx = 0;
+    const unsigned nq = four ? 4u : 8u;
+    if (four) {
+        dy = (lane == 1) ? -1 : (lane == 2) ? 1 : 0;
+        dx = (lane == 0) ? -1 : (lane == 3) ? 1 : 0;
+    } else {
+        const unsigned l8 = lane & 7u;         // (dy,dx) in push order: dx outer, dy inner
+        dx = (l8 < 3u) ? -1 : (l8 < 5u) ? 0 : 1;
+        dy = (l8 == 0u || l8 == 3u || l8 == 5u) ? -1 : (l8 == 1u || l8 == 6u) ? 0 : 1;
+    }
+    uint32_t wcur = 0;                           // first word that can still hold a set bit
+    for (;;) {
+        // ---- next seed = first set bit in raster order ----
+        uint32_t sword = 0xFFFFFFFFu, sbits = 0;
+        for (uint32_t w0 = wcur; w0 < nwords; w0 += 64u) {
+            const uint32_t wi = w0 + lane;
+            const uint32_t v = wi < nwords ? bm[wi] : 0u;
+            const unsigned long long m = __ballot(v != 0u);
+            if (m) {
+                const int fl = __builtin_ctzll(m);
+                sword = w0 + (uint32_t)fl;
+                sbits = (uint32_t)__builtin_amdgcn_readlane((int)v, fl);
+                break;
+            }
+        }
+        if (sword == 0xFFFFFFFFu) break;
+        wcur = sword;
+        const uint32_t sy = sword / wpr, sx = ((sword - sy * wpr) << 5) + (uint32_t)__builtin_ctz(sbits);
+        const uint32_t seed = (minr + sy) * ncols + minc + sx;
+        const uint32_t FL = seed | VIS_FLAG;
+        if (lane == 0) {
+            lab[seed] = FL;
+            bm[sword] = sbits & (sbits - 1u);   // clear the seed's (lowest) bit
+        }
+        __builtin_amdgcn_wave_barrier();
+        uint32_t sp_l = 0, sp_g = 0;
+        uint32_t ty = sy, tx = sx;
+        bool have = true;
+        uint32_t cnt = 0;
+        while (have && cnt < MAX_CLUMP_SIZE) {
+            const int ny = (int)ty + dy, nx = (int)tx + dx;
+            const bool valid = lane < nq && ny >= 0 && nx >= 0 && ny < (int)H && nx < (int)W;
+            const uint32_t wi = (uint32_t)ny * wpr + ((uint32_t)nx >> 5);
+            const uint32_t bit = 1u << ((uint32_t)nx & 31u);
+            const bool avail = valid && (bm[valid ? wi : 0u] & bit) != 0u;
+            const unsigned long long m = __ballot(avail);
+            if (avail) {
+                atomicAnd(&bm[wi], ~bit);
+                lab[(minr + (uint32_t)ny) * ncols + minc + (uint32_t)nx] = FL;
+            }
+            const uint32_t npush = (uint32_t)__popcll(m);
+            if (npush == 0) {
+                if (sp_l == 0 && sp_g > 0) {
+                    const uint32_t k = sp_g < DFS_SWN / 2u ? sp_g : DFS_SWN / 2u;
+                    for (uint32_t i = lane; i < k; i += 64u) sw[i] = gstack[sp_g - k + i];
+                    sp_g -= k;
+                    sp_l = k;
+                    __builtin_amdgcn_wave_barrier();
+                }
+                if (sp_l > 0) {
+                    const uint32_t e = sw[--sp_l];
+                    ty = e >> 16; tx = e & 0xffffu;
+                } else {
+                    have = false;
+                }
+            } else {
+                if (sp_l + 8u > DFS_SWN) {
+                    for (uint32_t i = lane; i < DFS_SWN / 2u; i += 64u) gstack[sp_g + i] = sw[i];
+                    __builtin_amdgcn_wave_barrier();
+                    for (uint32_t i0 = 0; i0 + DFS_SWN / 2u < sp_l; i0 += 64u) {
+                        const uint32_t i = i0 + lane;
+                        uint32_t v = 0;
+                        if (i + DFS_SWN / 2u < sp_l) v = sw[i + DFS_SWN / 2u];
+                        __builtin_amdgcn_wave_barrier();
+                        if (i + DFS_SWN / 2u < sp_l) sw[i] = v;
+                    }
+                    sp_g += DFS_SWN / 2u;
+                    sp_l -= DFS_SWN / 2u;
+                    __builtin_amdgcn_wave_barrier();
+                }
+                const unsigned last = 63u - (unsigned)__clzll(m);
+                const uint32_t packed = ((uint32_t)ny << 16) | (uint32_t)nx;
+                if (avail && lane != last) sw[sp_l + (uint32_t)__popcll(m & lt)] = packed;
+                sp_l += npush - 1u;
+                const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)packed, (int)last);
+                ty = e >> 16; tx = e & 0xffffu;
+                cnt += npush;
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(64) void k_dfs_split(uint32_t *lab, const BigInfo *__restrict__ big,
+                                                  const uint32_t *__restrict__ counters,
+                                                  uint32_t *stackbuf, uint32_t nrows,
+                                                  uint32_t ncols, int four)
+{
+    __shared__ uint32_t bm[DFS_BMW];
+    __shared__ uint32_t sw[DFS_SWN];
+    const uint32_t bi = blockIdx.x;
+    if (bi >= counters[0]) return;
+    const BigInfo B = big[bi];
+    if (dfs_fits_lds(B, ncols)) dfs_split_lds(lab, B, bm, sw, stackbuf, ncols, four);
+    else dfs_split_global(lab, B, sw, stackbuf, nrows, ncols, four);
 }
 
 struct SeedFn {
@@ -259,6 +425,8 @@ static int run_clump(shp_ctx *ctx, const uint16_t *d_clus, uint32_t nrows, uint3
 {
     const uint64_t n64 = (uint64_t)nrows * ncols;
     if (n64 >= 0x7fffffffull) SHP_FAIL(ctx, SHP_ERR_ARG, "tile too large (%llu px)", (unsigned long long)n64);
+    if (nrows > 65535u || ncols > 65535u)
+        SHP_FAIL(ctx, SHP_ERR_ARG, "tile dimensions above 65535 are not supported (%u x %u)", nrows, ncols);
     const uint32_t n = (uint32_t)n64;
     if (n == 0) { HIPCHK(ctx, hipMemsetAsync(nclumps_dev, 0, 4, ctx->stream)); return 0; }
     const uint32_t maxbig = n / (MAX_CLUMP_SIZE + 2u) + 1u;

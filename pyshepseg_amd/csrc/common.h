@@ -15,6 +15,7 @@
 #define MAX_CLUMP_SIZE 10000u  // shepseg.py:481
 #define PROF_N 16
 #define PROF_POOL 32
+#define SHP_PINNED_BYTES (1u << 20)   // pinned host staging per context
 
 struct DevBuf {
     void *p = nullptr;
@@ -33,8 +34,8 @@ struct shp_ctx {
     // named workspace buffers (grow-only)
     DevBuf img, clus, lab, seg, aux, aux2, stack, scan_tmp, sort_k0, sort_k1, sort_v1, sort_hist,
         pix, segsz, origsz, off, ssum, chnext, chtail, mergeto, tcount, toff, tfill, tlist, tsorted,
-        small, cen, fit_x, fit_lab, fit_part, big;
-    uint32_t *h_pinned = nullptr;   // 256 x u32 pinned host scratch for small read-backs
+        small, cen, fit_x, fit_lab, fit_part, big, srclist, tgtlist;
+    uint32_t *h_pinned = nullptr;   // SHP_PINNED_BYTES of pinned host staging (small transfers)
     hipEvent_t ev[16] = {};
     double timings[8] = {};
     // per-kernel device-time accounting (HIP events on this stream), see PROF_* below

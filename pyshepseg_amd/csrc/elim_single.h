@@ -50,14 +50,16 @@ __global__ __launch_bounds__(256) void k_single_apply(uint32_t *__restrict__ seg
                                                       uint32_t *nelim)
 {
     const uint32_t p = blockIdx.x * 256u + threadIdx.x;
-    if (p >= n) return;
-    const uint32_t t = tgt[p];
-    if (t == NO_TARGET) return;
-    const uint32_t old = seg[p];
-    seg[p] = t;
-    segsz[old] = 0;
-    atomicAdd(&segsz[t], 1u);
-    atomicAdd(nelim, 1u);
+    const uint32_t t = (p < n) ? tgt[p] : NO_TARGET;
+    const bool act = t != NO_TARGET;
+    if (act) {
+        const uint32_t old = seg[p];
+        seg[p] = t;
+        segsz[old] = 0;
+        atomicAdd(&segsz[t], 1u);
+    }
+    // the host only needs "did this pass merge anything" (the count is oldMax - newMax later)
+    if (act) *nelim = 1u;
 }
 
 // relabelSegments (shepseg.py:739-777): newid[k] = k - #{1 <= j < k : segsz[j] == 0}

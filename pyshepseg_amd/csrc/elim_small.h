@@ -103,146 +103,296 @@ __global__ __launch_bounds__(256) void k_small_init(const uint32_t *__restrict__
                                                     uint32_t *__restrict__ tfill, uint32_t *hist,
                                                     uint32_t S, uint32_t min_seg)
 {
+    __shared__ uint32_t lh[256];            // block-local histogram of sizes 1..255
+    lh[threadIdx.x] = 0;
+    __syncthreads();
     const uint32_t s = blockIdx.x * 256u + threadIdx.x;
-    if (s > S) return;
-    const uint32_t m = segsz[s];
-    origsz[s] = m;
-    chnext[s] = 0;
-    chtail[s] = s;
-    mergeto[s] = 0;
-    tcount[s] = 0;
-    tfill[s] = 0;
-    if (s >= 1u && m < min_seg) atomicAdd(&hist[m], 1u);
-}
-
-// findMergeSegment (shepseg.py:1003-1063), one thread per segment of the target size
-__global__ __launch_bounds__(256) void k_find_merge(
-    const uint32_t *__restrict__ seg, const uint32_t *__restrict__ segsz,
-    const float *__restrict__ ssum, const uint32_t *__restrict__ pix,
-    const uint32_t *__restrict__ off, const uint32_t *__restrict__ origsz,
-    const uint32_t *__restrict__ chnext, uint32_t *__restrict__ mergeto, uint32_t S,
-    uint32_t target, int nb, uint32_t nrows, uint32_t ncols, int four, double thr2)
-{
-    const uint32_t s = blockIdx.x * 256u + threadIdx.x + 1u;
-    if (s > S) return;
-    if (segsz[s] != target) return;
-    const float nf = (float)target;
-    uint32_t best = 0, last = 0;
-    float bestd = 0.0f;
-    for (uint32_t c = s; c != 0; c = chnext[c]) {
-        const uint32_t o = off[c], m = origsz[c];
-        for (uint32_t i = 0; i < m; i++) {
-            const uint32_t p = pix[o + i];
-            const uint32_t r = p / ncols, cc = p - r * ncols;
-            const uint32_t r0 = r > 0 ? r - 1 : 0, r1 = (r + 1 < nrows) ? r + 1 : nrows - 1;
-            const uint32_t c0 = cc > 0 ? cc - 1 : 0, c1 = (cc + 1 < ncols) ? cc + 1 : ncols - 1;
-            for (uint32_t ii = r0; ii <= r1; ii++)
-                for (uint32_t jj = c0; jj <= c1; jj++) {
-                    if (four && ii != r && jj != cc) continue;
-                    const uint32_t nbid = seg[ii * ncols + jj];
-                    if (nbid == s || nbid == 0 || nbid == last) continue;
-                    last = nbid;       // re-evaluating the same neighbour can never win ('<' is strict)
-                    const uint32_t szn = segsz[nbid];
-                    if (szn > target) {
-                        const float sf = (float)szn;
-                        float d = 0.0f;
-                        for (int b = 0; b < nb; b++) {
-                            const float a = ssum[(size_t)s * nb + b] / nf;
-                            const float e = ssum[(size_t)nbid * nb + b] / sf;
-                            const float t = a - e;
-                            const float t2 = t * t;
-                            d = d + t2;
-                        }
-                        if (best == 0 || d < bestd) { bestd = d; best = nbid; }
-                    }
-                }
+    if (s <= S) {
+        const uint32_t m = segsz[s];
+        origsz[s] = m;
+        chnext[s] = 0;
+        chtail[s] = s;
+        mergeto[s] = 0;
+        tcount[s] = 0;
+        tfill[s] = 0;
+        if (s >= 1u && m < min_seg) {
+            if (m < 256u) atomicAdd(&lh[m], 1u);
+            else atomicAdd(&hist[m], 1u);
         }
     }
-    if (best != 0 && (double)bestd > thr2) best = 0;
-    mergeto[s] = best;
+    __syncthreads();
+    if (threadIdx.x < min_seg && lh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], lh[threadIdx.x]);
 }
 
-// merge phase, step 1: count sources per target; relabel the source's pixels (doMerge :1107-1109)
-__global__ __launch_bounds__(256) void k_merge_mark(
-    uint32_t *__restrict__ seg, const uint32_t *__restrict__ mergeto,
-    const uint32_t *__restrict__ pix, const uint32_t *__restrict__ off,
-    const uint32_t *__restrict__ origsz, const uint32_t *__restrict__ chnext, uint32_t *tcount,
-    uint32_t S)
+// Device-side loop control of eliminateSmallSegments (shepseg.py:970-997).  The host enqueues
+// identical "pass slots" without reading anything back; the one-thread control kernel at the
+// head of each slot advances (target, prev, passes) exactly like the reference's for/while and
+// stops at the next pass that has sources to merge.  Every other kernel of the slot exits at
+// once when ctl->active == 0.
+struct SmallCtl {
+    uint32_t target;     // current targetSize
+    int32_t prev;        // prevCount (-1 = none)
+    uint32_t passes;     // numPasses for this target
+    uint32_t active;     // this slot runs a find/merge pass
+    uint32_t done;       // target reached minSegSize
+    uint32_t nelim;      // numElim
+    uint32_t nsrc, ntgt, bump, pad;
+};
+
+__global__ void k_small_ctl(SmallCtl *ctl, const uint32_t *__restrict__ hist, uint32_t min_seg)
 {
-    const uint32_t s = blockIdx.x * 256u + threadIdx.x + 1u;
-    if (s > S) return;
-    const uint32_t t = mergeto[s];
-    if (t == 0) return;
-    atomicAdd(&tcount[t], 1u);
-    for (uint32_t c = s; c != 0; c = chnext[c]) {
-        const uint32_t o = off[c], m = origsz[c];
-        for (uint32_t i = 0; i < m; i++) seg[pix[o + i]] = t;
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    ctl->nsrc = 0; ctl->ntgt = 0; ctl->bump = 0;
+    uint32_t target = ctl->target, passes = ctl->passes;
+    int32_t prev = ctl->prev;
+    uint32_t active = 0, done = 0;
+    for (;;) {
+        if (target >= min_seg) { done = 1; break; }
+        const int32_t count = (int32_t)hist[target];
+        if (count != prev && passes < 10u) {          // `while` condition, shepseg.py:980
+            prev = count;
+            passes++;
+            if (count > 0) { active = 1; break; }     // a pass with sources: run the kernels
+        } else {
+            target++; prev = -1; passes = 0;          // next targetSize, shepseg.py:970
+        }
+    }
+    ctl->target = target; ctl->prev = prev; ctl->passes = passes;
+    ctl->active = active; ctl->done = done;
+}
+
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const unsigned long long o = __shfl_xor(v, d, 64);
+        v = o < v ? o : v;
+    }
+    return v;
+}
+
+// findMergeSegment (shepseg.py:1003-1063) for one source, executed by a whole wavefront: one
+// lane per pixel of its list.  The reference keeps the FIRST strict minimum in (list index k,
+// ii outer, jj inner) order (N7) == the lexicographic minimum of (distSqr, k, neighbour
+// position), found with one 64-bit wave reduction (distSqr >= +0, so its float32 bit pattern
+// orders like the value).
+__device__ __forceinline__ void find_merge_wave(
+    uint32_t s, const uint32_t *__restrict__ seg, const uint32_t *__restrict__ segsz,
+    const float *__restrict__ ssum, const uint32_t *__restrict__ pix,
+    const uint32_t *__restrict__ off, const uint32_t *__restrict__ origsz,
+    const uint32_t *__restrict__ chnext, uint32_t *__restrict__ mergeto, uint32_t target, int nb,
+    uint32_t nrows, uint32_t ncols, int four, double thr2)
+{
+    const unsigned lane = lane_id();
+    const float nf = (float)target;
+    unsigned long long best = ~0ull;         // (float bits of distSqr << 32) | order
+    uint32_t bestnb = 0;
+    uint32_t k0 = 0;                         // list index of the current chunk's first pixel
+    for (uint32_t c = s; c != 0; c = (uint32_t)__builtin_amdgcn_readfirstlane((int)chnext[c])) {
+        const uint32_t o = (uint32_t)__builtin_amdgcn_readfirstlane((int)off[c]);
+        const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)origsz[c]);
+        for (uint32_t i0 = 0; i0 < m; i0 += 64u) {
+            const uint32_t i = i0 + lane;
+            if (i < m) {
+                const uint32_t k = k0 + i;
+                const uint32_t p = pix[o + i];
+                const uint32_t r = p / ncols, cc = p - r * ncols;
+                uint32_t last = 0, pos = 0;
+                for (int di = -1; di <= 1; di++)
+                    for (int dj = -1; dj <= 1; dj++) {
+                        if (di == 0 && dj == 0) continue;
+                        if (four && di != 0 && dj != 0) continue;
+                        const uint32_t mypos = pos++;
+                        const int ii = (int)r + di, jj = (int)cc + dj;
+                        if (ii < 0 || jj < 0 || ii >= (int)nrows || jj >= (int)ncols) continue;
+                        const uint32_t nbid = seg[(uint32_t)ii * ncols + (uint32_t)jj];
+                        if (nbid == s || nbid == 0 || nbid == last) continue;
+                        last = nbid;
+                        const uint32_t szn = segsz[nbid];
+                        if (szn > target) {
+                            const float sf = (float)szn;
+                            float d = 0.0f;
+                            for (int b = 0; b < nb; b++) {
+                                const float a = ssum[(size_t)s * nb + b] / nf;
+                                const float e = ssum[(size_t)nbid * nb + b] / sf;
+                                const float t = a - e;
+                                const float t2 = t * t;
+                                d = d + t2;
+                            }
+                            const unsigned long long key =
+                                ((unsigned long long)__float_as_uint(d) << 32) |
+                                (unsigned long long)(k * 8u + mypos);
+                            if (key < best) { best = key; bestnb = nbid; }
+                        }
+                    }
+            }
+        }
+        k0 += m;
+    }
+    const unsigned long long wmin = wave_min_u64(best);
+    if (wmin == ~0ull) { if (lane == 0) mergeto[s] = 0; return; }
+    if (best == wmin) {                      // unique: (k, position) differs between lanes
+        const float bd = __uint_as_float((uint32_t)(wmin >> 32));
+        mergeto[s] = ((double)bd > thr2) ? 0u : bestnb;
     }
 }
 
-__global__ __launch_bounds__(256) void k_merge_fill(const uint32_t *__restrict__ mergeto,
-                                                    const uint32_t *__restrict__ toff,
-                                                    uint32_t *tfill, uint32_t *__restrict__ tlist,
-                                                    uint32_t S)
+// find phase: each block finds the sources (size == target) among its 256 segment ids, appends
+// them to the global source list and lets its four wavefronts run findMergeSegment on them.
+__global__ __launch_bounds__(256) void k_find_merge(
+    const SmallCtl *ctlp, uint32_t *cnts, const uint32_t *__restrict__ seg,
+    const uint32_t *__restrict__ segsz, const float *__restrict__ ssum,
+    const uint32_t *__restrict__ pix, const uint32_t *__restrict__ off,
+    const uint32_t *__restrict__ origsz, const uint32_t *__restrict__ chnext,
+    uint32_t *__restrict__ mergeto, uint32_t *__restrict__ srclist, uint32_t S, int nb,
+    uint32_t nrows, uint32_t ncols, int four, double thr2)
 {
+    __shared__ uint32_t lsrc[256];
+    __shared__ uint32_t lcnt;
+    if (!ctlp->active) return;
+    const uint32_t target = ctlp->target;
+    if (threadIdx.x == 0) lcnt = 0;
+    __syncthreads();
     const uint32_t s = blockIdx.x * 256u + threadIdx.x + 1u;
-    if (s > S) return;
-    const uint32_t t = mergeto[s];
-    if (t == 0) return;
-    const uint32_t slot = atomicAdd(&tfill[t], 1u);
-    tlist[toff[t] + slot] = s;
+    const bool is = s <= S && segsz[s] == target;
+    const unsigned long long m = __ballot(is);
+    if (m != 0ull) {
+        uint32_t lbase = 0, gbase = 0;
+        if (lane_id() == 0) {
+            lbase = atomicAdd(&lcnt, (uint32_t)__popcll(m));
+            gbase = atomicAdd(&cnts[0], (uint32_t)__popcll(m));
+        }
+        lbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)lbase);
+        gbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)gbase);
+        if (is) {
+            const uint32_t r = (uint32_t)__popcll(m & lanemask_lt());
+            lsrc[lbase + r] = s;
+            srclist[gbase + r] = s;
+        }
+    }
+    __syncthreads();
+    const uint32_t n = lcnt;
+    for (uint32_t i = threadIdx.x >> 6; i < n; i += 4u) {
+        const uint32_t src = (uint32_t)__builtin_amdgcn_readfirstlane((int)lsrc[i]);
+        find_merge_wave(src, seg, segsz, ssum, pix, off, origsz, chnext, mergeto, target, nb, nrows,
+                        ncols, four, thr2);
+    }
 }
 
-__global__ __launch_bounds__(256) void k_merge_rank(const uint32_t *__restrict__ mergeto,
+// merge phase, step 1 (per source): count sources per target, list the targets, relabel the
+// source's pixels (doMerge :1107-1109)
+__global__ __launch_bounds__(256) void k_merge_mark(
+    const SmallCtl *ctlp, uint32_t *__restrict__ seg,
+    const uint32_t *__restrict__ mergeto, const uint32_t *__restrict__ pix,
+    const uint32_t *__restrict__ off, const uint32_t *__restrict__ origsz,
+    const uint32_t *__restrict__ chnext, uint32_t *tcount, const uint32_t *__restrict__ srclist,
+    uint32_t *cnts, uint32_t *__restrict__ tgtlist)
+{
+    if (!ctlp->active) return;
+    const uint32_t nsrc = cnts[0];
+    for (uint32_t w = blockIdx.x * 256u + threadIdx.x; w < nsrc; w += gridDim.x * 256u) {
+        const uint32_t s = srclist[w];
+        const uint32_t t = mergeto[s];
+        if (t == 0) continue;
+        if (atomicAdd(&tcount[t], 1u) == 0u) tgtlist[atomicAdd(&cnts[1], 1u)] = t;
+        for (uint32_t c = s; c != 0; c = chnext[c]) {
+            const uint32_t o = off[c], m = origsz[c];
+            for (uint32_t i = 0; i < m; i++) seg[pix[o + i]] = t;
+        }
+    }
+}
+
+// storage for each target's source list (bump allocation; order is irrelevant)
+__global__ __launch_bounds__(256) void k_merge_alloc(const SmallCtl *ctlp,
+                                                     const uint32_t *__restrict__ tgtlist,
+                                                     const uint32_t *__restrict__ tcount,
+                                                     uint32_t *__restrict__ toff, uint32_t *cnts)
+{
+    if (!ctlp->active) return;
+    const uint32_t ntgt = cnts[1];
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < ntgt; i += gridDim.x * 256u) {
+        const uint32_t t = tgtlist[i];
+        toff[t] = atomicAdd(&cnts[2], tcount[t]);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_merge_fill(const SmallCtl *ctlp,
+                                                    const uint32_t *__restrict__ mergeto,
+                                                    const uint32_t *__restrict__ toff,
+                                                    uint32_t *tfill, uint32_t *__restrict__ tlist,
+                                                    const uint32_t *__restrict__ srclist,
+                                                    const uint32_t *__restrict__ cnts)
+{
+    if (!ctlp->active) return;
+    const uint32_t nsrc = cnts[0];
+    for (uint32_t w = blockIdx.x * 256u + threadIdx.x; w < nsrc; w += gridDim.x * 256u) {
+        const uint32_t s = srclist[w];
+        const uint32_t t = mergeto[s];
+        if (t == 0) continue;
+        const uint32_t slot = atomicAdd(&tfill[t], 1u);
+        tlist[toff[t] + slot] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_merge_rank(const SmallCtl *ctlp,
+                                                    const uint32_t *__restrict__ mergeto,
                                                     const uint32_t *__restrict__ toff,
                                                     const uint32_t *__restrict__ tcount,
                                                     const uint32_t *__restrict__ tlist,
-                                                    uint32_t *__restrict__ tsorted, uint32_t S)
+                                                    uint32_t *__restrict__ tsorted,
+                                                    const uint32_t *__restrict__ srclist,
+                                                    const uint32_t *__restrict__ cnts)
 {
-    const uint32_t s = blockIdx.x * 256u + threadIdx.x + 1u;
-    if (s > S) return;
-    const uint32_t t = mergeto[s];
-    if (t == 0) return;
-    const uint32_t base = toff[t], cnt = tcount[t];
-    uint32_t rank = 0;
-    for (uint32_t i = 0; i < cnt; i++) rank += (tlist[base + i] < s) ? 1u : 0u;
-    tsorted[base + rank] = s;
+    if (!ctlp->active) return;
+    const uint32_t nsrc = cnts[0];
+    for (uint32_t w = blockIdx.x * 256u + threadIdx.x; w < nsrc; w += gridDim.x * 256u) {
+        const uint32_t s = srclist[w];
+        const uint32_t t = mergeto[s];
+        if (t == 0) continue;
+        const uint32_t base = toff[t], cnt = tcount[t];
+        uint32_t rank = 0;
+        for (uint32_t i = 0; i < cnt; i++) rank += (tlist[base + i] < s) ? 1u : 0u;
+        tsorted[base + rank] = s;
+    }
 }
 
 // merge phase, step 2: each target absorbs its sources in ascending id (doMerge :1112-1123)
 __global__ __launch_bounds__(256) void k_merge_apply(
-    uint32_t *segsz, float *ssum, uint32_t *chnext, uint32_t *chtail, uint32_t *mergeto,
-    uint32_t *tcount, uint32_t *tfill, const uint32_t *__restrict__ toff,
-    const uint32_t *__restrict__ tsorted, uint32_t *hist, uint32_t *nelim, uint32_t S,
-    uint32_t target, int nb, uint32_t min_seg)
+    SmallCtl *ctlp, uint32_t *segsz, float *ssum, uint32_t *chnext, uint32_t *chtail,
+    uint32_t *mergeto, uint32_t *tcount, uint32_t *tfill, const uint32_t *__restrict__ toff,
+    const uint32_t *__restrict__ tsorted, uint32_t *hist, const uint32_t *__restrict__ tgtlist,
+    const uint32_t *__restrict__ cnts, int nb, uint32_t min_seg)
 {
-    const uint32_t t = blockIdx.x * 256u + threadIdx.x + 1u;
-    if (t > S) return;
-    const uint32_t cnt = tcount[t];
-    if (cnt == 0) return;
-    const uint32_t base = toff[t];
-    const uint32_t a0 = segsz[t];
-    uint32_t sz = a0, tail = chtail[t];
-    for (uint32_t i = 0; i < cnt; i++) {
-        const uint32_t s = tsorted[base + i];
-        for (int b = 0; b < nb; b++) {
-            ssum[(size_t)t * nb + b] = ssum[(size_t)t * nb + b] + ssum[(size_t)s * nb + b];
-            ssum[(size_t)s * nb + b] = 0.0f;
+    if (!ctlp->active) return;
+    const uint32_t target = ctlp->target;
+    const uint32_t ntgt = cnts[1];
+    for (uint32_t i0 = blockIdx.x * 256u + threadIdx.x; i0 < ntgt; i0 += gridDim.x * 256u) {
+        const uint32_t t = tgtlist[i0];
+        const uint32_t cnt = tcount[t];
+        const uint32_t base = toff[t];
+        const uint32_t a0 = segsz[t];
+        uint32_t sz = a0, tail = chtail[t];
+        for (uint32_t i = 0; i < cnt; i++) {
+            const uint32_t s = tsorted[base + i];
+            for (int b = 0; b < nb; b++) {
+                ssum[(size_t)t * nb + b] = ssum[(size_t)t * nb + b] + ssum[(size_t)s * nb + b];
+                ssum[(size_t)s * nb + b] = 0.0f;
+            }
+            sz += segsz[s];
+            segsz[s] = 0;
+            chnext[tail] = s;
+            tail = chtail[s];
+            mergeto[s] = 0;
         }
-        sz += segsz[s];
-        segsz[s] = 0;
-        chnext[tail] = s;
-        tail = chtail[s];
-        mergeto[s] = 0;
+        segsz[t] = sz;
+        chtail[t] = tail;
+        tcount[t] = 0;
+        tfill[t] = 0;
+        atomicSub(&hist[target], cnt);
+        if (a0 < min_seg) atomicSub(&hist[a0], 1u);
+        if (sz < min_seg) atomicAdd(&hist[sz], 1u);
+        atomicAdd(&ctlp->nelim, cnt);
     }
-    segsz[t] = sz;
-    chtail[t] = tail;
-    tcount[t] = 0;
-    tfill[t] = 0;
-    atomicSub(&hist[target], cnt);
-    if (a0 < min_seg) atomicSub(&hist[a0], 1u);
-    if (sz < min_seg) atomicAdd(&hist[sz], 1u);
-    atomicAdd(nelim, cnt);
 }
 
 static inline int bits_for(uint32_t maxval)
@@ -274,7 +424,9 @@ static int run_eliminate_small(shp_ctx *ctx, const void *d_img, int dtype, int n
     CHK(buf_ensure(ctx, ctx->tfill, ns * 4));
     CHK(buf_ensure(ctx, ctx->tlist, ns * 4));
     CHK(buf_ensure(ctx, ctx->tsorted, ns * 4));
-    CHK(buf_ensure(ctx, ctx->small, ((size_t)min_seg + 8) * 4));
+    CHK(buf_ensure(ctx, ctx->srclist, ns * 4));
+    CHK(buf_ensure(ctx, ctx->tgtlist, ns * 4));
+    CHK(buf_ensure(ctx, ctx->small, ((size_t)min_seg + 32) * 4));
     CHK(buf_ensure(ctx, ctx->scan_tmp, scan_tmp_bytes(ns > n ? ns : n)));
     uint32_t *segsz = bp<uint32_t>(ctx->segsz), *origsz = bp<uint32_t>(ctx->origsz);
     uint32_t *off = bp<uint32_t>(ctx->off), *chnext = bp<uint32_t>(ctx->chnext);
@@ -282,9 +434,11 @@ static int run_eliminate_small(shp_ctx *ctx, const void *d_img, int dtype, int n
     uint32_t *tcount = bp<uint32_t>(ctx->tcount), *toff = bp<uint32_t>(ctx->toff);
     uint32_t *tfill = bp<uint32_t>(ctx->tfill), *tlist = bp<uint32_t>(ctx->tlist);
     uint32_t *tsorted = bp<uint32_t>(ctx->tsorted);
+    uint32_t *srclist = bp<uint32_t>(ctx->srclist), *tgtlist = bp<uint32_t>(ctx->tgtlist);
     float *ssum = bp<float>(ctx->ssum);
     uint32_t *hist = bp<uint32_t>(ctx->small);          // [0..min_seg] then nelim
-    uint32_t *nelim = hist + min_seg + 1;
+    SmallCtl *ctl = (SmallCtl *)(hist + ((min_seg + 4u + 3u) & ~3u));
+    uint32_t *cnts = &ctl->nsrc;                        // [0]=#sources [1]=#targets [2]=bump
     hipStream_t st = ctx->stream;
 
     CHK(run_seg_size(ctx, d_seg, n, S, segsz));
@@ -310,42 +464,40 @@ static int run_eliminate_small(shp_ctx *ctx, const void *d_img, int dtype, int n
     ps = prof_begin(ctx, PROF_SMALL_LOOP);
 
     const double thr2 = max_spectral_diff * max_spectral_diff;       // float64 square (N8)
-    std::vector<uint32_t> hhist((size_t)min_seg + 2, 0);
-    auto read_hist = [&]() -> int {
-        HIPCHK(ctx, hipMemcpyAsync(hhist.data(), hist, ((size_t)min_seg + 2) * 4,
-                                   hipMemcpyDeviceToHost, st));
-        HIPCHK(ctx, hipStreamSynchronize(st));
-        return 0;
-    };
-    CHK(read_hist());
-    for (uint32_t target = 1; target < min_seg; target++) {
-        long long count = hhist[target], prev = -1;
-        int passes = 0;
-        while (count != prev && passes < 10) {
-            prev = count;
-            if (count > 0) {
-                hipLaunchKernelGGL(k_find_merge, dim3(gs), dim3(256), 0, st, d_seg, segsz, ssum, pix,
-                                   off, origsz, chnext, mergeto, S, target, nb, nrows, ncols, four,
-                                   thr2); KCHK(ctx);
-                hipLaunchKernelGGL(k_merge_mark, dim3(gs), dim3(256), 0, st, d_seg, mergeto, pix,
-                                   off, origsz, chnext, tcount, S); KCHK(ctx);
-                ArrFn tf{tcount};
-                CHK(scan_exclusive(ctx, tf, S + 1u, toff, nullptr, stmp));
-                hipLaunchKernelGGL(k_merge_fill, dim3(gs), dim3(256), 0, st, mergeto, toff, tfill,
-                                   tlist, S); KCHK(ctx);
-                hipLaunchKernelGGL(k_merge_rank, dim3(gs), dim3(256), 0, st, mergeto, toff, tcount,
-                                   tlist, tsorted, S); KCHK(ctx);
-                hipLaunchKernelGGL(k_merge_apply, dim3(gs), dim3(256), 0, st, segsz, ssum, chnext,
-                                   chtail, mergeto, tcount, tfill, toff, tsorted, hist, nelim, S,
-                                   target, nb, min_seg); KCHK(ctx);
-                CHK(read_hist());
-                count = hhist[target];
-            }
-            passes++;
+    // pass slots: control kernel + find + merge kernels, enqueued SLOTS_PER_SYNC at a time
+    SmallCtl hctl;
+    memset(&hctl, 0, sizeof(hctl));
+    hctl.target = 1; hctl.prev = -1;
+    HIPCHK(ctx, hipMemcpyAsync(ctl, &hctl, sizeof(hctl), hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    const unsigned gfix = 128;                         // grid-stride kernels
+    const int SLOTS_PER_SYNC = 8;
+    SmallCtl *pin = (SmallCtl *)ctx->h_pinned;
+    for (int guard = 0; guard < 100000; guard++) {
+        for (int k = 0; k < SLOTS_PER_SYNC; k++) {
+            hipLaunchKernelGGL(k_small_ctl, dim3(1), dim3(64), 0, st, ctl, hist, min_seg); KCHK(ctx);
+            hipLaunchKernelGGL(k_find_merge, dim3(gs), dim3(256), 0, st, ctl, cnts, d_seg, segsz, ssum,
+                               pix, off, origsz, chnext, mergeto, srclist, S, nb, nrows, ncols, four,
+                               thr2); KCHK(ctx);
+            hipLaunchKernelGGL(k_merge_mark, dim3(gfix), dim3(256), 0, st, ctl, d_seg, mergeto, pix, off,
+                               origsz, chnext, tcount, srclist, cnts, tgtlist); KCHK(ctx);
+            hipLaunchKernelGGL(k_merge_alloc, dim3(gfix), dim3(256), 0, st, ctl, tgtlist, tcount, toff,
+                               cnts); KCHK(ctx);
+            hipLaunchKernelGGL(k_merge_fill, dim3(gfix), dim3(256), 0, st, ctl, mergeto, toff, tfill,
+                               tlist, srclist, cnts); KCHK(ctx);
+            hipLaunchKernelGGL(k_merge_rank, dim3(gfix), dim3(256), 0, st, ctl, mergeto, toff, tcount,
+                               tlist, tsorted, srclist, cnts); KCHK(ctx);
+            hipLaunchKernelGGL(k_merge_apply, dim3(gfix), dim3(256), 0, st, ctl, segsz, ssum, chnext,
+                               chtail, mergeto, tcount, tfill, toff, tsorted, hist, tgtlist, cnts, nb,
+                               min_seg); KCHK(ctx);
         }
+        HIPCHK(ctx, hipMemcpyAsync(pin, ctl, sizeof(SmallCtl), hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        if (pin->done) break;
     }
+    if (!pin->done) SHP_FAIL(ctx, SHP_ERR_STATE, "small-segment loop did not terminate");
     prof_end(ctx, ps);
-    *num_elim = (int64_t)hhist[min_seg + 1];
+    *num_elim = (int64_t)pin->nelim;
     uint32_t new_max = 0;
     CHK(run_relabel(ctx, d_seg, n, segsz, S, &new_max));
     *max_id = new_max;

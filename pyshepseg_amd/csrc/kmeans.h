@@ -11,6 +11,7 @@
 // SGPRs (uniform scalar loads); bytes are nB*sizeof(px) in + 2 B (uint16 label) out.
 #pragma once
 #include "common.h"
+#include <algorithm>
 
 #define ASSIGN_PPT 4   // pixels per thread (amortises the scalar centroid loads)
 
@@ -109,12 +110,13 @@ static int launch_assign(shp_ctx *ctx, const void *d_img, int dtype, int nb, siz
                          uint16_t *d_clus16, int32_t *d_clus32)
 {
     if (k < 1 || k > 65534) SHP_FAIL(ctx, SHP_ERR_ARG, "numClusters %d out of range", k);
-    std::vector<double> h((size_t)k * nb + k);
-    kmeans_prepare_host(centres, k, nb, h.data(), h.data() + (size_t)k * nb);
-    CHK(buf_ensure(ctx, ctx->cen, h.size() * sizeof(double)));
-    HIPCHK(ctx, hipMemcpyAsync(ctx->cen.p, h.data(), h.size() * sizeof(double),
-                               hipMemcpyHostToDevice, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // h is a stack-lifetime staging buffer
+    const size_t hn = (size_t)k * nb + k;
+    if (hn * 8 + 64 > SHP_PINNED_BYTES) SHP_FAIL(ctx, SHP_ERR_ARG, "k * nbands too large (%d x %d)", k, nb);
+    double *h = (double *)(ctx->h_pinned + 16);       // pinned staging (stream-ordered reuse)
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // earlier users of the staging area are done
+    kmeans_prepare_host(centres, k, nb, h, h + (size_t)k * nb);
+    CHK(buf_ensure(ctx, ctx->cen, hn * sizeof(double) * 2));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->cen.p, h, hn * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     const double *m2c = bp<double>(ctx->cen), *cn = m2c + (size_t)k * nb;
     const unsigned grid = grid_for((npix + ASSIGN_PPT - 1) / ASSIGN_PPT, 256, 256u * 16u);
 #define LA(NBT)                                                                                  \
@@ -151,39 +153,85 @@ static int launch_assign(shp_ctx *ctx, const void *d_img, int dtype, int nb, siz
 // in index order), then a second kernel adds the chunk partials in chunk order.  No float
 // atomics, so results are bitwise reproducible run to run.
 // ---------------------------------------------------------------------------------------
-#define FIT_CHUNK 4096u
+#define FIT_CHUNK 256u
+#define FIT_LDS_DOUBLES 4096u       // 32 KiB of staged sample rows: FIT_CHUNK rows x up to 16 bands
+#define FIT_GROUP 64u               // chunks per first-level reduction group
 
-__global__ __launch_bounds__(256) void k_fit_assign(const double *__restrict__ X, uint32_t n, int nb,
+template <int NB>
+__global__ __launch_bounds__(256) void k_fit_assign(const double *__restrict__ X, uint32_t n, int nb_rt,
                                                     const double *__restrict__ m2c,
                                                     const double *__restrict__ cnorm, int k,
                                                     int32_t *__restrict__ lab,
                                                     const int32_t *__restrict__ lab_old,
                                                     uint32_t *ndiff)
 {
+    const int nb = (NB > 0) ? NB : nb_rt;
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= n) return;
-    int best = 0;
-    double bestd = 0.0;
-    for (int j = 0; j < k; j++) {
-        double d = cnorm[j];
-        for (int b = 0; b < nb; b++) d = __builtin_fma(X[(size_t)i * nb + b], m2c[j * nb + b], d);
-        if (j == 0 || d < bestd) { bestd = d; best = j; }
+    bool diff = false;
+    if (i < n) {
+        double x[(NB > 0) ? NB : 1];
+        if (NB > 0) {
+#pragma unroll
+            for (int b = 0; b < NB; b++) x[b] = X[(size_t)i * NB + b];
+        }
+        int best = 0;
+        double bestd = 0.0;
+        for (int j = 0; j < k; j++) {
+            double d = cnorm[j];
+            if (NB > 0) {
+#pragma unroll
+                for (int b = 0; b < NB; b++) d = __builtin_fma(x[b], m2c[j * NB + b], d);
+            } else {
+                for (int b = 0; b < nb; b++) d = __builtin_fma(X[(size_t)i * nb + b], m2c[j * nb + b], d);
+            }
+            if (j == 0 || d < bestd) { bestd = d; best = j; }
+        }
+        lab[i] = best;
+        diff = lab_old && lab_old[i] != best;
     }
-    lab[i] = best;
-    if (lab_old && lab_old[i] != best) atomicAdd(ndiff, 1u);
+    const unsigned long long m = __ballot(diff);
+    if (m != 0ull && lane_id() == 0) atomicAdd(ndiff, (uint32_t)__popcll(m));
 }
 
-// partial[c][j*nb+b] = sum over rows of chunk c with label j of X[row][b]; pcount[c][j]
+static void launch_fit_assign(shp_ctx *ctx, unsigned g, const double *dX, uint32_t n, int nb,
+                              const double *dm2c, const double *dcn, int k, int32_t *dlab,
+                              const int32_t *dlab_old, uint32_t *ndiff)
+{
+#define FA(NBT)                                                                                   \
+    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fit_assign<NBT>), dim3(g), dim3(256), 0, ctx->stream, dX, \
+                       n, nb, dm2c, dcn, k, dlab, dlab_old, ndiff)
+    switch (nb) {
+    case 1: FA(1); break;
+    case 2: FA(2); break;
+    case 3: FA(3); break;
+    case 4: FA(4); break;
+    case 5: FA(5); break;
+    case 6: FA(6); break;
+    case 7: FA(7); break;
+    case 8: FA(8); break;
+    case 10: FA(10); break;
+    case 12: FA(12); break;
+    default: FA(0); break;
+    }
+#undef FA
+}
+
+// partial[c][j*nb+b] = sum over rows of chunk c with label j of X[row][b], rows in index order
+// (deterministic); pcount[c][j] = number of such rows.  The chunk (labels + rows) is staged in
+// LDS once and every (cluster, band) thread then walks it with broadcast LDS reads.
 __global__ __launch_bounds__(256) void k_fit_partial(const double *__restrict__ X, uint32_t n, int nb,
                                                      const int32_t *__restrict__ lab, int k,
                                                      double *__restrict__ partial,
-                                                     uint32_t *__restrict__ pcount)
+                                                     uint32_t *__restrict__ pcount, uint32_t chunk)
 {
     __shared__ int32_t sl[FIT_CHUNK];
+    __shared__ double sx[FIT_LDS_DOUBLES];
     const uint32_t c = blockIdx.x;
-    const uint32_t r0 = c * FIT_CHUNK;
-    const uint32_t cnt = (n - r0 < FIT_CHUNK) ? (n - r0) : FIT_CHUNK;
+    const uint32_t r0 = c * chunk;
+    const uint32_t cnt = (n - r0 < chunk) ? (n - r0) : chunk;
     for (uint32_t i = threadIdx.x; i < cnt; i += 256u) sl[i] = lab[r0 + i];
+    const uint32_t tot = cnt * (uint32_t)nb;
+    for (uint32_t i = threadIdx.x; i < tot; i += 256u) sx[i] = X[(size_t)r0 * nb + i];
     __syncthreads();
     const int kn = k * nb;
     for (int t = threadIdx.x; t < kn; t += 256) {
@@ -191,12 +239,45 @@ __global__ __launch_bounds__(256) void k_fit_partial(const double *__restrict__ 
         double acc = 0.0;
         uint32_t w = 0;
         for (uint32_t i = 0; i < cnt; i++)
-            if (sl[i] == j) { acc += X[(size_t)(r0 + i) * nb + b]; w++; }
+            if (sl[i] == j) { acc += sx[i * nb + b]; w++; }
         partial[(size_t)c * kn + t] = acc;
         if (b == 0) pcount[(size_t)c * k + j] = w;
     }
 }
 
+// level 1: partial2[g][t] = sum of partial[c][t] over the FIT_GROUP chunks of group g, chunk order
+__global__ __launch_bounds__(256) void k_fit_reduce1(const double *__restrict__ partial,
+                                                     const uint32_t *__restrict__ pcount,
+                                                     uint32_t nchunks, int k, int nb,
+                                                     double *__restrict__ partial2,
+                                                     uint32_t *__restrict__ pcount2)
+{
+    const int kn = k * nb;
+    const uint32_t g = blockIdx.y;
+    const uint32_t c0 = g * FIT_GROUP;
+    const uint32_t c1 = (c0 + FIT_GROUP < nchunks) ? c0 + FIT_GROUP : nchunks;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < kn) {
+        double acc = 0.0;
+        uint32_t c = c0;
+        for (; c + 8u <= c1; c += 8u) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = partial[(size_t)(c + u) * kn + t];
+#pragma unroll
+            for (int u = 0; u < 8; u++) acc += v[u];
+        }
+        for (; c < c1; c++) acc += partial[(size_t)c * kn + t];
+        partial2[(size_t)g * kn + t] = acc;
+    }
+    if (t < k) {
+        uint32_t ww = 0;
+        for (uint32_t c = c0; c < c1; c++) ww += pcount[(size_t)c * k + t];
+        pcount2[(size_t)g * k + t] = ww;
+    }
+}
+
+// level 2: S[t] = sum over groups in order; w[j] likewise
 __global__ __launch_bounds__(256) void k_fit_reduce(const double *__restrict__ partial,
                                                     const uint32_t *__restrict__ pcount,
                                                     uint32_t nchunks, int k, int nb,
@@ -262,46 +343,58 @@ static int run_kmeans_fit(shp_ctx *ctx, const double *xin, int64_t nrows, int nb
     std::vector<double> C(kn), Cn(kn), w(k), hm((size_t)kn + k);
     for (int t = 0; t < kn; t++) C[t] = init[t] - mu[t % nb];
 
-    const uint32_t nchunks = (n + FIT_CHUNK - 1) / FIT_CHUNK;
+    uint32_t chunk = FIT_LDS_DOUBLES / (uint32_t)nb;
+    if (chunk > FIT_CHUNK) chunk = FIT_CHUNK;
+    if (chunk < 1) SHP_FAIL(ctx, SHP_ERR_ARG, "too many bands for the k-means fit (%d)", nb);
+    const uint32_t nchunks = (n + chunk - 1) / chunk;
+    const uint32_t ngroups = (nchunks + FIT_GROUP - 1) / FIT_GROUP;
+    if ((size_t)(2 * kn + 2 * k + 8) * 8 > SHP_PINNED_BYTES)
+        SHP_FAIL(ctx, SHP_ERR_ARG, "k * nbands too large for the k-means fit (%d x %d)", k, nb);
     CHK(buf_ensure(ctx, ctx->fit_x, (size_t)n * nb * 8 + (size_t)n * 8));
     CHK(buf_ensure(ctx, ctx->fit_lab, (size_t)n * 4 * 2 + 64));
-    CHK(buf_ensure(ctx, ctx->fit_part, (size_t)nchunks * kn * 8 + (size_t)nchunks * k * 4 + (size_t)(kn + k) * 8 * 2 + 256));
+    CHK(buf_ensure(ctx, ctx->fit_part,
+                   ((size_t)nchunks + ngroups) * ((size_t)kn * 8 + (size_t)k * 4) + (size_t)(kn + k) * 8 * 2 + 512));
     CHK(buf_ensure(ctx, ctx->cen, (size_t)(kn + k) * 8 * 2));
     double *dX = bp<double>(ctx->fit_x), *ddist = dX + (size_t)n * nb;
-    int32_t *dlab = bp<int32_t>(ctx->fit_lab), *dlab_old = dlab + n;
-    uint32_t *ndiff = (uint32_t *)(dlab_old + n);
+    int32_t *dlabA = bp<int32_t>(ctx->fit_lab), *dlabB = dlabA + n;
+    uint32_t *ndiff = (uint32_t *)(dlabB + n);
     double *dpart = bp<double>(ctx->fit_part);
-    double *dS = dpart + (size_t)nchunks * kn, *dw = dS + kn;
+    double *dpart2 = dpart + (size_t)nchunks * kn;
+    double *dS = dpart2 + (size_t)ngroups * kn, *dw = dS + kn;
     uint32_t *dpc = (uint32_t *)(dw + k + 2);
+    uint32_t *dpc2 = dpc + (size_t)nchunks * k;
     double *dm2c = bp<double>(ctx->cen), *dcn = dm2c + kn, *dC = dcn + k;
     hipStream_t st = ctx->stream;
+    // pinned staging: [0] ndiff word, then m2c|cnorm|C (2kn+k doubles), then S|w (kn+k doubles)
+    double *pin_up = (double *)(ctx->h_pinned + 16);
+    double *pin_dn = pin_up + (2 * kn + k);
     HIPCHK(ctx, hipMemcpyAsync(dX, X.data(), (size_t)n * nb * 8, hipMemcpyHostToDevice, st));
-    HIPCHK(ctx, hipMemsetAsync(dlab_old, 0xff, (size_t)n * 4, st));     // labels_old = -1
+    HIPCHK(ctx, hipMemsetAsync(dlabB, 0xff, (size_t)n * 4, st));        // labels_old = -1
     const unsigned g = grid_for(n, 256);
     auto upload_centres = [&](const std::vector<double> &cc) -> int {
-        kmeans_prepare_host(cc.data(), k, nb, hm.data(), hm.data() + kn);
-        HIPCHK(ctx, hipMemcpyAsync(dm2c, hm.data(), (size_t)(kn + k) * 8, hipMemcpyHostToDevice, st));
-        HIPCHK(ctx, hipMemcpyAsync(dC, cc.data(), (size_t)kn * 8, hipMemcpyHostToDevice, st));
-        HIPCHK(ctx, hipStreamSynchronize(st));
+        kmeans_prepare_host(cc.data(), k, nb, pin_up, pin_up + kn);        // m2c | cnorm
+        memcpy(pin_up + kn + k, cc.data(), (size_t)kn * 8);              // C  (dC follows dcn)
+        HIPCHK(ctx, hipMemcpyAsync(dm2c, pin_up, (size_t)(2 * kn + k) * 8, hipMemcpyHostToDevice, st));
         return 0;
     };
     bool strict = false;
     int it = 0;
-    std::vector<double> hS(kn + k);
+    int32_t *dlab = dlabA, *dlab_old = dlabB;
     for (it = 1; it <= max_iter; it++) {
         CHK(upload_centres(C));
         HIPCHK(ctx, hipMemsetAsync(ndiff, 0, 4, st));
-        hipLaunchKernelGGL(k_fit_assign, dim3(g), dim3(256), 0, st, dX, n, nb, dm2c, dcn, k, dlab,
-                           dlab_old, ndiff); KCHK(ctx);
+        launch_fit_assign(ctx, g, dX, n, nb, dm2c, dcn, k, dlab, dlab_old, ndiff); KCHK(ctx);
         hipLaunchKernelGGL(k_fit_partial, dim3(nchunks), dim3(256), 0, st, dX, n, nb, dlab, k, dpart,
-                           dpc); KCHK(ctx);
-        hipLaunchKernelGGL(k_fit_reduce, dim3(grid_for(kn, 256)), dim3(256), 0, st, dpart, dpc,
-                           nchunks, k, nb, dS, dw); KCHK(ctx);
-        HIPCHK(ctx, hipMemcpyAsync(hS.data(), dS, (size_t)(kn + k) * 8, hipMemcpyDeviceToHost, st));
+                           dpc, chunk); KCHK(ctx);
+        hipLaunchKernelGGL(k_fit_reduce1, dim3(grid_for(kn, 256), ngroups), dim3(256), 0, st, dpart, dpc,
+                           nchunks, k, nb, dpart2, dpc2); KCHK(ctx);
+        hipLaunchKernelGGL(k_fit_reduce, dim3(grid_for(kn, 256)), dim3(256), 0, st, dpart2, dpc2,
+                           ngroups, k, nb, dS, dw); KCHK(ctx);
+        HIPCHK(ctx, hipMemcpyAsync(pin_dn, dS, (size_t)(kn + k) * 8, hipMemcpyDeviceToHost, st));
         HIPCHK(ctx, hipMemcpyAsync(ctx->h_pinned, ndiff, 4, hipMemcpyDeviceToHost, st));
         HIPCHK(ctx, hipStreamSynchronize(st));
-        for (int t = 0; t < kn; t++) Cn[t] = hS[t];
-        for (int j = 0; j < k; j++) w[j] = hS[kn + j];
+        for (int t = 0; t < kn; t++) Cn[t] = pin_dn[t];
+        for (int j = 0; j < k; j++) w[j] = pin_dn[kn + j];
         const uint32_t nd = ctx->h_pinned[0];
         int n_empty = 0;
         for (int j = 0; j < k; j++) n_empty += (w[j] == 0.0);
@@ -315,10 +408,15 @@ static int run_kmeans_fit(shp_ctx *ctx, const double *xin, int64_t nrows, int nb
             HIPCHK(ctx, hipStreamSynchronize(st));
             std::vector<int> empties;
             for (int j = 0; j < k; j++) if (w[j] == 0.0) empties.push_back(j);
+            // the n_empty farthest samples, distance descending / index ascending on ties
+            std::vector<uint32_t> order(n);
+            for (uint32_t i = 0; i < n; i++) order[i] = i;
+            std::partial_sort(order.begin(), order.begin() + n_empty, order.end(),
+                              [&dist](uint32_t a, uint32_t b) {
+                                  return dist[a] > dist[b] || (dist[a] == dist[b] && a < b);
+                              });
             for (int r = 0; r < n_empty; r++) {
-                uint32_t f = 0; double fd = -1.0;
-                for (uint32_t i = 0; i < n; i++) if (dist[i] > fd) { fd = dist[i]; f = i; }
-                dist[f] = -2.0;
+                const uint32_t f = order[r];
                 const int e = empties[r], old = hl[f];
                 for (int b = 0; b < nb; b++) {
                     Cn[old * nb + b] -= X[(size_t)f * nb + b];
@@ -343,13 +441,13 @@ static int run_kmeans_fit(shp_ctx *ctx, const double *xin, int64_t nrows, int nb
         C = Cn;
         if (nd == 0) { strict = true; break; }
         if (shift <= tol) break;
-        HIPCHK(ctx, hipMemcpyAsync(dlab_old, dlab, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
+        { int32_t *t = dlab; dlab = dlab_old; dlab_old = t; }            // labels_old[:] = labels
     }
     if (it > max_iter) it = max_iter;
     if (!strict) {
+        // extra E-step so that the labels match the final centres (either label buffer will do)
         CHK(upload_centres(C));
-        hipLaunchKernelGGL(k_fit_assign, dim3(g), dim3(256), 0, st, dX, n, nb, dm2c, dcn, k, dlab,
-                           (const int32_t *)nullptr, ndiff); KCHK(ctx);
+        launch_fit_assign(ctx, g, dX, n, nb, dm2c, dcn, k, dlab, (const int32_t *)nullptr, ndiff); KCHK(ctx);
     }
     if (labels_out) HIPCHK(ctx, hipMemcpyAsync(labels_out, dlab, (size_t)n * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipStreamSynchronize(st));

@@ -34,9 +34,15 @@ __global__ __launch_bounds__(256) void k_strip_minmax(const uint32_t *__restrict
     const uint32_t s = tile[r * xs + c];
     if (s == 0) return;
     const uint32_t v = horizontal ? r : c;
-    // cheap pruning: only extremal candidates need to touch memory
-    if (v < mn[s]) atomicMin(&mn[s], v);
-    if (v + 1u > mx[s]) atomicMax(&mx[s], v + 1u);     // mx holds max+1 (0 = absent)
+    // only a pixel whose predecessor / successor along the axis is another segment can be the
+    // segment's minimum / maximum; the plain pre-reads prune the remaining atomics
+    const uint32_t step = horizontal ? xs : 1u;
+    const uint32_t lim = horizontal ? srows : scols;
+    const uint32_t q = r * xs + c;
+    const bool lo = v == 0 || tile[q - step] != s;
+    const bool hi = v + 1u == lim || tile[q + step] != s;
+    if (lo && v < mn[s]) atomicMin(&mn[s], v);
+    if (hi && v + 1u > mx[s]) atomicMax(&mx[s], v + 1u);     // mx holds max+1 (0 = absent)
 }
 
 __global__ __launch_bounds__(256) void k_pair_count(
@@ -163,7 +169,9 @@ __global__ __launch_bounds__(256) void k_apply_lut(uint32_t *tile, uint32_t ys, 
         const uint32_t o = __shfl_xor(m, d, 64);
         m = o > m ? o : m;
     }
-    if (lane_id() == 0 && m != 0) atomicMax(tmax, m);
+    // one atomic per wavefront only if it can still raise the maximum (plain pre-read: a stale
+    // smaller value only costs a redundant atomic)
+    if (lane_id() == 0 && m != 0 && m > *(volatile uint32_t *)tmax) atomicMax(tmax, m);
 }
 
 __global__ void k_max_merge(uint32_t *max_seg_id, const uint32_t *tmax)

@@ -151,7 +151,7 @@ def _kmeans_plusplus(x, k, rng):
     return centres
 
 
-def _fit(xSample, init, max_iter=300, tol=1e-4):
+def _fit(xSample, init, max_iter=300, tol=1e-4, wantInertia=False):
     x = numpy.ascontiguousarray(xSample, dtype=numpy.float64)
     init = numpy.ascontiguousarray(init, dtype=numpy.float64)
     (n, nb) = x.shape
@@ -163,7 +163,7 @@ def _fit(xSample, init, max_iter=300, tol=1e-4):
     c.check(c._L.shp_kmeans_fit(c.handle, _lib.ptr(x), n, nb, k, _lib.ptr(init), int(max_iter),
                                 float(tol), _lib.ptr(centres), _lib.ptr(labels),
                                 ctypes.byref(nit)))
-    inertia = float(((x - centres[labels]) ** 2).sum())
+    inertia = float(((x - centres[labels]) ** 2).sum()) if wantInertia else None
     return KMeansModel(centres, nit.value, labels, inertia)
 
 
@@ -180,7 +180,7 @@ def fitSpectralClusters(img, numClusters, subsamplePcnt, imgNullVal, fixedKMeans
     rng = numpy.random.RandomState()
     xs = xSample.astype(numpy.float64)
     for _trial in range(5):                    # numKmeansTrials (shepseg.py:305)
-        km = _fit(xSample, _kmeans_plusplus(xs, numClusters, rng))
+        km = _fit(xSample, _kmeans_plusplus(xs, numClusters, rng), wantInertia=True)
         if best is None or km.inertia_ < best.inertia_:
             best = km
     return best

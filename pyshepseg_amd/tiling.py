@@ -212,6 +212,43 @@ def _open_source(infile):
 
 
 # ------------------------------------------------------------------------------------------
+# device scratch rasters (tile labels, stitched output) are cached between runs: hipMalloc /
+# hipFree of multi-GB blocks are slow and synchronise the whole device
+# ------------------------------------------------------------------------------------------
+_devCache = {}
+_devCacheLock = threading.Lock()
+
+
+def _devAlloc(c, nbytes):
+    nbytes = max(int(nbytes), 16)
+    with _devCacheLock:
+        lst = _devCache.get((c.device, nbytes))
+        if lst:
+            return ctypes.c_void_p(lst.pop())
+    p = ctypes.c_void_p()
+    c.check(c._L.shp_dev_alloc(c.handle, nbytes, ctypes.byref(p)))
+    return p
+
+
+def _devRelease(c, p, nbytes):
+    if p is None or not p.value:
+        return
+    nbytes = max(int(nbytes), 16)
+    with _devCacheLock:
+        _devCache.setdefault((c.device, nbytes), []).append(p.value)
+
+
+def clearDeviceCache():
+    """Free every cached device scratch raster."""
+    c = _lib.ctx()
+    with _devCacheLock:
+        for (_dev, _n), lst in _devCache.items():
+            for v in lst:
+                c._L.shp_dev_free(c.handle, ctypes.c_void_p(v))
+        _devCache.clear()
+
+
+# ------------------------------------------------------------------------------------------
 # tile grid (reference tiling.py:317-443)
 # ------------------------------------------------------------------------------------------
 class TileInfo(object):
@@ -400,12 +437,10 @@ def doTiledShepherdSegmentation(infile, outfile, tileSize=DFLT_TILESIZE,
             total += j.xsize * j.ysize
             jobs.append(j)
         jobmap = {(j.col, j.row): j for j in jobs}
-        d_tiles = ctypes.c_void_p()
-        d_out = ctypes.c_void_p()
-        d_scal = ctypes.c_void_p()
-        main.check(L.shp_dev_alloc(main.handle, max(total, 1) * 4, ctypes.byref(d_tiles)))
-        main.check(L.shp_dev_alloc(main.handle, max(inYsize * inXsize, 1) * 4, ctypes.byref(d_out)))
-        main.check(L.shp_dev_alloc(main.handle, 256, ctypes.byref(d_scal)))
+        nbTiles, nbOut = max(total, 1) * 4, max(inYsize * inXsize, 1) * 4
+        d_tiles = _devAlloc(main, nbTiles)
+        d_out = _devAlloc(main, nbOut)
+        d_scal = _devAlloc(main, 256)
         main.check(L.shp_dev_memset(main.handle, d_scal, 0, 256))
         try:
             nullFlag = int(imgNullVal is not None)
@@ -542,8 +577,8 @@ def doTiledShepherdSegmentation(infile, outfile, tileSize=DFLT_TILESIZE,
 
             result = TiledSegmentationResult()
             if outfile is _KEEP_ON_DEVICE:
-                result.outDev = (d_out.value, inYsize, inXsize)
-                d_out = ctypes.c_void_p()           # ownership moves to the caller
+                result.outDev = (d_out.value, inYsize, inXsize, nbOut)
+                d_out = None                        # ownership moves to the caller
             else:
                 segimg = numpy.empty((inYsize, inXsize), dtype=shepseg.SegIdType)
                 main.check(L.shp_dev_download(main.handle, _lib.ptr(segimg), d_out, segimg.nbytes))
@@ -560,9 +595,10 @@ def doTiledShepherdSegmentation(infile, outfile, tileSize=DFLT_TILESIZE,
             forceExit_ = locals().get('forceExit')
             if forceExit_ is not None:
                 forceExit_.set()
-            for p in (d_tiles, d_out, d_scal):
-                if p.value:
-                    L.shp_dev_free(main.handle, p)
+            L.shp_sync(main.handle)
+            _devRelease(main, d_tiles, nbTiles)
+            _devRelease(main, d_out, nbOut)
+            _devRelease(main, d_scal, 256)
 
     result.maxSegId = maxSegId
     result.numTileRows = tileInfo.nrows
@@ -583,8 +619,7 @@ def freeDeviceOutput(result):
     """Release the device raster kept by outfile=_KEEP_ON_DEVICE."""
     od = getattr(result, 'outDev', None)
     if od and od[0]:
-        c = _lib.ctx()
-        c.check(c._L.shp_dev_free(c.handle, ctypes.c_void_p(od[0])))
+        _devRelease(_lib.ctx(), ctypes.c_void_p(od[0]), od[3])
         result.outDev = None
 
 
