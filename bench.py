@@ -37,7 +37,7 @@ def parse():
     ap.add_argument('--bands', type=int, default=6)
     ap.add_argument('--tile', type=int, default=4096)
     ap.add_argument('--overlap', type=int, default=1024)
-    ap.add_argument('--workers', type=int, default=int(os.environ.get('SHEPSEG_WORKERS', '12')))
+    ap.add_argument('--workers', type=int, default=int(os.environ.get('SHEPSEG_WORKERS', '16')))
     ap.add_argument('--cpu-sample', type=int, default=6144,
                     help='window edge of the cpu_baseline sample (0 = skip)')
     return ap.parse_args()

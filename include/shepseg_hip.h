@@ -114,6 +114,7 @@ int shp_dev_free(shp_ctx *ctx, void *dptr);
 int shp_dev_upload(shp_ctx *ctx, void *dst_dev, const void *src_host, size_t bytes);
 int shp_dev_download(shp_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
 int shp_dev_memset(shp_ctx *ctx, void *dst_dev, int value, size_t bytes);
+int shp_dev_copy(shp_ctx *ctx, void *dst_dev, const void *src_dev, size_t bytes);   /* D2D */
 int shp_sync(shp_ctx *ctx);
 /* synthimg v1 window written straight into device memory (band-planar uint16) */
 int shp_dev_synthimg(shp_ctx *ctx, uint64_t seed, int nbands, int64_t y0, int64_t x0, int nrows,

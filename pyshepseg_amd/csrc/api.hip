@@ -392,6 +392,14 @@ API int shp_dev_download(shp_ctx *ctx, void *dst_host, const void *src_dev, size
     return 0;
 }
 
+API int shp_dev_copy(shp_ctx *ctx, void *dst_dev, const void *src_dev, size_t bytes)
+{
+    CHK(enter(ctx));
+    if (bytes) HIPCHK(ctx, hipMemcpyAsync(dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
 API int shp_dev_memset(shp_ctx *ctx, void *dst_dev, int value, size_t bytes)
 {
     CHK(enter(ctx));

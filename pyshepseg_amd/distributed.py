@@ -1,0 +1,459 @@
+"""Multi-GPU tiled Shepherd segmentation: one process per GPU (torch.distributed, RCCL over
+xGMI on the GPU box, gloo in the CPU tests).
+
+What shards and what does not
+-----------------------------
+* Tiles are independent once the global k-means model is known (reference tiling.py:1430-1453),
+  so tile ROWS are dealt to ranks in contiguous blocks balanced by area; every rank holds only
+  its slice of the raster and of the stitched output.  No collective on that path.
+* The cross-tile stitch is specified sequentially (reference stitchTiles, tiling.py:979-1043:
+  every tile's new ids start after the largest id of all earlier tiles, and shared segments
+  take the id the tile above / to the left already gave them).  It is kept exactly that way:
+  rank r stitches its rows as soon as it has received, from the rank holding the rows above,
+  the running maxSegId and the recoded bottom overlap strips of that rank's last tile row --
+  the one real exchange step (point-to-point send/recv, <= 25 MB per strip) -- and passes its
+  own on.  A final all-reduce sums the per-rank histograms.
+* The k-means fit runs on rank 0 from the sub-sample gathered from every rank's slice; the
+  centres (k x nBands float64) are broadcast.
+
+The driver below is engine-agnostic: ``HipEngine`` drives libshepseg_hip.so on this rank's GPU;
+the CPU tests plug in an engine built on the oracle to exercise the sharding / exchange logic
+with world_size 2 over gloo.
+"""
+import ctypes
+import json
+import os
+import time
+
+import numpy
+
+from . import _lib
+from . import shepseg
+from . import tiling
+
+
+# ------------------------------------------------------------------------------------------
+# sharding
+# ------------------------------------------------------------------------------------------
+def shardTileRows(tileInfo, world):
+    """Contiguous blocks of tile rows per rank, balanced by pixel area.  Returns a list of
+    (row0, row1) half-open ranges, one per rank (empty when there are more ranks than rows)."""
+    nrows = tileInfo.nrows
+    weights = []
+    for r in range(nrows):
+        weights.append(sum(tileInfo.getTile(c, r)[2] * tileInfo.getTile(c, r)[3]
+                           for c in range(tileInfo.ncols)))
+    total = float(sum(weights))
+    out = []
+    r = 0
+    acc = 0.0
+    for k in range(world):
+        r0 = r
+        remainingRanks = world - k
+        if nrows - r <= 0:
+            out.append((r, r))
+            continue
+        target = total * (k + 1) / world
+        # take rows while it brings the running sum closer to this rank's share, keeping at
+        # least one row for every later rank that can still get one
+        while r < nrows and (nrows - r) > (remainingRanks - 1):
+            if r > r0 and abs(acc + weights[r] - target) > abs(acc - target):
+                break
+            acc += weights[r]
+            r += 1
+        if r == r0 and r < nrows:
+            acc += weights[r]
+            r += 1
+        out.append((r0, r))
+    if r < nrows:                      # leftovers go to the last rank that has rows
+        last = max(i for i, (a, b) in enumerate(out) if b > a)
+        out[last] = (out[last][0], nrows)
+    return out
+
+
+class Comm(object):
+    """Thin torch.distributed wrapper (nccl = RCCL on the GPU box, gloo in CPU tests)."""
+    def __init__(self, dist=None, device=None):
+        self.dist = dist
+        self.rank = dist.get_rank() if dist is not None else 0
+        self.world = dist.get_world_size() if dist is not None else 1
+        self.device = device            # torch device for collectives' tensors
+
+    def _t(self, arr):
+        import torch
+        t = torch.from_numpy(numpy.ascontiguousarray(arr))
+        return t.to(self.device) if self.device is not None else t
+
+    def allgather_obj(self, obj):
+        if self.world == 1:
+            return [obj]
+        out = [None] * self.world
+        self.dist.all_gather_object(out, obj)
+        return out
+
+    def bcast_obj(self, obj, src=0):
+        if self.world == 1:
+            return obj
+        lst = [obj]
+        self.dist.broadcast_object_list(lst, src=src)
+        return lst[0]
+
+    def allreduce_sum_i64(self, arr):
+        if self.world == 1:
+            return arr
+        t = self._t(arr.astype(numpy.int64))
+        self.dist.all_reduce(t)
+        return t.cpu().numpy()
+
+    def max_f64(self, v):
+        if self.world == 1:
+            return v
+        import torch
+        t = self._t(numpy.array([v], dtype=numpy.float64))
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.cpu().numpy()[0])
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+
+    def send(self, tensor, dst):
+        self.dist.send(tensor, dst)
+
+    def recv(self, tensor, src):
+        self.dist.recv(tensor, src)
+
+
+# ------------------------------------------------------------------------------------------
+# the engine-agnostic driver
+# ------------------------------------------------------------------------------------------
+class DistResult(object):
+    pass
+
+
+def runDistributed(engine, comm, nRows, nCols, tileSize, overlapSize, minSegmentSize=50,
+                   numClusters=60, subsamplePcnt=None, maxSpectralDiff='auto', imgNullVal=None,
+                   fixedKMeansInit=True, fourConnected=True, simpleTileRecode=False,
+                   spectDistPcntile=50, kmeansObj=None):
+    """Tiled segmentation of an (nRows x nCols) raster sharded by tile rows over comm.world
+    ranks.  ``engine`` owns this rank's slice of the raster and of the output (see HipEngine).
+    Returns a DistResult with maxSegId, hist (global), kmeans, maxSpectralDiff, rowRange (tile
+    rows of this rank) and outRows (image rows of the output held by this rank)."""
+    if (overlapSize % 2) != 0:
+        raise tiling.PyShepSegTilingError("Overlap size must be an even number")
+
+    class _Ds(object):
+        RasterXSize, RasterYSize = nCols, nRows
+    tileInfo = tiling.getTilesForFile(_Ds(), tileSize, overlapSize)
+    shards = shardTileRows(tileInfo, comm.world)
+    (r0, r1) = shards[comm.rank]
+    myRows = list(range(r0, r1))
+    haveTiles = r1 > r0
+    jobs, total = tiling.makeTileJobs(tileInfo, rows=set(myRows))
+    # image rows this rank needs (its tiles) and owns in the output (their trimmed windows)
+    if haveTiles:
+        yLo = tileInfo.getTile(0, r0)[1]
+        lastT = tileInfo.getTile(0, r1 - 1)
+        yHi = lastT[1] + lastT[3]
+        w0 = tiling.trimmedWindow(tileInfo, 0, r0, *tileInfo.getTile(0, r0), overlapSize)
+        w1 = tiling.trimmedWindow(tileInfo, 0, r1 - 1, *lastT, overlapSize)
+        outLo, outHi = w0[5], w1[5] + (w1[1] - w1[0])
+    else:
+        yLo = yHi = outLo = outHi = 0
+    engine.setup(tileInfo, jobs, total, yLo, yHi, outLo, outHi, nCols, overlapSize)
+
+    # ---- one global k-means model (reference tiling.py:154-226) ----
+    if kmeansObj is None:
+        if subsamplePcnt is None:
+            subsampleProp = min(1, numpy.sqrt(1000000 / (nRows * nCols)))
+            subsamplePcnt = 100 * subsampleProp**2
+        else:
+            subsampleProp = numpy.sqrt(subsamplePcnt / 100.0)
+        skip = int(round(1. / subsampleProp))
+        ry = tiling._subsample_indices(nRows, skip)
+        rx = tiling._subsample_indices(nCols, skip)
+        mine = ry[(ry >= outLo) & (ry < outHi)] if haveTiles else ry[:0]
+        part = engine.subsample(mine, rx)                      # (nBands, len(mine), len(rx))
+        parts = comm.allgather_obj(part)
+        centres = None
+        if comm.rank == 0:
+            img = numpy.concatenate([p for p in parts if p.shape[1] > 0], axis=1)
+            km = engine.fit(img, numClusters, imgNullVal, fixedKMeansInit)
+            centres = numpy.ascontiguousarray(km.cluster_centers_, dtype=numpy.float64)
+        centres = comm.bcast_obj(centres, src=0)
+        kmeansObj = shepseg.KMeansModel(centres)
+    centres = numpy.ascontiguousarray(kmeansObj.cluster_centers_, dtype=numpy.float64)
+    msd = shepseg.autoMaxSpectralDiff(kmeansObj, maxSpectralDiff, spectDistPcntile)
+
+    # ---- segment this rank's tiles (asynchronously) ----
+    engine.startSegmentation(centres, msd, imgNullVal, fourConnected, minSegmentSize)
+
+    # ---- the stitch chain ----
+    nonEmpty = [i for i, (a, b) in enumerate(shards) if b > a]
+    maxSegId = 0
+    if haveTiles:
+        pos = nonEmpty.index(comm.rank)
+        prevRank = nonEmpty[pos - 1] if pos > 0 else None
+        nextRank = nonEmpty[pos + 1] if pos + 1 < len(nonEmpty) else None
+        topStrips = {}
+        if prevRank is not None:
+            maxSegId, topStrips = engine.recvBoundary(comm, prevRank, tileInfo, r0 - 1)
+        engine.setMaxSegId(maxSegId)
+        jobmap = {(j.col, j.row): j for j in jobs}
+        for j in jobs:
+            engine.waitTile(j)
+            win = tiling.trimmedWindow(tileInfo, j.col, j.row, j.xpos, j.ypos, j.xsize, j.ysize,
+                                       overlapSize)
+            top = left = None
+            if not simpleTileRecode:
+                if j.row > r0:
+                    top = engine.bottomStripOf(jobmap[(j.col, j.row - 1)])
+                elif j.row > 0:
+                    top = topStrips[j.col]
+                if j.col > 0:
+                    left = engine.rightStripOf(jobmap[(j.col - 1, j.row)])
+            engine.stitchTile(j, top, left, win, simpleTileRecode)
+        maxSegId = engine.getMaxSegId()
+        if nextRank is not None:
+            engine.sendBoundary(comm, nextRank, maxSegId,
+                                [jobmap[(c, r1 - 1)] for c in range(tileInfo.ncols)])
+    # final maxSegId lives on the last rank that has tiles
+    vals = comm.allgather_obj(int(maxSegId))
+    maxSegId = vals[nonEmpty[-1]] if nonEmpty else 0
+    hist = engine.histogram(maxSegId) if haveTiles else numpy.zeros(maxSegId + 1, numpy.int64)
+    hist = comm.allreduce_sum_i64(numpy.asarray(hist, dtype=numpy.int64)).astype(numpy.uint32)
+    hist[0] = 0
+    engine.finish()
+
+    res = DistResult()
+    res.maxSegId = int(maxSegId)
+    res.hist = hist
+    res.kmeans = kmeansObj
+    res.maxSpectralDiff = msd
+    res.subsamplePcnt = subsamplePcnt
+    res.rowRange = (r0, r1)
+    res.outRows = (outLo, outHi)
+    res.numTileRows, res.numTileCols = tileInfo.nrows, tileInfo.ncols
+    res.hasEmptySegments = bool((hist[1:] == 0).any())
+    return res
+
+
+# ------------------------------------------------------------------------------------------
+# HIP engine: this rank's GPU
+# ------------------------------------------------------------------------------------------
+class HipEngine(object):
+    """Holds rows [yLo, yHi) of the raster in HBM (a DeviceRaster created by `makeSlice`),
+    segments this rank's tiles with pooled worker contexts and stitches them on the device.
+    Boundary strips travel as torch CUDA tensors over torch.distributed (nccl = RCCL)."""
+
+    def __init__(self, makeSlice, numWorkers=16, keepOutput=False):
+        self.makeSlice = makeSlice          # f(yLo, yHi) -> DeviceRaster of those rows
+        self.numWorkers = numWorkers
+        self.keepOutput = keepOutput
+        self.ras = None
+        self.timings = tiling.Timers()
+        self._sliceKey = None
+
+    def setup(self, tileInfo, jobs, total, yLo, yHi, outLo, outHi, nCols, overlapSize):
+        self.c = _lib.ctx()
+        self.L = self.c._L
+        self.tileInfo, self.jobs = tileInfo, jobs
+        (self.yLo, self.yHi, self.outLo, self.outHi) = (yLo, yHi, outLo, outHi)
+        self.nCols, self.overlap = nCols, overlapSize
+        if self._sliceKey != (yLo, yHi):
+            if self.ras is not None:
+                self.ras.free()
+            self.ras = self.makeSlice(yLo, yHi) if yHi > yLo else None
+            self._sliceKey = (yLo, yHi)
+        self.nbTiles = max(total, 1) * 4
+        self.nbOut = max((outHi - outLo) * nCols, 1) * 4
+        self.d_tiles = tiling._devAlloc(self.c, self.nbTiles)
+        self.d_out = tiling._devAlloc(self.c, self.nbOut)
+        self.d_scal = tiling._devAlloc(self.c, 256)
+        self.c.check(self.L.shp_dev_memset(self.c.handle, self.d_scal, 0, 256))
+        self.threads, self.forceExit = [], None
+        self.recvBufs = []
+        self.recvDev = []
+
+    def subsample(self, rowsGlobal, cols):
+        nb = self.ras.shape[0] if self.ras is not None else 0
+        if self.ras is None or len(rowsGlobal) == 0:
+            return numpy.zeros((nb, 0, len(cols)), dtype=numpy.uint16)
+        ry = (rowsGlobal - self.yLo).astype(numpy.uint32)
+        out = numpy.empty((nb, len(ry), len(cols)), dtype=self.ras.dtype)
+        self.c.check(self.L.shp_dev_subsample(
+            self.c.handle, ctypes.c_void_p(self.ras.ptr), _lib.SHP_DTYPES[self.ras.dtype], nb,
+            self.ras.shape[1], self.ras.shape[2], _lib.ptr(ry), len(ry),
+            _lib.ptr(numpy.ascontiguousarray(cols, dtype=numpy.uint32)), len(cols), _lib.ptr(out)))
+        return out
+
+    def fit(self, img, numClusters, imgNullVal, fixedKMeansInit):
+        with self.timings.interval('spectralclusters'):
+            return shepseg.fitSpectralClusters(img, numClusters, 100, imgNullVal, fixedKMeansInit)
+
+    def startSegmentation(self, centres, msd, imgNullVal, fourConnected, minSegmentSize):
+        if not self.jobs:
+            return
+        self.threads, self.forceExit = tiling.startSegmentationWorkers(
+            self.ras, self.jobs, self.d_tiles, centres, msd, imgNullVal, fourConnected,
+            minSegmentSize, self.numWorkers, self.timings, yOrigin=self.yLo)
+
+    def waitTile(self, j):
+        tiling.waitForTile(j, self.jobs, self.threads, self.forceExit, 600)
+
+    def setMaxSegId(self, v):
+        a = numpy.array([v], dtype=numpy.uint32)
+        self.c.check(self.L.shp_dev_upload(self.c.handle, self.d_scal, _lib.ptr(a), 4))
+
+    def getMaxSegId(self):
+        a = numpy.zeros(1, dtype=numpy.uint32)
+        self.c.check(self.L.shp_sync(self.c.handle))
+        self.c.check(self.L.shp_dev_download(self.c.handle, _lib.ptr(a), self.d_scal, 4))
+        return int(a[0])
+
+    # strips are (device pointer, row pitch in elements)
+    def bottomStripOf(self, a):
+        return (self.d_tiles.value + 4 * (a.offset + (a.ysize - self.overlap) * a.xsize), a.xsize)
+
+    def rightStripOf(self, a):
+        return (self.d_tiles.value + 4 * (a.offset + (a.xsize - self.overlap)), a.xsize)
+
+    def stitchTile(self, j, top, left, win, simple):
+        (t, b, l, r, xout, yout) = win
+        with self.timings.interval('stitchtiles'):
+            self.c.check(self.L.shp_stitch_tile_dev(
+                self.c.handle, ctypes.c_void_p(self.d_tiles.value + 4 * j.offset), j.ysize, j.xsize,
+                self.overlap, ctypes.c_void_p(top[0]) if top else None, top[1] if top else 0,
+                ctypes.c_void_p(left[0]) if left else None, left[1] if left else 0, j.maxLocal,
+                int(bool(simple)), self.d_scal, t, b, l, r, self.d_out, self.nCols, xout,
+                yout - self.outLo))
+
+    @staticmethod
+    def _onGpu(comm):
+        return comm.device is not None and str(comm.device).startswith('cuda')
+
+    def sendBoundary(self, comm, dst, maxSegId, lastRowJobs):
+        import torch
+        self.c.check(self.L.shp_sync(self.c.handle))
+        gpu = self._onGpu(comm)
+        hdr = torch.tensor([maxSegId], dtype=torch.int64, device=comm.device)
+        comm.send(hdr, dst)
+        for a in lastRowJobs:
+            n = self.overlap * a.xsize
+            buf = torch.empty(n, dtype=torch.int32, device=comm.device)
+            (ptr, _pitch) = self.bottomStripOf(a)
+            if gpu:      # device-to-device into the RCCL send buffer
+                self.c.check(self.L.shp_dev_copy(self.c.handle, ctypes.c_void_p(buf.data_ptr()),
+                                                 ctypes.c_void_p(ptr), n * 4))
+            else:        # gloo (tests): stage through host memory
+                self.c.check(self.L.shp_dev_download(self.c.handle, ctypes.c_void_p(buf.data_ptr()),
+                                                     ctypes.c_void_p(ptr), n * 4))
+            comm.send(buf, dst)
+
+    def recvBoundary(self, comm, src, tileInfo, aboveRow):
+        import torch
+        gpu = self._onGpu(comm)
+        hdr = torch.zeros(1, dtype=torch.int64, device=comm.device)
+        comm.recv(hdr, src)
+        strips = {}
+        for col in range(tileInfo.ncols):
+            xsize = tileInfo.getTile(col, aboveRow)[2]
+            n = self.overlap * xsize
+            buf = torch.empty(n, dtype=torch.int32, device=comm.device)
+            comm.recv(buf, src)
+            if gpu:
+                self.recvBufs.append(buf)                # keep alive until finish()
+                strips[col] = (buf.data_ptr(), xsize)
+            else:
+                d = tiling._devAlloc(self.c, n * 4)
+                self.c.check(self.L.shp_dev_upload(self.c.handle, d, ctypes.c_void_p(buf.data_ptr()),
+                                                   n * 4))
+                self.recvDev.append((d, n * 4))
+                strips[col] = (d.value, xsize)
+        if gpu:
+            torch.cuda.synchronize()
+        return int(hdr.cpu()[0]), strips
+
+    def histogram(self, maxSegId):
+        hist = numpy.zeros(maxSegId + 1, dtype=numpy.uint32)
+        self.c.check(self.L.shp_histogram_dev(self.c.handle, self.d_out,
+                                              (self.outHi - self.outLo) * self.nCols, maxSegId,
+                                              _lib.ptr(hist)))
+        return hist
+
+    def localOutput(self):
+        out = numpy.empty((self.outHi - self.outLo, self.nCols), dtype=numpy.uint32)
+        self.c.check(self.L.shp_dev_download(self.c.handle, _lib.ptr(out), self._lastOut, out.nbytes))
+        return out
+
+    def finish(self):
+        for t in self.threads:
+            t.join()
+        self.c.check(self.L.shp_sync(self.c.handle))
+        self.recvBufs = []
+        for (d, nbytes) in self.recvDev:
+            tiling._devRelease(self.c, d, nbytes)
+        self.recvDev = []
+        tiling._devRelease(self.c, self.d_tiles, self.nbTiles)
+        tiling._devRelease(self.c, self.d_scal, 256)
+        if self.keepOutput:
+            self._lastOut = self.d_out               # caller must releaseOutput()
+        else:
+            tiling._devRelease(self.c, self.d_out, self.nbOut)
+
+    def releaseOutput(self):
+        tiling._devRelease(self.c, self.d_out, self.nbOut)
+
+
+# ------------------------------------------------------------------------------------------
+# bench.py entry for --gpus N > 1
+# ------------------------------------------------------------------------------------------
+def bench_main(args, rank, world, local_rank, dist):
+    """One rank of the multi-GPU benchmark: this rank's rows of the synthetic C3 image are
+    generated in its own HBM (synthimg is position-deterministic); a step = runDistributed."""
+    import torch
+    dev = torch.device('cuda', local_rank)
+    comm = Comm(dist, device=dev)
+    nb = args.bands
+
+    def makeSlice(yLo, yHi):
+        return tiling.DeviceRaster.synth(11, nb, yHi - yLo, args.size, y0=yLo, x0=0)
+    engine = HipEngine(makeSlice, numWorkers=args.workers)
+
+    def step():
+        return runDistributed(engine, comm, args.size, args.size, args.tile, args.overlap,
+                              minSegmentSize=50, numClusters=60, fixedKMeansInit=True)
+
+    for _ in range(args.warmup):
+        r = step()
+    comm.barrier()
+    torch.cuda.synchronize()
+    t0 = time.time()
+    for _ in range(args.steps):
+        r = step()
+    torch.cuda.synchronize()
+    comm.barrier()
+    dt = comm.max_f64((time.time() - t0) / max(args.steps, 1))
+    if rank == 0:
+        npix = args.size * args.size
+        value = npix / dt / 1e6
+        out = {
+            "metric": "Mpixels/sec segmented, 6-band 40k x 40k tiled",
+            "value": round(value, 3), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 2), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "u16", "data": "synthetic",
+            "config": {"workload": "C3: tiled %dx%d, %d-band uint16 synthimg v1, tileSize=%d, "
+                                   "overlap=%d, k=60, minSegmentSize=50, fixedKMeansInit, tile rows "
+                                   "sharded over %d GPUs, image + labels resident in HBM"
+                                   % (args.size, args.size, nb, args.tile, args.overlap, world),
+                       "tiles": r.numTileRows * r.numTileCols, "worker_streams": args.workers,
+                       "max_seg_id": int(r.maxSegId),
+                       "parallelism": "tile rows sharded; stitch chain over send/recv (RCCL)"},
+            "roofline": {"bound": "hbm", "kernel": "whole path", "achieved": round(
+                value * 1e6 * (2 * nb + 4) / 1e9, 3), "peak": 8000.0 * world, "unit": "GB/s",
+                "frac": round(value * 1e6 * (2 * nb + 4) / 1e9 / (8000.0 * world), 6),
+                "traffic": None},
+        }
+        print(json.dumps(out))
+    comm.barrier()
+    dist.destroy_process_group()

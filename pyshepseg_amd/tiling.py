@@ -376,6 +376,145 @@ class _TileJob(object):
                  'error')
 
 
+def trimmedWindow(tileInfo, col, row, xpos, ypos, xsize, ysize, overlapSize):
+    """(top, bottom, left, right, xout, yout) of a tile: the part of it that is written to the
+    output, i.e. the tile minus half the overlap on interior sides (reference tiling.py:997-1022)."""
+    marginSize = int(overlapSize / 2)
+    (top, bottom, left, right) = (marginSize, ysize - marginSize, marginSize, xsize - marginSize)
+    (xout, yout) = (xpos + marginSize, ypos + marginSize)
+    if row == 0:
+        top = 0
+        yout = ypos
+    if row == tileInfo.nrows - 1:
+        bottom = ysize
+    if col == 0:
+        left = 0
+        xout = xpos
+    if col == tileInfo.ncols - 1:
+        right = xsize
+    return (top, bottom, left, right, xout, yout)
+
+
+def makeTileJobs(tileInfo, rows=None):
+    """Row-major list of tile jobs (optionally only the given tile rows) with their offsets in
+    one contiguous label block; returns (jobs, total pixels)."""
+    jobs = []
+    total = 0
+    for (col, row) in sorted(tileInfo.tiles.keys(), key=lambda x: (x[1], x[0])):
+        if rows is not None and row not in rows:
+            continue
+        j = _TileJob()
+        (j.col, j.row) = (col, row)
+        (j.xpos, j.ypos, j.xsize, j.ysize) = tileInfo.getTile(col, row)
+        j.offset = total
+        j.maxLocal = 0
+        j.done = threading.Event()
+        j.error = None
+        total += j.xsize * j.ysize
+        jobs.append(j)
+    return jobs, total
+
+
+def startSegmentationWorkers(src, jobs, d_tiles, centres, msd, imgNullVal, fourConnected,
+        minSegmentSize, numWorkers, timings, bands=None, yOrigin=0, maxConcurrentReads=20,
+        verbose=False):
+    """Start `numWorkers` threads, each with a pooled HIP context (one stream), that segment
+    the jobs' windows of `src` (tile window rows are relative to yOrigin when src holds only a
+    slice of the raster) into the device label block d_tiles.  Mirrors SegThreadsMgr.worker
+    (reference tiling.py:1560-1600).  Returns (threads, forceExit event)."""
+    L = _lib.lib()
+    nullFlag = int(imgNullVal is not None)
+    nullV = 0 if imgNullVal is None else int(imgNullVal)
+    onDevice = isinstance(src, DeviceRaster)
+    nBandsAll = src.shape[0]
+    if bands is None:
+        bands = list(range(nBandsAll))
+    if onDevice and list(bands) != list(range(nBandsAll)):
+        raise PyShepSegTilingError("band selection on a DeviceRaster is not supported")
+    dtcode = _lib.SHP_DTYPES[numpy.dtype(src.dtype)] if onDevice else None
+    (srcYsize, srcXsize) = (src.shape[1], src.shape[2])
+    readSem = threading.BoundedSemaphore(max(1, maxConcurrentReads))
+    inQue = queue.Queue()
+    for j in jobs:
+        inQue.put(j)
+    forceExit = threading.Event()
+
+    def worker():
+        try:
+            with _lib.pooled_ctx() as c:
+                worker_loop(c)
+        except Exception as e:          # no GPU, library missing ...
+            forceExit.set()
+            for jj in jobs:
+                if jj.error is None and not jj.done.is_set():
+                    jj.error = e
+                jj.done.set()
+
+    def worker_loop(c):
+        while not forceExit.is_set():
+            try:
+                j = inQue.get_nowait()
+            except queue.Empty:
+                break
+            try:
+                mx = ctypes.c_uint32(0)
+                s1 = ctypes.c_int64(0)
+                s2 = ctypes.c_int64(0)
+                ncl = ctypes.c_uint32(0)
+                dseg = ctypes.c_void_p(d_tiles.value + 4 * j.offset)
+                if onDevice:
+                    with timings.interval('segmentation'):
+                        c.check(L.shp_segment_window_dev(
+                            c.handle, ctypes.c_void_p(src.ptr), dtcode, nBandsAll, srcYsize,
+                            srcXsize, j.xpos, j.ypos - yOrigin, j.xsize, j.ysize, _lib.ptr(centres),
+                            centres.shape[0], nullFlag, nullV, int(bool(fourConnected)),
+                            int(minSegmentSize), float(msd), dseg, ctypes.byref(mx),
+                            ctypes.byref(s1), ctypes.byref(s2), ctypes.byref(ncl)))
+                else:
+                    with timings.interval('reading'):
+                        with readSem:
+                            img = src.read(bands, j.xpos, j.ypos - yOrigin, j.xsize, j.ysize)
+                    img, dt = _lib.as_image(img)
+                    with timings.interval('segmentation'):
+                        c.check(L.shp_segment_tile_to_dev(
+                            c.handle, _lib.ptr(img), dt, img.shape[0], j.ysize, j.xsize,
+                            _lib.ptr(centres), centres.shape[0], nullFlag, nullV,
+                            int(bool(fourConnected)), int(minSegmentSize), float(msd), dseg,
+                            ctypes.byref(mx), ctypes.byref(s1), ctypes.byref(s2),
+                            ctypes.byref(ncl)))
+                j.maxLocal = mx.value
+                if verbose:
+                    print("Tile ({}, {}): {} segments".format(j.col, j.row, mx.value))
+            except Exception as e:
+                j.error = e
+                forceExit.set()
+            j.done.set()
+
+    with timings.interval('startworkers'):
+        threads = [threading.Thread(target=worker, daemon=True) for _ in range(max(1, numWorkers))]
+        for t in threads:
+            t.start()
+    return threads, forceExit
+
+
+def waitForTile(j, jobs, threads, forceExit, timeout):
+    """Block until tile job j is segmented; raise like the reference on failure / timeout
+    (tiling.py:1045-1053, :918-928)."""
+    while not j.done.wait(timeout=max(timeout, 1)):
+        if forceExit.is_set():
+            break
+        if not any(t.is_alive() for t in threads):
+            break
+    if j.error is not None or not j.done.is_set():
+        forceExit.set()
+        err = j.error
+        for jj in jobs:
+            err = err or jj.error
+        if isinstance(err, _lib.ShepsegHipError):
+            raise err
+        raise PyShepSegTilingError("Tile ({}, {}) failed: {}".format(j.col, j.row, err))
+
+
 def doTiledShepherdSegmentation(infile, outfile, tileSize=DFLT_TILESIZE,
         overlapSize=DFLT_OVERLAPSIZE, minSegmentSize=50, numClusters=60,
         bandNumbers=None, subsamplePcnt=None, maxSpectralDiff='auto',
@@ -424,127 +563,29 @@ def doTiledShepherdSegmentation(infile, outfile, tileSize=DFLT_TILESIZE,
         main = _lib.ctx()
         L = main._L
         # one device block for every tile's labels, one for the stitched raster
-        jobs = []
-        total = 0
-        for (col, row) in sorted(tileInfo.tiles.keys(), key=lambda x: (x[1], x[0])):
-            j = _TileJob()
-            (j.col, j.row) = (col, row)
-            (j.xpos, j.ypos, j.xsize, j.ysize) = tileInfo.getTile(col, row)
-            j.offset = total
-            j.maxLocal = 0
-            j.done = threading.Event()
-            j.error = None
-            total += j.xsize * j.ysize
-            jobs.append(j)
+        jobs, total = makeTileJobs(tileInfo)
         jobmap = {(j.col, j.row): j for j in jobs}
         nbTiles, nbOut = max(total, 1) * 4, max(inYsize * inXsize, 1) * 4
         d_tiles = _devAlloc(main, nbTiles)
         d_out = _devAlloc(main, nbOut)
         d_scal = _devAlloc(main, 256)
         main.check(L.shp_dev_memset(main.handle, d_scal, 0, 256))
+        forceExit = None
         try:
-            nullFlag = int(imgNullVal is not None)
-            nullV = 0 if imgNullVal is None else int(imgNullVal)
-            onDevice = isinstance(src, DeviceRaster)
-            if onDevice and bands != list(range(nBandsAll)):
-                raise PyShepSegTilingError("band selection on a DeviceRaster is not supported")
-            dtcode = _lib.SHP_DTYPES[numpy.dtype(src.dtype)] if onDevice else None
-            readSem = threading.BoundedSemaphore(max(1, concurrencyCfg.maxConcurrentReads))
-            inQue = queue.Queue()
-            for j in jobs:
-                inQue.put(j)
-            forceExit = threading.Event()
-
-            def worker():
-                try:
-                    with _lib.pooled_ctx() as c:
-                        worker_loop(c)
-                except Exception as e:          # no GPU, library missing ...
-                    forceExit.set()
-                    for jj in jobs:
-                        if jj.error is None and not jj.done.is_set():
-                            jj.error = e
-                        jj.done.set()
-
-            def worker_loop(c):
-                while not forceExit.is_set():
-                    try:
-                        j = inQue.get_nowait()
-                    except queue.Empty:
-                        break
-                    try:
-                        mx = ctypes.c_uint32(0)
-                        s1 = ctypes.c_int64(0)
-                        s2 = ctypes.c_int64(0)
-                        ncl = ctypes.c_uint32(0)
-                        dseg = ctypes.c_void_p(d_tiles.value + 4 * j.offset)
-                        if onDevice:
-                            with timings.interval('segmentation'):
-                                c.check(L.shp_segment_window_dev(
-                                    c.handle, ctypes.c_void_p(src.ptr), dtcode, nBandsAll, inYsize,
-                                    inXsize, j.xpos, j.ypos, j.xsize, j.ysize, _lib.ptr(centres),
-                                    centres.shape[0], nullFlag, nullV, int(bool(fourConnected)),
-                                    int(minSegmentSize), float(msd), dseg, ctypes.byref(mx),
-                                    ctypes.byref(s1), ctypes.byref(s2), ctypes.byref(ncl)))
-                        else:
-                            with timings.interval('reading'):
-                                with readSem:
-                                    img = src.read(bands, j.xpos, j.ypos, j.xsize, j.ysize)
-                            img, dt = _lib.as_image(img)
-                            with timings.interval('segmentation'):
-                                c.check(L.shp_segment_tile_to_dev(
-                                    c.handle, _lib.ptr(img), dt, img.shape[0], j.ysize, j.xsize,
-                                    _lib.ptr(centres), centres.shape[0], nullFlag, nullV,
-                                    int(bool(fourConnected)), int(minSegmentSize), float(msd), dseg,
-                                    ctypes.byref(mx), ctypes.byref(s1), ctypes.byref(s2),
-                                    ctypes.byref(ncl)))
-                        j.maxLocal = mx.value
-                        if verbose:
-                            print("Tile ({}, {}): {} segments".format(j.col, j.row, mx.value))
-                    except Exception as e:
-                        j.error = e
-                        forceExit.set()
-                    j.done.set()
-
             numWorkers = 1
             if concurrencyCfg.concurrencyType != CONC_NONE:
                 numWorkers = max(1, int(concurrencyCfg.numWorkers))
-            with timings.interval('startworkers'):
-                threads = [threading.Thread(target=worker, daemon=True) for _ in range(numWorkers)]
-                for t in threads:
-                    t.start()
+            threads, forceExit = startSegmentationWorkers(
+                src, jobs, d_tiles, centres, msd, imgNullVal, fourConnected, minSegmentSize,
+                numWorkers, timings, bands=bands, maxConcurrentReads=concurrencyCfg.maxConcurrentReads,
+                verbose=verbose)
 
             # ---- stitchTiles (tiling.py:950-1064): sequential, concurrent with the workers ----
-            marginSize = int(overlapSize / 2)
             with timings.interval('stitchtiles'):
                 for j in jobs:
-                    timeout = concurrencyCfg.tileCompletionTimeout
-                    while not j.done.wait(timeout=max(timeout, 1)):
-                        if forceExit.is_set():
-                            break
-                        if not any(t.is_alive() for t in threads):
-                            break
-                    if j.error is not None or not j.done.is_set():
-                        forceExit.set()
-                        err = j.error
-                        for jj in jobs:
-                            err = err or jj.error
-                        if isinstance(err, _lib.ShepsegHipError):
-                            raise err
-                        raise PyShepSegTilingError("Tile ({}, {}) failed: {}".format(j.col, j.row, err))
-                    (top, bottom, left, right) = (marginSize, j.ysize - marginSize, marginSize,
-                                                  j.xsize - marginSize)
-                    (xout, yout) = (j.xpos + marginSize, j.ypos + marginSize)
-                    if j.row == 0:
-                        top = 0
-                        yout = j.ypos
-                    if j.row == tileInfo.nrows - 1:
-                        bottom = j.ysize
-                    if j.col == 0:
-                        left = 0
-                        xout = j.xpos
-                    if j.col == tileInfo.ncols - 1:
-                        right = j.xsize
+                    waitForTile(j, jobs, threads, forceExit, concurrencyCfg.tileCompletionTimeout)
+                    (top, bottom, left, right, xout, yout) = trimmedWindow(
+                        tileInfo, j.col, j.row, j.xpos, j.ypos, j.xsize, j.ysize, overlapSize)
                     topB = leftB = None
                     (topPitch, leftPitch) = (0, 0)
                     if not simpleTileRecode:
@@ -560,7 +601,7 @@ def doTiledShepherdSegmentation(infile, outfile, tileSize=DFLT_TILESIZE,
                         main.handle, ctypes.c_void_p(d_tiles.value + 4 * j.offset), j.ysize, j.xsize,
                         overlapSize, topB, topPitch, leftB, leftPitch, j.maxLocal,
                         int(bool(simpleTileRecode)), d_scal, top, bottom, left, right, d_out,
-                        inXsize, xout - 0, yout - 0))
+                        inXsize, xout, yout))
                 main.check(L.shp_sync(main.handle))
             for t in threads:
                 t.join()
@@ -592,9 +633,8 @@ def doTiledShepherdSegmentation(infile, outfile, tileSize=DFLT_TILESIZE,
                     _writeGdal(outfile, segimg, hist, infile, outputDriver, creationOptions,
                                writeHistogram)
         finally:
-            forceExit_ = locals().get('forceExit')
-            if forceExit_ is not None:
-                forceExit_.set()
+            if forceExit is not None:
+                forceExit.set()
             L.shp_sync(main.handle)
             _devRelease(main, d_tiles, nbTiles)
             _devRelease(main, d_out, nbOut)

@@ -1,0 +1,96 @@
+"""Test-only engine for pyshepseg_amd.distributed.runDistributed built on the CPU oracle, so
+that the sharding / boundary-exchange logic of the multi-GPU driver can be exercised with
+world_size 2 over gloo on a machine without GPUs."""
+import numpy as np
+
+
+class _KM(object):
+    def __init__(self, c):
+        self.cluster_centers_ = c
+
+
+class OracleEngine(object):
+    def __init__(self, img, oracle):
+        self.img = img              # the whole raster; only this rank's rows are touched
+        self.orc = oracle
+
+    def setup(self, tileInfo, jobs, total, yLo, yHi, outLo, outHi, nCols, overlapSize):
+        self.tileInfo, self.jobs = tileInfo, jobs
+        (self.yLo, self.yHi, self.outLo, self.outHi) = (yLo, yHi, outLo, outHi)
+        self.nCols, self.ov = nCols, overlapSize
+        self.slice = self.img[:, yLo:yHi]
+        self.out = np.zeros((outHi - outLo, nCols), dtype=np.uint32)
+        self.local, self.recoded = {}, {}
+        self.maxSeg = 0
+        self.touched = set()
+
+    def subsample(self, rowsGlobal, cols):
+        assert len(rowsGlobal) == 0 or (rowsGlobal.min() >= self.yLo and rowsGlobal.max() < self.yHi)
+        return np.ascontiguousarray(self.slice[:, rowsGlobal - self.yLo][:, :, cols])
+
+    def fit(self, img, numClusters, imgNullVal, fixedKMeansInit):
+        from pyshepseg_amd import shepseg
+        xs = shepseg._sample_rows(img, 100, imgNullVal)
+        init = shepseg.diagonalClusterCentres(xs, numClusters).astype(np.float64)
+        c, _l, _n = self.orc.kmeans_fit(xs.astype(np.float64), init)
+        return _KM(c)
+
+    def startSegmentation(self, centres, msd, imgNullVal, fourConnected, minSegmentSize):
+        for j in self.jobs:
+            sub = np.ascontiguousarray(self.slice[:, j.ypos - self.yLo:j.ypos - self.yLo + j.ysize,
+                                                  j.xpos:j.xpos + j.xsize])
+            self.local[(j.col, j.row)] = self.orc.segment_tile(
+                sub, centres, minSegmentSize, float(msd), imgNullVal, fourConnected)['segimg']
+
+    def waitTile(self, j):
+        pass
+
+    def setMaxSegId(self, v):
+        self.maxSeg = int(v)
+
+    def getMaxSegId(self):
+        return self.maxSeg
+
+    def bottomStripOf(self, a):
+        return self.recoded[(a.col, a.row)][-self.ov:, :]
+
+    def rightStripOf(self, a):
+        return self.recoded[(a.col, a.row)][:, -self.ov:]
+
+    def stitchTile(self, j, top, left, win, simple):
+        (t, b, l, r, xout, yout) = win
+        tile = self.local[(j.col, j.row)]
+        if simple:
+            rec = np.where(tile == 0, 0, tile + np.uint32(self.maxSeg)).astype(np.uint32)
+        else:
+            rec = self.orc.recode_tile(tile, self.ov, top, left, self.maxSeg, t, b, l, r)
+        self.recoded[(j.col, j.row)] = rec
+        trimmed = rec[t:b, l:r]
+        self.out[yout - self.outLo:yout - self.outLo + trimmed.shape[0],
+                 xout:xout + trimmed.shape[1]] = trimmed
+        self.maxSeg = max(self.maxSeg, int(trimmed.max()))
+
+    def sendBoundary(self, comm, dst, maxSegId, lastRowJobs):
+        import torch
+        comm.send(torch.tensor([maxSegId], dtype=torch.int64), dst)
+        for a in lastRowJobs:
+            s = np.ascontiguousarray(self.bottomStripOf(a)).view(np.int32).reshape(-1)
+            comm.send(torch.from_numpy(s.copy()), dst)
+
+    def recvBoundary(self, comm, src, tileInfo, aboveRow):
+        import torch
+        hdr = torch.zeros(1, dtype=torch.int64)
+        comm.recv(hdr, src)
+        strips = {}
+        for col in range(tileInfo.ncols):
+            xsize = tileInfo.getTile(col, aboveRow)[2]
+            buf = torch.empty(self.ov * xsize, dtype=torch.int32)
+            comm.recv(buf, src)
+            strips[col] = buf.numpy().view(np.uint32).reshape(self.ov, xsize)
+        return int(hdr[0]), strips
+
+    def histogram(self, maxSegId):
+        return np.bincount(self.out.ravel(), minlength=maxSegId + 1)[:maxSegId + 1]
+
+    def finish(self):
+        pass

@@ -1,0 +1,74 @@
+"""CPU (gloo, world_size 2 and 3): the multi-GPU driver's sharding, k-means gather/broadcast,
+stitch chain with boundary exchange and histogram all-reduce, run with the oracle engine, must
+reproduce the single-process tiled result exactly."""
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+class _Ds(object):
+    def __init__(self, ys, xs):
+        self.RasterYSize, self.RasterXSize = ys, xs
+
+
+def test_shard_tile_rows():
+    from pyshepseg_amd import tiling, distributed
+    ti = tiling.getTilesForFile(_Ds(40000, 40000), 4096, 1024)
+    for world in (1, 2, 3, 4, 8, 12, 16):
+        sh = distributed.shardTileRows(ti, world)
+        assert len(sh) == world
+        rows = [r for (a, b) in sh for r in range(a, b)]
+        assert rows == list(range(ti.nrows))                       # contiguous, complete, ordered
+        assert sum(1 for (a, b) in sh if b > a) == min(world, ti.nrows)
+    sh = distributed.shardTileRows(ti, 8)
+    assert max(b - a for (a, b) in sh) <= 2
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.mark.parametrize('world,simple', [(2, 0), (3, 0), (2, 1)])
+def test_two_rank_chain_matches_single_process(world, simple, tmp_path, oracle):
+    img = oracle.synthimg(31, 3, 330, 260)
+    img[:, :4, :] = 65535                      # a null border row band (nulls are not given here)
+    np.save(tmp_path / 'img.npy', img)
+    tile, ov = 96, 32
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', OMP_NUM_THREADS='1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+           '--nproc-per-node', str(world), '--master-addr', '127.0.0.1',
+           '--master-port', str(_free_port()), os.path.join(ROOT, 'tests', 'dist_worker.py'),
+           str(tmp_path), str(tile), str(ov), str(simple)]
+    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    parts = [np.load(tmp_path / ('rank%d.npz' % r)) for r in range(world)]
+    # single-process reference: oracle tiles + oracle stitch with the same centres
+    centres, msd = parts[0]['centres'], float(parts[0]['msd'])
+    for q in parts[1:]:
+        assert np.array_equal(q['centres'], centres)
+    tiles, ntc, ntr = oracle.get_tiles(330, 260, tile, ov)
+    local = {}
+    for (c, r), (x, y, xs, ys) in tiles.items():
+        sub = np.ascontiguousarray(img[:, y:y + ys, x:x + xs])
+        local[(c, r)] = oracle.segment_tile(sub, centres, 12, msd, None, True)['segimg']
+    want, mx, hist = oracle.stitch_tiles(local, tiles, ntc, ntr, 330, 260, ov, simple=bool(simple))
+    got = np.zeros_like(want)
+    covered = 0
+    for q in parts:
+        lo, hi = int(q['outLo']), int(q['outHi'])
+        got[lo:hi] = q['out']
+        covered += hi - lo
+        assert int(q['maxSegId']) == mx
+        assert np.array_equal(q['hist'], hist)
+    assert covered == 330
+    assert np.array_equal(got, want)
