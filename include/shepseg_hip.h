@@ -154,6 +154,23 @@ int shp_stitch_tile_dev(shp_ctx *ctx, uint32_t *d_tile, int ys, int xs, int over
 int shp_histogram_dev(shp_ctx *ctx, const uint32_t *d_raster, int64_t npix, uint32_t max_seg_id,
                       uint32_t *hist_out_host);
 
+/* ---- per-segment statistics ("tilingstats") ----------------------------------------------------
+ * replaces tilingstats.accumulateSegDict / calcStatsForCompletedSegs / SegmentStats / RatPage
+ * (tilingstats.py:466-617, :866-1008, :1949-2045) for one image band against a label raster.
+ * stats_sel: nstats x 5 uint32 = {globalCol, statId, colType, colArrayIdx, param} exactly as
+ * tilingstats.makeFastStatsSelection (:798-863) builds it; statId 0..7 = min, max, mean, stddev,
+ * median, mode, percentile, pixcount; colType 0 = integer column, 1 = float column.
+ * intcols_out: (#int stats) x (max_seg_id+1) int64; floatcols_out: (#float stats) x
+ * (max_seg_id+1) float32 (the RatPage arrays, all pages concatenated); row 0 is zero. */
+int shp_segstats(shp_ctx *ctx, const uint32_t *seg, const void *band, int dtype, int64_t npix,
+                 uint32_t max_seg_id, int has_null, int64_t null_val, const uint32_t *stats_sel,
+                 int nstats, int64_t missing, int64_t *intcols_out, float *floatcols_out);
+/* same with the label raster and the band already in device memory */
+int shp_segstats_dev(shp_ctx *ctx, const uint32_t *d_seg, const void *d_band, int dtype,
+                     int64_t npix, uint32_t max_seg_id, int has_null, int64_t null_val,
+                     const uint32_t *stats_sel, int nstats, int64_t missing,
+                     int64_t *intcols_out, float *floatcols_out);
+
 #ifdef __cplusplus
 }
 #endif

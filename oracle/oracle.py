@@ -225,3 +225,40 @@ def stitch_tiles(tile_segs, tiles, ntcols, ntrows, nrows, ncols, overlap, simple
     hist = np.bincount(out.ravel(), minlength=max_seg + 1).astype(np.uint32)
     hist[0] = 0
     return out, max_seg, hist
+
+
+STAT_IDS = {'min': 0, 'max': 1, 'mean': 2, 'stddev': 3, 'median': 4, 'mode': 5, 'percentile': 6,
+            'pixcount': 7}
+
+
+def make_stats_sel(stats_selection):
+    """tilingstats.makeFastStatsSelection (:798-863) with global column index = position."""
+    sel = np.empty((len(stats_selection), 5), dtype=np.uint32)
+    ni = nf = 0
+    for i, st in enumerate(stats_selection):
+        name = st[1]
+        isf = name in ('mean', 'stddev')
+        sel[i] = (i, STAT_IDS[name], int(isf), nf if isf else ni,
+                  st[2] if name == 'percentile' else 0xFFFFFFFF)
+        if isf:
+            nf += 1
+        else:
+            ni += 1
+    return sel, ni, nf
+
+
+def segstats(seg, band, stats_selection, null_val=None, missing=-9999, max_seg_id=None):
+    seg = np.ascontiguousarray(seg, dtype=np.uint32)
+    band = np.ascontiguousarray(band)
+    assert band.dtype in DTYPES and band.size == seg.size
+    if max_seg_id is None:
+        max_seg_id = int(seg.max()) if seg.size else 0
+    sel, ni, nf = make_stats_sel(stats_selection)
+    ic = np.zeros((ni, max_seg_id + 1), dtype=np.int64)
+    fc = np.zeros((nf, max_seg_id + 1), dtype=np.float32)
+    rc = lib().orc_segstats(_p(seg), _p(band), DTYPES[band.dtype], ctypes.c_int64(seg.size),
+                            ctypes.c_uint32(max_seg_id), int(null_val is not None),
+                            ctypes.c_int64(0 if null_val is None else int(null_val)), _p(sel),
+                            len(stats_selection), ctypes.c_int64(int(missing)), _p(ic), _p(fc))
+    assert rc == 0
+    return ic, fc

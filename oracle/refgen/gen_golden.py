@@ -110,6 +110,66 @@ def main():
          p90=np.float64(shepseg.autoMaxSpectralDiff(km, 'auto', 90)),
          none=np.float64(shepseg.autoMaxSpectralDiff(km, None, 50)))
     stitch_cases()
+    stats_cases()
+
+
+def stats_case(name, seg, band, null_val, sel, missing=-9999, tile=64):
+    """tilingstats.calcPerSegmentStatsTiled's compute loop (tilingstats.py:183-206) driven
+    through the reference's accumulateSegDict / calcStatsForCompletedSegs / RatPage, on arrays."""
+    import osgeo  # noqa: F401  (import-only stub next to this script)
+    from pyshepseg import tilingstats as ts
+    seg_size = np.bincount(seg.ravel()).astype(np.uint32)
+    fast, nint, nflt = ts.makeFastStatsSelection(list(range(len(sel))), sel)
+    segDict = ts.createSegDict()
+    noData = ts.createNoDataDict()
+    paged = ts.createPagedRat()
+    nullv = None if null_val is None else ts.numbaTypeForImageType(null_val)
+    (nr, nc) = seg.shape
+    for y in range(0, nr, tile):
+        for x in range(0, nc, tile):
+            ts.accumulateSegDict(segDict, noData, nullv, seg[y:y + tile, x:x + tile],
+                                 band[y:y + tile, x:x + tile])
+            ts.calcStatsForCompletedSegs(segDict, noData, missing, paged, fast, seg_size, nint, nflt)
+    assert len(segDict) == 0
+    ns = len(seg_size)
+    ic = np.zeros((nint, ns), dtype=np.int64)
+    fc = np.zeros((nflt, ns), dtype=np.float32)
+    done = np.zeros(ns, dtype=bool)
+    for pid in paged:
+        pg = paged[pid]
+        n = pg.intcols.shape[1] if nint else pg.floatcols.shape[1]
+        ic[:, pid:pid + n] = pg.intcols
+        fc[:, pid:pid + n] = pg.floatcols
+        done[pid:pid + n] = pg.complete
+    save(name, seg=seg, band=band, null_val=np.int64(-1 if null_val is None else null_val),
+         has_null=np.int64(null_val is not None), missing=np.int64(missing),
+         sel_names=np.array([t[1] for t in sel]),
+         sel_params=np.array([t[2] if len(t) > 2 else -1 for t in sel], dtype=np.int64),
+         intcols=ic, floatcols=fc, complete=done)
+
+
+def stats_cases():
+    g = np.load(os.path.join(OUT, 'stitch_3x3_null.npz'))
+    seg = g['mosaic']
+    img = g['img']
+    sel = [('mn', 'min'), ('mx', 'max'), ('mean', 'mean'), ('sd', 'stddev'), ('med', 'median'),
+           ('mode', 'mode'), ('p0', 'percentile', 0), ('p25', 'percentile', 25),
+           ('p75', 'percentile', 75), ('p100', 'percentile', 100), ('n', 'pixcount')]
+    stats_case('stats_u16_nonull', seg, img[0], None, sel)
+    band = img[1].copy()
+    band[seg == 7] = 65535                      # one segment entirely nodata
+    stats_case('stats_u16_null', seg, band, 65535, sel)
+    rng = np.random.RandomState(8)
+    segb = (np.arange(96 * 120).reshape(96, 120) // 7 % 40 + 1).astype(np.uint32)
+    segb[:5] = 0
+    bandi = rng.randint(-300, 300, size=segb.shape).astype(np.int16)
+    stats_case('stats_i16_ties', segb, bandi, -7, [('mode', 'mode'), ('med', 'median'),
+                                                    ('mean', 'mean'), ('sd', 'stddev'),
+                                                    ('n', 'pixcount'), ('p10', 'percentile', 10)])
+    big = (rng.randint(0, 4, size=(200, 200)) + 1).astype(np.uint32)    # 4 segments x ~10k px
+    bandb = rng.randint(60000, 65535, size=big.shape).astype(np.uint16)
+    stats_case('stats_big_segments', big, bandb, None, [('mean', 'mean'), ('sd', 'stddev'),
+                                                        ('med', 'median'), ('mode', 'mode')])
 
 
 def stitch_case(name, img, tile_size, overlap, k, min_seg, null_val, four):

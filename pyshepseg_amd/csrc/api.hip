@@ -9,6 +9,7 @@
 #include "elim_small.h"
 #include "synth.h"
 #include "stitch.h"
+#include "segstats.h"
 
 #define API extern "C" __attribute__((visibility("default")))
 
@@ -604,4 +605,37 @@ API int shp_prof_get(shp_ctx *ctx, double *ms_out, uint64_t *count_out, int n, i
     for (int i = 0; i < n && i < PROF_N; i++) { ms_out[i] = ctx->prof_ms[i]; count_out[i] = ctx->prof_cnt[i]; }
     if (reset) for (int i = 0; i < PROF_N; i++) { ctx->prof_ms[i] = 0; ctx->prof_cnt[i] = 0; }
     return 0;
+}
+
+// ---- per-segment statistics (tilingstats) -------------------------------------------------------
+API int shp_segstats_dev(shp_ctx *ctx, const uint32_t *d_seg, const void *d_band, int dtype,
+                         int64_t npix, uint32_t max_seg_id, int has_null, int64_t null_val,
+                         const uint32_t *stats_sel, int nstats, int64_t missing,
+                         int64_t *intcols_out, float *floatcols_out)
+{
+    CHK(enter(ctx));
+    if (!d_seg || !d_band || !stats_sel || nstats < 1 || dtype_size(dtype) == 0)
+        SHP_FAIL(ctx, SHP_ERR_ARG, "bad argument");
+    if (npix < 0 || npix >= 0xffffffffll) SHP_FAIL(ctx, SHP_ERR_ARG, "raster too large (%lld px)", (long long)npix);
+    return run_segstats(ctx, d_seg, d_band, dtype, (uint32_t)npix, max_seg_id, has_null, null_val,
+                        stats_sel, nstats, missing, intcols_out, floatcols_out);
+}
+
+API int shp_segstats(shp_ctx *ctx, const uint32_t *seg, const void *band, int dtype, int64_t npix,
+                     uint32_t max_seg_id, int has_null, int64_t null_val, const uint32_t *stats_sel,
+                     int nstats, int64_t missing, int64_t *intcols_out, float *floatcols_out)
+{
+    CHK(enter(ctx));
+    if (!seg || !band || !stats_sel || nstats < 1 || dtype_size(dtype) == 0)
+        SHP_FAIL(ctx, SHP_ERR_ARG, "bad argument");
+    if (npix < 0 || npix >= 0xffffffffll) SHP_FAIL(ctx, SHP_ERR_ARG, "raster too large (%lld px)", (long long)npix);
+    CHK(buf_ensure(ctx, ctx->seg, (size_t)npix * 4));
+    CHK(buf_ensure(ctx, ctx->img, (size_t)npix * dtype_size(dtype)));
+    if (npix) {
+        HIPCHK(ctx, hipMemcpyAsync(ctx->seg.p, seg, (size_t)npix * 4, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->img.p, band, (size_t)npix * dtype_size(dtype), hipMemcpyHostToDevice,
+                                   ctx->stream));
+    }
+    return run_segstats(ctx, bp<uint32_t>(ctx->seg), ctx->img.p, dtype, (uint32_t)npix, max_seg_id,
+                        has_null, null_val, stats_sel, nstats, missing, intcols_out, floatcols_out);
 }
