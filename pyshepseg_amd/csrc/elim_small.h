@@ -124,41 +124,79 @@ __global__ __launch_bounds__(256) void k_small_init(const uint32_t *__restrict__
     if (threadIdx.x < min_seg && lh[threadIdx.x]) atomicAdd(&hist[threadIdx.x], lh[threadIdx.x]);
 }
 
-// Device-side loop control of eliminateSmallSegments (shepseg.py:970-997).  The host enqueues
-// identical "pass slots" without reading anything back; the one-thread control kernel at the
-// head of each slot advances (target, prev, passes) exactly like the reference's for/while and
-// stops at the next pass that has sources to merge.  Every other kernel of the slot exits at
-// once when ctl->active == 0.
+// ---------------------------------------------------------------------------------------------
+// The find/merge pass loop of eliminateSmallSegments (shepseg.py:970-997) as ONE persistent
+// kernel per tile.  A pass needs six grid-wide dependencies (find -> mark -> alloc -> fill ->
+// rank -> apply); as separate launches that was ~400 tiny dispatches per tile, each costing
+// 0.1-0.3 ms once 16 tiles share the GPU.  Here SMALL_BLOCKS workgroups stay resident and
+// meet at software grid barriers (agent-scope release / acquire as MI355X_MICROARCH.md and
+// cdna_hip_programming.md Guideline 16 prescribe: every storing wave drains vmcnt, workgroup
+// barrier, one lane's release fence, arrive; poll; one lane's acquire fence, drain, workgroup
+// barrier).  Every spin is bounded; on a timeout the kernel sets ctl->fail and every workgroup
+// leaves.  The loop control (target, prevCount, numPasses) is recomputed identically by every
+// workgroup from the device-side size histogram, so no launch and no host read-back happens
+// between passes.  The host caps the number of concurrently running persistent kernels so
+// that all their workgroups are co-resident.
+// ---------------------------------------------------------------------------------------------
+#define SMALL_BLOCKS 64u
+#define SMALL_SPIN_LIMIT (1u << 25)
+
+struct SmallCnt { uint32_t nsrc, ntgt, bump, pad; };
+struct SmallState { uint32_t target; int32_t prev; uint32_t passes; uint32_t pad; };
 struct SmallCtl {
-    uint32_t target;     // current targetSize
-    int32_t prev;        // prevCount (-1 = none)
-    uint32_t passes;     // numPasses for this target
-    uint32_t active;     // this slot runs a find/merge pass
-    uint32_t done;       // target reached minSegSize
-    uint32_t nelim;      // numElim
-    uint32_t nsrc, ntgt, bump, pad;
+    SmallState st[2];        // double-buffered loop state (slot parity)
+    SmallCnt cnt[2];         // double-buffered per-pass counters
+    uint32_t bar_count, bar_gen;
+    uint32_t nelim, fail, done, slots;
 };
 
-__global__ void k_small_ctl(SmallCtl *ctl, const uint32_t *__restrict__ hist, uint32_t min_seg)
+struct SmallArgs {
+    SmallCtl *ctl;
+    uint32_t *hist;
+    uint32_t *seg, *segsz;
+    float *ssum;
+    const uint32_t *pix, *off, *origsz;
+    uint32_t *chnext, *chtail, *mergeto, *tcount, *toff, *tfill, *tlist, *tsorted, *srclist, *tgtlist;
+    uint32_t S, min_seg, nrows, ncols;
+    int nb, four;
+    double thr2;
+};
+
+__device__ __forceinline__ bool small_grid_barrier(SmallCtl *ctl, uint32_t nblocks)
 {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    ctl->nsrc = 0; ctl->ntgt = 0; ctl->bump = 0;
-    uint32_t target = ctl->target, passes = ctl->passes;
-    int32_t prev = ctl->prev;
-    uint32_t active = 0, done = 0;
-    for (;;) {
-        if (target >= min_seg) { done = 1; break; }
-        const int32_t count = (int32_t)hist[target];
-        if (count != prev && passes < 10u) {          // `while` condition, shepseg.py:980
-            prev = count;
-            passes++;
-            if (count > 0) { active = 1; break; }     // a pass with sources: run the kernels
+    __shared__ uint32_t s_ok;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's stores have left
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t ok = 1;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint32_t gen = __hip_atomic_load(&ctl->bar_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t arrived = __hip_atomic_fetch_add(&ctl->bar_count, 1u, __ATOMIC_RELAXED,
+                                                        __HIP_MEMORY_SCOPE_AGENT) + 1u;
+        if (arrived == nblocks) {
+            __hip_atomic_store(&ctl->bar_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_fetch_add(&ctl->bar_gen, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
-            target++; prev = -1; passes = 0;          // next targetSize, shepseg.py:970
+            uint32_t spins = 0;
+            while (__hip_atomic_load(&ctl->bar_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) {
+                __builtin_amdgcn_s_sleep(8);
+                if (++spins > SMALL_SPIN_LIMIT ||
+                    __hip_atomic_load(&ctl->fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    __hip_atomic_store(&ctl->fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    ok = 0;
+                    break;
+                }
+            }
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        s_ok = ok;
     }
-    ctl->target = target; ctl->prev = prev; ctl->passes = passes;
-    ctl->active = active; ctl->done = done;
+    __syncthreads();
+    return s_ok != 0;
 }
 
 __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
@@ -171,229 +209,243 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
     return v;
 }
 
-// findMergeSegment (shepseg.py:1003-1063) for one source, executed by a whole wavefront: one
-// lane per pixel of its list.  The reference keeps the FIRST strict minimum in (list index k,
-// ii outer, jj inner) order (N7) == the lexicographic minimum of (distSqr, k, neighbour
-// position), found with one 64-bit wave reduction (distSqr >= +0, so its float32 bit pattern
-// orders like the value).
-__device__ __forceinline__ void find_merge_wave(
-    uint32_t s, const uint32_t *__restrict__ seg, const uint32_t *__restrict__ segsz,
-    const float *__restrict__ ssum, const uint32_t *__restrict__ pix,
-    const uint32_t *__restrict__ off, const uint32_t *__restrict__ origsz,
-    const uint32_t *__restrict__ chnext, uint32_t *__restrict__ mergeto, uint32_t target, int nb,
-    uint32_t nrows, uint32_t ncols, int four, double thr2)
+// findMergeSegment (shepseg.py:1003-1063) for one source by one wavefront.  The source's pixel
+// list (chunk chain = the reference's list order) is gathered 64 entries at a time into this
+// wave's LDS slice; lanes then own (pixel k, neighbour position) pairs.  The reference keeps
+// the FIRST strict minimum in (k, ii outer, jj inner) order (N7) == the lexicographic minimum
+// of (distSqr, k, position): one 64-bit wave reduction (distSqr >= +0, so its float32 bit
+// pattern orders like the value).
+__device__ __forceinline__ void find_merge_wave(uint32_t s, uint32_t target, const SmallArgs &a,
+                                                uint32_t *wpix)
 {
     const unsigned lane = lane_id();
     const float nf = (float)target;
+    const uint32_t nq = a.four ? 4u : 8u;
     unsigned long long best = ~0ull;         // (float bits of distSqr << 32) | order
     uint32_t bestnb = 0;
-    uint32_t k0 = 0;                         // list index of the current chunk's first pixel
-    for (uint32_t c = s; c != 0; c = (uint32_t)__builtin_amdgcn_readfirstlane((int)chnext[c])) {
-        const uint32_t o = (uint32_t)__builtin_amdgcn_readfirstlane((int)off[c]);
-        const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)origsz[c]);
-        for (uint32_t i0 = 0; i0 < m; i0 += 64u) {
-            const uint32_t i = i0 + lane;
-            if (i < m) {
-                const uint32_t k = k0 + i;
-                const uint32_t p = pix[o + i];
-                const uint32_t r = p / ncols, cc = p - r * ncols;
-                uint32_t last = 0, pos = 0;
-                for (int di = -1; di <= 1; di++)
-                    for (int dj = -1; dj <= 1; dj++) {
-                        if (di == 0 && dj == 0) continue;
-                        if (four && di != 0 && dj != 0) continue;
-                        const uint32_t mypos = pos++;
-                        const int ii = (int)r + di, jj = (int)cc + dj;
-                        if (ii < 0 || jj < 0 || ii >= (int)nrows || jj >= (int)ncols) continue;
-                        const uint32_t nbid = seg[(uint32_t)ii * ncols + (uint32_t)jj];
-                        if (nbid == s || nbid == 0 || nbid == last) continue;
-                        last = nbid;
-                        const uint32_t szn = segsz[nbid];
+    uint32_t c = s, ci = 0;                  // chain cursor: chunk id, index inside the chunk
+    uint32_t co = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.off[c]);
+    uint32_t cm = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.origsz[c]);
+    for (uint32_t kbase = 0; kbase < target; kbase += 64u) {
+        const uint32_t want = (target - kbase < 64u) ? (target - kbase) : 64u;
+        // gather list entries kbase .. kbase+want-1
+        uint32_t got = 0;
+        while (got < want) {
+            if (ci >= cm) {
+                c = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.chnext[c]);
+                if (c == 0) break;
+                ci = 0;
+                co = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.off[c]);
+                cm = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.origsz[c]);
+                continue;
+            }
+            uint32_t take = cm - ci;
+            if (take > want - got) take = want - got;
+            if (lane < take) wpix[got + lane] = a.pix[co + ci + lane];
+            got += take;
+            ci += take;
+        }
+        __builtin_amdgcn_wave_barrier();
+        const uint32_t npairs = got * nq;
+        for (uint32_t q0 = 0; q0 < npairs; q0 += 64u) {
+            const uint32_t q = q0 + lane;
+            if (q < npairs) {
+                const uint32_t kk = q / nq, pos = q - kk * nq;
+                const uint32_t p = wpix[kk];
+                const uint32_t r = p / a.ncols, cc = p - r * a.ncols;
+                int di, dj;                  // neighbour `pos` in (ii outer, jj inner) order
+                if (a.four) {
+                    di = (pos == 0u) ? -1 : (pos == 3u) ? 1 : 0;
+                    dj = (pos == 1u) ? -1 : (pos == 2u) ? 1 : 0;
+                } else {
+                    const uint32_t e = pos < 4u ? pos : pos + 1u;      // skip the centre
+                    di = (int)(e / 3u) - 1;
+                    dj = (int)(e % 3u) - 1;
+                }
+                const int ii = (int)r + di, jj = (int)cc + dj;
+                if (ii >= 0 && jj >= 0 && ii < (int)a.nrows && jj < (int)a.ncols) {
+                    const uint32_t nbid = a.seg[(uint32_t)ii * a.ncols + (uint32_t)jj];
+                    if (nbid != s && nbid != 0u) {
+                        const uint32_t szn = a.segsz[nbid];
                         if (szn > target) {
                             const float sf = (float)szn;
                             float d = 0.0f;
-                            for (int b = 0; b < nb; b++) {
-                                const float a = ssum[(size_t)s * nb + b] / nf;
-                                const float e = ssum[(size_t)nbid * nb + b] / sf;
-                                const float t = a - e;
+                            for (int b = 0; b < a.nb; b++) {
+                                const float x = a.ssum[(size_t)s * a.nb + b] / nf;
+                                const float e2 = a.ssum[(size_t)nbid * a.nb + b] / sf;
+                                const float t = x - e2;
                                 const float t2 = t * t;
                                 d = d + t2;
                             }
                             const unsigned long long key =
                                 ((unsigned long long)__float_as_uint(d) << 32) |
-                                (unsigned long long)(k * 8u + mypos);
+                                (unsigned long long)((kbase + kk) * 8u + pos);
                             if (key < best) { best = key; bestnb = nbid; }
                         }
                     }
+                }
             }
         }
-        k0 += m;
+        __builtin_amdgcn_wave_barrier();
+        if (c == 0) break;
     }
     const unsigned long long wmin = wave_min_u64(best);
-    if (wmin == ~0ull) { if (lane == 0) mergeto[s] = 0; return; }
+    if (wmin == ~0ull) { if (lane == 0) a.mergeto[s] = 0; return; }
     if (best == wmin) {                      // unique: (k, position) differs between lanes
         const float bd = __uint_as_float((uint32_t)(wmin >> 32));
-        mergeto[s] = ((double)bd > thr2) ? 0u : bestnb;
+        a.mergeto[s] = ((double)bd > a.thr2) ? 0u : bestnb;
     }
 }
 
-// find phase: each block finds the sources (size == target) among its 256 segment ids, appends
-// them to the global source list and lets its four wavefronts run findMergeSegment on them.
-__global__ __launch_bounds__(256) void k_find_merge(
-    const SmallCtl *ctlp, uint32_t *cnts, const uint32_t *__restrict__ seg,
-    const uint32_t *__restrict__ segsz, const float *__restrict__ ssum,
-    const uint32_t *__restrict__ pix, const uint32_t *__restrict__ off,
-    const uint32_t *__restrict__ origsz, const uint32_t *__restrict__ chnext,
-    uint32_t *__restrict__ mergeto, uint32_t *__restrict__ srclist, uint32_t S, int nb,
-    uint32_t nrows, uint32_t ncols, int four, double thr2)
+__global__ __launch_bounds__(256) void k_small_loop(SmallArgs a)
 {
     __shared__ uint32_t lsrc[256];
-    __shared__ uint32_t lcnt;
-    if (!ctlp->active) return;
-    const uint32_t target = ctlp->target;
-    if (threadIdx.x == 0) lcnt = 0;
-    __syncthreads();
-    const uint32_t s = blockIdx.x * 256u + threadIdx.x + 1u;
-    const bool is = s <= S && segsz[s] == target;
-    const unsigned long long m = __ballot(is);
-    if (m != 0ull) {
-        uint32_t lbase = 0, gbase = 0;
-        if (lane_id() == 0) {
-            lbase = atomicAdd(&lcnt, (uint32_t)__popcll(m));
-            gbase = atomicAdd(&cnts[0], (uint32_t)__popcll(m));
-        }
-        lbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)lbase);
-        gbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)gbase);
-        if (is) {
-            const uint32_t r = (uint32_t)__popcll(m & lanemask_lt());
-            lsrc[lbase + r] = s;
-            srclist[gbase + r] = s;
-        }
-    }
-    __syncthreads();
-    const uint32_t n = lcnt;
-    for (uint32_t i = threadIdx.x >> 6; i < n; i += 4u) {
-        const uint32_t src = (uint32_t)__builtin_amdgcn_readfirstlane((int)lsrc[i]);
-        find_merge_wave(src, seg, segsz, ssum, pix, off, origsz, chnext, mergeto, target, nb, nrows,
-                        ncols, four, thr2);
-    }
-}
-
-// merge phase, step 1 (per source): count sources per target, list the targets, relabel the
-// source's pixels (doMerge :1107-1109)
-__global__ __launch_bounds__(256) void k_merge_mark(
-    const SmallCtl *ctlp, uint32_t *__restrict__ seg,
-    const uint32_t *__restrict__ mergeto, const uint32_t *__restrict__ pix,
-    const uint32_t *__restrict__ off, const uint32_t *__restrict__ origsz,
-    const uint32_t *__restrict__ chnext, uint32_t *tcount, const uint32_t *__restrict__ srclist,
-    uint32_t *cnts, uint32_t *__restrict__ tgtlist)
-{
-    if (!ctlp->active) return;
-    const uint32_t nsrc = cnts[0];
-    for (uint32_t w = blockIdx.x * 256u + threadIdx.x; w < nsrc; w += gridDim.x * 256u) {
-        const uint32_t s = srclist[w];
-        const uint32_t t = mergeto[s];
-        if (t == 0) continue;
-        if (atomicAdd(&tcount[t], 1u) == 0u) tgtlist[atomicAdd(&cnts[1], 1u)] = t;
-        for (uint32_t c = s; c != 0; c = chnext[c]) {
-            const uint32_t o = off[c], m = origsz[c];
-            for (uint32_t i = 0; i < m; i++) seg[pix[o + i]] = t;
-        }
-    }
-}
-
-// storage for each target's source list (bump allocation; order is irrelevant)
-__global__ __launch_bounds__(256) void k_merge_alloc(const SmallCtl *ctlp,
-                                                     const uint32_t *__restrict__ tgtlist,
-                                                     const uint32_t *__restrict__ tcount,
-                                                     uint32_t *__restrict__ toff, uint32_t *cnts)
-{
-    if (!ctlp->active) return;
-    const uint32_t ntgt = cnts[1];
-    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < ntgt; i += gridDim.x * 256u) {
-        const uint32_t t = tgtlist[i];
-        toff[t] = atomicAdd(&cnts[2], tcount[t]);
-    }
-}
-
-__global__ __launch_bounds__(256) void k_merge_fill(const SmallCtl *ctlp,
-                                                    const uint32_t *__restrict__ mergeto,
-                                                    const uint32_t *__restrict__ toff,
-                                                    uint32_t *tfill, uint32_t *__restrict__ tlist,
-                                                    const uint32_t *__restrict__ srclist,
-                                                    const uint32_t *__restrict__ cnts)
-{
-    if (!ctlp->active) return;
-    const uint32_t nsrc = cnts[0];
-    for (uint32_t w = blockIdx.x * 256u + threadIdx.x; w < nsrc; w += gridDim.x * 256u) {
-        const uint32_t s = srclist[w];
-        const uint32_t t = mergeto[s];
-        if (t == 0) continue;
-        const uint32_t slot = atomicAdd(&tfill[t], 1u);
-        tlist[toff[t] + slot] = s;
-    }
-}
-
-__global__ __launch_bounds__(256) void k_merge_rank(const SmallCtl *ctlp,
-                                                    const uint32_t *__restrict__ mergeto,
-                                                    const uint32_t *__restrict__ toff,
-                                                    const uint32_t *__restrict__ tcount,
-                                                    const uint32_t *__restrict__ tlist,
-                                                    uint32_t *__restrict__ tsorted,
-                                                    const uint32_t *__restrict__ srclist,
-                                                    const uint32_t *__restrict__ cnts)
-{
-    if (!ctlp->active) return;
-    const uint32_t nsrc = cnts[0];
-    for (uint32_t w = blockIdx.x * 256u + threadIdx.x; w < nsrc; w += gridDim.x * 256u) {
-        const uint32_t s = srclist[w];
-        const uint32_t t = mergeto[s];
-        if (t == 0) continue;
-        const uint32_t base = toff[t], cnt = tcount[t];
-        uint32_t rank = 0;
-        for (uint32_t i = 0; i < cnt; i++) rank += (tlist[base + i] < s) ? 1u : 0u;
-        tsorted[base + rank] = s;
-    }
-}
-
-// merge phase, step 2: each target absorbs its sources in ascending id (doMerge :1112-1123)
-__global__ __launch_bounds__(256) void k_merge_apply(
-    SmallCtl *ctlp, uint32_t *segsz, float *ssum, uint32_t *chnext, uint32_t *chtail,
-    uint32_t *mergeto, uint32_t *tcount, uint32_t *tfill, const uint32_t *__restrict__ toff,
-    const uint32_t *__restrict__ tsorted, uint32_t *hist, const uint32_t *__restrict__ tgtlist,
-    const uint32_t *__restrict__ cnts, int nb, uint32_t min_seg)
-{
-    if (!ctlp->active) return;
-    const uint32_t target = ctlp->target;
-    const uint32_t ntgt = cnts[1];
-    for (uint32_t i0 = blockIdx.x * 256u + threadIdx.x; i0 < ntgt; i0 += gridDim.x * 256u) {
-        const uint32_t t = tgtlist[i0];
-        const uint32_t cnt = tcount[t];
-        const uint32_t base = toff[t];
-        const uint32_t a0 = segsz[t];
-        uint32_t sz = a0, tail = chtail[t];
-        for (uint32_t i = 0; i < cnt; i++) {
-            const uint32_t s = tsorted[base + i];
-            for (int b = 0; b < nb; b++) {
-                ssum[(size_t)t * nb + b] = ssum[(size_t)t * nb + b] + ssum[(size_t)s * nb + b];
-                ssum[(size_t)s * nb + b] = 0.0f;
+    __shared__ uint32_t wpix[4][64];
+    __shared__ uint32_t lcnt, s_target, s_done;
+    SmallCtl *ctl = a.ctl;
+    const uint32_t G = gridDim.x;
+    const uint32_t gtid = blockIdx.x * 256u + threadIdx.x, gthreads = G * 256u;
+    const uint32_t gwave = gtid >> 6, gwaves = gthreads >> 6;
+    const unsigned lane = lane_id(), w = threadIdx.x >> 6;
+    const uint32_t nchunks = (a.S + 255u) / 256u;       // segment ids 1..S in chunks of 256
+    for (uint32_t slot = 0;; slot++) {
+        const uint32_t par = slot & 1u;
+        // ---- loop control (identical in every workgroup; shepseg.py:970-997) ----
+        if (threadIdx.x == 0) {
+            uint32_t target = ctl->st[par].target, passes = ctl->st[par].passes;
+            int32_t prev = ctl->st[par].prev;
+            uint32_t done = 0;
+            for (;;) {
+                if (target >= a.min_seg) { done = 1; break; }
+                const int32_t count = (int32_t)a.hist[target];
+                if (count != prev && passes < 10u) {          // `while` condition, shepseg.py:980
+                    prev = count;
+                    passes++;
+                    if (count > 0) break;                      // a pass with sources
+                } else {
+                    target++; prev = -1; passes = 0;          // next targetSize, shepseg.py:970
+                }
             }
-            sz += segsz[s];
-            segsz[s] = 0;
-            chnext[tail] = s;
-            tail = chtail[s];
-            mergeto[s] = 0;
+            s_target = target; s_done = done;
+            if (blockIdx.x == 0) {
+                ctl->st[par ^ 1u].target = target; ctl->st[par ^ 1u].prev = prev;
+                ctl->st[par ^ 1u].passes = passes;
+                ctl->cnt[par ^ 1u].nsrc = 0; ctl->cnt[par ^ 1u].ntgt = 0; ctl->cnt[par ^ 1u].bump = 0;
+                if (done) { ctl->done = 1; ctl->slots = slot; }
+            }
         }
-        segsz[t] = sz;
-        chtail[t] = tail;
-        tcount[t] = 0;
-        tfill[t] = 0;
-        atomicSub(&hist[target], cnt);
-        if (a0 < min_seg) atomicSub(&hist[a0], 1u);
-        if (sz < min_seg) atomicAdd(&hist[sz], 1u);
-        atomicAdd(&ctlp->nelim, cnt);
+        __syncthreads();
+        if (s_done) break;
+        const uint32_t target = s_target;
+        SmallCnt *cnt = &ctl->cnt[par];
+        // ---- find phase: sources = segments of the target size ----
+        for (uint32_t ch = blockIdx.x; ch < nchunks; ch += G) {
+            if (threadIdx.x == 0) lcnt = 0;
+            __syncthreads();
+            const uint32_t s = ch * 256u + threadIdx.x + 1u;
+            const bool is = s <= a.S && a.segsz[s] == target;
+            const unsigned long long m = __ballot(is);
+            if (m != 0ull) {
+                uint32_t lbase = 0, gbase = 0;
+                if (lane == 0) {
+                    lbase = atomicAdd(&lcnt, (uint32_t)__popcll(m));
+                    gbase = atomicAdd(&cnt->nsrc, (uint32_t)__popcll(m));
+                }
+                lbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)lbase);
+                gbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)gbase);
+                if (is) {
+                    const uint32_t r = (uint32_t)__popcll(m & lanemask_lt());
+                    lsrc[lbase + r] = s;
+                    a.srclist[gbase + r] = s;
+                }
+            }
+            __syncthreads();
+            const uint32_t n = lcnt;
+            for (uint32_t i = w; i < n; i += 4u) {
+                const uint32_t src = (uint32_t)__builtin_amdgcn_readfirstlane((int)lsrc[i]);
+                find_merge_wave(src, target, a, wpix[w]);
+            }
+            __syncthreads();
+        }
+        if (!small_grid_barrier(ctl, G)) return;
+        const uint32_t nsrc = cnt->nsrc;
+        // ---- merge step 1 (wave per source): count per target, list targets, relabel pixels
+        //      (doMerge :1107-1109) ----
+        for (uint32_t i = gwave; i < nsrc; i += gwaves) {
+            const uint32_t s = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.srclist[i]);
+            const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.mergeto[s]);
+            if (t == 0) continue;
+            if (lane == 0 && atomicAdd(&a.tcount[t], 1u) == 0u) a.tgtlist[atomicAdd(&cnt->ntgt, 1u)] = t;
+            for (uint32_t c = s; c != 0; c = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.chnext[c])) {
+                const uint32_t o = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.off[c]);
+                const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.origsz[c]);
+                for (uint32_t j = lane; j < m; j += 64u) a.seg[a.pix[o + j]] = t;
+            }
+        }
+        if (!small_grid_barrier(ctl, G)) return;
+        const uint32_t ntgt = cnt->ntgt;
+        // ---- storage for each target's source list ----
+        for (uint32_t i = gtid; i < ntgt; i += gthreads) {
+            const uint32_t t = a.tgtlist[i];
+            a.toff[t] = atomicAdd(&cnt->bump, a.tcount[t]);
+        }
+        if (!small_grid_barrier(ctl, G)) return;
+        for (uint32_t i = gtid; i < nsrc; i += gthreads) {
+            const uint32_t s = a.srclist[i];
+            const uint32_t t = a.mergeto[s];
+            if (t == 0) continue;
+            a.tlist[a.toff[t] + atomicAdd(&a.tfill[t], 1u)] = s;
+        }
+        if (!small_grid_barrier(ctl, G)) return;
+        // ---- rank of every source inside its target's list (ascending id) ----
+        for (uint32_t i = gtid; i < nsrc; i += gthreads) {
+            const uint32_t s = a.srclist[i];
+            const uint32_t t = a.mergeto[s];
+            if (t == 0) continue;
+            const uint32_t base = a.toff[t], n = a.tcount[t];
+            uint32_t rank = 0;
+            for (uint32_t j = 0; j < n; j++) rank += (a.tlist[base + j] < s) ? 1u : 0u;
+            a.tsorted[base + rank] = s;
+        }
+        if (!small_grid_barrier(ctl, G)) return;
+        // ---- merge step 2: each target absorbs its sources in ascending id (doMerge :1112-1123)
+        for (uint32_t i0 = gtid; i0 < ntgt; i0 += gthreads) {
+            const uint32_t t = a.tgtlist[i0];
+            const uint32_t n = a.tcount[t], base = a.toff[t];
+            const uint32_t a0 = a.segsz[t];
+            uint32_t sz = a0, tail = a.chtail[t];
+            for (uint32_t i = 0; i < n; i++) {
+                const uint32_t s = a.tsorted[base + i];
+                for (int b = 0; b < a.nb; b++) {
+                    a.ssum[(size_t)t * a.nb + b] = a.ssum[(size_t)t * a.nb + b] + a.ssum[(size_t)s * a.nb + b];
+                    a.ssum[(size_t)s * a.nb + b] = 0.0f;
+                }
+                sz += a.segsz[s];
+                a.segsz[s] = 0;
+                a.chnext[tail] = s;
+                tail = a.chtail[s];
+                a.mergeto[s] = 0;
+            }
+            a.segsz[t] = sz;
+            a.chtail[t] = tail;
+            a.tcount[t] = 0;
+            a.tfill[t] = 0;
+            atomicSub(&a.hist[target], n);
+            if (a0 < a.min_seg) atomicSub(&a.hist[a0], 1u);
+            if (sz < a.min_seg) atomicAdd(&a.hist[sz], 1u);
+            atomicAdd(&ctl->nelim, n);
+        }
+        if (!small_grid_barrier(ctl, G)) return;
     }
 }
+
+// at most this many persistent loop kernels run at once (co-residency of all their workgroups)
+#include <mutex>
+#include <condition_variable>
+static std::mutex g_small_mu;
+static std::condition_variable g_small_cv;
+static int g_small_running = 0;
+#define SMALL_MAX_CONCURRENT 16
 
 static inline int bits_for(uint32_t maxval)
 {
@@ -426,7 +478,7 @@ static int run_eliminate_small(shp_ctx *ctx, const void *d_img, int dtype, int n
     CHK(buf_ensure(ctx, ctx->tsorted, ns * 4));
     CHK(buf_ensure(ctx, ctx->srclist, ns * 4));
     CHK(buf_ensure(ctx, ctx->tgtlist, ns * 4));
-    CHK(buf_ensure(ctx, ctx->small, ((size_t)min_seg + 32) * 4));
+    CHK(buf_ensure(ctx, ctx->small, ((size_t)min_seg + 64) * 4));
     CHK(buf_ensure(ctx, ctx->scan_tmp, scan_tmp_bytes(ns > n ? ns : n)));
     uint32_t *segsz = bp<uint32_t>(ctx->segsz), *origsz = bp<uint32_t>(ctx->origsz);
     uint32_t *off = bp<uint32_t>(ctx->off), *chnext = bp<uint32_t>(ctx->chnext);
@@ -438,7 +490,6 @@ static int run_eliminate_small(shp_ctx *ctx, const void *d_img, int dtype, int n
     float *ssum = bp<float>(ctx->ssum);
     uint32_t *hist = bp<uint32_t>(ctx->small);          // [0..min_seg] then nelim
     SmallCtl *ctl = (SmallCtl *)(hist + ((min_seg + 4u + 3u) & ~3u));
-    uint32_t *cnts = &ctl->nsrc;                        // [0]=#sources [1]=#targets [2]=bump
     hipStream_t st = ctx->stream;
 
     CHK(run_seg_size(ctx, d_seg, n, S, segsz));
@@ -464,38 +515,36 @@ static int run_eliminate_small(shp_ctx *ctx, const void *d_img, int dtype, int n
     ps = prof_begin(ctx, PROF_SMALL_LOOP);
 
     const double thr2 = max_spectral_diff * max_spectral_diff;       // float64 square (N8)
-    // pass slots: control kernel + find + merge kernels, enqueued SLOTS_PER_SYNC at a time
-    SmallCtl hctl;
-    memset(&hctl, 0, sizeof(hctl));
-    hctl.target = 1; hctl.prev = -1;
-    HIPCHK(ctx, hipMemcpyAsync(ctl, &hctl, sizeof(hctl), hipMemcpyHostToDevice, st));
-    HIPCHK(ctx, hipStreamSynchronize(st));
-    const unsigned gfix = 128;                         // grid-stride kernels
-    const int SLOTS_PER_SYNC = 8;
-    SmallCtl *pin = (SmallCtl *)ctx->h_pinned;
-    for (int guard = 0; guard < 100000; guard++) {
-        for (int k = 0; k < SLOTS_PER_SYNC; k++) {
-            hipLaunchKernelGGL(k_small_ctl, dim3(1), dim3(64), 0, st, ctl, hist, min_seg); KCHK(ctx);
-            hipLaunchKernelGGL(k_find_merge, dim3(gs), dim3(256), 0, st, ctl, cnts, d_seg, segsz, ssum,
-                               pix, off, origsz, chnext, mergeto, srclist, S, nb, nrows, ncols, four,
-                               thr2); KCHK(ctx);
-            hipLaunchKernelGGL(k_merge_mark, dim3(gfix), dim3(256), 0, st, ctl, d_seg, mergeto, pix, off,
-                               origsz, chnext, tcount, srclist, cnts, tgtlist); KCHK(ctx);
-            hipLaunchKernelGGL(k_merge_alloc, dim3(gfix), dim3(256), 0, st, ctl, tgtlist, tcount, toff,
-                               cnts); KCHK(ctx);
-            hipLaunchKernelGGL(k_merge_fill, dim3(gfix), dim3(256), 0, st, ctl, mergeto, toff, tfill,
-                               tlist, srclist, cnts); KCHK(ctx);
-            hipLaunchKernelGGL(k_merge_rank, dim3(gfix), dim3(256), 0, st, ctl, mergeto, toff, tcount,
-                               tlist, tsorted, srclist, cnts); KCHK(ctx);
-            hipLaunchKernelGGL(k_merge_apply, dim3(gfix), dim3(256), 0, st, ctl, segsz, ssum, chnext,
-                               chtail, mergeto, tcount, tfill, toff, tsorted, hist, tgtlist, cnts, nb,
-                               min_seg); KCHK(ctx);
-        }
-        HIPCHK(ctx, hipMemcpyAsync(pin, ctl, sizeof(SmallCtl), hipMemcpyDeviceToHost, st));
-        HIPCHK(ctx, hipStreamSynchronize(st));
-        if (pin->done) break;
+    // one persistent kernel runs every pass (see k_small_loop)
+    SmallCtl *pin = (SmallCtl *)(ctx->h_pinned + 16);
+    memset(pin, 0, sizeof(SmallCtl));
+    pin->st[0].target = 1; pin->st[0].prev = -1;
+    HIPCHK(ctx, hipMemcpyAsync(ctl, pin, sizeof(SmallCtl), hipMemcpyHostToDevice, st));
+    SmallArgs args;
+    args.ctl = ctl; args.hist = hist; args.seg = d_seg; args.segsz = segsz; args.ssum = ssum;
+    args.pix = pix; args.off = off; args.origsz = origsz; args.chnext = chnext; args.chtail = chtail;
+    args.mergeto = mergeto; args.tcount = tcount; args.toff = toff; args.tfill = tfill;
+    args.tlist = tlist; args.tsorted = tsorted; args.srclist = srclist; args.tgtlist = tgtlist;
+    args.S = S; args.min_seg = min_seg; args.nrows = nrows; args.ncols = ncols;
+    args.nb = nb; args.four = four; args.thr2 = thr2;
+    {
+        std::unique_lock<std::mutex> lk(g_small_mu);
+        g_small_cv.wait(lk, [] { return g_small_running < SMALL_MAX_CONCURRENT; });
+        g_small_running++;
     }
-    if (!pin->done) SHP_FAIL(ctx, SHP_ERR_STATE, "small-segment loop did not terminate");
+    hipLaunchKernelGGL(k_small_loop, dim3(SMALL_BLOCKS), dim3(256), 0, st, args);
+    hipError_t lerr = hipGetLastError();
+    hipError_t cerr = hipMemcpyAsync(pin, ctl, sizeof(SmallCtl), hipMemcpyDeviceToHost, st);
+    hipError_t serr = hipStreamSynchronize(st);
+    {
+        std::lock_guard<std::mutex> lk(g_small_mu);
+        g_small_running--;
+    }
+    g_small_cv.notify_one();
+    HIPCHK(ctx, lerr); HIPCHK(ctx, cerr); HIPCHK(ctx, serr);
+    if (pin->fail || !pin->done)
+        SHP_FAIL(ctx, SHP_ERR_STATE, "small-segment loop: grid barrier timed out (fail=%u done=%u)",
+                 pin->fail, pin->done);
     prof_end(ctx, ps);
     *num_elim = (int64_t)pin->nelim;
     uint32_t new_max = 0;
