@@ -40,6 +40,7 @@ def parse():
     ap.add_argument('--tile', type=int, default=4096)
     ap.add_argument('--overlap', type=int, default=1024)
     ap.add_argument('--workers', type=int, default=int(os.environ.get('SHEPSEG_WORKERS', '16')))
+    ap.add_argument('--simple-recode', type=int, default=0, help='diagnostic: simpleTileRecode')
     ap.add_argument('--cpu-sample', type=int, default=6144,
                     help='window edge of the cpu_baseline sample (0 = skip)')
     return ap.parse_args()
@@ -110,7 +111,8 @@ def main():
     def step():
         r = tiling.doTiledShepherdSegmentation(
             ras, tiling._KEEP_ON_DEVICE, tileSize=args.tile, overlapSize=args.overlap,
-            minSegmentSize=50, numClusters=60, fixedKMeansInit=True, concurrencyCfg=cfg)
+            minSegmentSize=50, numClusters=60, fixedKMeansInit=True, concurrencyCfg=cfg,
+            simpleTileRecode=bool(args.simple_recode))
         tiling.freeDeviceOutput(r)
         return r
 

@@ -44,12 +44,15 @@ API int shp_ctx_create(int device, shp_ctx **out)
         return SHP_ERR_HIP;
     }
     for (int i = 0; i < 16; i++) hipEventCreate(&ctx->ev[i]);
+    hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking);
+    hipEventCreateWithFlags(&ctx->evfork, hipEventDisableTiming);
+    hipEventCreateWithFlags(&ctx->evjoin, hipEventDisableTiming);
     ctx->bufs = {&ctx->img, &ctx->clus, &ctx->lab, &ctx->seg, &ctx->aux, &ctx->aux2, &ctx->stack,
                  &ctx->scan_tmp, &ctx->sort_k0, &ctx->sort_k1, &ctx->sort_v1, &ctx->sort_hist,
                  &ctx->pix, &ctx->segsz, &ctx->origsz, &ctx->off, &ctx->ssum, &ctx->chnext,
                  &ctx->chtail, &ctx->mergeto, &ctx->tcount, &ctx->toff, &ctx->tfill, &ctx->tlist,
                  &ctx->tsorted, &ctx->small, &ctx->cen, &ctx->fit_x, &ctx->fit_lab, &ctx->fit_part,
-                 &ctx->big, &ctx->srclist, &ctx->tgtlist};
+                 &ctx->big, &ctx->srclist, &ctx->tgtlist, &ctx->bigbits};
     *out = ctx;
     return SHP_OK;
 }
@@ -67,6 +70,9 @@ API void shp_ctx_destroy(shp_ctx *ctx)
         for (int j = 0; j < 2; j++)
             if (ctx->prof_ev[i][j]) hipEventDestroy(ctx->prof_ev[i][j]);
     if (ctx->h_pinned) hipHostFree(ctx->h_pinned);
+    if (ctx->stream2) { hipStreamSynchronize(ctx->stream2); hipStreamDestroy(ctx->stream2); }
+    if (ctx->evfork) hipEventDestroy(ctx->evfork);
+    if (ctx->evjoin) hipEventDestroy(ctx->evjoin);
     hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -283,17 +289,18 @@ static int segment_device(shp_ctx *ctx, const void *d_img, uint32_t *d_seg, int 
     CHK(launch_assign(ctx, d_img, dtype, nb, n, centres, k, has_null, null_val,
                       bp<uint16_t>(ctx->clus), nullptr));
     hipEventRecord(ctx->ev[2], ctx->stream);
-    CHK(run_clump(ctx, bp<uint16_t>(ctx->clus), nrows, ncols, four, d_seg, scal + 2));
+    CHK(buf_ensure(ctx, ctx->segsz, ((size_t)n + 2) * 4));
+    CHK(run_clump(ctx, bp<uint16_t>(ctx->clus), nrows, ncols, four, d_seg, scal + 2, bp<uint32_t>(ctx->segsz)));
     uint32_t nclumps = 0;
     CHK(read_u32(ctx, scal + 2, &nclumps));
     hipEventRecord(ctx->ev[3], ctx->stream);
     uint32_t max_id = nclumps;
-    CHK(run_eliminate_single(ctx, d_img, dtype, nb, nrows, ncols, four, d_seg, &max_id));
+    CHK(run_eliminate_single(ctx, d_img, dtype, nb, nrows, ncols, four, d_seg, &max_id, 1));
     hipEventRecord(ctx->ev[4], ctx->stream);
     if (singles) *singles = (int64_t)nclumps - (int64_t)max_id;        // shepseg.py:226-227
     int64_t ne = 0;
     CHK(run_eliminate_small(ctx, d_img, dtype, nb, nrows, ncols, four, min_seg_size, msd, d_seg,
-                            &max_id, &ne));
+                            &max_id, &ne, 1));
     hipEventRecord(ctx->ev[5], ctx->stream);
     if (small) *small = ne;
     if (max_seg_id) *max_seg_id = max_id;

@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void k_run_count(const uint32_t *__restrict__ 
 
 __global__ __launch_bounds__(256) void k_big_list(const uint32_t *__restrict__ lab,
                                                   uint32_t *csize, uint32_t n, uint32_t ncols,
-                                                  BigInfo *big, uint32_t *counters)
+                                                  BigInfo *big, uint32_t *counters, uint32_t *bigbits)
 {
     const uint32_t p = blockIdx.x * 256u + threadIdx.x;
     if (p >= n || lab[p] != p) return;
@@ -126,16 +126,19 @@ __global__ __launch_bounds__(256) void k_big_list(const uint32_t *__restrict__ l
     b.root = p; b.size = s; b.off = off; b.minc = ncols; b.maxc = 0; b.maxr = 0;
     big[bi] = b;
     csize[p] = VIS_FLAG | bi;
+    atomicOr(&bigbits[p >> 5], 1u << (p & 31u));      // N-bit map of cut-able roots (L2-resident)
 }
 
 __global__ __launch_bounds__(256) void k_big_bbox(const uint32_t *__restrict__ lab,
                                                   const uint32_t *__restrict__ csize, uint32_t n,
-                                                  uint32_t ncols, BigInfo *big)
+                                                  uint32_t ncols, BigInfo *big,
+                                                  const uint32_t *__restrict__ bigbits)
 {
     const uint32_t p = blockIdx.x * 256u + threadIdx.x;
     if (p >= n) return;
     const uint32_t r = lab[p];
     if (r == NULL_LAB) return;
+    if (!((bigbits[r >> 5] >> (r & 31u)) & 1u)) return;     // 2 MB bitmap instead of a 4N-byte gather
     const uint32_t c = csize[r];
     if (!(c & VIS_FLAG)) return;
     const uint32_t bi = c & ~VIS_FLAG;
@@ -155,8 +158,8 @@ __global__ __launch_bounds__(256) void k_big_bbox(const uint32_t *__restrict__ l
 //     order (cx outer, cy inner): one ballot decides which are unvisited members, they are
 //     labelled together and pushed in lane order, the last one becoming the next pop;
 //   * all 64 lanes scan the bounding box for the next seed in raster order.
-#define DFS_SWN 4096u        // stack window entries in LDS (16 KiB)
-__device__ __forceinline__ bool dfs_fits_lds(const BigInfo &B, uint32_t ncols);
+#define DFS_SWN 1536u        // stack window entries in LDS (6 KiB)
+__device__ __forceinline__ unsigned long long dfs_bitmap_words(const BigInfo &B, uint32_t ncols);
 
 __device__ __forceinline__ void dfs_split_global(uint32_t *lab, const BigInfo &B, uint32_t *sw,
                                                  uint32_t *stackbuf, uint32_t nrows, uint32_t ncols,
@@ -258,13 +261,14 @@ __device__ __forceinline__ void dfs_split_global(uint32_t *lab, const BigInfo &B
 // in LDS (64 KiB), so a pop costs one LDS round trip instead of a dependent HBM/L2 access, and the walk
 // no longer suffers when other streams pollute L2.  Labels are still written to `lab` with
 // fire-and-forget stores.  Components that do not fit take dfs_split_global.
-#define DFS_BMW 16384u       // bitmap words (524288 bounding-box pixels, 64 KiB)
+#define DFS_BMW_SMALL 6144u  // class A bitmap words (196608 bounding-box pixels, 24 KiB)
+#define DFS_BMW_LARGE 16384u // class B bitmap words (524288 bounding-box pixels, 64 KiB)
 
-__device__ __forceinline__ bool dfs_fits_lds(const BigInfo &B, uint32_t ncols)
+__device__ __forceinline__ unsigned long long dfs_bitmap_words(const BigInfo &B, uint32_t ncols)
 {
     const uint32_t minr = B.root / ncols;
     const uint32_t H = B.maxr - minr + 1u, W = B.maxc - B.minc + 1u;
-    return (unsigned long long)H * ((W + 31u) >> 5) <= DFS_BMW;
+    return (unsigned long long)H * ((W + 31u) >> 5);
 }
 
 __device__ __forceinline__ void dfs_split_lds(uint32_t *lab, const BigInfo &B, uint32_t *bm,
@@ -385,18 +389,26 @@ __device__ __forceinline__ void dfs_split_lds(uint32_t *lab, const BigInfo &B, u
     }
 }
 
+// Two launches per tile share this kernel: class A (bitmap <= 24 KiB: ~90 % of the components,
+// 30 KiB of LDS per workgroup so five fit a CU and other kernels still find LDS) and class B
+// (<= 64 KiB bitmap, or no bitmap at all -> global path).  Keeping the footprint small matters:
+// with 80 KiB per workgroup the replays of 16 concurrent tiles filled every CU's LDS and
+// starved every other kernel that needs a few KiB of it.
 __global__ __launch_bounds__(64) void k_dfs_split(uint32_t *lab, const BigInfo *__restrict__ big,
                                                   const uint32_t *__restrict__ counters,
                                                   uint32_t *stackbuf, uint32_t nrows,
-                                                  uint32_t ncols, int four)
+                                                  uint32_t ncols, int four, uint32_t bmw_lo,
+                                                  uint32_t bmw_hi, int take_global)
 {
-    __shared__ uint32_t bm[DFS_BMW];
-    __shared__ uint32_t sw[DFS_SWN];
+    extern __shared__ __attribute__((aligned(16))) uint32_t dfs_lds[];
+    uint32_t *sw = dfs_lds;                  // DFS_SWN entries
+    uint32_t *bm = dfs_lds + DFS_SWN;        // bmw_hi words
     const uint32_t bi = blockIdx.x;
     if (bi >= counters[0]) return;
     const BigInfo B = big[bi];
-    if (dfs_fits_lds(B, ncols)) dfs_split_lds(lab, B, bm, sw, stackbuf, ncols, four);
-    else dfs_split_global(lab, B, sw, stackbuf, nrows, ncols, four);
+    const unsigned long long words = dfs_bitmap_words(B, ncols);
+    if (words > bmw_lo && words <= bmw_hi) dfs_split_lds(lab, B, bm, sw, stackbuf, ncols, four);
+    else if (take_global && words > bmw_hi) dfs_split_global(lab, B, sw, stackbuf, nrows, ncols, four);
 }
 
 struct SeedFn {
@@ -408,20 +420,46 @@ struct SeedFn {
     }
 };
 
+// seg[p] = raster rank of the piece's seed + 1, and the segment-size table of the clumps
+// (makeSegSize, shepseg.py:544-569) in the same pass: an uncut component's size is already
+// known at its root (csize); pixels of cut components and null pixels are counted with one
+// atomic per run per wavefront.
 __global__ __launch_bounds__(256) void k_clump_final(const uint32_t *__restrict__ lab,
                                                      const uint32_t *__restrict__ rank,
-                                                     uint32_t *__restrict__ seg, uint32_t n)
+                                                     const uint32_t *__restrict__ csize,
+                                                     uint32_t *__restrict__ seg, uint32_t *segsz,
+                                                     uint32_t n)
 {
     const uint32_t p = blockIdx.x * 256u + threadIdx.x;
-    if (p >= n) return;
-    const uint32_t l = lab[p];
-    seg[p] = (l == NULL_LAB) ? 0u : rank[l & ~VIS_FLAG] + 1u;
+    const bool inb = p < n;
+    const unsigned lane = lane_id();
+    uint32_t key = 0xFFFFFFFFu;                 // id to count by atomics (none)
+    if (inb) {
+        const uint32_t l = lab[p];
+        if (l == NULL_LAB) { seg[p] = 0u; key = 0u; }
+        else {
+            const uint32_t seed = l & ~VIS_FLAG;
+            const uint32_t id = rank[seed] + 1u;
+            seg[p] = id;
+            if (l & VIS_FLAG) key = id;
+            else if (seed == p) segsz[id] = csize[p];
+        }
+    }
+    const uint32_t pk = __shfl_up(key, 1, 64);
+    const bool head = lane == 0 || pk != key;
+    const unsigned long long heads = __ballot(head);
+    if (head && key != 0xFFFFFFFFu) {
+        const unsigned long long nxt = (lane == 63) ? 0ull : (heads & ~((2ull << lane) - 1ull));
+        const unsigned nl = nxt ? (unsigned)__builtin_ctzll(nxt) : 64u;
+        atomicAdd(&segsz[key], nl - lane);
+    }
 }
 
 // d_clus (uint16, 0 = null) -> ctx->seg (uint32 clump ids 1..nclumps, 0 = null).
 // *nclumps_dev: device uint32 receiving the number of clumps.
+// d_segsz (optional): receives the clump sizes, must hold n + 2 entries.
 static int run_clump(shp_ctx *ctx, const uint16_t *d_clus, uint32_t nrows, uint32_t ncols, int four,
-                     uint32_t *d_seg, uint32_t *nclumps_dev)
+                     uint32_t *d_seg, uint32_t *nclumps_dev, uint32_t *d_segsz = nullptr)
 {
     const uint64_t n64 = (uint64_t)nrows * ncols;
     if (n64 >= 0x7fffffffull) SHP_FAIL(ctx, SHP_ERR_ARG, "tile too large (%llu px)", (unsigned long long)n64);
@@ -432,7 +470,13 @@ static int run_clump(shp_ctx *ctx, const uint16_t *d_clus, uint32_t nrows, uint3
     const uint32_t maxbig = n / (MAX_CLUMP_SIZE + 2u) + 1u;
     CHK(buf_ensure(ctx, ctx->lab, (size_t)n * 4));
     CHK(buf_ensure(ctx, ctx->aux, (size_t)n * 4));
+    CHK(buf_ensure(ctx, ctx->aux2, (size_t)n * 4));
     CHK(buf_ensure(ctx, ctx->stack, (size_t)n * 4));
+    CHK(buf_ensure(ctx, ctx->bigbits, ((size_t)n / 32 + 2) * 4));
+    if (!d_segsz) {
+        CHK(buf_ensure(ctx, ctx->segsz, ((size_t)n + 2) * 4));
+        d_segsz = bp<uint32_t>(ctx->segsz);
+    }
     CHK(buf_ensure(ctx, ctx->big, (size_t)maxbig * sizeof(BigInfo) + 64));
     CHK(buf_ensure(ctx, ctx->scan_tmp, scan_tmp_bytes(n)));
     uint32_t *lab = bp<uint32_t>(ctx->lab), *csize = bp<uint32_t>(ctx->aux);
@@ -447,18 +491,30 @@ static int run_clump(shp_ctx *ctx, const uint16_t *d_clus, uint32_t nrows, uint3
     prof_end(ctx, ps);
     HIPCHK(ctx, hipMemsetAsync(csize, 0, (size_t)n * 4, st));
     HIPCHK(ctx, hipMemsetAsync(counters, 0, 16, st));
+    uint32_t *bigbits = bp<uint32_t>(ctx->bigbits), *rank = bp<uint32_t>(ctx->aux2);
+    HIPCHK(ctx, hipMemsetAsync(bigbits, 0, ((size_t)n / 32 + 1) * 4, st));
+    HIPCHK(ctx, hipMemsetAsync(d_segsz, 0, ((size_t)n + 1) * 4, st));
     hipLaunchKernelGGL(k_run_count, dim3(g), dim3(256), 0, st, lab, n, csize, NULL_LAB, 1); KCHK(ctx);
-    hipLaunchKernelGGL(k_big_list, dim3(g), dim3(256), 0, st, lab, csize, n, ncols, big, counters); KCHK(ctx);
-    hipLaunchKernelGGL(k_big_bbox, dim3(g), dim3(256), 0, st, lab, csize, n, ncols, big); KCHK(ctx);
+    hipLaunchKernelGGL(k_big_list, dim3(g), dim3(256), 0, st, lab, csize, n, ncols, big, counters, bigbits); KCHK(ctx);
+    hipLaunchKernelGGL(k_big_bbox, dim3(g), dim3(256), 0, st, lab, csize, n, ncols, big, bigbits); KCHK(ctx);
     ps = prof_begin(ctx, PROF_DFS);
-    hipLaunchKernelGGL(k_dfs_split, dim3(maxbig), dim3(64), 0, st, lab, big, counters,
-                       bp<uint32_t>(ctx->stack), nrows, ncols, four); KCHK(ctx);
+    // fork: the two size classes touch disjoint components, so they run on two streams
+    HIPCHK(ctx, hipEventRecord(ctx->evfork, st));
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream2, ctx->evfork, 0));
+    hipLaunchKernelGGL(k_dfs_split, dim3(maxbig), dim3(64), (DFS_SWN + DFS_BMW_LARGE) * 4, st, lab, big,
+                       counters, bp<uint32_t>(ctx->stack), nrows, ncols, four, DFS_BMW_SMALL,
+                       DFS_BMW_LARGE, 1); KCHK(ctx);
+    hipLaunchKernelGGL(k_dfs_split, dim3(maxbig), dim3(64), (DFS_SWN + DFS_BMW_SMALL) * 4, ctx->stream2, lab,
+                       big, counters, bp<uint32_t>(ctx->stack), nrows, ncols, four, 0u, DFS_BMW_SMALL, 0);
+    KCHK(ctx);
+    HIPCHK(ctx, hipEventRecord(ctx->evjoin, ctx->stream2));
+    HIPCHK(ctx, hipStreamWaitEvent(st, ctx->evjoin, 0));
     prof_end(ctx, ps);
     ps = prof_begin(ctx, PROF_LABEL);
     // seed rank -> clump id
     SeedFn sf{lab};
-    CHK(scan_exclusive(ctx, sf, n, csize, nclumps_dev, bp<uint32_t>(ctx->scan_tmp)));
-    hipLaunchKernelGGL(k_clump_final, dim3(g), dim3(256), 0, st, lab, csize, d_seg, n); KCHK(ctx);
+    CHK(scan_exclusive(ctx, sf, n, rank, nclumps_dev, bp<uint32_t>(ctx->scan_tmp)));
+    hipLaunchKernelGGL(k_clump_final, dim3(g), dim3(256), 0, st, lab, rank, csize, d_seg, d_segsz, n); KCHK(ctx);
     prof_end(ctx, ps);
     return 0;
 }

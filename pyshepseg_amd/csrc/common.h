@@ -29,12 +29,14 @@ struct StageTimer {
 struct shp_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream2 = nullptr;     // side stream for fork/join inside one call
+    hipEvent_t evfork = nullptr, evjoin = nullptr;
     std::string err;
     std::vector<DevBuf *> bufs;
     // named workspace buffers (grow-only)
     DevBuf img, clus, lab, seg, aux, aux2, stack, scan_tmp, sort_k0, sort_k1, sort_v1, sort_hist,
         pix, segsz, origsz, off, ssum, chnext, chtail, mergeto, tcount, toff, tfill, tlist, tsorted,
-        small, cen, fit_x, fit_lab, fit_part, big, srclist, tgtlist;
+        small, cen, fit_x, fit_lab, fit_part, big, srclist, tgtlist, bigbits;
     uint32_t *h_pinned = nullptr;   // SHP_PINNED_BYTES of pinned host staging (small transfers)
     hipEvent_t ev[16] = {};
     double timings[8] = {};

@@ -13,36 +13,59 @@
 
 #define NO_TARGET 0xFFFFFFFFu
 
+// nearest spectrally-similar neighbouring pixel in a segment of size > 1 (shepseg.py:677-736)
+__device__ __forceinline__ uint32_t single_target(const void *__restrict__ img, int dtype, int nb,
+                                                  const uint32_t *__restrict__ seg,
+                                                  const uint32_t *__restrict__ segsz, uint32_t p,
+                                                  uint32_t n, uint32_t nrows, uint32_t ncols, int four)
+{
+    uint32_t out = NO_TARGET;
+    const uint32_t i = p / ncols, j = p - i * ncols;
+    const uint32_t i0 = i > 0 ? i - 1 : 0, i1 = (i + 1 < nrows) ? i + 1 : nrows - 1;
+    const uint32_t j0 = j > 0 ? j - 1 : 0, j1 = (j + 1 < ncols) ? j + 1 : ncols - 1;
+    long long mind = -1;
+    for (uint32_t a = i0; a <= i1; a++)
+        for (uint32_t b = j0; b <= j1; b++) {
+            if (four && a != i && b != j) continue;
+            const uint32_t q = a * ncols + b;
+            const uint32_t sn = seg[q];
+            if (segsz[sn] > 1u) {
+                long long d = 0;
+                for (int k = 0; k < nb; k++) {
+                    const long long t = ld_px(img, dtype, (size_t)k * n + p) -
+                                        ld_px(img, dtype, (size_t)k * n + q);
+                    d += t * t;
+                }
+                if (mind < 0 || d < mind) { mind = d; out = sn; }
+            }
+        }
+    return out;
+}
+
+// first pass: every pixel.  Single pixels that find no target yet are appended to `rest`
+// (they are the only candidates of the later passes: sizes never shrink to 1).
 __global__ __launch_bounds__(256) void k_single_scan(
     const void *__restrict__ img, int dtype, int nb, const uint32_t *__restrict__ seg,
     const uint32_t *__restrict__ segsz, uint32_t *__restrict__ tgt, uint32_t n, uint32_t nrows,
-    uint32_t ncols, int four)
+    uint32_t ncols, int four, uint32_t *__restrict__ rest, uint32_t *nrest)
 {
     const uint32_t p = blockIdx.x * 256u + threadIdx.x;
-    if (p >= n) return;
     uint32_t out = NO_TARGET;
-    if (segsz[seg[p]] == 1u) {
-        const uint32_t i = p / ncols, j = p - i * ncols;
-        const uint32_t i0 = i > 0 ? i - 1 : 0, i1 = (i + 1 < nrows) ? i + 1 : nrows - 1;
-        const uint32_t j0 = j > 0 ? j - 1 : 0, j1 = (j + 1 < ncols) ? j + 1 : ncols - 1;
-        long long mind = -1;
-        for (uint32_t a = i0; a <= i1; a++)
-            for (uint32_t b = j0; b <= j1; b++) {
-                if (four && a != i && b != j) continue;
-                const uint32_t q = a * ncols + b;
-                const uint32_t sn = seg[q];
-                if (segsz[sn] > 1u) {
-                    long long d = 0;
-                    for (int k = 0; k < nb; k++) {
-                        const long long t = ld_px(img, dtype, (size_t)k * n + p) -
-                                            ld_px(img, dtype, (size_t)k * n + q);
-                        d += t * t;
-                    }
-                    if (mind < 0 || d < mind) { mind = d; out = sn; }
-                }
-            }
+    bool keep = false;
+    if (p < n) {
+        if (segsz[seg[p]] == 1u) {
+            out = single_target(img, dtype, nb, seg, segsz, p, n, nrows, ncols, four);
+            keep = out == NO_TARGET;
+        }
+        tgt[p] = out;
     }
-    tgt[p] = out;
+    const unsigned long long m = __ballot(keep);
+    if (m != 0ull) {
+        uint32_t base = 0;
+        if (lane_id() == 0) base = atomicAdd(nrest, (uint32_t)__popcll(m));
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        if (keep) rest[base + (uint32_t)__popcll(m & lanemask_lt())] = p;
+    }
 }
 
 __global__ __launch_bounds__(256) void k_single_apply(uint32_t *__restrict__ seg, uint32_t *segsz,
@@ -51,15 +74,46 @@ __global__ __launch_bounds__(256) void k_single_apply(uint32_t *__restrict__ seg
 {
     const uint32_t p = blockIdx.x * 256u + threadIdx.x;
     const uint32_t t = (p < n) ? tgt[p] : NO_TARGET;
-    const bool act = t != NO_TARGET;
-    if (act) {
+    if (t != NO_TARGET) {
         const uint32_t old = seg[p];
         seg[p] = t;
         segsz[old] = 0;
         atomicAdd(&segsz[t], 1u);
+        // the host only needs "did this pass merge anything" (the count is oldMax - newMax later)
+        *nelim = 1u;
     }
-    // the host only needs "did this pass merge anything" (the count is oldMax - newMax later)
-    if (act) *nelim = 1u;
+}
+
+// later passes: only the remaining single pixels
+__global__ __launch_bounds__(256) void k_single_scan_list(
+    const void *__restrict__ img, int dtype, int nb, const uint32_t *__restrict__ seg,
+    const uint32_t *__restrict__ segsz, uint32_t *__restrict__ tgt_l, uint32_t n, uint32_t nrows,
+    uint32_t ncols, int four, const uint32_t *__restrict__ rest, const uint32_t *__restrict__ nrest)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= *nrest) return;
+    const uint32_t p = rest[i];
+    uint32_t out = NO_TARGET;
+    if (segsz[seg[p]] == 1u) out = single_target(img, dtype, nb, seg, segsz, p, n, nrows, ncols, four);
+    tgt_l[i] = out;
+}
+
+__global__ __launch_bounds__(256) void k_single_apply_list(uint32_t *__restrict__ seg, uint32_t *segsz,
+                                                           const uint32_t *__restrict__ tgt_l,
+                                                           const uint32_t *__restrict__ rest,
+                                                           const uint32_t *__restrict__ nrest,
+                                                           uint32_t *nelim)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= *nrest) return;
+    const uint32_t t = tgt_l[i];
+    if (t == NO_TARGET) return;
+    const uint32_t p = rest[i];
+    const uint32_t old = seg[p];
+    seg[p] = t;
+    segsz[old] = 0;
+    atomicAdd(&segsz[t], 1u);
+    *nelim = 1u;
 }
 
 // relabelSegments (shepseg.py:739-777): newid[k] = k - #{1 <= j < k : segsz[j] == 0}
@@ -70,6 +124,18 @@ struct EmptyFn {      // f(i) = 1 if id i (>= 1) is unused; f(0) = 0
         return (i >= 1u && segsz[i] == 0u) ? 1u : 0u;
     }
 };
+
+// sizes of the surviving ids under their new numbers (the reference recomputes makeSegSize)
+__global__ __launch_bounds__(256) void k_compact_sizes(const uint32_t *__restrict__ segsz,
+                                                       const uint32_t *__restrict__ sub, uint32_t ns,
+                                                       uint32_t *__restrict__ out)
+{
+    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+    if (k >= ns) return;
+    const uint32_t v = segsz[k];
+    if (k == 0u) out[0] = v;
+    else if (v != 0u) out[k - sub[k]] = v;
+}
 
 __global__ __launch_bounds__(256) void k_relabel(uint32_t *__restrict__ seg,
                                                  const uint32_t *__restrict__ sub, uint32_t n)
@@ -83,7 +149,7 @@ __global__ __launch_bounds__(256) void k_relabel(uint32_t *__restrict__ seg,
 // Compacts ids in d_seg given segsz[0..max_id].  *new_max_host = max_id - (#unused ids >= 1)
 // which equals seg.max() after the relabel (0 when every pixel is null).
 static int run_relabel(shp_ctx *ctx, uint32_t *d_seg, uint32_t n, const uint32_t *d_segsz,
-                       uint32_t max_id, uint32_t *new_max_host)
+                       uint32_t max_id, uint32_t *new_max_host, uint32_t *d_sizes_out = nullptr)
 {
     const uint32_t ns = max_id + 1u;
     CHK(buf_ensure(ctx, ctx->toff, (size_t)ns * 4 + 16));
@@ -95,6 +161,11 @@ static int run_relabel(shp_ctx *ctx, uint32_t *d_seg, uint32_t n, const uint32_t
     if (n) {
         hipLaunchKernelGGL(k_relabel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, d_seg,
                            sub, n);
+        KCHK(ctx);
+    }
+    if (d_sizes_out) {
+        hipLaunchKernelGGL(k_compact_sizes, dim3(grid_for(ns, 256)), dim3(256), 0, ctx->stream,
+                           d_segsz, sub, ns, d_sizes_out);
         KCHK(ctx);
     }
     HIPCHK(ctx, hipMemcpyAsync(ctx->h_pinned, tot, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -117,32 +188,47 @@ static int run_seg_size(shp_ctx *ctx, const uint32_t *d_seg, uint32_t n, uint32_
 }
 
 // d_seg: clump ids (in place).  max_id in: largest id; out: largest id after relabel.
+// sizes_ready: ctx->segsz already holds makeSegSize(d_seg) (run_clump provides it).
+// On return ctx->origsz holds the segment sizes under the NEW ids (max_id+1 entries).
 static int run_eliminate_single(shp_ctx *ctx, const void *d_img, int dtype, int nb, uint32_t nrows,
-                                uint32_t ncols, int four, uint32_t *d_seg, uint32_t *max_id)
+                                uint32_t ncols, int four, uint32_t *d_seg, uint32_t *max_id,
+                                int sizes_ready = 0)
 {
     const uint32_t n = nrows * ncols;
     CHK(buf_ensure(ctx, ctx->segsz, ((size_t)*max_id + 2) * 4));
+    CHK(buf_ensure(ctx, ctx->origsz, ((size_t)*max_id + 2) * 4));
     CHK(buf_ensure(ctx, ctx->aux, (size_t)n * 4));
+    CHK(buf_ensure(ctx, ctx->stack, (size_t)n * 4));
     CHK(buf_ensure(ctx, ctx->small, 4096));
     uint32_t *segsz = bp<uint32_t>(ctx->segsz), *tgt = bp<uint32_t>(ctx->aux);
-    uint32_t *nelim = bp<uint32_t>(ctx->small);
-    CHK(run_seg_size(ctx, d_seg, n, *max_id, segsz));
+    uint32_t *rest = bp<uint32_t>(ctx->stack);
+    uint32_t *nelim = bp<uint32_t>(ctx->small), *nrest = nelim + 1;
+    if (!sizes_ready) CHK(run_seg_size(ctx, d_seg, n, *max_id, segsz));
     if (n == 0) return 0;
     const unsigned g = grid_for(n, 256);
-    for (;;) {
-        HIPCHK(ctx, hipMemsetAsync(nelim, 0, 4, ctx->stream));
-        hipLaunchKernelGGL(k_single_scan, dim3(g), dim3(256), 0, ctx->stream, d_img, dtype, nb,
-                           d_seg, segsz, tgt, n, nrows, ncols, four);
-        KCHK(ctx);
-        hipLaunchKernelGGL(k_single_apply, dim3(g), dim3(256), 0, ctx->stream, d_seg, segsz, tgt, n,
-                           nelim);
-        KCHK(ctx);
-        HIPCHK(ctx, hipMemcpyAsync(ctx->h_pinned, nelim, 4, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-        if (ctx->h_pinned[0] == 0) break;
+    hipStream_t st = ctx->stream;
+    HIPCHK(ctx, hipMemsetAsync(nelim, 0, 8, st));
+    hipLaunchKernelGGL(k_single_scan, dim3(g), dim3(256), 0, st, d_img, dtype, nb, d_seg, segsz, tgt, n,
+                       nrows, ncols, four, rest, nrest); KCHK(ctx);
+    hipLaunchKernelGGL(k_single_apply, dim3(g), dim3(256), 0, st, d_seg, segsz, tgt, n, nelim); KCHK(ctx);
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_pinned, nelim, 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    uint32_t merged = ctx->h_pinned[0];
+    const uint32_t nr = ctx->h_pinned[1];
+    // later passes touch only the single pixels that could not merge in the first one
+    while (merged != 0 && nr != 0) {
+        const unsigned gl = grid_for(nr, 256);
+        HIPCHK(ctx, hipMemsetAsync(nelim, 0, 4, st));
+        hipLaunchKernelGGL(k_single_scan_list, dim3(gl), dim3(256), 0, st, d_img, dtype, nb, d_seg, segsz,
+                           tgt, n, nrows, ncols, four, rest, nrest); KCHK(ctx);
+        hipLaunchKernelGGL(k_single_apply_list, dim3(gl), dim3(256), 0, st, d_seg, segsz, tgt, rest, nrest,
+                           nelim); KCHK(ctx);
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_pinned, nelim, 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        merged = ctx->h_pinned[0];
     }
     uint32_t new_max = 0;
-    CHK(run_relabel(ctx, d_seg, n, segsz, *max_id, &new_max));
+    CHK(run_relabel(ctx, d_seg, n, segsz, *max_id, &new_max, bp<uint32_t>(ctx->origsz)));
     *max_id = new_max;
     return 0;
 }

@@ -455,9 +455,11 @@ static inline int bits_for(uint32_t maxval)
 }
 
 // d_seg in place; *max_id in: seg.max(); out: seg.max() after the final relabel.
+// sizes_in_origsz: ctx->origsz already holds makeSegSize(d_seg) (run_eliminate_single leaves it)
 static int run_eliminate_small(shp_ctx *ctx, const void *d_img, int dtype, int nb, uint32_t nrows,
                                uint32_t ncols, int four, int min_seg_size, double max_spectral_diff,
-                               uint32_t *d_seg, uint32_t *max_id, int64_t *num_elim)
+                               uint32_t *d_seg, uint32_t *max_id, int64_t *num_elim,
+                               int sizes_in_origsz = 0)
 {
     const uint32_t n = nrows * ncols;
     const uint32_t S = *max_id;
@@ -492,7 +494,10 @@ static int run_eliminate_small(shp_ctx *ctx, const void *d_img, int dtype, int n
     SmallCtl *ctl = (SmallCtl *)(hist + ((min_seg + 4u + 3u) & ~3u));
     hipStream_t st = ctx->stream;
 
-    CHK(run_seg_size(ctx, d_seg, n, S, segsz));
+    if (sizes_in_origsz)
+        HIPCHK(ctx, hipMemcpyAsync(segsz, origsz, ((size_t)S + 1) * 4, hipMemcpyDeviceToDevice, st));
+    else
+        CHK(run_seg_size(ctx, d_seg, n, S, segsz));
     if (n == 0 || S == 0) return 0;
     // CSR: pixels grouped by segment id, raster order inside (stable sort of (seg, index))
     uint32_t *ksorted = nullptr, *pix = nullptr;
