@@ -52,7 +52,7 @@ API int shp_ctx_create(int device, shp_ctx **out)
                  &ctx->pix, &ctx->segsz, &ctx->origsz, &ctx->off, &ctx->ssum, &ctx->chnext,
                  &ctx->chtail, &ctx->mergeto, &ctx->tcount, &ctx->toff, &ctx->tfill, &ctx->tlist,
                  &ctx->tsorted, &ctx->small, &ctx->cen, &ctx->fit_x, &ctx->fit_lab, &ctx->fit_part,
-                 &ctx->big, &ctx->srclist, &ctx->tgtlist, &ctx->bigbits};
+                 &ctx->big, &ctx->srclist, &ctx->tgtlist, &ctx->bigbits, &ctx->singles};
     *out = ctx;
     return SHP_OK;
 }
@@ -290,12 +290,19 @@ static int segment_device(shp_ctx *ctx, const void *d_img, uint32_t *d_seg, int 
                       bp<uint16_t>(ctx->clus), nullptr));
     hipEventRecord(ctx->ev[2], ctx->stream);
     CHK(buf_ensure(ctx, ctx->segsz, ((size_t)n + 2) * 4));
-    CHK(run_clump(ctx, bp<uint16_t>(ctx->clus), nrows, ncols, four, d_seg, scal + 2, bp<uint32_t>(ctx->segsz)));
-    uint32_t nclumps = 0;
-    CHK(read_u32(ctx, scal + 2, &nclumps));
+    CHK(buf_ensure(ctx, ctx->singles, ((size_t)n + 2) * 4));
+    CHK(run_clump(ctx, bp<uint16_t>(ctx->clus), nrows, ncols, four, d_seg, scal + 2, bp<uint32_t>(ctx->segsz),
+                  bp<uint32_t>(ctx->singles), scal + 3));
+    // read back: number of clumps, number of one-pixel clumps, null-pixel count
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_pinned, scal + 2, 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_pinned + 2, ctx->segsz.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    const uint32_t nclumps = ctx->h_pinned[0], nsingles = ctx->h_pinned[1], nnull = ctx->h_pinned[2];
     hipEventRecord(ctx->ev[3], ctx->stream);
     uint32_t max_id = nclumps;
-    CHK(run_eliminate_single(ctx, d_img, dtype, nb, nrows, ncols, four, d_seg, &max_id, 1));
+    // (a lone null pixel is itself a size-1 "segment" 0: then fall back to the full scan, N4)
+    CHK(run_eliminate_single(ctx, d_img, dtype, nb, nrows, ncols, four, d_seg, &max_id, 1, nnull != 1u,
+                             nsingles));
     hipEventRecord(ctx->ev[4], ctx->stream);
     if (singles) *singles = (int64_t)nclumps - (int64_t)max_id;        // shepseg.py:226-227
     int64_t ne = 0;

@@ -18,6 +18,7 @@
 #pragma once
 #include "common.h"
 #include "scan.h"
+#include <stdlib.h>
 
 struct BigInfo {
     uint32_t root, size, off, minc, maxc, maxr;
@@ -131,7 +132,7 @@ __global__ __launch_bounds__(256) void k_big_list(const uint32_t *__restrict__ l
 
 __global__ __launch_bounds__(256) void k_big_bbox(const uint32_t *__restrict__ lab,
                                                   const uint32_t *__restrict__ csize, uint32_t n,
-                                                  uint32_t ncols, BigInfo *big,
+                                                  uint32_t ncols, volatile BigInfo *big,
                                                   const uint32_t *__restrict__ bigbits)
 {
     const uint32_t p = blockIdx.x * 256u + threadIdx.x;
@@ -145,8 +146,12 @@ __global__ __launch_bounds__(256) void k_big_bbox(const uint32_t *__restrict__ l
     const uint32_t row = p / ncols, col = p - row * ncols;
     const bool headrun = col == 0 || lab[p - 1] != r;
     const bool tailrun = col == ncols - 1 || lab[p + 1] != r;
-    if (headrun) { atomicMin(&big[bi].minc, col); atomicMax(&big[bi].maxr, row); }
-    if (tailrun) atomicMax(&big[bi].maxc, col);
+    // plain pre-reads prune the same-address atomics (a stale value only costs a redundant atomic)
+    if (headrun) {
+        if (col < big[bi].minc) atomicMin((uint32_t *)&big[bi].minc, col);
+        if (row > big[bi].maxr) atomicMax((uint32_t *)&big[bi].maxr, row);
+    }
+    if (tailrun && col > big[bi].maxc) atomicMax((uint32_t *)&big[bi].maxc, col);
 }
 
 // One wavefront per cut-able component: exact replay of shepseg.py:490-539 restricted to the
@@ -163,7 +168,7 @@ __device__ __forceinline__ unsigned long long dfs_bitmap_words(const BigInfo &B,
 
 __device__ __forceinline__ void dfs_split_global(uint32_t *lab, const BigInfo &B, uint32_t *sw,
                                                  uint32_t *stackbuf, uint32_t nrows, uint32_t ncols,
-                                                 int four)
+                                                 int four, uint32_t *singles, uint32_t *nsingles)
 {
     const uint32_t root = B.root;
     uint32_t *gstack = stackbuf + B.off;
@@ -250,6 +255,8 @@ __device__ __forceinline__ void dfs_split_global(uint32_t *lab, const BigInfo &B
                 __builtin_amdgcn_wave_barrier();
             }
         }
+        // a piece that never grew is a one-pixel clump: candidate of the single-pixel pass
+        if (cnt == 0 && singles && lane == 0) singles[atomicAdd(nsingles, 1u)] = seed;
         __threadfence();
         cursor = seed + 1;
         if (cursor >= nrows * ncols) break;
@@ -273,7 +280,7 @@ __device__ __forceinline__ unsigned long long dfs_bitmap_words(const BigInfo &B,
 
 __device__ __forceinline__ void dfs_split_lds(uint32_t *lab, const BigInfo &B, uint32_t *bm,
                                               uint32_t *sw, uint32_t *stackbuf, uint32_t ncols,
-                                              int four)
+                                              int four, uint32_t *singles, uint32_t *nsingles)
 {
     const uint32_t root = B.root;
     uint32_t *gstack = stackbuf + B.off;
@@ -386,6 +393,7 @@ __device__ __forceinline__ void dfs_split_lds(uint32_t *lab, const BigInfo &B, u
                 __builtin_amdgcn_wave_barrier();
             }
         }
+        if (cnt == 0 && singles && lane == 0) singles[atomicAdd(nsingles, 1u)] = seed;
     }
 }
 
@@ -398,17 +406,21 @@ __global__ __launch_bounds__(64) void k_dfs_split(uint32_t *lab, const BigInfo *
                                                   const uint32_t *__restrict__ counters,
                                                   uint32_t *stackbuf, uint32_t nrows,
                                                   uint32_t ncols, int four, uint32_t bmw_lo,
-                                                  uint32_t bmw_hi, int take_global)
+                                                  uint32_t bmw_hi, int take_global,
+                                                  uint32_t *singles, uint32_t *nsingles)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t dfs_lds[];
     uint32_t *sw = dfs_lds;                  // DFS_SWN entries
     uint32_t *bm = dfs_lds + DFS_SWN;        // bmw_hi words
     const uint32_t bi = blockIdx.x;
     if (bi >= counters[0]) return;
+    __builtin_amdgcn_s_setprio(3);          // a lone latency-bound wave: win issue arbitration
     const BigInfo B = big[bi];
     const unsigned long long words = dfs_bitmap_words(B, ncols);
-    if (words > bmw_lo && words <= bmw_hi) dfs_split_lds(lab, B, bm, sw, stackbuf, ncols, four);
-    else if (take_global && words > bmw_hi) dfs_split_global(lab, B, sw, stackbuf, nrows, ncols, four);
+    if (words > bmw_lo && words <= bmw_hi)
+        dfs_split_lds(lab, B, bm, sw, stackbuf, ncols, four, singles, nsingles);
+    else if (take_global && words > bmw_hi)
+        dfs_split_global(lab, B, sw, stackbuf, nrows, ncols, four, singles, nsingles);
 }
 
 struct SeedFn {
@@ -428,11 +440,13 @@ __global__ __launch_bounds__(256) void k_clump_final(const uint32_t *__restrict_
                                                      const uint32_t *__restrict__ rank,
                                                      const uint32_t *__restrict__ csize,
                                                      uint32_t *__restrict__ seg, uint32_t *segsz,
-                                                     uint32_t n)
+                                                     uint32_t n, uint32_t *__restrict__ singles,
+                                                     uint32_t *nsingles)
 {
     const uint32_t p = blockIdx.x * 256u + threadIdx.x;
     const bool inb = p < n;
     const unsigned lane = lane_id();
+    bool single = false;                        // one-pixel clump: candidate of the single-pixel pass
     uint32_t key = 0xFFFFFFFFu;                 // id to count by atomics (none)
     if (inb) {
         const uint32_t l = lab[p];
@@ -442,7 +456,20 @@ __global__ __launch_bounds__(256) void k_clump_final(const uint32_t *__restrict_
             const uint32_t id = rank[seed] + 1u;
             seg[p] = id;
             if (l & VIS_FLAG) key = id;
-            else if (seed == p) segsz[id] = csize[p];
+            else if (seed == p) {
+                const uint32_t sz = csize[p];
+                segsz[id] = sz;
+                single = sz == 1u;
+            }
+        }
+    }
+    if (singles) {
+        const unsigned long long ms = __ballot(single);
+        if (ms != 0ull) {
+            uint32_t base = 0;
+            if (lane == 0) base = atomicAdd(nsingles, (uint32_t)__popcll(ms));
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            if (single) singles[base + (uint32_t)__popcll(ms & lanemask_lt())] = p;
         }
     }
     const uint32_t pk = __shfl_up(key, 1, 64);
@@ -459,7 +486,8 @@ __global__ __launch_bounds__(256) void k_clump_final(const uint32_t *__restrict_
 // *nclumps_dev: device uint32 receiving the number of clumps.
 // d_segsz (optional): receives the clump sizes, must hold n + 2 entries.
 static int run_clump(shp_ctx *ctx, const uint16_t *d_clus, uint32_t nrows, uint32_t ncols, int four,
-                     uint32_t *d_seg, uint32_t *nclumps_dev, uint32_t *d_segsz = nullptr)
+                     uint32_t *d_seg, uint32_t *nclumps_dev, uint32_t *d_segsz = nullptr,
+                     uint32_t *d_singles = nullptr, uint32_t *d_nsingles = nullptr)
 {
     const uint64_t n64 = (uint64_t)nrows * ncols;
     if (n64 >= 0x7fffffffull) SHP_FAIL(ctx, SHP_ERR_ARG, "tile too large (%llu px)", (unsigned long long)n64);
@@ -498,23 +526,32 @@ static int run_clump(shp_ctx *ctx, const uint16_t *d_clus, uint32_t nrows, uint3
     hipLaunchKernelGGL(k_big_list, dim3(g), dim3(256), 0, st, lab, csize, n, ncols, big, counters, bigbits); KCHK(ctx);
     hipLaunchKernelGGL(k_big_bbox, dim3(g), dim3(256), 0, st, lab, csize, n, ncols, big, bigbits); KCHK(ctx);
     ps = prof_begin(ctx, PROF_DFS);
-    // fork: the two size classes touch disjoint components, so they run on two streams
-    HIPCHK(ctx, hipEventRecord(ctx->evfork, st));
-    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream2, ctx->evfork, 0));
+    if (d_nsingles) HIPCHK(ctx, hipMemsetAsync(d_nsingles, 0, 4, st));
+    // fork: the two size classes touch disjoint components, so they can run on two streams
+    static const int fork2 = getenv("SHEPSEG_DFS_FORK") ? atoi(getenv("SHEPSEG_DFS_FORK")) : 0;
+    hipStream_t st2 = fork2 ? ctx->stream2 : st;
+    if (fork2) {
+        HIPCHK(ctx, hipEventRecord(ctx->evfork, st));
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->stream2, ctx->evfork, 0));
+    }
     hipLaunchKernelGGL(k_dfs_split, dim3(maxbig), dim3(64), (DFS_SWN + DFS_BMW_LARGE) * 4, st, lab, big,
                        counters, bp<uint32_t>(ctx->stack), nrows, ncols, four, DFS_BMW_SMALL,
-                       DFS_BMW_LARGE, 1); KCHK(ctx);
-    hipLaunchKernelGGL(k_dfs_split, dim3(maxbig), dim3(64), (DFS_SWN + DFS_BMW_SMALL) * 4, ctx->stream2, lab,
-                       big, counters, bp<uint32_t>(ctx->stack), nrows, ncols, four, 0u, DFS_BMW_SMALL, 0);
+                       DFS_BMW_LARGE, 1, d_singles, d_nsingles); KCHK(ctx);
+    hipLaunchKernelGGL(k_dfs_split, dim3(maxbig), dim3(64), (DFS_SWN + DFS_BMW_SMALL) * 4, st2, lab,
+                       big, counters, bp<uint32_t>(ctx->stack), nrows, ncols, four, 0u, DFS_BMW_SMALL, 0,
+                       d_singles, d_nsingles);
     KCHK(ctx);
-    HIPCHK(ctx, hipEventRecord(ctx->evjoin, ctx->stream2));
-    HIPCHK(ctx, hipStreamWaitEvent(st, ctx->evjoin, 0));
+    if (fork2) {
+        HIPCHK(ctx, hipEventRecord(ctx->evjoin, ctx->stream2));
+        HIPCHK(ctx, hipStreamWaitEvent(st, ctx->evjoin, 0));
+    }
     prof_end(ctx, ps);
     ps = prof_begin(ctx, PROF_LABEL);
     // seed rank -> clump id
     SeedFn sf{lab};
     CHK(scan_exclusive(ctx, sf, n, rank, nclumps_dev, bp<uint32_t>(ctx->scan_tmp)));
-    hipLaunchKernelGGL(k_clump_final, dim3(g), dim3(256), 0, st, lab, rank, csize, d_seg, d_segsz, n); KCHK(ctx);
+    hipLaunchKernelGGL(k_clump_final, dim3(g), dim3(256), 0, st, lab, rank, csize, d_seg, d_segsz, n,
+                       d_singles, d_nsingles); KCHK(ctx);
     prof_end(ctx, ps);
     return 0;
 }

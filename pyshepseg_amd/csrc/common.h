@@ -36,7 +36,7 @@ struct shp_ctx {
     // named workspace buffers (grow-only)
     DevBuf img, clus, lab, seg, aux, aux2, stack, scan_tmp, sort_k0, sort_k1, sort_v1, sort_hist,
         pix, segsz, origsz, off, ssum, chnext, chtail, mergeto, tcount, toff, tfill, tlist, tsorted,
-        small, cen, fit_x, fit_lab, fit_part, big, srclist, tgtlist, bigbits;
+        small, cen, fit_x, fit_lab, fit_part, big, srclist, tgtlist, bigbits, singles;
     uint32_t *h_pinned = nullptr;   // SHP_PINNED_BYTES of pinned host staging (small transfers)
     hipEvent_t ev[16] = {};
     double timings[8] = {};

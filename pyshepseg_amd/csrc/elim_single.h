@@ -190,9 +190,11 @@ static int run_seg_size(shp_ctx *ctx, const uint32_t *d_seg, uint32_t n, uint32_
 // d_seg: clump ids (in place).  max_id in: largest id; out: largest id after relabel.
 // sizes_ready: ctx->segsz already holds makeSegSize(d_seg) (run_clump provides it).
 // On return ctx->origsz holds the segment sizes under the NEW ids (max_id+1 entries).
+// singles_ready: ctx->singles holds nsingles one-pixel clumps (run_clump provides them) and
+// they are the only size-1 segments (the caller checked that the null count is not 1).
 static int run_eliminate_single(shp_ctx *ctx, const void *d_img, int dtype, int nb, uint32_t nrows,
                                 uint32_t ncols, int four, uint32_t *d_seg, uint32_t *max_id,
-                                int sizes_ready = 0)
+                                int sizes_ready = 0, int singles_ready = 0, uint32_t nsingles = 0)
 {
     const uint32_t n = nrows * ncols;
     CHK(buf_ensure(ctx, ctx->segsz, ((size_t)*max_id + 2) * 4));
@@ -207,14 +209,25 @@ static int run_eliminate_single(shp_ctx *ctx, const void *d_img, int dtype, int 
     if (n == 0) return 0;
     const unsigned g = grid_for(n, 256);
     hipStream_t st = ctx->stream;
-    HIPCHK(ctx, hipMemsetAsync(nelim, 0, 8, st));
-    hipLaunchKernelGGL(k_single_scan, dim3(g), dim3(256), 0, st, d_img, dtype, nb, d_seg, segsz, tgt, n,
-                       nrows, ncols, four, rest, nrest); KCHK(ctx);
-    hipLaunchKernelGGL(k_single_apply, dim3(g), dim3(256), 0, st, d_seg, segsz, tgt, n, nelim); KCHK(ctx);
-    HIPCHK(ctx, hipMemcpyAsync(ctx->h_pinned, nelim, 8, hipMemcpyDeviceToHost, st));
-    HIPCHK(ctx, hipStreamSynchronize(st));
-    uint32_t merged = ctx->h_pinned[0];
-    const uint32_t nr = ctx->h_pinned[1];
+    uint32_t merged = 0, nr = 0;
+    if (singles_ready) {
+        // the candidates are known: every pass (the first included) walks the list only
+        rest = bp<uint32_t>(ctx->singles);
+        nr = nsingles;
+        merged = 1;
+        uint32_t hn[2] = {0u, nsingles};
+        ctx->h_pinned[8] = hn[0]; ctx->h_pinned[9] = hn[1];
+        HIPCHK(ctx, hipMemcpyAsync(nelim, ctx->h_pinned + 8, 8, hipMemcpyHostToDevice, st));
+    } else {
+        HIPCHK(ctx, hipMemsetAsync(nelim, 0, 8, st));
+        hipLaunchKernelGGL(k_single_scan, dim3(g), dim3(256), 0, st, d_img, dtype, nb, d_seg, segsz, tgt, n,
+                           nrows, ncols, four, rest, nrest); KCHK(ctx);
+        hipLaunchKernelGGL(k_single_apply, dim3(g), dim3(256), 0, st, d_seg, segsz, tgt, n, nelim); KCHK(ctx);
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_pinned, nelim, 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        merged = ctx->h_pinned[0];
+        nr = ctx->h_pinned[1];
+    }
     // later passes touch only the single pixels that could not merge in the first one
     while (merged != 0 && nr != 0) {
         const unsigned gl = grid_for(nr, 256);

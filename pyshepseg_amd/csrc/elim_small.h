@@ -303,6 +303,7 @@ __global__ __launch_bounds__(256) void k_small_loop(SmallArgs a)
     __shared__ uint32_t wpix[4][64];
     __shared__ uint32_t lcnt, s_target, s_done;
     SmallCtl *ctl = a.ctl;
+    __builtin_amdgcn_s_setprio(2);
     const uint32_t G = gridDim.x;
     const uint32_t gtid = blockIdx.x * 256u + threadIdx.x, gthreads = G * 256u;
     const uint32_t gwave = gtid >> 6, gwaves = gthreads >> 6;
