@@ -133,7 +133,7 @@ def main():
     # dominant kernel by accumulated device time
     names = {0: 'k_assign', 1: 'ccl (k_ccl_init+k_ccl_merge+k_ccl_flatten)', 2: 'k_dfs_split',
              3: 'radix sort (k_sort_hist+k_sort_scatter)', 4: 'k_spectra_small+k_spectra_big',
-             5: 'small-segment pass loop', 7: 'seed scan + k_clump_final'}
+             5: 'k_small_loop', 7: 'seed scan + k_clump_final'}
     dom = max((i for i in names), key=lambda i: prof.get(i, (0, 0))[0])
     ms, cnt = prof[dom]
     ti = tiling.getTilesForFile(ras, args.tile, args.overlap)
@@ -143,6 +143,16 @@ def main():
     bpp = {0: 2 * args.bands + 2, 1: 6, 2: 6, 7: 6}.get(dom, 2 * args.bands + 4)
     avg_s = (ms / max(cnt, 1)) / 1e3
     achieved = (bpp * tile_px / avg_s / 1e9) if avg_s > 0 else 0.0
+    # HBM traffic per launch of that kernel from the committed PMC passes (rocprofv3 cannot run
+    # inside this process): FETCH_SIZE + WRITE_SIZE in KB, see profiles/r01_c_pmc_summary.json
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_c_pmc_summary.json')))['kernels']
+        k = pmc.get(names[dom].split(' ')[0])
+        if k and args.size == 40000:
+            traffic = int((k['FETCH_SIZE_KB_per_launch'] + k['WRITE_SIZE_KB_per_launch']) * 1024)
+    except Exception:
+        traffic = None
     out = {
         "metric": "Mpixels/sec segmented, 6-band 40k x 40k tiled",
         "value": round(value, 3), "unit": "Mpixels/s", "n_gpus": 1, "steps": args.steps,
@@ -156,7 +166,7 @@ def main():
                    "max_seg_id": int(r.maxSegId)},
         "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 3),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                     "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                      "avg_launch_ms": round(ms / max(cnt, 1), 3), "launches": int(cnt),
                      "bytes_per_launch": int(bpp * tile_px),
                      "whole_path_frac_of_hbm_roofline":
