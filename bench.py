@@ -41,7 +41,7 @@ def parse():
     ap.add_argument('--overlap', type=int, default=1024)
     ap.add_argument('--workers', type=int, default=int(os.environ.get('SHEPSEG_WORKERS', '16')))
     ap.add_argument('--simple-recode', type=int, default=0, help='diagnostic: simpleTileRecode')
-    ap.add_argument('--cpu-sample', type=int, default=6144,
+    ap.add_argument('--cpu-sample', type=int, default=9216,
                     help='window edge of the cpu_baseline sample (0 = skip)')
     return ap.parse_args()
 

@@ -150,6 +150,28 @@ int shp_stitch_tile_dev(shp_ctx *ctx, uint32_t *d_tile, int ys, int xs, int over
                         int64_t left_pitch, uint32_t max_local, int simple_recode,
                         uint32_t *d_max_seg_id, int top, int bottom, int left, int right,
                         uint32_t *d_out, int64_t out_pitch, int xout, int yout);
+/* The same stitch split in phases so that only a thin part is sequential (tiling.py:950-1306):
+ *  shp_stitch_prepare_dev -- purely local to the tile, run by the worker that segmented it:
+ *     fills d_meta = 4 x (max_local+1) uint32: flags (1 = crosses the top strip's midline,
+ *     2 = crosses the left strip's, 4 = has a pixel in the trimmed window), bounding-box top row,
+ *     bounding-box left column, and room for the LUT.  Synchronous.
+ *  shp_stitch_chain_dev -- the sequential step (asynchronous on the ctx stream): modes over the
+ *     overlap strips of the tile above / to the left (d_top_b / d_left_b as in
+ *     shp_stitch_tile_dev, but they now point at the DENSE recoded strips written by earlier
+ *     chain calls), new-id ranks, LUT, *d_max_seg_id advance, and the tile's own recoded right
+ *     strip (ys x overlap, pitch overlap) / bottom strip (overlap x xs, pitch xs) into
+ *     d_right_out / d_bottom_out (NULL = not needed).  The tile itself is not modified.  If
+ *     d_out is not NULL the trimmed window is written through the LUT to d_out on the ctx's side
+ *     stream, off the chain (shp_sync waits for both streams). */
+int shp_stitch_prepare_dev(shp_ctx *ctx, const uint32_t *d_tile, int ys, int xs, int overlap,
+                           int has_top, int has_left, uint32_t max_local, int top, int bottom,
+                           int left, int right, uint32_t *d_meta);
+int shp_stitch_chain_dev(shp_ctx *ctx, const uint32_t *d_tile, int ys, int xs, int overlap,
+                         const uint32_t *d_top_b, int64_t top_pitch, const uint32_t *d_left_b,
+                         int64_t left_pitch, uint32_t max_local, int simple_recode,
+                         uint32_t *d_max_seg_id, int top, int bottom, int left, int right,
+                         uint32_t *d_meta, uint32_t *d_right_out, uint32_t *d_bottom_out,
+                         uint32_t *d_out, int64_t out_pitch, int xout, int yout);
 /* histogram of a device label raster, hist_out_host[0..max_seg_id], entry 0 zeroed */
 int shp_histogram_dev(shp_ctx *ctx, const uint32_t *d_raster, int64_t npix, uint32_t max_seg_id,
                       uint32_t *hist_out_host);

@@ -583,6 +583,45 @@ API int shp_sync(shp_ctx *ctx)
 {
     CHK(enter(ctx));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->stream2) HIPCHK(ctx, hipStreamSynchronize(ctx->stream2));
+    return 0;
+}
+
+API int shp_stitch_prepare_dev(shp_ctx *ctx, const uint32_t *d_tile, int ys, int xs, int overlap,
+                               int has_top, int has_left, uint32_t max_local, int top, int bottom,
+                               int left, int right, uint32_t *d_meta)
+{
+    CHK(enter(ctx));
+    if (!d_tile || !d_meta || ys < 0 || xs < 0 || overlap < 0) SHP_FAIL(ctx, SHP_ERR_ARG, "bad argument");
+    if (top < 0 || left < 0 || bottom > ys || right > xs || top > bottom || left > right)
+        SHP_FAIL(ctx, SHP_ERR_ARG, "bad trimmed window");
+    CHK(run_stitch_prepare(ctx, d_tile, (uint32_t)ys, (uint32_t)xs, (uint32_t)overlap, has_top, has_left,
+                           max_local, (uint32_t)top, (uint32_t)bottom, (uint32_t)left, (uint32_t)right,
+                           d_meta));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+API int shp_stitch_chain_dev(shp_ctx *ctx, const uint32_t *d_tile, int ys, int xs, int overlap,
+                             const uint32_t *d_top_b, int64_t top_pitch, const uint32_t *d_left_b,
+                             int64_t left_pitch, uint32_t max_local, int simple_recode,
+                             uint32_t *d_max_seg_id, int top, int bottom, int left, int right,
+                             uint32_t *d_meta, uint32_t *d_right_out, uint32_t *d_bottom_out,
+                             uint32_t *d_out, int64_t out_pitch, int xout, int yout)
+{
+    CHK(enter(ctx));
+    if (!d_tile || !d_max_seg_id || !d_meta || ys < 0 || xs < 0 || overlap < 0)
+        SHP_FAIL(ctx, SHP_ERR_ARG, "bad argument");
+    if (top < 0 || left < 0 || bottom > ys || right > xs || top > bottom || left > right)
+        SHP_FAIL(ctx, SHP_ERR_ARG, "bad trimmed window");
+    CHK(run_stitch_chain(ctx, d_tile, (uint32_t)ys, (uint32_t)xs, (uint32_t)overlap, d_top_b,
+                         (size_t)top_pitch, d_left_b, (size_t)left_pitch, max_local, simple_recode,
+                         d_max_seg_id, (uint32_t)top, (uint32_t)bottom, (uint32_t)left, (uint32_t)right,
+                         d_meta, d_right_out, d_bottom_out));
+    if (d_out)
+        CHK(run_stitch_finish(ctx, d_tile, (uint32_t)ys, (uint32_t)xs, max_local, (uint32_t)top,
+                              (uint32_t)bottom, (uint32_t)left, (uint32_t)right, d_meta, d_out,
+                              (size_t)out_pitch, (uint32_t)xout, (uint32_t)yout));
     return 0;
 }
 

@@ -259,3 +259,232 @@ static int run_stitch_tile(shp_ctx *ctx, uint32_t *d_tile, uint32_t ys, uint32_t
     hipLaunchKernelGGL(k_max_merge, dim3(1), dim3(64), 0, st, d_max_seg_id, tmax); KCHK(ctx);
     return 0;
 }
+
+// =============================================================================================
+// Three-phase stitch.  The reference's stitch is sequential in tile order, but most of a tile's
+// work does not depend on its neighbours:
+//   prepare (worker stream, right after the tile is segmented; purely local):
+//       which local segments cross the midline of the top / left overlap strip, every segment's
+//       bounding-box corner, and whether it has a pixel in the trimmed window
+//   chain   (the one sequential stream; needs the recoded strips of the tiles above / left and
+//       the running maxSegId): pair counts over the two strips -> modes, new-id ranks, the LUT,
+//       maxSegId advance (a per-SEGMENT reduction: no pixel pass), and the recoded right /
+//       bottom overlap strips that later tiles will read
+//   finish  (side stream): LUT over the trimmed window -> output raster
+// Per-tile meta block (uint32 arrays of max_local+1 entries): flags | segtop | segleft | lut.
+// =============================================================================================
+#define META_CROSS_TOP 1u
+#define META_CROSS_LEFT 2u
+#define META_IN_TRIM 4u
+
+__global__ __launch_bounds__(256) void k_meta_cross(const uint32_t *__restrict__ mn,
+                                                    const uint32_t *__restrict__ mx, uint32_t mid,
+                                                    uint32_t nseg, uint32_t bit, uint32_t *flags)
+{
+    const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+    if (s >= nseg || s == 0) return;
+    if (mn[s] < mid && mx[s] >= mid + 1u) flags[s] |= bit;
+}
+
+// bounding-box corner of every segment + "has a pixel in the trimmed window"
+__global__ __launch_bounds__(256) void k_meta_pixels(const uint32_t *__restrict__ tile, uint32_t ys,
+                                                     uint32_t xs, uint32_t top, uint32_t bottom,
+                                                     uint32_t left, uint32_t right, uint32_t *segtop,
+                                                     uint32_t *segleft, uint32_t *flags)
+{
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (p >= ys * xs) return;
+    const uint32_t s = tile[p];
+    if (s == 0) return;
+    const uint32_t r = p / xs, c = p - r * xs;
+    const bool firstInCol = r == 0 || tile[p - xs] != s, firstInRow = c == 0 || tile[p - 1] != s;
+    if (firstInCol && r < segtop[s]) atomicMin(&segtop[s], r);
+    if (firstInRow && c < segleft[s]) atomicMin(&segleft[s], c);
+    // only run heads need to raise the flag (every run inside the window has a head inside it
+    // or starts at the window's left edge)
+    if (r >= top && r < bottom && c >= left && c < right && (firstInRow || c == left) &&
+        !(flags[s] & META_IN_TRIM))
+        atomicOr(&flags[s], META_IN_TRIM);
+}
+
+static int run_stitch_prepare(shp_ctx *ctx, const uint32_t *d_tile, uint32_t ys, uint32_t xs,
+                              uint32_t overlap, int has_top, int has_left, uint32_t max_local,
+                              uint32_t top, uint32_t bottom, uint32_t left, uint32_t right,
+                              uint32_t *d_meta)
+{
+    hipStream_t st = ctx->stream;
+    const uint32_t n = ys * xs, nseg = max_local + 1u;
+    uint32_t *flags = d_meta, *segtop = d_meta + nseg, *segleft = d_meta + 2 * (size_t)nseg;
+    HIPCHK(ctx, hipMemsetAsync(flags, 0, (size_t)nseg * 4, st));
+    HIPCHK(ctx, hipMemsetAsync(segtop, 0xff, (size_t)nseg * 8, st));
+    if (n == 0) return 0;
+    CHK(buf_ensure(ctx, ctx->aux, (size_t)nseg * 8 + 64));
+    uint32_t *mn = bp<uint32_t>(ctx->aux), *mx = mn + nseg;
+    const uint32_t an_rows = overlap < ys ? overlap : ys, an_cols = overlap < xs ? overlap : xs;
+    for (int pass = 0; pass < 2; pass++) {
+        const int horizontal = pass == 0;
+        if (horizontal ? !has_top : !has_left) continue;
+        const uint32_t srows = horizontal ? an_rows : ys, scols = horizontal ? xs : an_cols;
+        if (srows * scols == 0) continue;
+        HIPCHK(ctx, hipMemsetAsync(mn, 0xff, (size_t)nseg * 4, st));
+        HIPCHK(ctx, hipMemsetAsync(mx, 0, (size_t)nseg * 4, st));
+        hipLaunchKernelGGL(k_strip_minmax, dim3(grid_for(srows * scols, 256)), dim3(256), 0, st, d_tile, xs,
+                           srows, scols, horizontal, mn, mx); KCHK(ctx);
+        hipLaunchKernelGGL(k_meta_cross, dim3(grid_for(nseg, 256)), dim3(256), 0, st, mn, mx,
+                           (horizontal ? srows : scols) / 2u, nseg,
+                           horizontal ? META_CROSS_TOP : META_CROSS_LEFT, flags); KCHK(ctx);
+    }
+    hipLaunchKernelGGL(k_meta_pixels, dim3(grid_for(n, 256)), dim3(256), 0, st, d_tile, ys, xs, top, bottom,
+                       left, right, segtop, segleft, flags); KCHK(ctx);
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void k_pair_count_flag(
+    const uint32_t *__restrict__ tile, uint32_t xs, uint32_t srows, uint32_t scols,
+    const uint32_t *__restrict__ B, size_t bpitch, const uint32_t *__restrict__ flags, uint32_t bit,
+    unsigned long long *keys, uint32_t *cnts, uint32_t hmask)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    const bool inb = i < srows * scols;
+    unsigned long long key = 0;
+    if (inb) {
+        const uint32_t r = i / scols, c = i - r * scols;
+        const uint32_t s = tile[r * xs + c];
+        if (s != 0 && (flags[s] & bit))
+            key = ((unsigned long long)s << 32) | (unsigned long long)B[(size_t)r * bpitch + c];
+    }
+    const unsigned lane = lane_id();
+    const unsigned long long pk = __shfl_up(key, 1, 64);
+    const bool head = lane == 0 || pk != key;
+    const unsigned long long heads = __ballot(head);
+    if (head && key != 0) {
+        const unsigned long long nxt = (lane == 63) ? 0ull : (heads & ~((2ull << lane) - 1ull));
+        const uint32_t len = (nxt ? (unsigned)__builtin_ctzll(nxt) : 64u) - lane;
+        uint32_t h = hash64(key) & hmask;
+        for (;;) {
+            const unsigned long long old = atomicCAS(&keys[h], 0ull, key);
+            if (old == 0ull || old == key) { atomicAdd(&cnts[h], len); break; }
+            h = (h + 1u) & hmask;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_lut_simple(uint32_t *__restrict__ lut, uint32_t nseg,
+                                                    const uint32_t *__restrict__ max_seg_id)
+{
+    const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+    if (s >= nseg) return;
+    lut[s] = s ? s + *max_seg_id : 0u;
+}
+
+// largest recoded id among segments present in the trimmed window (== trimmed.max())
+__global__ __launch_bounds__(256) void k_tmax_segments(const uint32_t *__restrict__ lut,
+                                                       const uint32_t *__restrict__ flags,
+                                                       uint32_t nseg, uint32_t *tmax)
+{
+    const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+    uint32_t m = (s < nseg && s != 0 && (flags[s] & META_IN_TRIM)) ? lut[s] : 0u;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t o = __shfl_xor(m, d, 64);
+        m = o > m ? o : m;
+    }
+    if (lane_id() == 0 && m != 0) atomicMax(tmax, m);
+}
+
+// out[r][c] = lut[tile[(r0 + r) * xs + c0 + c]] for an (nr x nc) sub-window -> dense strip
+__global__ __launch_bounds__(256) void k_recode_window(const uint32_t *__restrict__ tile, uint32_t xs,
+                                                       uint32_t r0, uint32_t c0, uint32_t nr,
+                                                       uint32_t nc, const uint32_t *__restrict__ lut,
+                                                       uint32_t *__restrict__ out, size_t opitch)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= nr * nc) return;
+    const uint32_t r = i / nc, c = i - r * nc;
+    out[(size_t)r * opitch + c] = lut[tile[(r0 + r) * xs + c0 + c]];
+}
+
+static int run_stitch_chain(shp_ctx *ctx, const uint32_t *d_tile, uint32_t ys, uint32_t xs,
+                            uint32_t overlap, const uint32_t *d_top_b, size_t top_pitch,
+                            const uint32_t *d_left_b, size_t left_pitch, uint32_t max_local, int simple,
+                            uint32_t *d_max_seg_id, uint32_t top, uint32_t bottom, uint32_t left,
+                            uint32_t right, uint32_t *d_meta, uint32_t *d_right_out,
+                            uint32_t *d_bottom_out)
+{
+    hipStream_t st = ctx->stream;
+    const uint32_t n = ys * xs;
+    if (n == 0) return 0;
+    const uint32_t nseg = max_local + 1u;
+    uint32_t *flags = d_meta, *segtop = d_meta + nseg, *segleft = d_meta + 2 * (size_t)nseg;
+    uint32_t *lut = d_meta + 3 * (size_t)nseg;
+    const uint32_t an_rows = overlap < ys ? overlap : ys, an_cols = overlap < xs ? overlap : xs;
+    CHK(buf_ensure(ctx, ctx->small, 4096));
+    uint32_t *tmax = bp<uint32_t>(ctx->small) + 32;
+    HIPCHK(ctx, hipMemsetAsync(tmax, 0, 4, st));
+    if (simple) {
+        hipLaunchKernelGGL(k_lut_simple, dim3(grid_for(nseg, 256)), dim3(256), 0, st, lut, nseg, d_max_seg_id); KCHK(ctx);
+    } else {
+        uint32_t maxstrip = 0;
+        if (d_top_b) maxstrip = an_rows * xs;
+        if (d_left_b && ys * an_cols > maxstrip) maxstrip = ys * an_cols;
+        uint32_t hsize = 1024;
+        while (hsize < 2u * maxstrip) hsize <<= 1;
+        CHK(buf_ensure(ctx, ctx->aux, (size_t)nseg * 4 * 6 + 256));
+        CHK(buf_ensure(ctx, ctx->aux2, (size_t)hsize * 12 + 256));
+        CHK(buf_ensure(ctx, ctx->scan_tmp, scan_tmp_bytes(nseg)));
+        uint32_t *w = bp<uint32_t>(ctx->aux);
+        uint32_t *in_dict = w, *recode = w + nseg, *rank = w + 2 * (size_t)nseg;
+        unsigned long long *best = (unsigned long long *)(w + 4 * (size_t)nseg);
+        unsigned long long *keys = bp<unsigned long long>(ctx->aux2);
+        uint32_t *cnts = (uint32_t *)(keys + hsize);
+        HIPCHK(ctx, hipMemsetAsync(in_dict, 0, (size_t)nseg * 4, st));
+        for (int pass = 0; pass < 2; pass++) {
+            const int horizontal = pass == 0;
+            const uint32_t *B = horizontal ? d_top_b : d_left_b;
+            if (!B) continue;
+            const uint32_t srows = horizontal ? an_rows : ys, scols = horizontal ? xs : an_cols;
+            const uint32_t npx = srows * scols;
+            if (npx == 0) continue;
+            HIPCHK(ctx, hipMemsetAsync(best, 0, (size_t)nseg * 8, st));
+            HIPCHK(ctx, hipMemsetAsync(keys, 0, (size_t)hsize * 8, st));
+            HIPCHK(ctx, hipMemsetAsync(cnts, 0, (size_t)hsize * 4, st));
+            hipLaunchKernelGGL(k_pair_count_flag, dim3(grid_for(npx, 256)), dim3(256), 0, st, d_tile, xs, srows,
+                               scols, B, horizontal ? top_pitch : left_pitch, flags,
+                               horizontal ? META_CROSS_TOP : META_CROSS_LEFT, keys, cnts, hsize - 1u); KCHK(ctx);
+            hipLaunchKernelGGL(k_pair_best, dim3(grid_for(hsize, 256)), dim3(256), 0, st, keys, cnts, hsize, best); KCHK(ctx);
+            hipLaunchKernelGGL(k_best_to_dict, dim3(grid_for(nseg, 256)), dim3(256), 0, st, best, nseg, in_dict, recode); KCHK(ctx);
+        }
+        OwnFn own{in_dict, segtop, segleft, top, bottom, left, right};
+        CHK(scan_exclusive(ctx, own, nseg, rank, nullptr, bp<uint32_t>(ctx->scan_tmp)));
+        hipLaunchKernelGGL(k_build_lut, dim3(grid_for(nseg, 256)), dim3(256), 0, st, own, rank, recode,
+                           d_max_seg_id, nseg, lut); KCHK(ctx);
+    }
+    hipLaunchKernelGGL(k_tmax_segments, dim3(grid_for(nseg, 256)), dim3(256), 0, st, lut, flags, nseg, tmax); KCHK(ctx);
+    hipLaunchKernelGGL(k_max_merge, dim3(1), dim3(64), 0, st, d_max_seg_id, tmax); KCHK(ctx);
+    // the recoded overlap strips that the tiles to the right / below will read
+    if (d_right_out && an_cols)
+        { hipLaunchKernelGGL(k_recode_window, dim3(grid_for(ys * an_cols, 256)), dim3(256), 0, st, d_tile, xs, 0u,
+                             xs - an_cols, ys, an_cols, lut, d_right_out, (size_t)an_cols); KCHK(ctx); }
+    if (d_bottom_out && an_rows)
+        { hipLaunchKernelGGL(k_recode_window, dim3(grid_for(an_rows * xs, 256)), dim3(256), 0, st, d_tile, xs,
+                             ys - an_rows, 0u, an_rows, xs, lut, d_bottom_out, (size_t)xs); KCHK(ctx); }
+    return 0;
+}
+
+// trimmed window of the tile through the LUT into the output raster, on the side stream
+static int run_stitch_finish(shp_ctx *ctx, const uint32_t *d_tile, uint32_t ys, uint32_t xs,
+                             uint32_t max_local, uint32_t top, uint32_t bottom, uint32_t left,
+                             uint32_t right, const uint32_t *d_meta, uint32_t *d_out, size_t out_pitch,
+                             uint32_t xout, uint32_t yout)
+{
+    if (bottom <= top || right <= left) return 0;
+    const uint32_t nseg = max_local + 1u;
+    const uint32_t *lut = d_meta + 3 * (size_t)nseg;
+    HIPCHK(ctx, hipEventRecord(ctx->evfork, ctx->stream));          // after this tile's chain step
+    HIPCHK(ctx, hipStreamWaitEvent(ctx->stream2, ctx->evfork, 0));
+    const uint32_t nr = bottom - top, nc = right - left;
+    hipLaunchKernelGGL(k_recode_window, dim3(grid_for(nr * nc, 256)), dim3(256), 0, ctx->stream2, d_tile, xs,
+                       top, left, nr, nc, lut, d_out + (size_t)yout * out_pitch + xout, out_pitch); KCHK(ctx);
+    (void)ys;
+    return 0;
+}

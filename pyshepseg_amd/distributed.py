@@ -271,6 +271,10 @@ class HipEngine(object):
         self.d_out = tiling._devAlloc(self.c, self.nbOut)
         self.d_scal = tiling._devAlloc(self.c, 256)
         self.c.check(self.L.shp_dev_memset(self.c.handle, self.d_scal, 0, 256))
+        self.nbStrips = max(tiling.layoutStrips(jobs, overlapSize), 1) * 4
+        self.d_strips = tiling._devAlloc(self.c, self.nbStrips)
+        self.arena = tiling._MetaArena(self.c, 16 * (total // 8 + 1024))
+        self.simple = False
         self.threads, self.forceExit = [], None
         self.recvBufs = []
         self.recvDev = []
@@ -296,7 +300,8 @@ class HipEngine(object):
             return
         self.threads, self.forceExit = tiling.startSegmentationWorkers(
             self.ras, self.jobs, self.d_tiles, centres, msd, imgNullVal, fourConnected,
-            minSegmentSize, self.numWorkers, self.timings, yOrigin=self.yLo)
+            minSegmentSize, self.numWorkers, self.timings, yOrigin=self.yLo,
+            stitchPrep=(self.tileInfo, self.overlap, self.arena, self.simple))
 
     def waitTile(self, j):
         tiling.waitForTile(j, self.jobs, self.threads, self.forceExit, 600)
@@ -312,20 +317,23 @@ class HipEngine(object):
         return int(a[0])
 
     # strips are (device pointer, row pitch in elements)
-    def bottomStripOf(self, a):
-        return (self.d_tiles.value + 4 * (a.offset + (a.ysize - self.overlap) * a.xsize), a.xsize)
+    def bottomStripOf(self, a):      # dense recoded strip written by the chain step of tile a
+        return (self.d_strips.value + 4 * a.bottomOff, a.xsize)
 
     def rightStripOf(self, a):
-        return (self.d_tiles.value + 4 * (a.offset + (a.xsize - self.overlap)), a.xsize)
+        return (self.d_strips.value + 4 * a.rightOff, min(self.overlap, a.xsize))
 
     def stitchTile(self, j, top, left, win, simple):
         (t, b, l, r, xout, yout) = win
         with self.timings.interval('stitchtiles'):
-            self.c.check(self.L.shp_stitch_tile_dev(
+            # every tile's strips are written: a later rank may need the last row's bottom strips
+            self.c.check(self.L.shp_stitch_chain_dev(
                 self.c.handle, ctypes.c_void_p(self.d_tiles.value + 4 * j.offset), j.ysize, j.xsize,
                 self.overlap, ctypes.c_void_p(top[0]) if top else None, top[1] if top else 0,
                 ctypes.c_void_p(left[0]) if left else None, left[1] if left else 0, j.maxLocal,
-                int(bool(simple)), self.d_scal, t, b, l, r, self.d_out, self.nCols, xout,
+                int(bool(simple)), self.d_scal, t, b, l, r, ctypes.c_void_p(j.meta),
+                ctypes.c_void_p(self.d_strips.value + 4 * j.rightOff),
+                ctypes.c_void_p(self.d_strips.value + 4 * j.bottomOff), self.d_out, self.nCols, xout,
                 yout - self.outLo))
 
     @staticmethod
@@ -396,6 +404,8 @@ class HipEngine(object):
         self.recvDev = []
         tiling._devRelease(self.c, self.d_tiles, self.nbTiles)
         tiling._devRelease(self.c, self.d_scal, 256)
+        tiling._devRelease(self.c, self.d_strips, self.nbStrips)
+        self.arena.release()
         if self.keepOutput:
             self._lastOut = self.d_out               # caller must releaseOutput()
         else:

@@ -373,7 +373,49 @@ def fitSpectralClustersWholeFile(inDs, bandNumbers, numClusters=60, subsamplePcn
 # ------------------------------------------------------------------------------------------
 class _TileJob(object):
     __slots__ = ('col', 'row', 'xpos', 'ypos', 'xsize', 'ysize', 'offset', 'maxLocal', 'done',
-                 'error')
+                 'error', 'meta', 'rightOff', 'bottomOff')
+
+
+class _MetaArena(object):
+    """Bump allocator over one device block for the per-tile stitch tables (4 uint32 arrays of
+    maxLocal+1 entries each); falls back to individual allocations when the block is full."""
+    def __init__(self, c, nbytes):
+        self.c = c
+        self.nbytes = max(int(nbytes), 1 << 20)
+        self.base = _devAlloc(c, self.nbytes)
+        self.used = 0
+        self.extra = []
+        self.lock = threading.Lock()
+
+    def alloc(self, nseg):
+        need = (16 * int(nseg) + 255) & ~255
+        with self.lock:
+            if self.used + need <= self.nbytes:
+                p = self.base.value + self.used
+                self.used += need
+                return p
+        d = _devAlloc(self.c, need)
+        with self.lock:
+            self.extra.append((d, need))
+        return d.value
+
+    def release(self):
+        _devRelease(self.c, self.base, self.nbytes)
+        for (d, n) in self.extra:
+            _devRelease(self.c, d, n)
+        self.extra = []
+
+
+def layoutStrips(jobs, overlapSize):
+    """Offsets (in uint32 elements) of every tile's dense recoded right strip (ysize x overlap)
+    and bottom strip (overlap x xsize) inside one block; returns the block's element count."""
+    total = 0
+    for j in jobs:
+        j.rightOff = total
+        total += j.ysize * min(overlapSize, j.xsize)
+        j.bottomOff = total
+        total += min(overlapSize, j.ysize) * j.xsize
+    return total
 
 
 def trimmedWindow(tileInfo, col, row, xpos, ypos, xsize, ysize, overlapSize):
@@ -417,7 +459,7 @@ def makeTileJobs(tileInfo, rows=None):
 
 def startSegmentationWorkers(src, jobs, d_tiles, centres, msd, imgNullVal, fourConnected,
         minSegmentSize, numWorkers, timings, bands=None, yOrigin=0, maxConcurrentReads=20,
-        verbose=False):
+        verbose=False, stitchPrep=None):
     """Start `numWorkers` threads, each with a pooled HIP context (one stream), that segment
     the jobs' windows of `src` (tile window rows are relative to yOrigin when src holds only a
     slice of the raster) into the device label block d_tiles.  Mirrors SegThreadsMgr.worker
@@ -483,6 +525,16 @@ def startSegmentationWorkers(src, jobs, d_tiles, centres, msd, imgNullVal, fourC
                             ctypes.byref(mx), ctypes.byref(s1), ctypes.byref(s2),
                             ctypes.byref(ncl)))
                 j.maxLocal = mx.value
+                if stitchPrep is not None:
+                    # the tile-local part of the stitch, off the sequential chain
+                    (tileInfo, overlapSize, arena, simple) = stitchPrep
+                    (top, bottom, left, right, _x, _y) = trimmedWindow(
+                        tileInfo, j.col, j.row, j.xpos, j.ypos, j.xsize, j.ysize, overlapSize)
+                    j.meta = arena.alloc(mx.value + 1)
+                    c.check(L.shp_stitch_prepare_dev(
+                        c.handle, dseg, j.ysize, j.xsize, overlapSize,
+                        int(j.row > 0 and not simple), int(j.col > 0 and not simple), mx.value,
+                        top, bottom, left, right, ctypes.c_void_p(j.meta)))
                 if verbose:
                     print("Tile ({}, {}): {} segments".format(j.col, j.row, mx.value))
             except Exception as e:
@@ -570,6 +622,9 @@ def doTiledShepherdSegmentation(infile, outfile, tileSize=DFLT_TILESIZE,
         d_out = _devAlloc(main, nbOut)
         d_scal = _devAlloc(main, 256)
         main.check(L.shp_dev_memset(main.handle, d_scal, 0, 256))
+        nbStrips = max(layoutStrips(jobs, overlapSize), 1) * 4
+        d_strips = _devAlloc(main, nbStrips)
+        arena = _MetaArena(main, 16 * (total // 8 + 1024))
         forceExit = None
         try:
             numWorkers = 1
@@ -578,7 +633,7 @@ def doTiledShepherdSegmentation(infile, outfile, tileSize=DFLT_TILESIZE,
             threads, forceExit = startSegmentationWorkers(
                 src, jobs, d_tiles, centres, msd, imgNullVal, fourConnected, minSegmentSize,
                 numWorkers, timings, bands=bands, maxConcurrentReads=concurrencyCfg.maxConcurrentReads,
-                verbose=verbose)
+                verbose=verbose, stitchPrep=(tileInfo, overlapSize, arena, bool(simpleTileRecode)))
 
             # ---- stitchTiles (tiling.py:950-1064): sequential, concurrent with the workers ----
             with timings.interval('stitchtiles'):
@@ -591,17 +646,22 @@ def doTiledShepherdSegmentation(infile, outfile, tileSize=DFLT_TILESIZE,
                     if not simpleTileRecode:
                         if j.row > 0:
                             a = jobmap[(j.col, j.row - 1)]
-                            topB = ctypes.c_void_p(d_tiles.value + 4 * (a.offset + (a.ysize - overlapSize) * a.xsize))
+                            topB = ctypes.c_void_p(d_strips.value + 4 * a.bottomOff)
                             topPitch = a.xsize
                         if j.col > 0:
                             a = jobmap[(j.col - 1, j.row)]
-                            leftB = ctypes.c_void_p(d_tiles.value + 4 * (a.offset + (a.xsize - overlapSize)))
-                            leftPitch = a.xsize
-                    main.check(L.shp_stitch_tile_dev(
+                            leftB = ctypes.c_void_p(d_strips.value + 4 * a.rightOff)
+                            leftPitch = min(overlapSize, a.xsize)
+                    rightOut = bottomOut = None
+                    if j.col != tileInfo.ncols - 1:
+                        rightOut = ctypes.c_void_p(d_strips.value + 4 * j.rightOff)
+                    if j.row != tileInfo.nrows - 1:
+                        bottomOut = ctypes.c_void_p(d_strips.value + 4 * j.bottomOff)
+                    main.check(L.shp_stitch_chain_dev(
                         main.handle, ctypes.c_void_p(d_tiles.value + 4 * j.offset), j.ysize, j.xsize,
                         overlapSize, topB, topPitch, leftB, leftPitch, j.maxLocal,
-                        int(bool(simpleTileRecode)), d_scal, top, bottom, left, right, d_out,
-                        inXsize, xout, yout))
+                        int(bool(simpleTileRecode)), d_scal, top, bottom, left, right,
+                        ctypes.c_void_p(j.meta), rightOut, bottomOut, d_out, inXsize, xout, yout))
                 main.check(L.shp_sync(main.handle))
             for t in threads:
                 t.join()
@@ -639,6 +699,8 @@ def doTiledShepherdSegmentation(infile, outfile, tileSize=DFLT_TILESIZE,
             _devRelease(main, d_tiles, nbTiles)
             _devRelease(main, d_out, nbOut)
             _devRelease(main, d_scal, 256)
+            _devRelease(main, d_strips, nbStrips)
+            arena.release()
 
     result.maxSegId = maxSegId
     result.numTileRows = tileInfo.nrows
