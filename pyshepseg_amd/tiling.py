@@ -476,9 +476,15 @@ def startSegmentationWorkers(src, jobs, d_tiles, centres, msd, imgNullVal, fourC
     dtcode = _lib.SHP_DTYPES[numpy.dtype(src.dtype)] if onDevice else None
     (srcYsize, srcXsize) = (src.shape[1], src.shape[2])
     readSem = threading.BoundedSemaphore(max(1, maxConcurrentReads))
+    # longest-processing-time-first: the edge tiles are up to 2.3x larger; starting them first
+    # avoids a tail where a few workers finish the big ones alone (the stitch consumes in
+    # row-major order regardless and its sequential part is thin)
+    order = sorted(range(len(jobs)), key=lambda i: (-(jobs[i].xsize * jobs[i].ysize), i))
+    if os.environ.get('SHEPSEG_TILE_ORDER', 'lpt') != 'lpt':
+        order = list(range(len(jobs)))
     inQue = queue.Queue()
-    for j in jobs:
-        inQue.put(j)
+    for i in order:
+        inQue.put(jobs[i])
     forceExit = threading.Event()
 
     def worker():
