@@ -330,6 +330,7 @@ API int shp_segment_tile(shp_ctx *ctx, const void *img, int dtype, int nbands, i
     if (small_elim_out) *small_elim_out = 0;
     if (num_clumps_out) *num_clumps_out = 0;
     if (n == 0) return 0;
+    ctx->dfs_fork = 1;
     hipEventRecord(ctx->ev[0], ctx->stream);
     CHK(upload_img(ctx, img, dtype, nbands, n));
     CHK(buf_ensure(ctx, ctx->seg, (size_t)n * 4));
@@ -514,6 +515,7 @@ API int shp_segment_window_dev(shp_ctx *ctx, const void *d_img, int dtype, int n
     if (small_elim_out) *small_elim_out = 0;
     if (num_clumps_out) *num_clumps_out = 0;
     if (n == 0) return 0;
+    ctx->dfs_fork = 0;      // many tiles in flight: one stream per worker is enough
     hipEventRecord(ctx->ev[0], ctx->stream);
     const void *tile_img = d_img;
     if (!(x == 0 && y == 0 && xs == img_cols && ys == img_rows)) {
@@ -551,6 +553,7 @@ API int shp_segment_tile_to_dev(shp_ctx *ctx, const void *img, int dtype, int nb
     if (small_elim_out) *small_elim_out = 0;
     if (num_clumps_out) *num_clumps_out = 0;
     if (n == 0) return 0;
+    ctx->dfs_fork = 0;
     hipEventRecord(ctx->ev[0], ctx->stream);
     CHK(upload_img(ctx, img, dtype, nbands, n));
     CHK(segment_device(ctx, ctx->img.p, d_seg_out, dtype, nbands, nrows, ncols, centres, k, has_null,

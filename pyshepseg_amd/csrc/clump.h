@@ -397,6 +397,24 @@ __device__ __forceinline__ void dfs_split_lds(uint32_t *lab, const BigInfo &B, u
     }
 }
 
+// order[rank] = component index, largest first: the longest replays start first (LPT), which
+// shortens the makespan whenever there are more components than resident workgroups
+__global__ __launch_bounds__(256) void k_big_order(const BigInfo *__restrict__ big,
+                                                   const uint32_t *__restrict__ counters,
+                                                   uint32_t *__restrict__ order)
+{
+    const uint32_t nbig = counters[0];
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= nbig) return;
+    const uint32_t si = big[i].size;
+    uint32_t rank = 0;
+    for (uint32_t j = 0; j < nbig; j++) {
+        const uint32_t sj = big[j].size;
+        rank += (sj > si || (sj == si && j < i)) ? 1u : 0u;
+    }
+    order[rank] = i;
+}
+
 // Two launches per tile share this kernel: class A (bitmap <= 24 KiB: ~90 % of the components,
 // 30 KiB of LDS per workgroup so five fit a CU and other kernels still find LDS) and class B
 // (<= 64 KiB bitmap, or no bitmap at all -> global path).  Keeping the footprint small matters:
@@ -407,13 +425,14 @@ __global__ __launch_bounds__(64) void k_dfs_split(uint32_t *lab, const BigInfo *
                                                   uint32_t *stackbuf, uint32_t nrows,
                                                   uint32_t ncols, int four, uint32_t bmw_lo,
                                                   uint32_t bmw_hi, int take_global,
-                                                  uint32_t *singles, uint32_t *nsingles)
+                                                  uint32_t *singles, uint32_t *nsingles,
+                                                  const uint32_t *__restrict__ order)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t dfs_lds[];
     uint32_t *sw = dfs_lds;                  // DFS_SWN entries
     uint32_t *bm = dfs_lds + DFS_SWN;        // bmw_hi words
-    const uint32_t bi = blockIdx.x;
-    if (bi >= counters[0]) return;
+    if (blockIdx.x >= counters[0]) return;
+    const uint32_t bi = order[blockIdx.x];
     __builtin_amdgcn_s_setprio(3);          // a lone latency-bound wave: win issue arbitration
     const BigInfo B = big[bi];
     const unsigned long long words = dfs_bitmap_words(B, ncols);
@@ -464,13 +483,19 @@ __global__ __launch_bounds__(256) void k_clump_final(const uint32_t *__restrict_
         }
     }
     if (singles) {
+        // block-level compaction: one global atomic per workgroup (a per-wave atomic on the one
+        // counter serialises ~10^5 same-address atomics per tile)
+        __shared__ uint32_t s_cnt, s_base;
+        if (threadIdx.x == 0) s_cnt = 0;
+        __syncthreads();
         const unsigned long long ms = __ballot(single);
-        if (ms != 0ull) {
-            uint32_t base = 0;
-            if (lane == 0) base = atomicAdd(nsingles, (uint32_t)__popcll(ms));
-            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-            if (single) singles[base + (uint32_t)__popcll(ms & lanemask_lt())] = p;
-        }
+        uint32_t wbase = 0;
+        if (ms != 0ull && lane == 0) wbase = atomicAdd(&s_cnt, (uint32_t)__popcll(ms));
+        wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wbase);
+        __syncthreads();
+        if (threadIdx.x == 0 && s_cnt) s_base = atomicAdd(nsingles, s_cnt);
+        __syncthreads();
+        if (single) singles[s_base + wbase + (uint32_t)__popcll(ms & lanemask_lt())] = p;
     }
     const uint32_t pk = __shfl_up(key, 1, 64);
     const bool head = lane == 0 || pk != key;
@@ -505,7 +530,7 @@ static int run_clump(shp_ctx *ctx, const uint16_t *d_clus, uint32_t nrows, uint3
         CHK(buf_ensure(ctx, ctx->segsz, ((size_t)n + 2) * 4));
         d_segsz = bp<uint32_t>(ctx->segsz);
     }
-    CHK(buf_ensure(ctx, ctx->big, (size_t)maxbig * sizeof(BigInfo) + 64));
+    CHK(buf_ensure(ctx, ctx->big, (size_t)maxbig * (sizeof(BigInfo) + 4) + 128));
     CHK(buf_ensure(ctx, ctx->scan_tmp, scan_tmp_bytes(n)));
     uint32_t *lab = bp<uint32_t>(ctx->lab), *csize = bp<uint32_t>(ctx->aux);
     uint32_t *counters = (uint32_t *)((char *)ctx->big.p + (size_t)maxbig * sizeof(BigInfo));
@@ -526,9 +551,12 @@ static int run_clump(shp_ctx *ctx, const uint16_t *d_clus, uint32_t nrows, uint3
     hipLaunchKernelGGL(k_big_list, dim3(g), dim3(256), 0, st, lab, csize, n, ncols, big, counters, bigbits); KCHK(ctx);
     hipLaunchKernelGGL(k_big_bbox, dim3(g), dim3(256), 0, st, lab, csize, n, ncols, big, bigbits); KCHK(ctx);
     ps = prof_begin(ctx, PROF_DFS);
+    uint32_t *order = (uint32_t *)((char *)ctx->big.p + (size_t)maxbig * sizeof(BigInfo) + 64);
+    hipLaunchKernelGGL(k_big_order, dim3(grid_for(maxbig, 256)), dim3(256), 0, st, big, counters, order); KCHK(ctx);
     if (d_nsingles) HIPCHK(ctx, hipMemsetAsync(d_nsingles, 0, 4, st));
     // fork: the two size classes touch disjoint components, so they can run on two streams
-    static const int fork2 = getenv("SHEPSEG_DFS_FORK") ? atoi(getenv("SHEPSEG_DFS_FORK")) : 0;
+    static const int fork_env = getenv("SHEPSEG_DFS_FORK") ? atoi(getenv("SHEPSEG_DFS_FORK")) : -1;
+    const int fork2 = fork_env >= 0 ? fork_env : ctx->dfs_fork;
     hipStream_t st2 = fork2 ? ctx->stream2 : st;
     if (fork2) {
         HIPCHK(ctx, hipEventRecord(ctx->evfork, st));
@@ -536,10 +564,10 @@ static int run_clump(shp_ctx *ctx, const uint16_t *d_clus, uint32_t nrows, uint3
     }
     hipLaunchKernelGGL(k_dfs_split, dim3(maxbig), dim3(64), (DFS_SWN + DFS_BMW_LARGE) * 4, st, lab, big,
                        counters, bp<uint32_t>(ctx->stack), nrows, ncols, four, DFS_BMW_SMALL,
-                       DFS_BMW_LARGE, 1, d_singles, d_nsingles); KCHK(ctx);
+                       DFS_BMW_LARGE, 1, d_singles, d_nsingles, order); KCHK(ctx);
     hipLaunchKernelGGL(k_dfs_split, dim3(maxbig), dim3(64), (DFS_SWN + DFS_BMW_SMALL) * 4, st2, lab,
                        big, counters, bp<uint32_t>(ctx->stack), nrows, ncols, four, 0u, DFS_BMW_SMALL, 0,
-                       d_singles, d_nsingles);
+                       d_singles, d_nsingles, order);
     KCHK(ctx);
     if (fork2) {
         HIPCHK(ctx, hipEventRecord(ctx->evjoin, ctx->stream2));

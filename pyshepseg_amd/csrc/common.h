@@ -46,6 +46,7 @@ struct shp_ctx {
     hipEvent_t prof_ev[PROF_POOL][2] = {};
     int prof_id[PROF_POOL] = {};
     int prof_used = 0;
+    int dfs_fork = 1;   // run the two DFS size classes on two streams (single-tile latency)
 };
 
 // kernels whose launch durations bench.py reports against the roofline

@@ -302,6 +302,7 @@ __global__ __launch_bounds__(256) void k_small_loop(SmallArgs a)
     __shared__ uint32_t lsrc[256];
     __shared__ uint32_t wpix[4][64];
     __shared__ uint32_t lcnt, s_target, s_done;
+    __shared__ uint32_t lhist[256];
     SmallCtl *ctl = a.ctl;
     __builtin_amdgcn_s_setprio(2);
     const uint32_t G = gridDim.x;
@@ -370,13 +371,29 @@ __global__ __launch_bounds__(256) void k_small_loop(SmallArgs a)
         }
         if (!small_grid_barrier(ctl, G)) return;
         const uint32_t nsrc = cnt->nsrc;
-        // ---- merge step 1 (wave per source): count per target, list targets, relabel pixels
-        //      (doMerge :1107-1109) ----
+        // ---- merge step 1: count sources per target and list the targets (thread per source,
+        //      one counter atomic per wavefront), then relabel the sources' pixels (wave per
+        //      source; doMerge :1107-1109) ----
+        for (uint32_t i0 = 0; i0 < nsrc; i0 += gthreads) {
+            const uint32_t i = i0 + gtid;
+            uint32_t t = 0;
+            bool first = false;
+            if (i < nsrc) {
+                t = a.mergeto[a.srclist[i]];
+                if (t != 0) first = atomicAdd(&a.tcount[t], 1u) == 0u;
+            }
+            const unsigned long long mf = __ballot(first);
+            if (mf != 0ull) {
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(&cnt->ntgt, (uint32_t)__popcll(mf));
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                if (first) a.tgtlist[base + (uint32_t)__popcll(mf & lanemask_lt())] = t;
+            }
+        }
         for (uint32_t i = gwave; i < nsrc; i += gwaves) {
             const uint32_t s = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.srclist[i]);
             const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.mergeto[s]);
             if (t == 0) continue;
-            if (lane == 0 && atomicAdd(&a.tcount[t], 1u) == 0u) a.tgtlist[atomicAdd(&cnt->ntgt, 1u)] = t;
             for (uint32_t c = s; c != 0; c = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.chnext[c])) {
                 const uint32_t o = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.off[c]);
                 const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.origsz[c]);
@@ -385,10 +402,22 @@ __global__ __launch_bounds__(256) void k_small_loop(SmallArgs a)
         }
         if (!small_grid_barrier(ctl, G)) return;
         const uint32_t ntgt = cnt->ntgt;
-        // ---- storage for each target's source list ----
-        for (uint32_t i = gtid; i < ntgt; i += gthreads) {
-            const uint32_t t = a.tgtlist[i];
-            a.toff[t] = atomicAdd(&cnt->bump, a.tcount[t]);
+        // ---- storage for each target's source list (wave prefix sum, one bump atomic/wave) ----
+        for (uint32_t i0 = 0; i0 < ntgt; i0 += gthreads) {
+            const uint32_t i = i0 + gtid;
+            const uint32_t t = (i < ntgt) ? a.tgtlist[i] : 0u;
+            const uint32_t c = (i < ntgt) ? a.tcount[t] : 0u;
+            uint32_t incl = c;
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) {
+                const uint32_t o = __shfl_up(incl, d, 64);
+                if (lane >= (unsigned)d) incl += o;
+            }
+            const uint32_t tot = __shfl(incl, 63, 64);
+            uint32_t base = 0;
+            if (lane == 0 && tot) base = atomicAdd(&cnt->bump, tot);
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            if (i < ntgt) a.toff[t] = base + incl - c;
         }
         if (!small_grid_barrier(ctl, G)) return;
         for (uint32_t i = gtid; i < nsrc; i += gthreads) {
@@ -410,6 +439,10 @@ __global__ __launch_bounds__(256) void k_small_loop(SmallArgs a)
         }
         if (!small_grid_barrier(ctl, G)) return;
         // ---- merge step 2: each target absorbs its sources in ascending id (doMerge :1112-1123)
+        //      size-histogram updates go through LDS, numElim through a wave reduction ----
+        for (uint32_t b = threadIdx.x; b < 256u; b += 256u) lhist[b] = 0;
+        __syncthreads();
+        uint32_t my_elim = 0;
         for (uint32_t i0 = gtid; i0 < ntgt; i0 += gthreads) {
             const uint32_t t = a.tgtlist[i0];
             const uint32_t n = a.tcount[t], base = a.toff[t];
@@ -431,11 +464,20 @@ __global__ __launch_bounds__(256) void k_small_loop(SmallArgs a)
             a.chtail[t] = tail;
             a.tcount[t] = 0;
             a.tfill[t] = 0;
-            atomicSub(&a.hist[target], n);
-            if (a0 < a.min_seg) atomicSub(&a.hist[a0], 1u);
-            if (sz < a.min_seg) atomicAdd(&a.hist[sz], 1u);
-            atomicAdd(&ctl->nelim, n);
+            my_elim += n;
+            // histogram of sizes < min_seg: bins < 256 via LDS (signed deltas as uint32 wrap)
+            if (a0 < a.min_seg) { if (a0 < 256u) atomicSub(&lhist[a0], 1u); else atomicSub(&a.hist[a0], 1u); }
+            if (sz < a.min_seg) { if (sz < 256u) atomicAdd(&lhist[sz], 1u); else atomicAdd(&a.hist[sz], 1u); }
         }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) my_elim += __shfl_xor(my_elim, d, 64);
+        if (lane == 0 && my_elim) {
+            atomicAdd(&ctl->nelim, my_elim);
+            if (target < 256u) atomicSub(&lhist[target], my_elim); else atomicSub(&a.hist[target], my_elim);
+        }
+        __syncthreads();
+        if (threadIdx.x < a.min_seg && lhist[threadIdx.x] != 0u)
+            atomicAdd(&a.hist[threadIdx.x], lhist[threadIdx.x]);          // wrapping add of the delta
         if (!small_grid_barrier(ctl, G)) return;
     }
 }
