@@ -151,3 +151,46 @@ def test_edge_shapes(shepseg, oracle):
     assert np.array_equal(r.segimg, want['segimg'])
     ids = np.unique(r.segimg)
     assert ids[0] >= 1 and np.array_equal(ids, np.arange(ids[0], ids[-1] + 1))
+
+
+@pytest.mark.parametrize('dtype,nb,null,four', [
+    (np.uint16, 10, 65535, True),       # C4-like: 10 bands (generic-NB kernels), null border
+    (np.int16, 9, -32768, False),       # odd band count -> runtime-NB assign path, 8-connected
+    (np.uint8, 3, None, True),
+    (np.int32, 2, None, True),
+])
+def test_oracle_parity_dtypes_bands(dtype, nb, null, four, shepseg, oracle):
+    rng = np.random.RandomState(nb)
+    base = oracle.synthimg(40 + nb, nb, 300, 340).astype(np.int64)
+    if dtype == np.uint8:
+        img = (base // 24).astype(np.uint8)
+    elif dtype == np.int16:
+        img = (base - 3000).astype(np.int16)
+    elif dtype == np.int32:
+        img = (base * 37 - 50000).astype(np.int32)
+    else:
+        img = base.astype(np.uint16)
+    if null is not None:
+        img[:, :5, :] = null
+        img[nb // 2][rng.rand(300, 340) < 0.01] = null
+    xs = shepseg._sample_rows(img, 2, null)
+    init = shepseg.diagonalClusterCentres(xs, 20).astype(np.float64)
+    centres, _l, _n = oracle.kmeans_fit(xs.astype(np.float64), init)
+    km = shepseg.KMeansModel(centres)
+    got = shepseg.doShepherdSegmentation(img, minSegmentSize=30, imgNullVal=null,
+                                         fourConnected=four, kmeansObj=km)
+    want = oracle.segment_tile(img, centres, 30, float(got.maxSpectralDiff), null, four)
+    assert np.array_equal(got.segimg, want['segimg'])
+    assert got.singlePixelsEliminated == want['singlePixelsEliminated']
+    assert got.smallSegmentsEliminated == want['smallSegmentsEliminated']
+
+
+def test_default_kmeanspp_path_runs(shepseg, oracle):
+    """fixedKMeansInit=False (the reference's default): k-means++ seeding x 5 device fits.  No
+    parity definition (unseeded in the reference); the result must be a valid segmentation that
+    the oracle reproduces from the model that was chosen."""
+    img = oracle.synthimg(77, 3, 200, 220)
+    r = shepseg.doShepherdSegmentation(img, numClusters=8, clusterSubsamplePcnt=10, minSegmentSize=15)
+    assert r.kmeans.cluster_centers_.shape == (8, 3) and r.kmeans.inertia_ > 0
+    want = oracle.segment_tile(img, r.kmeans.cluster_centers_, 15, float(r.maxSpectralDiff), None, True)
+    assert np.array_equal(r.segimg, want['segimg'])
