@@ -85,13 +85,17 @@ __global__ __launch_bounds__(256) void k_ccl_merge(const uint16_t *__restrict__ 
     }
 }
 
-__global__ __launch_bounds__(256) void k_ccl_flatten(uint32_t *lab, uint32_t n)
+// lab[p] = root; the size accumulator of every root is zeroed here so that no N-sized memset
+// is needed before k_run_count (only roots are ever read)
+__global__ __launch_bounds__(256) void k_ccl_flatten(uint32_t *lab, uint32_t n, uint32_t *csize)
 {
     const uint32_t p = blockIdx.x * 256u + threadIdx.x;
     if (p >= n) return;
     const uint32_t l = lab[p];
     if (l == NULL_LAB) return;
-    lab[p] = uf_find(lab, p);
+    const uint32_t r = uf_find(lab, p);
+    lab[p] = r;
+    if (r == p) csize[p] = 0u;
 }
 
 // cnt[key[p]] += 1 for every pixel, one atomic per run of equal keys per wavefront.
@@ -168,7 +172,8 @@ __device__ __forceinline__ unsigned long long dfs_bitmap_words(const BigInfo &B,
 
 __device__ __forceinline__ void dfs_split_global(uint32_t *lab, const BigInfo &B, uint32_t *sw,
                                                  uint32_t *stackbuf, uint32_t nrows, uint32_t ncols,
-                                                 int four, uint32_t *singles, uint32_t *nsingles)
+                                                 int four, uint32_t *singles, uint32_t *nsingles,
+                                                 uint32_t *csize)
 {
     const uint32_t root = B.root;
     uint32_t *gstack = stackbuf + B.off;
@@ -255,8 +260,12 @@ __device__ __forceinline__ void dfs_split_global(uint32_t *lab, const BigInfo &B
                 __builtin_amdgcn_wave_barrier();
             }
         }
-        // a piece that never grew is a one-pixel clump: candidate of the single-pixel pass
-        if (cnt == 0 && singles && lane == 0) singles[atomicAdd(nsingles, 1u)] = seed;
+        // the piece's size is known here: cnt pixels were added after the seed (makeSegSize for
+        // free); a piece that never grew is a one-pixel clump = candidate of the single-pixel pass
+        if (lane == 0) {
+            csize[seed] = cnt + 1u;
+            if (cnt == 0 && singles) singles[atomicAdd(nsingles, 1u)] = seed;
+        }
         __threadfence();
         cursor = seed + 1;
         if (cursor >= nrows * ncols) break;
@@ -280,7 +289,8 @@ __device__ __forceinline__ unsigned long long dfs_bitmap_words(const BigInfo &B,
 
 __device__ __forceinline__ void dfs_split_lds(uint32_t *lab, const BigInfo &B, uint32_t *bm,
                                               uint32_t *sw, uint32_t *stackbuf, uint32_t ncols,
-                                              int four, uint32_t *singles, uint32_t *nsingles)
+                                              int four, uint32_t *singles, uint32_t *nsingles,
+                                              uint32_t *csize)
 {
     const uint32_t root = B.root;
     uint32_t *gstack = stackbuf + B.off;
@@ -393,7 +403,10 @@ __device__ __forceinline__ void dfs_split_lds(uint32_t *lab, const BigInfo &B, u
                 __builtin_amdgcn_wave_barrier();
             }
         }
-        if (cnt == 0 && singles && lane == 0) singles[atomicAdd(nsingles, 1u)] = seed;
+        if (lane == 0) {
+            csize[seed] = cnt + 1u;
+            if (cnt == 0 && singles) singles[atomicAdd(nsingles, 1u)] = seed;
+        }
     }
 }
 
@@ -426,7 +439,7 @@ __global__ __launch_bounds__(64) void k_dfs_split(uint32_t *lab, const BigInfo *
                                                   uint32_t ncols, int four, uint32_t bmw_lo,
                                                   uint32_t bmw_hi, int take_global,
                                                   uint32_t *singles, uint32_t *nsingles,
-                                                  const uint32_t *__restrict__ order)
+                                                  const uint32_t *__restrict__ order, uint32_t *csize)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t dfs_lds[];
     uint32_t *sw = dfs_lds;                  // DFS_SWN entries
@@ -437,9 +450,9 @@ __global__ __launch_bounds__(64) void k_dfs_split(uint32_t *lab, const BigInfo *
     const BigInfo B = big[bi];
     const unsigned long long words = dfs_bitmap_words(B, ncols);
     if (words > bmw_lo && words <= bmw_hi)
-        dfs_split_lds(lab, B, bm, sw, stackbuf, ncols, four, singles, nsingles);
+        dfs_split_lds(lab, B, bm, sw, stackbuf, ncols, four, singles, nsingles, csize);
     else if (take_global && words > bmw_hi)
-        dfs_split_global(lab, B, sw, stackbuf, nrows, ncols, four, singles, nsingles);
+        dfs_split_global(lab, B, sw, stackbuf, nrows, ncols, four, singles, nsingles, csize);
 }
 
 struct SeedFn {
@@ -452,9 +465,9 @@ struct SeedFn {
 };
 
 // seg[p] = raster rank of the piece's seed + 1, and the segment-size table of the clumps
-// (makeSegSize, shepseg.py:544-569) in the same pass: an uncut component's size is already
-// known at its root (csize); pixels of cut components and null pixels are counted with one
-// atomic per run per wavefront.
+// (makeSegSize, shepseg.py:544-569) in the same pass: every piece's size sits at its seed
+// (uncut components: k_run_count; cut pieces: the replay kernel), so each id gets exactly one
+// plain store; only the null pixels are counted here (one atomic per run per wavefront).
 __global__ __launch_bounds__(256) void k_clump_final(const uint32_t *__restrict__ lab,
                                                      const uint32_t *__restrict__ rank,
                                                      const uint32_t *__restrict__ csize,
@@ -465,23 +478,24 @@ __global__ __launch_bounds__(256) void k_clump_final(const uint32_t *__restrict_
     const uint32_t p = blockIdx.x * 256u + threadIdx.x;
     const bool inb = p < n;
     const unsigned lane = lane_id();
-    bool single = false;                        // one-pixel clump: candidate of the single-pixel pass
-    uint32_t key = 0xFFFFFFFFu;                 // id to count by atomics (none)
+    bool single = false;                        // one-pixel UNCUT clump (cut ones come from the replay)
+    bool isnull = false;
     if (inb) {
         const uint32_t l = lab[p];
-        if (l == NULL_LAB) { seg[p] = 0u; key = 0u; }
+        if (l == NULL_LAB) { seg[p] = 0u; isnull = true; }
         else {
             const uint32_t seed = l & ~VIS_FLAG;
             const uint32_t id = rank[seed] + 1u;
             seg[p] = id;
-            if (l & VIS_FLAG) key = id;
-            else if (seed == p) {
+            if (seed == p) {
                 const uint32_t sz = csize[p];
                 segsz[id] = sz;
-                single = sz == 1u;
+                single = sz == 1u && !(l & VIS_FLAG);
             }
         }
     }
+    const unsigned long long mn = __ballot(isnull);
+    if (mn != 0ull && lane == 0) atomicAdd(&segsz[0], (uint32_t)__popcll(mn));
     if (singles) {
         // block-level compaction: one global atomic per workgroup (a per-wave atomic on the one
         // counter serialises ~10^5 same-address atomics per tile)
@@ -496,14 +510,6 @@ __global__ __launch_bounds__(256) void k_clump_final(const uint32_t *__restrict_
         if (threadIdx.x == 0 && s_cnt) s_base = atomicAdd(nsingles, s_cnt);
         __syncthreads();
         if (single) singles[s_base + wbase + (uint32_t)__popcll(ms & lanemask_lt())] = p;
-    }
-    const uint32_t pk = __shfl_up(key, 1, 64);
-    const bool head = lane == 0 || pk != key;
-    const unsigned long long heads = __ballot(head);
-    if (head && key != 0xFFFFFFFFu) {
-        const unsigned long long nxt = (lane == 63) ? 0ull : (heads & ~((2ull << lane) - 1ull));
-        const unsigned nl = nxt ? (unsigned)__builtin_ctzll(nxt) : 64u;
-        atomicAdd(&segsz[key], nl - lane);
     }
 }
 
@@ -540,13 +546,12 @@ static int run_clump(shp_ctx *ctx, const uint16_t *d_clus, uint32_t nrows, uint3
     int ps = prof_begin(ctx, PROF_CCL);
     hipLaunchKernelGGL(k_ccl_init, dim3(g), dim3(256), 0, st, d_clus, lab, n, ncols); KCHK(ctx);
     hipLaunchKernelGGL(k_ccl_merge, dim3(g), dim3(256), 0, st, d_clus, lab, n, nrows, ncols, four); KCHK(ctx);
-    hipLaunchKernelGGL(k_ccl_flatten, dim3(g), dim3(256), 0, st, lab, n); KCHK(ctx);
+    hipLaunchKernelGGL(k_ccl_flatten, dim3(g), dim3(256), 0, st, lab, n, csize); KCHK(ctx);
     prof_end(ctx, ps);
-    HIPCHK(ctx, hipMemsetAsync(csize, 0, (size_t)n * 4, st));
     HIPCHK(ctx, hipMemsetAsync(counters, 0, 16, st));
     uint32_t *bigbits = bp<uint32_t>(ctx->bigbits), *rank = bp<uint32_t>(ctx->aux2);
     HIPCHK(ctx, hipMemsetAsync(bigbits, 0, ((size_t)n / 32 + 1) * 4, st));
-    HIPCHK(ctx, hipMemsetAsync(d_segsz, 0, ((size_t)n + 1) * 4, st));
+    HIPCHK(ctx, hipMemsetAsync(d_segsz, 0, 4, st));         // only the null count accumulates
     hipLaunchKernelGGL(k_run_count, dim3(g), dim3(256), 0, st, lab, n, csize, NULL_LAB, 1); KCHK(ctx);
     hipLaunchKernelGGL(k_big_list, dim3(g), dim3(256), 0, st, lab, csize, n, ncols, big, counters, bigbits); KCHK(ctx);
     hipLaunchKernelGGL(k_big_bbox, dim3(g), dim3(256), 0, st, lab, csize, n, ncols, big, bigbits); KCHK(ctx);
@@ -564,10 +569,10 @@ static int run_clump(shp_ctx *ctx, const uint16_t *d_clus, uint32_t nrows, uint3
     }
     hipLaunchKernelGGL(k_dfs_split, dim3(maxbig), dim3(64), (DFS_SWN + DFS_BMW_LARGE) * 4, st, lab, big,
                        counters, bp<uint32_t>(ctx->stack), nrows, ncols, four, DFS_BMW_SMALL,
-                       DFS_BMW_LARGE, 1, d_singles, d_nsingles, order); KCHK(ctx);
+                       DFS_BMW_LARGE, 1, d_singles, d_nsingles, order, csize); KCHK(ctx);
     hipLaunchKernelGGL(k_dfs_split, dim3(maxbig), dim3(64), (DFS_SWN + DFS_BMW_SMALL) * 4, st2, lab,
                        big, counters, bp<uint32_t>(ctx->stack), nrows, ncols, four, 0u, DFS_BMW_SMALL, 0,
-                       d_singles, d_nsingles, order);
+                       d_singles, d_nsingles, order, csize);
     KCHK(ctx);
     if (fork2) {
         HIPCHK(ctx, hipEventRecord(ctx->evjoin, ctx->stream2));
