@@ -45,6 +45,7 @@ enum {
 int shp_version(void);
 int shp_device_count(void);                      /* number of usable HIP devices (0 = none) */
 int shp_ctx_create(int device, shp_ctx **out);   /* owns one HIP stream + device workspace */
+int shp_ctx_create_priority(int device, shp_ctx **out);  /* same, highest stream priority */
 void shp_ctx_destroy(shp_ctx *ctx);
 const char *shp_last_error(const shp_ctx *ctx);  /* valid until the next call on ctx */
 /* device-time (HIP events on the ctx stream) of the stages of the last shp_segment_tile /

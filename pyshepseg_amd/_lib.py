@@ -10,7 +10,7 @@ import threading
 
 # more hardware queues than ROCm's default of 4, so that the per-tile worker streams do not
 # queue behind each other's long-running kernels (must be set before the HIP runtime starts)
-os.environ.setdefault('GPU_MAX_HW_QUEUES', '16')
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '20')
 
 import numpy
 
@@ -34,6 +34,7 @@ _SIGS = {
     'shp_version': (_c.c_int, []),
     'shp_device_count': (_c.c_int, []),
     'shp_ctx_create': (_c.c_int, [_c.c_int, _c.POINTER(_vp)]),
+    'shp_ctx_create_priority': (_c.c_int, [_c.c_int, _c.POINTER(_vp)]),
     'shp_ctx_destroy': (None, [_vp]),
     'shp_last_error': (_c.c_char_p, [_vp]),
     'shp_last_timings': (_c.c_int, [_vp, _vp]),
@@ -120,7 +121,7 @@ def lib():
 class Context(object):
     """One shp_ctx: a HIP stream plus device workspace.  Not shared between threads."""
 
-    def __init__(self, device=None):
+    def __init__(self, device=None, highPriority=False):
         L = lib()
         if device is None:
             device = int(os.environ.get('SHEPSEG_DEVICE', os.environ.get('LOCAL_RANK', '0')))
@@ -130,7 +131,7 @@ class Context(object):
                                   "(gfx950 / MI355X); there is no CPU fallback")
         device = device % ndev
         h = _vp()
-        rc = L.shp_ctx_create(device, ctypes.byref(h))
+        rc = (L.shp_ctx_create_priority if highPriority else L.shp_ctx_create)(device, ctypes.byref(h))
         if rc != 0:
             raise ShepsegHipError("shp_ctx_create(device=%d) failed with code %d" % (device, rc))
         self.handle = h
@@ -194,6 +195,18 @@ class pooled_ctx(object):
 def pool_contexts():
     with _pool_lock:
         return list(_pool)
+
+
+_chain_ctx = {}
+
+
+def chain_ctx():
+    """A per-thread high-priority context for the sequential stitch chain."""
+    c = getattr(_tls, 'chain', None)
+    if c is None or c.handle is None:
+        c = Context(highPriority=True)
+        _tls.chain = c
+    return c
 
 
 def ptr(a):

@@ -24,7 +24,16 @@ API int shp_device_count(void)
     return n;
 }
 
-API int shp_ctx_create(int device, shp_ctx **out)
+static int ctx_create(int device, int high_priority, shp_ctx **out);
+
+API int shp_ctx_create(int device, shp_ctx **out) { return ctx_create(device, 0, out); }
+
+// a context whose streams are created with the highest stream priority (the tiled drivers use
+// one for the sequential stitch chain so that its small kernels are not queued behind the
+// worker streams' launches)
+API int shp_ctx_create_priority(int device, shp_ctx **out) { return ctx_create(device, 1, out); }
+
+static int ctx_create(int device, int high_priority, shp_ctx **out)
 {
     if (!out) return SHP_ERR_ARG;
     *out = nullptr;
@@ -34,7 +43,10 @@ API int shp_ctx_create(int device, shp_ctx **out)
     if (hipSetDevice(device) != hipSuccess) return SHP_ERR_HIP;
     shp_ctx *ctx = new shp_ctx();
     ctx->device = device;
-    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+    int prio_lo = 0, prio_hi = 0;
+    hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);      // hi = numerically lowest
+    ctx->stream_priority = high_priority ? prio_hi : 0;
+    if (hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, ctx->stream_priority) != hipSuccess) {
         delete ctx;
         return SHP_ERR_HIP;
     }
@@ -44,7 +56,6 @@ API int shp_ctx_create(int device, shp_ctx **out)
         return SHP_ERR_HIP;
     }
     for (int i = 0; i < 16; i++) hipEventCreate(&ctx->ev[i]);
-    hipStreamCreateWithFlags(&ctx->stream2, hipStreamNonBlocking);
     hipEventCreateWithFlags(&ctx->evfork, hipEventDisableTiming);
     hipEventCreateWithFlags(&ctx->evjoin, hipEventDisableTiming);
     ctx->bufs = {&ctx->img, &ctx->clus, &ctx->lab, &ctx->seg, &ctx->aux, &ctx->aux2, &ctx->stack,

@@ -562,6 +562,7 @@ static int run_clump(shp_ctx *ctx, const uint16_t *d_clus, uint32_t nrows, uint3
     // fork: the two size classes touch disjoint components, so they can run on two streams
     static const int fork_env = getenv("SHEPSEG_DFS_FORK") ? atoi(getenv("SHEPSEG_DFS_FORK")) : -1;
     const int fork2 = fork_env >= 0 ? fork_env : ctx->dfs_fork;
+    if (fork2) CHK(ensure_stream2(ctx));
     hipStream_t st2 = fork2 ? ctx->stream2 : st;
     if (fork2) {
         HIPCHK(ctx, hipEventRecord(ctx->evfork, st));

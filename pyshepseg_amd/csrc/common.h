@@ -29,7 +29,8 @@ struct StageTimer {
 struct shp_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t stream2 = nullptr;     // side stream for fork/join inside one call
+    hipStream_t stream2 = nullptr;     // side stream for fork/join inside one call (created lazily)
+    int stream_priority = 0;
     hipEvent_t evfork = nullptr, evjoin = nullptr;
     std::string err;
     std::vector<DevBuf *> bufs;
@@ -102,6 +103,15 @@ static inline void prof_collect(shp_ctx *ctx)
     } while (0)
 
 #define KCHK(ctx) HIPCHK(ctx, hipGetLastError())
+
+// the side stream is only created when a call really forks: every stream costs a slot in the
+// 16 hardware queues the worker streams are spread over
+static inline int ensure_stream2(shp_ctx *ctx)
+{
+    if (ctx->stream2) return 0;
+    HIPCHK(ctx, hipStreamCreateWithPriority(&ctx->stream2, hipStreamNonBlocking, ctx->stream_priority));
+    return 0;
+}
 
 static inline int buf_ensure(shp_ctx *ctx, DevBuf &b, size_t bytes)
 {

@@ -480,6 +480,7 @@ static int run_stitch_finish(shp_ctx *ctx, const uint32_t *d_tile, uint32_t ys, 
     if (bottom <= top || right <= left) return 0;
     const uint32_t nseg = max_local + 1u;
     const uint32_t *lut = d_meta + 3 * (size_t)nseg;
+    CHK(ensure_stream2(ctx));
     HIPCHK(ctx, hipEventRecord(ctx->evfork, ctx->stream));          // after this tile's chain step
     HIPCHK(ctx, hipStreamWaitEvent(ctx->stream2, ctx->evfork, 0));
     const uint32_t nr = bottom - top, nc = right - left;

@@ -255,7 +255,7 @@ class HipEngine(object):
         self._sliceKey = None
 
     def setup(self, tileInfo, jobs, total, yLo, yHi, outLo, outHi, nCols, overlapSize):
-        self.c = _lib.ctx()
+        self.c = _lib.chain_ctx()
         self.L = self.c._L
         self.tileInfo, self.jobs = tileInfo, jobs
         (self.yLo, self.yHi, self.outLo, self.outHi) = (yLo, yHi, outLo, outHi)

@@ -618,7 +618,7 @@ def doTiledShepherdSegmentation(infile, outfile, tileSize=DFLT_TILESIZE,
             print("Found {} tiles, with {} rows and {} cols".format(
                 tileInfo.getNumTiles(), tileInfo.nrows, tileInfo.ncols))
 
-        main = _lib.ctx()
+        main = _lib.chain_ctx()          # high-priority stream: the stitch chain must not lag
         L = main._L
         # one device block for every tile's labels, one for the stitched raster
         jobs, total = makeTileJobs(tileInfo)

@@ -7,7 +7,7 @@ with open(f) as fh:
     cols = rd.fieldnames
     for r in rd:
         rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name'][:40], r.get('Queue_Id', '0'),
-                     int(r.get('Grid_Size', 0) or 0), int(r.get('Workgroup_Size', 0) or 0)))
+                     int(r.get('Grid_Size_X', 0) or 0), int(r.get('Workgroup_Size_X', 0) or 0)))
 print('columns', cols)
 rows.sort()
 t0 = rows[0][0]; t1 = max(r[1] for r in rows)
@@ -47,3 +47,13 @@ gaps.sort()
 import statistics
 print('queues', len(byq), 'gap between consecutive kernels of a queue: median %.1f us p90 %.1f us mean %.1f us sum %.1f ms' % (
     gaps[len(gaps)//2] / 1e3, gaps[int(len(gaps)*0.9)] / 1e3, statistics.mean(gaps) / 1e3, sum(g for g in gaps if g > 0) / 1e6))
+
+# per-queue busy fraction
+for q, lst in sorted(byq.items()):
+    b = sum(e - s for s, e, n in lst)
+    print('queue', q, 'kernels', len(lst), 'busy %.3f' % (b / span), 'first %.1f ms last %.1f ms' % ((lst[0][0]-t0)/1e6, (max(e for s,e,n in lst)-t0)/1e6))
+# time-weighted kernel mix
+mix = collections.Counter()
+for s, e, n, q, g, w in rows: mix[n.split('(')[0]] += e - s
+tot = sum(mix.values())
+print('kernel-time share:', [(k, round(v / tot, 3)) for k, v in mix.most_common(8)], 'sum/span = %.2f' % (tot / span))
