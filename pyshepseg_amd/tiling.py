@@ -217,6 +217,8 @@ def _open_source(infile):
 # ------------------------------------------------------------------------------------------
 _devCache = {}
 _devCacheLock = threading.Lock()
+_devCacheBytes = [0]
+_DEV_CACHE_CAP = int(os.environ.get('SHEPSEG_DEVCACHE_GB', '96')) << 30     # keep at most this much
 
 
 def _devAlloc(c, nbytes):
@@ -224,6 +226,7 @@ def _devAlloc(c, nbytes):
     with _devCacheLock:
         lst = _devCache.get((c.device, nbytes))
         if lst:
+            _devCacheBytes[0] -= nbytes
             return ctypes.c_void_p(lst.pop())
     p = ctypes.c_void_p()
     c.check(c._L.shp_dev_alloc(c.handle, nbytes, ctypes.byref(p)))
@@ -235,7 +238,11 @@ def _devRelease(c, p, nbytes):
         return
     nbytes = max(int(nbytes), 16)
     with _devCacheLock:
-        _devCache.setdefault((c.device, nbytes), []).append(p.value)
+        if _devCacheBytes[0] + nbytes <= _DEV_CACHE_CAP:
+            _devCache.setdefault((c.device, nbytes), []).append(p.value)
+            _devCacheBytes[0] += nbytes
+            return
+    c._L.shp_dev_free(c.handle, p)
 
 
 def clearDeviceCache():
@@ -246,6 +253,7 @@ def clearDeviceCache():
             for v in lst:
                 c._L.shp_dev_free(c.handle, ctypes.c_void_p(v))
         _devCache.clear()
+        _devCacheBytes[0] = 0
 
 
 # ------------------------------------------------------------------------------------------
