@@ -46,9 +46,10 @@ __device__ __forceinline__ void uf_merge(uint32_t *lab, uint32_t a, uint32_t b)
 }
 
 // lab[p] = first pixel of p's horizontal run inside this wavefront's 64-pixel span
+// and the size accumulator of every run head (a superset of the final roots) is zeroed
 __global__ __launch_bounds__(256) void k_ccl_init(const uint16_t *__restrict__ clus,
                                                   uint32_t *__restrict__ lab, uint32_t n,
-                                                  uint32_t ncols)
+                                                  uint32_t ncols, uint32_t *__restrict__ csize)
 {
     const uint32_t p = blockIdx.x * 256u + threadIdx.x;
     const bool inb = p < n;
@@ -61,6 +62,7 @@ __global__ __launch_bounds__(256) void k_ccl_init(const uint16_t *__restrict__ c
     const unsigned long long m = heads & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
     const unsigned start = 63u - (unsigned)__clzll(m);
     if (inb) lab[p] = (c == 0) ? NULL_LAB : p - (lane - start);
+    if (inb && c != 0 && start == lane) csize[p] = 0u;
 }
 
 __global__ __launch_bounds__(256) void k_ccl_merge(const uint16_t *__restrict__ clus,
@@ -85,17 +87,26 @@ __global__ __launch_bounds__(256) void k_ccl_merge(const uint16_t *__restrict__ 
     }
 }
 
-// lab[p] = root; the size accumulator of every root is zeroed here so that no N-sized memset
-// is needed before k_run_count (only roots are ever read)
+// lab[p] = root, and the component sizes in the same pass: csize[root] += run length, one atomic
+// per run of equal roots per wavefront
 __global__ __launch_bounds__(256) void k_ccl_flatten(uint32_t *lab, uint32_t n, uint32_t *csize)
 {
     const uint32_t p = blockIdx.x * 256u + threadIdx.x;
-    if (p >= n) return;
-    const uint32_t l = lab[p];
-    if (l == NULL_LAB) return;
-    const uint32_t r = uf_find(lab, p);
-    lab[p] = r;
-    if (r == p) csize[p] = 0u;
+    const bool inb = p < n;
+    const unsigned lane = lane_id();
+    uint32_t r = NULL_LAB;
+    if (inb && lab[p] != NULL_LAB) {
+        r = uf_find(lab, p);
+        lab[p] = r;
+    }
+    const uint32_t pr = __shfl_up(r, 1, 64);
+    const bool head = lane == 0 || pr != r || !inb;
+    const unsigned long long heads = __ballot(head);
+    if (head && r != NULL_LAB) {
+        const unsigned long long nxt = (lane == 63) ? 0ull : (heads & ~((2ull << lane) - 1ull));
+        const unsigned nl = nxt ? (unsigned)__builtin_ctzll(nxt) : 64u;
+        atomicAdd(&csize[r], nl - lane);
+    }
 }
 
 // cnt[key[p]] += 1 for every pixel, one atomic per run of equal keys per wavefront.
@@ -134,28 +145,53 @@ __global__ __launch_bounds__(256) void k_big_list(const uint32_t *__restrict__ l
     atomicOr(&bigbits[p >> 5], 1u << (p & 31u));      // N-bit map of cut-able roots (L2-resident)
 }
 
+// Bounding box (min col, max col, max row; the min row is the root's) of every cut-able
+// component.  A wavefront covers 64 consecutive pixels; its lanes are grouped by component and
+// ONE lane per (wavefront, component) updates the box, after plain pre-reads that prune almost
+// all of the atomics (a stale pre-read only costs a redundant atomic).
 __global__ __launch_bounds__(256) void k_big_bbox(const uint32_t *__restrict__ lab,
                                                   const uint32_t *__restrict__ csize, uint32_t n,
-                                                  uint32_t ncols, volatile BigInfo *big,
+                                                  uint32_t ncols, BigInfo *big,
                                                   const uint32_t *__restrict__ bigbits)
 {
     const uint32_t p = blockIdx.x * 256u + threadIdx.x;
-    if (p >= n) return;
-    const uint32_t r = lab[p];
-    if (r == NULL_LAB) return;
-    if (!((bigbits[r >> 5] >> (r & 31u)) & 1u)) return;     // 2 MB bitmap instead of a 4N-byte gather
-    const uint32_t c = csize[r];
-    if (!(c & VIS_FLAG)) return;
-    const uint32_t bi = c & ~VIS_FLAG;
-    const uint32_t row = p / ncols, col = p - row * ncols;
-    const bool headrun = col == 0 || lab[p - 1] != r;
-    const bool tailrun = col == ncols - 1 || lab[p + 1] != r;
-    // plain pre-reads prune the same-address atomics (a stale value only costs a redundant atomic)
-    if (headrun) {
-        if (col < big[bi].minc) atomicMin((uint32_t *)&big[bi].minc, col);
-        if (row > big[bi].maxr) atomicMax((uint32_t *)&big[bi].maxr, row);
+    const unsigned lane = lane_id();
+    bool act = false;
+    uint32_t bi = 0;
+    if (p < n) {
+        const uint32_t r = lab[p];
+        // 2 MB bitmap instead of a 4N-byte gather
+        if (r != NULL_LAB && ((bigbits[r >> 5] >> (r & 31u)) & 1u)) {
+            const uint32_t c = csize[r];
+            act = (c & VIS_FLAG) != 0u;
+            bi = c & ~VIS_FLAG;
+        }
     }
-    if (tailrun && col > big[bi].maxc) atomicMax((uint32_t *)&big[bi].maxc, col);
+    unsigned long long todo = __ballot(act);
+    if (todo == 0ull) return;
+    const uint32_t row = p / ncols, col = p - row * ncols;
+    while (todo) {
+        const int l0 = __builtin_ctzll(todo);
+        const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)bi, l0);
+        const bool mine = act && bi == b;
+        const unsigned long long m = __ballot(mine);
+        todo &= ~m;
+        const int l1 = 63 - __builtin_clzll(m);
+        const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)row, l0);
+        const uint32_t r1 = (uint32_t)__builtin_amdgcn_readlane((int)row, l1);
+        // in one image row (the usual case) the group's first / last lane hold its extreme
+        // columns; a wavefront that wraps around a row end lets every lane speak for itself
+        const bool same_row = r0 == r1;
+        const bool lo = same_row ? (int)lane == l0 : mine, hi = same_row ? (int)lane == l1 : mine;
+        if (lo || hi) {
+            // the three box fields in one 12-byte read: one L2 round trip instead of three
+            const uint32_t *bx = &big[b].minc;
+            const uint32_t cminc = L2LOAD(bx), cmaxc = L2LOAD(bx + 1), cmaxr = L2LOAD(bx + 2);
+            if (lo && col < cminc) atomicMin(&big[b].minc, col);
+            if (lo && row > cmaxr) atomicMax(&big[b].maxr, row);
+            if (hi && col > cmaxc) atomicMax(&big[b].maxc, col);
+        }
+    }
 }
 
 // One wavefront per cut-able component: exact replay of shepseg.py:490-539 restricted to the
@@ -468,6 +504,7 @@ struct SeedFn {
 // (makeSegSize, shepseg.py:544-569) in the same pass: every piece's size sits at its seed
 // (uncut components: k_run_count; cut pieces: the replay kernel), so each id gets exactly one
 // plain store; only the null pixels are counted here (one atomic per run per wavefront).
+#define FINAL_SPAN 16u       // 256-pixel steps per workgroup
 __global__ __launch_bounds__(256) void k_clump_final(const uint32_t *__restrict__ lab,
                                                      const uint32_t *__restrict__ rank,
                                                      const uint32_t *__restrict__ csize,
@@ -475,42 +512,50 @@ __global__ __launch_bounds__(256) void k_clump_final(const uint32_t *__restrict_
                                                      uint32_t n, uint32_t *__restrict__ singles,
                                                      uint32_t *nsingles)
 {
-    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
-    const bool inb = p < n;
+    // one-pixel clumps and the null count are gathered in LDS over the workgroup's whole span and
+    // flushed with ONE global atomic each: atomics on a single counter serialise at L2, a
+    // per-wavefront (or even per-256-pixel) update costs more than the rest of the kernel
+    __shared__ uint32_t s_buf[256u * FINAL_SPAN];
+    __shared__ uint32_t s_cnt, s_base, s_null;
+    if (threadIdx.x == 0) { s_cnt = 0; s_null = 0; }
+    __syncthreads();
     const unsigned lane = lane_id();
-    bool single = false;                        // one-pixel UNCUT clump (cut ones come from the replay)
-    bool isnull = false;
-    if (inb) {
-        const uint32_t l = lab[p];
-        if (l == NULL_LAB) { seg[p] = 0u; isnull = true; }
-        else {
-            const uint32_t seed = l & ~VIS_FLAG;
-            const uint32_t id = rank[seed] + 1u;
-            seg[p] = id;
-            if (seed == p) {
-                const uint32_t sz = csize[p];
-                segsz[id] = sz;
-                single = sz == 1u && !(l & VIS_FLAG);
+    const uint32_t base = blockIdx.x * (256u * FINAL_SPAN);
+    for (uint32_t it = 0; it < FINAL_SPAN; it++) {
+        const uint32_t p = base + it * 256u + threadIdx.x;
+        bool single = false;                    // one-pixel UNCUT clump (cut ones come from the replay)
+        bool isnull = false;
+        if (p < n) {
+            const uint32_t l = lab[p];
+            if (l == NULL_LAB) { seg[p] = 0u; isnull = true; }
+            else {
+                const uint32_t seed = l & ~VIS_FLAG;
+                const uint32_t id = rank[seed] + 1u;
+                seg[p] = id;
+                if (seed == p) {
+                    const uint32_t sz = csize[p];
+                    segsz[id] = sz;
+                    single = sz == 1u && !(l & VIS_FLAG);
+                }
             }
         }
+        const unsigned long long mn = __ballot(isnull);
+        if (mn != 0ull && lane == 0) atomicAdd(&s_null, (uint32_t)__popcll(mn));
+        const unsigned long long ms = singles ? __ballot(single) : 0ull;
+        if (ms != 0ull) {
+            uint32_t wbase = 0;
+            if (lane == 0) wbase = atomicAdd(&s_cnt, (uint32_t)__popcll(ms));
+            wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wbase);
+            if (single) s_buf[wbase + (uint32_t)__popcll(ms & lanemask_lt())] = p;
+        }
     }
-    const unsigned long long mn = __ballot(isnull);
-    if (mn != 0ull && lane == 0) atomicAdd(&segsz[0], (uint32_t)__popcll(mn));
-    if (singles) {
-        // block-level compaction: one global atomic per workgroup (a per-wave atomic on the one
-        // counter serialises ~10^5 same-address atomics per tile)
-        __shared__ uint32_t s_cnt, s_base;
-        if (threadIdx.x == 0) s_cnt = 0;
-        __syncthreads();
-        const unsigned long long ms = __ballot(single);
-        uint32_t wbase = 0;
-        if (ms != 0ull && lane == 0) wbase = atomicAdd(&s_cnt, (uint32_t)__popcll(ms));
-        wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wbase);
-        __syncthreads();
-        if (threadIdx.x == 0 && s_cnt) s_base = atomicAdd(nsingles, s_cnt);
-        __syncthreads();
-        if (single) singles[s_base + wbase + (uint32_t)__popcll(ms & lanemask_lt())] = p;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (s_null) atomicAdd(&segsz[0], s_null);
+        s_base = s_cnt ? atomicAdd(nsingles, s_cnt) : 0u;
     }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < s_cnt; i += 256u) singles[s_base + i] = s_buf[i];
 }
 
 // d_clus (uint16, 0 = null) -> ctx->seg (uint32 clump ids 1..nclumps, 0 = null).
@@ -544,7 +589,7 @@ static int run_clump(shp_ctx *ctx, const uint16_t *d_clus, uint32_t nrows, uint3
     const unsigned g = grid_for(n, 256);
     hipStream_t st = ctx->stream;
     int ps = prof_begin(ctx, PROF_CCL);
-    hipLaunchKernelGGL(k_ccl_init, dim3(g), dim3(256), 0, st, d_clus, lab, n, ncols); KCHK(ctx);
+    hipLaunchKernelGGL(k_ccl_init, dim3(g), dim3(256), 0, st, d_clus, lab, n, ncols, csize); KCHK(ctx);
     hipLaunchKernelGGL(k_ccl_merge, dim3(g), dim3(256), 0, st, d_clus, lab, n, nrows, ncols, four); KCHK(ctx);
     hipLaunchKernelGGL(k_ccl_flatten, dim3(g), dim3(256), 0, st, lab, n, csize); KCHK(ctx);
     prof_end(ctx, ps);
@@ -552,7 +597,6 @@ static int run_clump(shp_ctx *ctx, const uint16_t *d_clus, uint32_t nrows, uint3
     uint32_t *bigbits = bp<uint32_t>(ctx->bigbits), *rank = bp<uint32_t>(ctx->aux2);
     HIPCHK(ctx, hipMemsetAsync(bigbits, 0, ((size_t)n / 32 + 1) * 4, st));
     HIPCHK(ctx, hipMemsetAsync(d_segsz, 0, 4, st));         // only the null count accumulates
-    hipLaunchKernelGGL(k_run_count, dim3(g), dim3(256), 0, st, lab, n, csize, NULL_LAB, 1); KCHK(ctx);
     hipLaunchKernelGGL(k_big_list, dim3(g), dim3(256), 0, st, lab, csize, n, ncols, big, counters, bigbits); KCHK(ctx);
     hipLaunchKernelGGL(k_big_bbox, dim3(g), dim3(256), 0, st, lab, csize, n, ncols, big, bigbits); KCHK(ctx);
     ps = prof_begin(ctx, PROF_DFS);
@@ -584,7 +628,7 @@ static int run_clump(shp_ctx *ctx, const uint16_t *d_clus, uint32_t nrows, uint3
     // seed rank -> clump id
     SeedFn sf{lab};
     CHK(scan_exclusive(ctx, sf, n, rank, nclumps_dev, bp<uint32_t>(ctx->scan_tmp)));
-    hipLaunchKernelGGL(k_clump_final, dim3(g), dim3(256), 0, st, lab, rank, csize, d_seg, d_segsz, n,
+    hipLaunchKernelGGL(k_clump_final, dim3(grid_for(n, 256u * FINAL_SPAN)), dim3(256), 0, st, lab, rank, csize, d_seg, d_segsz, n,
                        d_singles, d_nsingles); KCHK(ctx);
     prof_end(ctx, ps);
     return 0;

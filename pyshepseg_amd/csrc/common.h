@@ -165,6 +165,10 @@ __device__ __forceinline__ long long ld_px(const void *__restrict__ img, int dty
     }
 }
 
+// relaxed agent-scope load: served by L2, where the atomics land (a plain load may be answered
+// by a stale line of the CU's vector L1)
+#define L2LOAD(ptr) __hip_atomic_load((ptr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+
 __device__ __forceinline__ unsigned lane_id() { return threadIdx.x & 63u; }
 __device__ __forceinline__ unsigned long long lanemask_lt()
 {

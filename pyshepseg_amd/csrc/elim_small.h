@@ -23,13 +23,38 @@
 #include "scan.h"
 #include "sort.h"
 #include "elim_single.h"
+#include <type_traits>
 
 __device__ __forceinline__ float f32_acc(float acc, long long v)
 {
     return (float)((double)acc + (double)v);     // numba: float32 + pixel, stored to float32 (N5)
 }
 
-// segments with <= 64 pixels: one thread each
+// Spectral sums of every segment (buildSegmentSpectra, shepseg.py:780-806).
+//   k_spectra_small  a segment of <= 64 pixels is summed by its own thread (pixel list read once,
+//                    all bands of the group accumulated together);
+//   k_big_seg_list   the ids of the larger ones are compacted into a list (one global atomic per
+//                    4096 ids);
+//   k_spectra_big    a persistent grid of wavefronts takes list entries round-robin, 64 pixels a
+//                    step.  While sum(|v|) stays below 2^24 every float32 partial sum is an exact
+//                    integer, so lanes keep private integer partial sums (512 pixels = 8 independent
+//                    steps in flight) and one wave reduction per 512 pixels checks the bound
+//                    (summed over lanes of the per-lane band maximum: an upper bound, so the test
+//                    is conservative).  Past the bound the order of the float32 additions matters:
+//                    the values of a step go through LDS transposed, lane b then adds band b's 64
+//                    values in list order while the next step's gathers are already in flight.
+// WIDE = 32-bit pixel types, whose values need the float64 form of the reference's
+// `float32 + pixel` (N5); for 8/16-bit types a float32 add is the same correctly rounded sum.
+#define SPECTRA_BG 8        // bands per pass
+#define SPECTRA_GRID 1024   // workgroups of the persistent k_spectra_big
+template <typename T> __device__ __forceinline__ T wave_sum_t(T v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+template <bool WIDE>
 __global__ __launch_bounds__(256) void k_spectra_small(
     const void *__restrict__ img, int dtype, int nb, uint32_t n, const uint32_t *__restrict__ pix,
     const uint32_t *__restrict__ off, const uint32_t *__restrict__ segsz, float *__restrict__ ssum,
@@ -38,59 +63,153 @@ __global__ __launch_bounds__(256) void k_spectra_small(
     const uint32_t s = blockIdx.x * 256u + threadIdx.x + 1u;
     if (s > S) return;
     const uint32_t m = segsz[s];
-    if (m > 64u) return;
+    if (m == 0u || m > 64u) return;
     const uint32_t o = off[s];
-    for (int b = 0; b < nb; b++) {
-        float acc = 0.0f;
-        for (uint32_t i = 0; i < m; i++) acc = f32_acc(acc, ld_px(img, dtype, (size_t)b * n + pix[o + i]));
-        ssum[(size_t)s * nb + b] = acc;
+    for (int b0 = 0; b0 < nb; b0 += SPECTRA_BG) {
+        const int bg = nb - b0 < SPECTRA_BG ? nb - b0 : SPECTRA_BG;
+        const size_t base = (size_t)b0 * n;
+        float acc[SPECTRA_BG];
+#pragma unroll
+        for (int j = 0; j < SPECTRA_BG; j++) acc[j] = 0.0f;
+        for (uint32_t i = 0; i < m; i++) {
+            const uint32_t idx = pix[o + i];
+#pragma unroll
+            for (int j = 0; j < SPECTRA_BG; j++)
+                if (j < bg) {
+                    const long long v = ld_px(img, dtype, base + (size_t)j * n + idx);
+                    acc[j] = WIDE ? f32_acc(acc[j], v) : acc[j] + (float)(int)v;
+                }
+        }
+#pragma unroll
+        for (int j = 0; j < SPECTRA_BG; j++)
+            if (j < bg) ssum[(size_t)s * nb + b0 + j] = acc[j];
     }
 }
 
-__device__ __forceinline__ long long wave_sum_ll(long long v)
+// list[0] = number of segments with > 64 pixels (zeroed by k_small_init), ids from list[16]
+__global__ __launch_bounds__(256) void k_big_seg_list(const uint32_t *__restrict__ segsz, uint32_t S,
+                                                      uint32_t *list)
 {
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-    return v;
+    __shared__ uint32_t s_buf[4096];
+    __shared__ uint32_t s_cnt, s_base;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    const unsigned lane = lane_id();
+    for (uint32_t it = 0; it < 16u; it++) {
+        const uint32_t s = blockIdx.x * 4096u + it * 256u + threadIdx.x + 1u;
+        const bool big = s <= S && segsz[s] > 64u;
+        const unsigned long long mb = __ballot(big);
+        if (mb != 0ull) {
+            uint32_t wbase = 0;
+            if (lane == 0) wbase = atomicAdd(&s_cnt, (uint32_t)__popcll(mb));
+            wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wbase);
+            if (big) s_buf[wbase + (uint32_t)__popcll(mb & lanemask_lt())] = s;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) s_base = s_cnt ? atomicAdd(&list[0], s_cnt) : 0u;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < s_cnt; i += 256u) list[16u + s_base + i] = s_buf[i];
 }
 
-// segments with > 64 pixels: one wavefront each
+template <bool WIDE>
 __global__ __launch_bounds__(256) void k_spectra_big(
     const void *__restrict__ img, int dtype, int nb, uint32_t n, const uint32_t *__restrict__ pix,
     const uint32_t *__restrict__ off, const uint32_t *__restrict__ segsz, float *__restrict__ ssum,
-    uint32_t S)
+    const uint32_t *__restrict__ list)
 {
-    const uint32_t s =
-        (uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256u + threadIdx.x) / 64u)) + 1u;
-    if (s > S) return;
-    const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)segsz[s]);
-    if (m <= 64u) return;
-    const uint32_t o = (uint32_t)__builtin_amdgcn_readfirstlane((int)off[s]);
-    const unsigned lane = lane_id();
-    for (int b = 0; b < nb; b++) {
-        float acc = 0.0f;
-        long long exact = 0, sabs = 0;
-        for (uint32_t i0 = 0; i0 < m; i0 += 64u) {
-            const bool valid = i0 + lane < m;
-            const long long v = valid ? ld_px(img, dtype, (size_t)b * n + pix[o + i0 + lane]) : 0;
-            const long long csum = wave_sum_ll(v);
-            const long long cabs = wave_sum_ll(v < 0 ? -v : v);
-            if (sabs + cabs < (1ll << 24)) {
-                exact += csum;                 // every partial sum is an exact float32 integer
-                acc = (float)exact;
-            } else {
-                const uint32_t cnt = (m - i0 < 64u) ? (m - i0) : 64u;
-                const double dv = (double)v;
-                const int lo = __double2loint(dv), hi = __double2hiint(dv);
-                for (uint32_t j = 0; j < cnt; j++) {
-                    const int l = __builtin_amdgcn_readlane(lo, j);
-                    const int h = __builtin_amdgcn_readlane(hi, j);
-                    acc = (float)((double)acc + __hiloint2double(h, l));
+    typedef typename std::conditional<WIDE, long long, int>::type IT;
+    typedef typename std::conditional<WIDE, double, float>::type FT;
+    __shared__ FT tv[4][SPECTRA_BG][65];     // 65: lanes (= bands) read down their rows conflict-free
+    const unsigned lane = lane_id(), wv = threadIdx.x >> 6;
+    const uint32_t nbig = list[0];
+    const IT LIM = (IT)1 << 24;
+    for (uint32_t e = blockIdx.x * 4u + wv; e < nbig; e += gridDim.x * 4u) {
+        const uint32_t bs = (uint32_t)__builtin_amdgcn_readfirstlane((int)list[16u + e]);
+        const uint32_t bm = (uint32_t)__builtin_amdgcn_readfirstlane((int)segsz[bs]);
+        const uint32_t bo = (uint32_t)__builtin_amdgcn_readfirstlane((int)off[bs]);
+        for (int b0 = 0; b0 < nb; b0 += SPECTRA_BG) {
+            const int bg = nb - b0 < SPECTRA_BG ? nb - b0 : SPECTRA_BG;
+            const size_t base = (size_t)b0 * n;
+            // ---- exact phase: private integer partial sums, bound checked per 512 pixels ----
+            IT psum[SPECTRA_BG], pabs[SPECTRA_BG];
+#pragma unroll
+            for (int j = 0; j < SPECTRA_BG; j++) { psum[j] = 0; pabs[j] = 0; }
+            uint32_t i0 = 0;
+            while (i0 < bm) {
+                const uint32_t gend = bm - i0 > 512u ? i0 + 512u : bm;
+                IT ts[SPECTRA_BG], ta[SPECTRA_BG];
+#pragma unroll
+                for (int j = 0; j < SPECTRA_BG; j++) { ts[j] = psum[j]; ta[j] = pabs[j]; }
+                uint32_t idx[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+                    const uint32_t i = i0 + (uint32_t)u * 64u + lane;
+                    idx[u] = i < gend ? pix[bo + i] : 0xFFFFFFFFu;
+                }
+#pragma unroll
+                for (int u = 0; u < 8; u++) {
+#pragma unroll
+                    for (int j = 0; j < SPECTRA_BG; j++)
+                        if (j < bg && idx[u] != 0xFFFFFFFFu) {
+                            const IT v = (IT)ld_px(img, dtype, base + (size_t)j * n + idx[u]);
+                            ts[j] += v;
+                            ta[j] += v < 0 ? -v : v;
+                        }
+                }
+                IT mx = 0;
+#pragma unroll
+                for (int j = 0; j < SPECTRA_BG; j++) mx = ta[j] > mx ? ta[j] : mx;
+                // per-lane maxima stay below 2^24 while the phase lasts, so 64 of them fit IT
+                const IT bound = wave_sum_t<IT>(mx);
+                if (bound >= LIM) break;
+#pragma unroll
+                for (int j = 0; j < SPECTRA_BG; j++) { psum[j] = ts[j]; pabs[j] = ta[j]; }
+                i0 = gend;
+            }
+            float acc = 0.0f;                        // lane j < bg: running float32 sum of band b0 + j
+#pragma unroll
+            for (int j = 0; j < SPECTRA_BG; j++)
+                if (j < bg) {
+                    const IT t = wave_sum_t<IT>(psum[j]);
+                    if (lane == (unsigned)j) acc = (float)t;
+                }
+            // ---- ordered phase: list order float32 additions, lane = band ----
+            if (i0 < bm) {
+                IT cur[SPECTRA_BG];
+                {
+                    const bool valid = i0 + lane < bm;
+                    const uint32_t ix = valid ? pix[bo + i0 + lane] : 0u;
+#pragma unroll
+                    for (int j = 0; j < SPECTRA_BG; j++)
+                        cur[j] = (j < bg && valid) ? (IT)ld_px(img, dtype, base + (size_t)j * n + ix) : (IT)0;
+                }
+                for (uint32_t c0 = i0; c0 < bm; c0 += 64u) {
+#pragma unroll
+                    for (int j = 0; j < SPECTRA_BG; j++)
+                        if (j < bg) tv[wv][j][lane] = (FT)cur[j];
+                    __builtin_amdgcn_wave_barrier();
+                    const uint32_t nx = c0 + 64u;
+                    if (nx < bm) {                   // next step's gathers overlap this step's chain
+                        const bool valid = nx + lane < bm;
+                        const uint32_t ix = valid ? pix[bo + nx + lane] : 0u;
+#pragma unroll
+                        for (int j = 0; j < SPECTRA_BG; j++)
+                            cur[j] = (j < bg && valid) ? (IT)ld_px(img, dtype, base + (size_t)j * n + ix) : (IT)0;
+                    }
+                    const uint32_t cnt = bm - c0 < 64u ? bm - c0 : 64u;
+                    if (lane < (unsigned)bg) {
+                        const FT *row = tv[wv][lane];
+                        for (uint32_t q = 0; q < cnt; q++) {
+                            if (WIDE) acc = (float)((double)acc + (double)row[q]);
+                            else acc = acc + (float)row[q];
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
                 }
             }
-            sabs += cabs;
+            if (lane < (unsigned)bg) ssum[(size_t)bs * nb + b0 + lane] = acc;
         }
-        if (lane == 0) ssum[(size_t)s * nb + b] = acc;
     }
 }
 
@@ -101,7 +220,7 @@ __global__ __launch_bounds__(256) void k_small_init(const uint32_t *__restrict__
                                                     uint32_t *__restrict__ mergeto,
                                                     uint32_t *__restrict__ tcount,
                                                     uint32_t *__restrict__ tfill, uint32_t *hist,
-                                                    uint32_t S, uint32_t min_seg)
+                                                    uint32_t S, uint32_t min_seg, uint32_t *tlist)
 {
     __shared__ uint32_t lh[256];            // block-local histogram of sizes 1..255
     lh[threadIdx.x] = 0;
@@ -115,6 +234,7 @@ __global__ __launch_bounds__(256) void k_small_init(const uint32_t *__restrict__
         mergeto[s] = 0;
         tcount[s] = 0;
         tfill[s] = 0;
+        if (s == 0u) tlist[0] = 0u;             // counter of k_big_seg_list
         if (s >= 1u && m < min_seg) {
             if (m < 256u) atomicAdd(&lh[m], 1u);
             else atomicAdd(&hist[m], 1u);
@@ -519,7 +639,7 @@ static int run_eliminate_small(shp_ctx *ctx, const void *d_img, int dtype, int n
     CHK(buf_ensure(ctx, ctx->tcount, ns * 4));
     CHK(buf_ensure(ctx, ctx->toff, ns * 4 + 16));
     CHK(buf_ensure(ctx, ctx->tfill, ns * 4));
-    CHK(buf_ensure(ctx, ctx->tlist, ns * 4));
+    CHK(buf_ensure(ctx, ctx->tlist, (ns + 32) * 4));      // + header of the big-segment list
     CHK(buf_ensure(ctx, ctx->tsorted, ns * 4));
     CHK(buf_ensure(ctx, ctx->srclist, ns * 4));
     CHK(buf_ensure(ctx, ctx->tgtlist, ns * 4));
@@ -553,12 +673,23 @@ static int run_eliminate_small(shp_ctx *ctx, const void *d_img, int dtype, int n
     const unsigned gs = grid_for((size_t)S + 1, 256);
     HIPCHK(ctx, hipMemsetAsync(hist, 0, ((size_t)min_seg + 2) * 4, st));
     hipLaunchKernelGGL(k_small_init, dim3(gs), dim3(256), 0, st, segsz, origsz, chnext, chtail,
-                       mergeto, tcount, tfill, hist, S, min_seg); KCHK(ctx);
+                       mergeto, tcount, tfill, hist, S, min_seg, tlist); KCHK(ctx);
     ps = prof_begin(ctx, PROF_SPECTRA);
-    hipLaunchKernelGGL(k_spectra_small, dim3(gs), dim3(256), 0, st, d_img, dtype, nb, n, pix, off,
-                       segsz, ssum, S); KCHK(ctx);
-    hipLaunchKernelGGL(k_spectra_big, dim3(grid_for((size_t)S * 64, 256)), dim3(256), 0, st, d_img,
-                       dtype, nb, n, pix, off, segsz, ssum, S); KCHK(ctx);
+    uint32_t *biglist = tlist;          // free until the pass loop starts
+    hipLaunchKernelGGL(k_big_seg_list, dim3(grid_for((size_t)S, 4096)), dim3(256), 0, st, segsz, S, biglist);
+    KCHK(ctx);
+    if (dtype == SHP_I32 || dtype == SHP_U32) {
+        hipLaunchKernelGGL(k_spectra_small<true>, dim3(gs), dim3(256), 0, st, d_img, dtype, nb, n, pix,
+                           off, segsz, ssum, S);
+        hipLaunchKernelGGL(k_spectra_big<true>, dim3(SPECTRA_GRID), dim3(256), 0, st, d_img, dtype, nb, n,
+                           pix, off, segsz, ssum, biglist);
+    } else {
+        hipLaunchKernelGGL(k_spectra_small<false>, dim3(gs), dim3(256), 0, st, d_img, dtype, nb, n, pix,
+                           off, segsz, ssum, S);
+        hipLaunchKernelGGL(k_spectra_big<false>, dim3(SPECTRA_GRID), dim3(256), 0, st, d_img, dtype, nb, n,
+                           pix, off, segsz, ssum, biglist);
+    }
+    KCHK(ctx);
     prof_end(ctx, ps);
     ps = prof_begin(ctx, PROF_SMALL_LOOP);
 

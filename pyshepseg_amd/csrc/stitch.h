@@ -33,16 +33,20 @@ __global__ __launch_bounds__(256) void k_strip_minmax(const uint32_t *__restrict
     const uint32_t r = i / scols, c = i - r * scols;
     const uint32_t s = tile[r * xs + c];
     if (s == 0) return;
-    const uint32_t v = horizontal ? r : c;
-    // only a pixel whose predecessor / successor along the axis is another segment can be the
-    // segment's minimum / maximum; the plain pre-reads prune the remaining atomics
-    const uint32_t step = horizontal ? xs : 1u;
-    const uint32_t lim = horizontal ? srows : scols;
+    // Run heads / tails along the image row are enough: every row a segment touches holds one of
+    // its run heads (min / max ROW over the heads = over all pixels), and the extreme COLUMNS of a
+    // segment are the head / tail of some run.
     const uint32_t q = r * xs + c;
-    const bool lo = v == 0 || tile[q - step] != s;
-    const bool hi = v + 1u == lim || tile[q + step] != s;
-    if (lo && v < mn[s]) atomicMin(&mn[s], v);
-    if (hi && v + 1u > mx[s]) atomicMax(&mx[s], v + 1u);     // mx holds max+1 (0 = absent)
+    const bool head = c == 0 || tile[q - 1] != s;
+    if (horizontal) {
+        if (!head) return;
+        if (r < mn[s]) atomicMin(&mn[s], r);
+        if (r + 1u > mx[s]) atomicMax(&mx[s], r + 1u);     // mx holds max+1 (0 = absent)
+    } else {
+        const bool tail = c + 1u == scols || tile[q + 1] != s;
+        if (head && c < mn[s]) atomicMin(&mn[s], c);
+        if (tail && c + 1u > mx[s]) atomicMax(&mx[s], c + 1u);
+    }
 }
 
 __global__ __launch_bounds__(256) void k_pair_count(
@@ -107,8 +111,9 @@ __global__ __launch_bounds__(256) void k_seg_topleft(const uint32_t *__restrict_
     const uint32_t s = tile[p];
     if (s == 0) return;
     const uint32_t r = p / xs, c = p - r * xs;
-    if ((r == 0 || tile[p - xs] != s) && r < segtop[s]) atomicMin(&segtop[s], r);
-    if ((c == 0 || tile[p - 1] != s) && c < segleft[s]) atomicMin(&segleft[s], c);
+    if (!(c == 0 || tile[p - 1] != s)) return;          // run heads suffice (see k_meta_pixels)
+    if (r < segtop[s]) atomicMin(&segtop[s], r);
+    if (c < segleft[s]) atomicMin(&segleft[s], c);
 }
 
 struct OwnFn {
@@ -296,15 +301,20 @@ __global__ __launch_bounds__(256) void k_meta_pixels(const uint32_t *__restrict_
     if (p >= ys * xs) return;
     const uint32_t s = tile[p];
     if (s == 0) return;
+    // Only the head of a horizontal run acts: every image row a segment touches holds one of
+    // its run heads, so the heads alone give the top row, the left column and (a run inside the
+    // window has its head inside it or starts on the window's left edge) the in-window flag.
+    // Plain pre-reads prune nearly all of the atomics (a stale value from the CU's L1 only costs
+    // a redundant atomic; agent-scope loads that bypass L1 measured 30 % slower here).
     const uint32_t r = p / xs, c = p - r * xs;
-    const bool firstInCol = r == 0 || tile[p - xs] != s, firstInRow = c == 0 || tile[p - 1] != s;
-    if (firstInCol && r < segtop[s]) atomicMin(&segtop[s], r);
-    if (firstInRow && c < segleft[s]) atomicMin(&segleft[s], c);
-    // only run heads need to raise the flag (every run inside the window has a head inside it
-    // or starts at the window's left edge)
-    if (r >= top && r < bottom && c >= left && c < right && (firstInRow || c == left) &&
-        !(flags[s] & META_IN_TRIM))
-        atomicOr(&flags[s], META_IN_TRIM);
+    const bool head = c == 0 || tile[p - 1] != s;
+    const bool inwin = r >= top && r < bottom && c >= left && c < right;
+    if (!head && !(inwin && c == left)) return;
+    if (head) {
+        if (r < segtop[s]) atomicMin(&segtop[s], r);
+        if (c < segleft[s]) atomicMin(&segleft[s], c);
+    }
+    if (inwin && !(flags[s] & META_IN_TRIM)) atomicOr(&flags[s], META_IN_TRIM);
 }
 
 static int run_stitch_prepare(shp_ctx *ctx, const uint32_t *d_tile, uint32_t ys, uint32_t xs,
