@@ -146,52 +146,32 @@ __global__ __launch_bounds__(256) void k_big_list(const uint32_t *__restrict__ l
 }
 
 // Bounding box (min col, max col, max row; the min row is the root's) of every cut-able
-// component.  A wavefront covers 64 consecutive pixels; its lanes are grouped by component and
-// ONE lane per (wavefront, component) updates the box, after plain pre-reads that prune almost
-// all of the atomics (a stale pre-read only costs a redundant atomic).
+// component.  Only corner pixels can hold an extreme (the topmost pixel of the leftmost column
+// has no member above or to its left, ...), which leaves a handful of candidates per component
+// instead of one per row: atomics on one address serialise at L2.
 __global__ __launch_bounds__(256) void k_big_bbox(const uint32_t *__restrict__ lab,
                                                   const uint32_t *__restrict__ csize, uint32_t n,
                                                   uint32_t ncols, BigInfo *big,
                                                   const uint32_t *__restrict__ bigbits)
 {
     const uint32_t p = blockIdx.x * 256u + threadIdx.x;
-    const unsigned lane = lane_id();
-    bool act = false;
-    uint32_t bi = 0;
-    if (p < n) {
-        const uint32_t r = lab[p];
-        // 2 MB bitmap instead of a 4N-byte gather
-        if (r != NULL_LAB && ((bigbits[r >> 5] >> (r & 31u)) & 1u)) {
-            const uint32_t c = csize[r];
-            act = (c & VIS_FLAG) != 0u;
-            bi = c & ~VIS_FLAG;
-        }
-    }
-    unsigned long long todo = __ballot(act);
-    if (todo == 0ull) return;
+    if (p >= n) return;
+    const uint32_t r = lab[p];
+    if (r == NULL_LAB) return;
+    if (!((bigbits[r >> 5] >> (r & 31u)) & 1u)) return;     // 2 MB bitmap instead of a 4N-byte gather
     const uint32_t row = p / ncols, col = p - row * ncols;
-    while (todo) {
-        const int l0 = __builtin_ctzll(todo);
-        const uint32_t b = (uint32_t)__builtin_amdgcn_readlane((int)bi, l0);
-        const bool mine = act && bi == b;
-        const unsigned long long m = __ballot(mine);
-        todo &= ~m;
-        const int l1 = 63 - __builtin_clzll(m);
-        const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)row, l0);
-        const uint32_t r1 = (uint32_t)__builtin_amdgcn_readlane((int)row, l1);
-        // in one image row (the usual case) the group's first / last lane hold its extreme
-        // columns; a wavefront that wraps around a row end lets every lane speak for itself
-        const bool same_row = r0 == r1;
-        const bool lo = same_row ? (int)lane == l0 : mine, hi = same_row ? (int)lane == l1 : mine;
-        if (lo || hi) {
-            // the three box fields in one 12-byte read: one L2 round trip instead of three
-            const uint32_t *bx = &big[b].minc;
-            const uint32_t cminc = L2LOAD(bx), cmaxc = L2LOAD(bx + 1), cmaxr = L2LOAD(bx + 2);
-            if (lo && col < cminc) atomicMin(&big[b].minc, col);
-            if (lo && row > cmaxr) atomicMax(&big[b].maxr, row);
-            if (hi && col > cmaxc) atomicMax(&big[b].maxc, col);
-        }
-    }
+    const bool ldiff = col == 0 || lab[p - 1] != r;
+    const bool udiff = p < ncols || lab[p - ncols] != r;
+    const bool rdiff = col + 1u == ncols || lab[p + 1] != r;
+    const bool ddiff = p + ncols >= n || lab[p + ncols] != r;
+    const bool cminc = ldiff && udiff, cmaxc = rdiff && udiff, cmaxr = ddiff && ldiff;
+    if (!(cminc || cmaxc || cmaxr)) return;
+    const uint32_t c = csize[r];
+    if (!(c & VIS_FLAG)) return;
+    const uint32_t bi = c & ~VIS_FLAG;
+    if (cminc && col < big[bi].minc) atomicMin(&big[bi].minc, col);
+    if (cmaxc && col > big[bi].maxc) atomicMax(&big[bi].maxc, col);
+    if (cmaxr && row > big[bi].maxr) atomicMax(&big[bi].maxr, row);
 }
 
 // One wavefront per cut-able component: exact replay of shepseg.py:490-539 restricted to the

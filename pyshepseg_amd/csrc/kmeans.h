@@ -156,6 +156,18 @@ static int launch_assign(shp_ctx *ctx, const void *d_img, int dtype, int nb, siz
 #define FIT_CHUNK 256u
 #define FIT_LDS_DOUBLES 4096u       // 32 KiB of staged sample rows: FIT_CHUNK rows x up to 16 bands
 #define FIT_GROUP 64u               // chunks per first-level reduction group
+#define FIT_BATCH 8                 // Lloyd iterations enqueued between two host synchronisations
+#define FIT_SORT_MAXK 256           // the in-LDS counting sort of k_fit_partial handles k up to this
+
+// loop control of the Lloyd iterations, owned by the device between host synchronisations
+struct FitCtl {
+    uint32_t stop;      // 0 running; 1 labels unchanged (strict convergence); 2 an empty cluster:
+                        // the host finishes this iteration; 3 centre shift <= tol
+    uint32_t iters;     // completed iterations
+    uint32_t ndiff;     // labels changed by the E-step of the running iteration
+    uint32_t pad;
+    double shift;
+};
 
 template <int NB>
 __global__ __launch_bounds__(256) void k_fit_assign(const double *__restrict__ X, uint32_t n, int nb_rt,
@@ -163,8 +175,9 @@ __global__ __launch_bounds__(256) void k_fit_assign(const double *__restrict__ X
                                                     const double *__restrict__ cnorm, int k,
                                                     int32_t *__restrict__ lab,
                                                     const int32_t *__restrict__ lab_old,
-                                                    uint32_t *ndiff)
+                                                    FitCtl *ctl)
 {
+    if (ctl && ctl->stop) return;               // the loop has ended: the rest of the batch is a no-op
     const int nb = (NB > 0) ? NB : nb_rt;
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     bool diff = false;
@@ -190,12 +203,12 @@ __global__ __launch_bounds__(256) void k_fit_assign(const double *__restrict__ X
         diff = lab_old && lab_old[i] != best;
     }
     const unsigned long long m = __ballot(diff);
-    if (m != 0ull && lane_id() == 0) atomicAdd(ndiff, (uint32_t)__popcll(m));
+    if (m != 0ull && lane_id() == 0) atomicAdd(&ctl->ndiff, (uint32_t)__popcll(m));
 }
 
 static void launch_fit_assign(shp_ctx *ctx, unsigned g, const double *dX, uint32_t n, int nb,
                               const double *dm2c, const double *dcn, int k, int32_t *dlab,
-                              const int32_t *dlab_old, uint32_t *ndiff)
+                              const int32_t *dlab_old, FitCtl *ndiff)
 {
 #define FA(NBT)                                                                                   \
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_fit_assign<NBT>), dim3(g), dim3(256), 0, ctx->stream, dX, \
@@ -218,30 +231,76 @@ static void launch_fit_assign(shp_ctx *ctx, unsigned g, const double *dX, uint32
 
 // partial[c][j*nb+b] = sum over rows of chunk c with label j of X[row][b], rows in index order
 // (deterministic); pcount[c][j] = number of such rows.  The chunk (labels + rows) is staged in
-// LDS once and every (cluster, band) thread then walks it with broadcast LDS reads.
+// LDS once.  SORTED: the chunk's rows are grouped by label with a stable counting sort in LDS
+// (rank inside a wavefront by ballot matching, across wavefronts by a small count table), so
+// the (cluster, band) threads only walk their own rows -- same additions in the same order as
+// the plain walk (every thread scans the whole chunk), which remains for k > FIT_SORT_MAXK.
+template <bool SORTED>
 __global__ __launch_bounds__(256) void k_fit_partial(const double *__restrict__ X, uint32_t n, int nb,
                                                      const int32_t *__restrict__ lab, int k,
                                                      double *__restrict__ partial,
-                                                     uint32_t *__restrict__ pcount, uint32_t chunk)
+                                                     uint32_t *__restrict__ pcount, uint32_t chunk,
+                                                     const FitCtl *__restrict__ ctl)
 {
+    if (ctl->stop) return;
     __shared__ int32_t sl[FIT_CHUNK];
     __shared__ double sx[FIT_LDS_DOUBLES];
+    __shared__ uint16_t order[SORTED ? FIT_CHUNK : 1];
+    __shared__ uint16_t cntw[SORTED ? 4 * FIT_SORT_MAXK : 1];
+    __shared__ uint16_t start[SORTED ? FIT_SORT_MAXK + 1 : 1];
     const uint32_t c = blockIdx.x;
     const uint32_t r0 = c * chunk;
-    const uint32_t cnt = (n - r0 < chunk) ? (n - r0) : chunk;
-    for (uint32_t i = threadIdx.x; i < cnt; i += 256u) sl[i] = lab[r0 + i];
+    const uint32_t cnt = (n - r0 < chunk) ? (n - r0) : chunk;     // <= FIT_CHUNK = blockDim
+    const int kn = k * nb;
+    int32_t mylab = -1;
+    if (threadIdx.x < cnt) { mylab = lab[r0 + threadIdx.x]; sl[threadIdx.x] = mylab; }
     const uint32_t tot = cnt * (uint32_t)nb;
     for (uint32_t i = threadIdx.x; i < tot; i += 256u) sx[i] = X[(size_t)r0 * nb + i];
-    __syncthreads();
-    const int kn = k * nb;
-    for (int t = threadIdx.x; t < kn; t += 256) {
-        const int j = t / nb, b = t - j * nb;
-        double acc = 0.0;
-        uint32_t w = 0;
-        for (uint32_t i = 0; i < cnt; i++)
-            if (sl[i] == j) { acc += sx[i * nb + b]; w++; }
-        partial[(size_t)c * kn + t] = acc;
-        if (b == 0) pcount[(size_t)c * k + j] = w;
+    if (SORTED) {
+        for (int i = threadIdx.x; i < 4 * k; i += 256) cntw[i] = 0;
+        __syncthreads();
+        const unsigned lane = lane_id(), wv = threadIdx.x >> 6;
+        const bool valid = threadIdx.x < cnt;
+        unsigned long long same = __ballot(valid);
+        for (int bit = 0; (k - 1) >> bit; bit++) {
+            const bool one = (mylab >> bit) & 1;
+            const unsigned long long bal = __ballot(one);
+            same &= one ? bal : ~bal;
+        }
+        const uint32_t wrank = (uint32_t)__popcll(same & lanemask_lt());
+        if (valid && (same >> lane) >> 1 == 0ull) cntw[wv * k + mylab] = (uint16_t)__popcll(same);
+        __syncthreads();
+        for (int j = threadIdx.x; j <= k; j += 256) {         // start[j] = rows with a label < j
+            uint32_t a = 0;
+            for (int q = 0; q < j; q++) a += cntw[q] + cntw[k + q] + cntw[2 * k + q] + cntw[3 * k + q];
+            start[j] = (uint16_t)a;
+        }
+        __syncthreads();
+        if (valid) {
+            uint32_t pos = start[mylab] + wrank;
+            for (unsigned w2 = 0; w2 < wv; w2++) pos += cntw[w2 * k + mylab];
+            order[pos] = (uint16_t)threadIdx.x;
+        }
+        __syncthreads();
+        for (int t = threadIdx.x; t < kn; t += 256) {
+            const int j = t / nb, b = t - j * nb;
+            const uint32_t q0 = start[j], q1 = start[j + 1];
+            double acc = 0.0;
+            for (uint32_t q = q0; q < q1; q++) acc += sx[(uint32_t)order[q] * nb + b];
+            partial[(size_t)c * kn + t] = acc;
+            if (b == 0) pcount[(size_t)c * k + j] = q1 - q0;
+        }
+    } else {
+        __syncthreads();
+        for (int t = threadIdx.x; t < kn; t += 256) {
+            const int j = t / nb, b = t - j * nb;
+            double acc = 0.0;
+            uint32_t w = 0;
+            for (uint32_t i = 0; i < cnt; i++)
+                if (sl[i] == j) { acc += sx[i * nb + b]; w++; }
+            partial[(size_t)c * kn + t] = acc;
+            if (b == 0) pcount[(size_t)c * k + j] = w;
+        }
     }
 }
 
@@ -250,8 +309,10 @@ __global__ __launch_bounds__(256) void k_fit_reduce1(const double *__restrict__ 
                                                      const uint32_t *__restrict__ pcount,
                                                      uint32_t nchunks, int k, int nb,
                                                      double *__restrict__ partial2,
-                                                     uint32_t *__restrict__ pcount2)
+                                                     uint32_t *__restrict__ pcount2,
+                                                     const FitCtl *__restrict__ ctl)
 {
+    if (ctl->stop) return;
     const int kn = k * nb;
     const uint32_t g = blockIdx.y;
     const uint32_t c0 = g * FIT_GROUP;
@@ -277,23 +338,83 @@ __global__ __launch_bounds__(256) void k_fit_reduce1(const double *__restrict__ 
     }
 }
 
-// level 2: S[t] = sum over groups in order; w[j] likewise
-__global__ __launch_bounds__(256) void k_fit_reduce(const double *__restrict__ partial,
+// End of a Lloyd iteration in one workgroup: level-2 sums (S[t] = sum over groups in order,
+// w[j] likewise), then -- unless a cluster came out empty, which is left to the host --
+// centres = S * (1 / w), the squared centre shift, the convergence tests of sklearn 0.24.2
+// (labels unchanged -> strict; shift <= tol) and the E-step operands of the next iteration
+// (m2c = -2c, cnorm = |c|^2 as kmeans_prepare_host).  Every float64 operation and its order are
+// those of the host code this replaces, so the iteration count and the centres are unchanged.
+__global__ __launch_bounds__(256) void k_fit_update(const double *__restrict__ partial,
                                                     const uint32_t *__restrict__ pcount,
-                                                    uint32_t nchunks, int k, int nb,
-                                                    double *__restrict__ S, double *__restrict__ w)
+                                                    uint32_t ngroups, int k, int nb, double *S,
+                                                    double *w, double *C, double *m2c, double *cnorm,
+                                                    FitCtl *ctl, double tol, uint32_t it)
 {
-    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (ctl->stop) return;
+    __shared__ int s_empty;
     const int kn = k * nb;
-    if (t >= kn) return;
-    const int j = t / nb, b = t - j * nb;
-    double acc = 0.0;
-    for (uint32_t c = 0; c < nchunks; c++) acc += partial[(size_t)c * kn + t];
-    S[t] = acc;
-    if (b == 0) {
+    if (threadIdx.x == 0) s_empty = 0;
+    for (int t = threadIdx.x; t < kn; t += 256) {
+        double acc = 0.0;
+        uint32_t g = 0;
+        for (; g + 8u <= ngroups; g += 8u) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = partial[(size_t)(g + u) * kn + t];
+#pragma unroll
+            for (int u = 0; u < 8; u++) acc += v[u];
+        }
+        for (; g < ngroups; g++) acc += partial[(size_t)g * kn + t];
+        S[t] = acc;
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < k; j += 256) {
         uint32_t ww = 0;
-        for (uint32_t c = 0; c < nchunks; c++) ww += pcount[(size_t)c * k + j];
+        for (uint32_t g = 0; g < ngroups; g++) ww += pcount[(size_t)g * k + j];
         w[j] = (double)ww;
+        if (ww == 0u) s_empty = 1;
+    }
+    __syncthreads();
+    if (s_empty) {
+        if (threadIdx.x == 0) ctl->stop = 2u;
+        return;
+    }
+    for (int t = threadIdx.x; t < kn; t += 256) {
+        const double alpha = 1.0 / w[t / nb];
+        S[t] = S[t] * alpha;                                 // the new centres
+    }
+    __syncthreads();
+    for (int j = threadIdx.x; j < k; j += 256) {
+        const double *a = &S[j * nb], *c = &C[j * nb];
+        double r = 0.0;
+        int b = 0;
+        for (; b + 4 <= nb; b += 4)
+            r += ((a[b] - c[b]) * (a[b] - c[b]) + (a[b + 1] - c[b + 1]) * (a[b + 1] - c[b + 1]) +
+                  (a[b + 2] - c[b + 2]) * (a[b + 2] - c[b + 2]) + (a[b + 3] - c[b + 3]) * (a[b + 3] - c[b + 3]));
+        for (; b < nb; b++) r += (a[b] - c[b]) * (a[b] - c[b]);
+        const double sq = __builtin_sqrt(r);
+        w[j] = sq * sq;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double shift = 0.0;
+        for (int j = 0; j < k; j++) shift += w[j];
+        const uint32_t nd = ctl->ndiff;
+        ctl->shift = shift;
+        ctl->iters = it;
+        ctl->ndiff = 0u;
+        if (nd == 0u) ctl->stop = 1u;
+        else if (shift <= tol) ctl->stop = 3u;
+    }
+    for (int t = threadIdx.x; t < kn; t += 256) C[t] = S[t];
+    for (int j = threadIdx.x; j < k; j += 256) {
+        double sn = 0.0;
+        for (int b = 0; b < nb; b++) {
+            const double c = S[j * nb + b];
+            sn = __builtin_fma(c, c, sn);
+            m2c[j * nb + b] = -2.0 * c;
+        }
+        cnorm[j] = sn;
     }
 }
 
@@ -357,7 +478,7 @@ static int run_kmeans_fit(shp_ctx *ctx, const double *xin, int64_t nrows, int nb
     CHK(buf_ensure(ctx, ctx->cen, (size_t)(kn + k) * 8 * 2));
     double *dX = bp<double>(ctx->fit_x), *ddist = dX + (size_t)n * nb;
     int32_t *dlabA = bp<int32_t>(ctx->fit_lab), *dlabB = dlabA + n;
-    uint32_t *ndiff = (uint32_t *)(dlabB + n);
+    FitCtl *dctl = (FitCtl *)(dlabB + n);
     double *dpart = bp<double>(ctx->fit_part);
     double *dpart2 = dpart + (size_t)nchunks * kn;
     double *dS = dpart2 + (size_t)ngroups * kn, *dw = dS + kn;
@@ -365,9 +486,11 @@ static int run_kmeans_fit(shp_ctx *ctx, const double *xin, int64_t nrows, int nb
     uint32_t *dpc2 = dpc + (size_t)nchunks * k;
     double *dm2c = bp<double>(ctx->cen), *dcn = dm2c + kn, *dC = dcn + k;
     hipStream_t st = ctx->stream;
-    // pinned staging: [0] ndiff word, then m2c|cnorm|C (2kn+k doubles), then S|w (kn+k doubles)
+    // pinned staging: [0..] FitCtl, then m2c|cnorm|C (2kn+k doubles), then S|w (kn+k doubles)
+    FitCtl *pin_ctl = (FitCtl *)ctx->h_pinned;
     double *pin_up = (double *)(ctx->h_pinned + 16);
     double *pin_dn = pin_up + (2 * kn + k);
+    HIPCHK(ctx, hipStreamSynchronize(st));           // earlier users of the staging area are done
     HIPCHK(ctx, hipMemcpyAsync(dX, X.data(), (size_t)n * nb * 8, hipMemcpyHostToDevice, st));
     HIPCHK(ctx, hipMemsetAsync(dlabB, 0xff, (size_t)n * 4, st));        // labels_old = -1
     const unsigned g = grid_for(n, 256);
@@ -377,53 +500,81 @@ static int run_kmeans_fit(shp_ctx *ctx, const double *xin, int64_t nrows, int nb
         HIPCHK(ctx, hipMemcpyAsync(dm2c, pin_up, (size_t)(2 * kn + k) * 8, hipMemcpyHostToDevice, st));
         return 0;
     };
-    bool strict = false;
-    int it = 0;
-    int32_t *dlab = dlabA, *dlab_old = dlabB;
-    for (it = 1; it <= max_iter; it++) {
-        CHK(upload_centres(C));
-        HIPCHK(ctx, hipMemsetAsync(ndiff, 0, 4, st));
-        launch_fit_assign(ctx, g, dX, n, nb, dm2c, dcn, k, dlab, dlab_old, ndiff); KCHK(ctx);
-        hipLaunchKernelGGL(k_fit_partial, dim3(nchunks), dim3(256), 0, st, dX, n, nb, dlab, k, dpart,
-                           dpc, chunk); KCHK(ctx);
-        hipLaunchKernelGGL(k_fit_reduce1, dim3(grid_for(kn, 256), ngroups), dim3(256), 0, st, dpart, dpc,
-                           nchunks, k, nb, dpart2, dpc2); KCHK(ctx);
-        hipLaunchKernelGGL(k_fit_reduce, dim3(grid_for(kn, 256)), dim3(256), 0, st, dpart2, dpc2,
-                           ngroups, k, nb, dS, dw); KCHK(ctx);
-        HIPCHK(ctx, hipMemcpyAsync(pin_dn, dS, (size_t)(kn + k) * 8, hipMemcpyDeviceToHost, st));
-        HIPCHK(ctx, hipMemcpyAsync(ctx->h_pinned, ndiff, 4, hipMemcpyDeviceToHost, st));
+    auto upload_ctl = [&](uint32_t iters) -> int {
+        memset(pin_ctl, 0, sizeof(FitCtl));
+        pin_ctl->iters = iters;
+        HIPCHK(ctx, hipMemcpyAsync(dctl, pin_ctl, sizeof(FitCtl), hipMemcpyHostToDevice, st));
+        return 0;
+    };
+    // The iterations run in batches of FIT_BATCH without a host round trip: the last kernel of an
+    // iteration (k_fit_update) owns the convergence tests and, once it raises ctl->stop, the
+    // kernels still queued behind it return at once.  Iteration `it` writes its labels to buffer
+    // A when it is odd, B when even, and compares them with the other buffer (labels_old).
+    const bool sorted = k <= FIT_SORT_MAXK;
+    bool strict = false, finished = false;
+    int it_done = 0;
+    CHK(upload_centres(C));
+    CHK(upload_ctl(0));
+    while (it_done < max_iter && !finished) {
+        const int b_end = it_done + FIT_BATCH < max_iter ? it_done + FIT_BATCH : max_iter;
+        for (int it = it_done + 1; it <= b_end; it++) {
+            int32_t *dlab = (it & 1) ? dlabA : dlabB, *dlab_old = (it & 1) ? dlabB : dlabA;
+            launch_fit_assign(ctx, g, dX, n, nb, dm2c, dcn, k, dlab, dlab_old, dctl); KCHK(ctx);
+            if (sorted)
+                hipLaunchKernelGGL(k_fit_partial<true>, dim3(nchunks), dim3(256), 0, st, dX, n, nb, dlab, k,
+                                   dpart, dpc, chunk, dctl);
+            else
+                hipLaunchKernelGGL(k_fit_partial<false>, dim3(nchunks), dim3(256), 0, st, dX, n, nb, dlab, k,
+                                   dpart, dpc, chunk, dctl);
+            KCHK(ctx);
+            hipLaunchKernelGGL(k_fit_reduce1, dim3(grid_for(kn, 256), ngroups), dim3(256), 0, st, dpart, dpc,
+                               nchunks, k, nb, dpart2, dpc2, dctl); KCHK(ctx);
+            hipLaunchKernelGGL(k_fit_update, dim3(1), dim3(256), 0, st, dpart2, dpc2, ngroups, k, nb, dS, dw,
+                               dC, dm2c, dcn, dctl, tol, (uint32_t)it); KCHK(ctx);
+        }
+        HIPCHK(ctx, hipMemcpyAsync(pin_ctl, dctl, sizeof(FitCtl), hipMemcpyDeviceToHost, st));
         HIPCHK(ctx, hipStreamSynchronize(st));
-        for (int t = 0; t < kn; t++) Cn[t] = pin_dn[t];
+        const uint32_t stop = pin_ctl->stop;
+        if (stop == 0u) { it_done = b_end; continue; }
+        if (stop == 1u || stop == 3u) {
+            it_done = (int)pin_ctl->iters;
+            strict = stop == 1u;
+            finished = true;
+            break;
+        }
+        // stop == 2: iteration `it` found an empty cluster after its E-step and level-2 sums; the
+        // host finishes it (_relocate_empty_clusters_dense: farthest samples from their OLD centres)
+        const int it = (int)pin_ctl->iters + 1;
+        const uint32_t nd = pin_ctl->ndiff;
+        int32_t *dlab = (it & 1) ? dlabA : dlabB;
+        HIPCHK(ctx, hipMemcpyAsync(pin_dn, dS, (size_t)(kn + k) * 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipMemcpyAsync(pin_up, dC, (size_t)kn * 8, hipMemcpyDeviceToHost, st));
+        hipLaunchKernelGGL(k_fit_dist, dim3(g), dim3(256), 0, st, dX, n, nb, dlab, dC, ddist); KCHK(ctx);
+        std::vector<double> dist(n);
+        std::vector<int32_t> hl(n);
+        HIPCHK(ctx, hipMemcpyAsync(dist.data(), ddist, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipMemcpyAsync(hl.data(), dlab, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        for (int t = 0; t < kn; t++) { Cn[t] = pin_dn[t]; C[t] = pin_up[t]; }
         for (int j = 0; j < k; j++) w[j] = pin_dn[kn + j];
-        const uint32_t nd = ctx->h_pinned[0];
-        int n_empty = 0;
-        for (int j = 0; j < k; j++) n_empty += (w[j] == 0.0);
-        if (n_empty > 0) {
-            // _relocate_empty_clusters_dense: farthest samples from their OLD centres
-            hipLaunchKernelGGL(k_fit_dist, dim3(g), dim3(256), 0, st, dX, n, nb, dlab, dC, ddist); KCHK(ctx);
-            std::vector<double> dist(n);
-            std::vector<int32_t> hl(n);
-            HIPCHK(ctx, hipMemcpyAsync(dist.data(), ddist, (size_t)n * 8, hipMemcpyDeviceToHost, st));
-            HIPCHK(ctx, hipMemcpyAsync(hl.data(), dlab, (size_t)n * 4, hipMemcpyDeviceToHost, st));
-            HIPCHK(ctx, hipStreamSynchronize(st));
-            std::vector<int> empties;
-            for (int j = 0; j < k; j++) if (w[j] == 0.0) empties.push_back(j);
-            // the n_empty farthest samples, distance descending / index ascending on ties
-            std::vector<uint32_t> order(n);
-            for (uint32_t i = 0; i < n; i++) order[i] = i;
-            std::partial_sort(order.begin(), order.begin() + n_empty, order.end(),
-                              [&dist](uint32_t a, uint32_t b) {
-                                  return dist[a] > dist[b] || (dist[a] == dist[b] && a < b);
-                              });
-            for (int r = 0; r < n_empty; r++) {
-                const uint32_t f = order[r];
-                const int e = empties[r], old = hl[f];
-                for (int b = 0; b < nb; b++) {
-                    Cn[old * nb + b] -= X[(size_t)f * nb + b];
-                    Cn[e * nb + b] = X[(size_t)f * nb + b];
-                }
-                w[e] = 1.0; w[old] -= 1.0;
+        std::vector<int> empties;
+        for (int j = 0; j < k; j++) if (w[j] == 0.0) empties.push_back(j);
+        const int n_empty = (int)empties.size();
+        // the n_empty farthest samples, distance descending / index ascending on ties
+        std::vector<uint32_t> order(n);
+        for (uint32_t i = 0; i < n; i++) order[i] = i;
+        std::partial_sort(order.begin(), order.begin() + n_empty, order.end(),
+                          [&dist](uint32_t a, uint32_t b) {
+                              return dist[a] > dist[b] || (dist[a] == dist[b] && a < b);
+                          });
+        for (int r = 0; r < n_empty; r++) {
+            const uint32_t f = order[r];
+            const int e = empties[r], old = hl[f];
+            for (int b = 0; b < nb; b++) {
+                Cn[old * nb + b] -= X[(size_t)f * nb + b];
+                Cn[e * nb + b] = X[(size_t)f * nb + b];
             }
+            w[e] = 1.0; w[old] -= 1.0;
         }
         for (int j = 0; j < k; j++)
             if (w[j] > 0.0) { const double alpha = 1.0 / w[j]; for (int b = 0; b < nb; b++) Cn[j * nb + b] *= alpha; }
@@ -435,20 +586,27 @@ static int run_kmeans_fit(shp_ctx *ctx, const double *xin, int64_t nrows, int nb
                 r += ((a[b] - c[b]) * (a[b] - c[b]) + (a[b + 1] - c[b + 1]) * (a[b + 1] - c[b + 1]) +
                       (a[b + 2] - c[b + 2]) * (a[b + 2] - c[b + 2]) + (a[b + 3] - c[b + 3]) * (a[b + 3] - c[b + 3]));
             for (; b < nb; b++) r += (a[b] - c[b]) * (a[b] - c[b]);
-            const double s = __builtin_sqrt(r);
-            shift += s * s;
+            const double sq = __builtin_sqrt(r);
+            shift += sq * sq;
         }
         C = Cn;
-        if (nd == 0) { strict = true; break; }
-        if (shift <= tol) break;
-        { int32_t *t = dlab; dlab = dlab_old; dlab_old = t; }            // labels_old[:] = labels
-    }
-    if (it > max_iter) it = max_iter;
-    if (!strict) {
-        // extra E-step so that the labels match the final centres (either label buffer will do)
+        it_done = it;
         CHK(upload_centres(C));
-        launch_fit_assign(ctx, g, dX, n, nb, dm2c, dcn, k, dlab, (const int32_t *)nullptr, ndiff); KCHK(ctx);
+        CHK(upload_ctl((uint32_t)it));
+        if (nd == 0) { strict = true; finished = true; }
+        else if (shift <= tol) finished = true;
     }
+    int it = it_done;
+    int32_t *dlab = (it_done & 1) ? dlabA : dlabB;
+    if (it_done == 0) dlab = dlabA;                  // max_iter < 1: labels of the initial centres
+    if (!strict) {
+        // extra E-step so that the labels match the final centres (the device already holds their
+        // m2c | cnorm; either label buffer will do)
+        launch_fit_assign(ctx, g, dX, n, nb, dm2c, dcn, k, dlab, (const int32_t *)nullptr, (FitCtl *)nullptr); KCHK(ctx);
+    }
+    HIPCHK(ctx, hipMemcpyAsync(pin_up, dC, (size_t)kn * 8, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    for (int t = 0; t < kn; t++) C[t] = pin_up[t];
     if (labels_out) HIPCHK(ctx, hipMemcpyAsync(labels_out, dlab, (size_t)n * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipStreamSynchronize(st));
     for (int t = 0; t < kn; t++) centres_out[t] = C[t] + mu[t % nb];

@@ -33,19 +33,23 @@ __global__ __launch_bounds__(256) void k_strip_minmax(const uint32_t *__restrict
     const uint32_t r = i / scols, c = i - r * scols;
     const uint32_t s = tile[r * xs + c];
     if (s == 0) return;
-    // Run heads / tails along the image row are enough: every row a segment touches holds one of
-    // its run heads (min / max ROW over the heads = over all pixels), and the extreme COLUMNS of a
-    // segment are the head / tail of some run.
+    // Only corner pixels can hold an extreme: the topmost pixel of a segment's leftmost column has
+    // neither the segment above it nor to its left, and so on for the other three extremes.  That
+    // leaves a handful of candidates per segment, so the atomics no longer pile up on one address
+    // (rows of a segment are processed concurrently, pre-reads alone cannot prune them).
     const uint32_t q = r * xs + c;
-    const bool head = c == 0 || tile[q - 1] != s;
+    const bool ldiff = c == 0 || tile[q - 1] != s;
+    const bool udiff = r == 0 || tile[q - xs] != s;
     if (horizontal) {
-        if (!head) return;
-        if (r < mn[s]) atomicMin(&mn[s], r);
-        if (r + 1u > mx[s]) atomicMax(&mx[s], r + 1u);     // mx holds max+1 (0 = absent)
+        if (!ldiff) return;
+        const bool ddiff = r + 1u == srows || tile[q + xs] != s;
+        if (udiff && r < mn[s]) atomicMin(&mn[s], r);
+        if (ddiff && r + 1u > mx[s]) atomicMax(&mx[s], r + 1u);     // mx holds max+1 (0 = absent)
     } else {
-        const bool tail = c + 1u == scols || tile[q + 1] != s;
-        if (head && c < mn[s]) atomicMin(&mn[s], c);
-        if (tail && c + 1u > mx[s]) atomicMax(&mx[s], c + 1u);
+        if (!udiff) return;
+        const bool rdiff = c + 1u == scols || tile[q + 1] != s;
+        if (ldiff && c < mn[s]) atomicMin(&mn[s], c);
+        if (rdiff && c + 1u > mx[s]) atomicMax(&mx[s], c + 1u);
     }
 }
 
@@ -111,7 +115,7 @@ __global__ __launch_bounds__(256) void k_seg_topleft(const uint32_t *__restrict_
     const uint32_t s = tile[p];
     if (s == 0) return;
     const uint32_t r = p / xs, c = p - r * xs;
-    if (!(c == 0 || tile[p - 1] != s)) return;          // run heads suffice (see k_meta_pixels)
+    if (!(c == 0 || tile[p - 1] != s) || !(r == 0 || tile[p - xs] != s)) return;   // corners only
     if (r < segtop[s]) atomicMin(&segtop[s], r);
     if (c < segleft[s]) atomicMin(&segleft[s], c);
 }
@@ -301,20 +305,19 @@ __global__ __launch_bounds__(256) void k_meta_pixels(const uint32_t *__restrict_
     if (p >= ys * xs) return;
     const uint32_t s = tile[p];
     if (s == 0) return;
-    // Only the head of a horizontal run acts: every image row a segment touches holds one of
-    // its run heads, so the heads alone give the top row, the left column and (a run inside the
-    // window has its head inside it or starts on the window's left edge) the in-window flag.
-    // Plain pre-reads prune nearly all of the atomics (a stale value from the CU's L1 only costs
-    // a redundant atomic; agent-scope loads that bypass L1 measured 30 % slower here).
+    // Only corner pixels act (see k_strip_minmax): the top row and the left column of a segment
+    // are both found on pixels that have neither the segment above nor to the left, and the
+    // topmost-leftmost pixel of (segment n window) has the same property relative to the window.
     const uint32_t r = p / xs, c = p - r * xs;
-    const bool head = c == 0 || tile[p - 1] != s;
-    const bool inwin = r >= top && r < bottom && c >= left && c < right;
-    if (!head && !(inwin && c == left)) return;
-    if (head) {
+    const bool ldiff = c == 0 || tile[p - 1] != s;
+    const bool udiff = r == 0 || tile[p - xs] != s;
+    if (ldiff && udiff) {
         if (r < segtop[s]) atomicMin(&segtop[s], r);
         if (c < segleft[s]) atomicMin(&segleft[s], c);
     }
-    if (inwin && !(flags[s] & META_IN_TRIM)) atomicOr(&flags[s], META_IN_TRIM);
+    const bool inwin = r >= top && r < bottom && c >= left && c < right;
+    if (inwin && (ldiff || c == left) && (udiff || r == top) && !(flags[s] & META_IN_TRIM))
+        atomicOr(&flags[s], META_IN_TRIM);
 }
 
 static int run_stitch_prepare(shp_ctx *ctx, const uint32_t *d_tile, uint32_t ys, uint32_t xs,
