@@ -81,6 +81,7 @@ API void shp_ctx_destroy(shp_ctx *ctx)
         for (int j = 0; j < 2; j++)
             if (ctx->prof_ev[i][j]) hipEventDestroy(ctx->prof_ev[i][j]);
     if (ctx->h_pinned) hipHostFree(ctx->h_pinned);
+    if (ctx->h_fit) hipHostFree(ctx->h_fit);
     if (ctx->stream2) { hipStreamSynchronize(ctx->stream2); hipStreamDestroy(ctx->stream2); }
     if (ctx->evfork) hipEventDestroy(ctx->evfork);
     if (ctx->evjoin) hipEventDestroy(ctx->evjoin);

@@ -39,6 +39,8 @@ struct shp_ctx {
         pix, segsz, origsz, off, ssum, chnext, chtail, mergeto, tcount, toff, tfill, tlist, tsorted,
         small, cen, fit_x, fit_lab, fit_part, big, srclist, tgtlist, bigbits, singles;
     uint32_t *h_pinned = nullptr;   // SHP_PINNED_BYTES of pinned host staging (small transfers)
+    double *h_fit = nullptr;        // pinned, grow-only: the centred k-means sample
+    size_t h_fit_cap = 0;
     hipEvent_t ev[16] = {};
     double timings[8] = {};
     // per-kernel device-time accounting (HIP events on this stream), see PROF_* below
@@ -168,6 +170,28 @@ __device__ __forceinline__ long long ld_px(const void *__restrict__ img, int dty
 // relaxed agent-scope load: served by L2, where the atomics land (a plain load may be answered
 // by a stale line of the CU's vector L1)
 #define L2LOAD(ptr) __hip_atomic_load((ptr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+
+// Typed pixel fetch for kernels whose inner loops issue many loads: with the pixel type a template
+// parameter the loads of an unrolled loop sit in one basic block and overlap, whereas the
+// run-time switch of ld_px puts every load behind its own branch.
+template <int DT> struct PxT { typedef uint32_t type; };
+template <> struct PxT<SHP_U8> { typedef uint8_t type; };
+template <> struct PxT<SHP_I16> { typedef int16_t type; };
+template <> struct PxT<SHP_U16> { typedef uint16_t type; };
+template <> struct PxT<SHP_I32> { typedef int32_t type; };
+template <int DT> __device__ __forceinline__ long long ld_t(const void *__restrict__ img, size_t i)
+{
+    return ((const typename PxT<DT>::type *)img)[i];
+}
+// expands STMT once per pixel type with `DT` a compile-time constant
+#define DISPATCH_DTYPE(dtype, ...)                                    \
+    switch (dtype) {                                                  \
+    case SHP_U8: { constexpr int DT = SHP_U8; __VA_ARGS__; } break;          \
+    case SHP_I16: { constexpr int DT = SHP_I16; __VA_ARGS__; } break;        \
+    case SHP_U16: { constexpr int DT = SHP_U16; __VA_ARGS__; } break;        \
+    case SHP_I32: { constexpr int DT = SHP_I32; __VA_ARGS__; } break;        \
+    default: { constexpr int DT = SHP_U32; __VA_ARGS__; } break;             \
+    }
 
 __device__ __forceinline__ unsigned lane_id() { return threadIdx.x & 63u; }
 __device__ __forceinline__ unsigned long long lanemask_lt()

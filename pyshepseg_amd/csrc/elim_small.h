@@ -54,34 +54,37 @@ template <typename T> __device__ __forceinline__ T wave_sum_t(T v)
     return v;
 }
 
-template <bool WIDE>
+// BG = bands per pass, a compile-time constant (= nb when nb <= 8) so that the loads of one pixel
+// are a straight run of independent instructions; a last pass with fewer bands than BG re-reads
+// band 0 for the surplus slots and drops the result.
+template <int DT, int BG>
 __global__ __launch_bounds__(256) void k_spectra_small(
-    const void *__restrict__ img, int dtype, int nb, uint32_t n, const uint32_t *__restrict__ pix,
+    const void *__restrict__ img, int nb, uint32_t n, const uint32_t *__restrict__ pix,
     const uint32_t *__restrict__ off, const uint32_t *__restrict__ segsz, float *__restrict__ ssum,
     uint32_t S)
 {
+    constexpr bool WIDE = DT == SHP_I32 || DT == SHP_U32;
     const uint32_t s = blockIdx.x * 256u + threadIdx.x + 1u;
     if (s > S) return;
     const uint32_t m = segsz[s];
     if (m == 0u || m > 64u) return;
     const uint32_t o = off[s];
-    for (int b0 = 0; b0 < nb; b0 += SPECTRA_BG) {
-        const int bg = nb - b0 < SPECTRA_BG ? nb - b0 : SPECTRA_BG;
+    for (int b0 = 0; b0 < nb; b0 += BG) {
+        const int bg = nb - b0 < BG ? nb - b0 : BG;
         const size_t base = (size_t)b0 * n;
-        float acc[SPECTRA_BG];
+        float acc[BG];
 #pragma unroll
-        for (int j = 0; j < SPECTRA_BG; j++) acc[j] = 0.0f;
+        for (int j = 0; j < BG; j++) acc[j] = 0.0f;
         for (uint32_t i = 0; i < m; i++) {
             const uint32_t idx = pix[o + i];
+            long long v[BG];
 #pragma unroll
-            for (int j = 0; j < SPECTRA_BG; j++)
-                if (j < bg) {
-                    const long long v = ld_px(img, dtype, base + (size_t)j * n + idx);
-                    acc[j] = WIDE ? f32_acc(acc[j], v) : acc[j] + (float)(int)v;
-                }
+            for (int j = 0; j < BG; j++) v[j] = ld_t<DT>(img, base + (size_t)(j < bg ? j : 0) * n + idx);
+#pragma unroll
+            for (int j = 0; j < BG; j++) acc[j] = WIDE ? f32_acc(acc[j], v[j]) : acc[j] + (float)(int)v[j];
         }
 #pragma unroll
-        for (int j = 0; j < SPECTRA_BG; j++)
+        for (int j = 0; j < BG; j++)
             if (j < bg) ssum[(size_t)s * nb + b0 + j] = acc[j];
     }
 }
@@ -112,15 +115,16 @@ __global__ __launch_bounds__(256) void k_big_seg_list(const uint32_t *__restrict
     for (uint32_t i = threadIdx.x; i < s_cnt; i += 256u) list[16u + s_base + i] = s_buf[i];
 }
 
-template <bool WIDE>
+template <int DT, int BG>
 __global__ __launch_bounds__(256) void k_spectra_big(
-    const void *__restrict__ img, int dtype, int nb, uint32_t n, const uint32_t *__restrict__ pix,
+    const void *__restrict__ img, int nb, uint32_t n, const uint32_t *__restrict__ pix,
     const uint32_t *__restrict__ off, const uint32_t *__restrict__ segsz, float *__restrict__ ssum,
     const uint32_t *__restrict__ list)
 {
+    constexpr bool WIDE = DT == SHP_I32 || DT == SHP_U32;
     typedef typename std::conditional<WIDE, long long, int>::type IT;
     typedef typename std::conditional<WIDE, double, float>::type FT;
-    __shared__ FT tv[4][SPECTRA_BG][65];     // 65: lanes (= bands) read down their rows conflict-free
+    __shared__ FT tv[4][BG][65];     // 65: lanes (= bands) read down their rows conflict-free
     const unsigned lane = lane_id(), wv = threadIdx.x >> 6;
     const uint32_t nbig = list[0];
     const IT LIM = (IT)1 << 24;
@@ -128,79 +132,90 @@ __global__ __launch_bounds__(256) void k_spectra_big(
         const uint32_t bs = (uint32_t)__builtin_amdgcn_readfirstlane((int)list[16u + e]);
         const uint32_t bm = (uint32_t)__builtin_amdgcn_readfirstlane((int)segsz[bs]);
         const uint32_t bo = (uint32_t)__builtin_amdgcn_readfirstlane((int)off[bs]);
-        for (int b0 = 0; b0 < nb; b0 += SPECTRA_BG) {
-            const int bg = nb - b0 < SPECTRA_BG ? nb - b0 : SPECTRA_BG;
-            const size_t base = (size_t)b0 * n;
-            // ---- exact phase: private integer partial sums, bound checked per 512 pixels ----
-            IT psum[SPECTRA_BG], pabs[SPECTRA_BG];
+        for (int b0 = 0; b0 < nb; b0 += BG) {
+            const int bg = nb - b0 < BG ? nb - b0 : BG;
+            size_t boff[BG];                         // band offsets; surplus slots re-read band 0
 #pragma unroll
-            for (int j = 0; j < SPECTRA_BG; j++) { psum[j] = 0; pabs[j] = 0; }
+            for (int j = 0; j < BG; j++) boff[j] = (size_t)(b0 + (j < bg ? j : 0)) * n;
+            // ---- exact phase: private integer partial sums, bound checked per 512 pixels ----
+            IT psum[BG], pabs[BG];
+#pragma unroll
+            for (int j = 0; j < BG; j++) { psum[j] = 0; pabs[j] = 0; }
             uint32_t i0 = 0;
             while (i0 < bm) {
                 const uint32_t gend = bm - i0 > 512u ? i0 + 512u : bm;
-                IT ts[SPECTRA_BG], ta[SPECTRA_BG];
+                IT ts[BG], ta[BG];
 #pragma unroll
-                for (int j = 0; j < SPECTRA_BG; j++) { ts[j] = psum[j]; ta[j] = pabs[j]; }
+                for (int j = 0; j < BG; j++) { ts[j] = psum[j]; ta[j] = pabs[j]; }
                 uint32_t idx[8];
+                bool ok[8];
 #pragma unroll
                 for (int u = 0; u < 8; u++) {
                     const uint32_t i = i0 + (uint32_t)u * 64u + lane;
-                    idx[u] = i < gend ? pix[bo + i] : 0xFFFFFFFFu;
+                    ok[u] = i < gend;
+                    idx[u] = pix[bo + (ok[u] ? i : i0)];         // unconditional loads: they all overlap
                 }
 #pragma unroll
                 for (int u = 0; u < 8; u++) {
 #pragma unroll
-                    for (int j = 0; j < SPECTRA_BG; j++)
-                        if (j < bg && idx[u] != 0xFFFFFFFFu) {
-                            const IT v = (IT)ld_px(img, dtype, base + (size_t)j * n + idx[u]);
-                            ts[j] += v;
-                            ta[j] += v < 0 ? -v : v;
-                        }
+                    for (int j = 0; j < BG; j++) {
+                        IT v = (IT)ld_t<DT>(img, boff[j] + idx[u]);
+                        v = ok[u] ? v : (IT)0;
+                        ts[j] += v;
+                        ta[j] += v < 0 ? -v : v;
+                    }
                 }
                 IT mx = 0;
 #pragma unroll
-                for (int j = 0; j < SPECTRA_BG; j++) mx = ta[j] > mx ? ta[j] : mx;
+                for (int j = 0; j < BG; j++) mx = ta[j] > mx ? ta[j] : mx;
                 // per-lane maxima stay below 2^24 while the phase lasts, so 64 of them fit IT
                 const IT bound = wave_sum_t<IT>(mx);
                 if (bound >= LIM) break;
 #pragma unroll
-                for (int j = 0; j < SPECTRA_BG; j++) { psum[j] = ts[j]; pabs[j] = ta[j]; }
+                for (int j = 0; j < BG; j++) { psum[j] = ts[j]; pabs[j] = ta[j]; }
                 i0 = gend;
             }
             float acc = 0.0f;                        // lane j < bg: running float32 sum of band b0 + j
 #pragma unroll
-            for (int j = 0; j < SPECTRA_BG; j++)
-                if (j < bg) {
-                    const IT t = wave_sum_t<IT>(psum[j]);
-                    if (lane == (unsigned)j) acc = (float)t;
-                }
+            for (int j = 0; j < BG; j++) {
+                const IT t = wave_sum_t<IT>(psum[j]);
+                if (lane == (unsigned)j) acc = (float)t;
+            }
             // ---- ordered phase: list order float32 additions, lane = band ----
             if (i0 < bm) {
-                IT cur[SPECTRA_BG];
+                IT cur[BG];
                 {
                     const bool valid = i0 + lane < bm;
-                    const uint32_t ix = valid ? pix[bo + i0 + lane] : 0u;
+                    const uint32_t ix = pix[bo + (valid ? i0 + lane : i0)];
 #pragma unroll
-                    for (int j = 0; j < SPECTRA_BG; j++)
-                        cur[j] = (j < bg && valid) ? (IT)ld_px(img, dtype, base + (size_t)j * n + ix) : (IT)0;
+                    for (int j = 0; j < BG; j++) cur[j] = (IT)ld_t<DT>(img, boff[j] + ix);
                 }
                 for (uint32_t c0 = i0; c0 < bm; c0 += 64u) {
 #pragma unroll
-                    for (int j = 0; j < SPECTRA_BG; j++)
-                        if (j < bg) tv[wv][j][lane] = (FT)cur[j];
+                    for (int j = 0; j < BG; j++) tv[wv][j][lane] = (FT)cur[j];
                     __builtin_amdgcn_wave_barrier();
                     const uint32_t nx = c0 + 64u;
                     if (nx < bm) {                   // next step's gathers overlap this step's chain
                         const bool valid = nx + lane < bm;
-                        const uint32_t ix = valid ? pix[bo + nx + lane] : 0u;
+                        const uint32_t ix = pix[bo + (valid ? nx + lane : nx)];
 #pragma unroll
-                        for (int j = 0; j < SPECTRA_BG; j++)
-                            cur[j] = (j < bg && valid) ? (IT)ld_px(img, dtype, base + (size_t)j * n + ix) : (IT)0;
+                        for (int j = 0; j < BG; j++) cur[j] = (IT)ld_t<DT>(img, boff[j] + ix);
                     }
-                    const uint32_t cnt = bm - c0 < 64u ? bm - c0 : 64u;
+                    const uint32_t cnt = bm - c0 < 64u ? bm - c0 : 64u;      // lanes >= cnt staged junk
                     if (lane < (unsigned)bg) {
                         const FT *row = tv[wv][lane];
-                        for (uint32_t q = 0; q < cnt; q++) {
+                        uint32_t q = 0;
+                        for (; q + 8u <= cnt; q += 8u) {
+                            FT r[8];
+#pragma unroll
+                            for (int u = 0; u < 8; u++) r[u] = row[q + u];
+#pragma unroll
+                            for (int u = 0; u < 8; u++) {
+                                if (WIDE) acc = (float)((double)acc + (double)r[u]);
+                                else acc = acc + (float)r[u];
+                            }
+                        }
+                        for (; q < cnt; q++) {
                             if (WIDE) acc = (float)((double)acc + (double)row[q]);
                             else acc = acc + (float)row[q];
                         }
@@ -678,17 +693,23 @@ static int run_eliminate_small(shp_ctx *ctx, const void *d_img, int dtype, int n
     uint32_t *biglist = tlist;          // free until the pass loop starts
     hipLaunchKernelGGL(k_big_seg_list, dim3(grid_for((size_t)S, 4096)), dim3(256), 0, st, segsz, S, biglist);
     KCHK(ctx);
-    if (dtype == SHP_I32 || dtype == SHP_U32) {
-        hipLaunchKernelGGL(k_spectra_small<true>, dim3(gs), dim3(256), 0, st, d_img, dtype, nb, n, pix,
-                           off, segsz, ssum, S);
-        hipLaunchKernelGGL(k_spectra_big<true>, dim3(SPECTRA_GRID), dim3(256), 0, st, d_img, dtype, nb, n,
-                           pix, off, segsz, ssum, biglist);
-    } else {
-        hipLaunchKernelGGL(k_spectra_small<false>, dim3(gs), dim3(256), 0, st, d_img, dtype, nb, n, pix,
-                           off, segsz, ssum, S);
-        hipLaunchKernelGGL(k_spectra_big<false>, dim3(SPECTRA_GRID), dim3(256), 0, st, d_img, dtype, nb, n,
-                           pix, off, segsz, ssum, biglist);
+#define SPECTRA_LAUNCH(BGN)                                                                           \
+    DISPATCH_DTYPE(dtype,                                                                             \
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_spectra_small<DT, BGN>), dim3(gs), dim3(256), 0, st, d_img, \
+                           nb, n, pix, off, segsz, ssum, S);                                          \
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_spectra_big<DT, BGN>), dim3(SPECTRA_GRID), dim3(256), 0, st, \
+                           d_img, nb, n, pix, off, segsz, ssum, biglist))
+    switch (nb >= SPECTRA_BG ? SPECTRA_BG : nb) {
+    case 1: SPECTRA_LAUNCH(1); break;
+    case 2: SPECTRA_LAUNCH(2); break;
+    case 3: SPECTRA_LAUNCH(3); break;
+    case 4: SPECTRA_LAUNCH(4); break;
+    case 5: SPECTRA_LAUNCH(5); break;
+    case 6: SPECTRA_LAUNCH(6); break;
+    case 7: SPECTRA_LAUNCH(7); break;
+    default: SPECTRA_LAUNCH(8); break;
     }
+#undef SPECTRA_LAUNCH
     KCHK(ctx);
     prof_end(ctx, ps);
     ps = prof_begin(ctx, PROF_SMALL_LOOP);

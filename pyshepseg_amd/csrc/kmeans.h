@@ -15,9 +15,9 @@
 
 #define ASSIGN_PPT 4   // pixels per thread (amortises the scalar centroid loads)
 
-template <int NB>
+template <int NB, int DT>
 __global__ __launch_bounds__(256) void k_assign(
-    const void *__restrict__ img, int dtype, size_t npix, int nb_rt,
+    const void *__restrict__ img, size_t npix, int nb_rt,
     const double *__restrict__ m2c, const double *__restrict__ cnorm, int k, int has_null,
     long long null_val, uint16_t *__restrict__ clus16, int32_t *__restrict__ clus32)
 {
@@ -37,13 +37,13 @@ __global__ __launch_bounds__(256) void k_assign(
             if (NB > 0) {
 #pragma unroll
                 for (int b = 0; b < NB; b++) {
-                    long long v = (p < npix) ? ld_px(img, dtype, (size_t)b * npix + p) : 0;
+                    long long v = (p < npix) ? ld_t<DT>(img, (size_t)b * npix + p) : 0;
                     if (has_null && v == null_val) isnull[q] = true;
                     x[q][b] = (double)v;
                 }
             } else {
                 for (int b = 0; b < nb; b++) {
-                    long long v = (p < npix) ? ld_px(img, dtype, (size_t)b * npix + p) : 0;
+                    long long v = (p < npix) ? ld_t<DT>(img, (size_t)b * npix + p) : 0;
                     if (has_null && v == null_val) isnull[q] = true;
                 }
             }
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(256) void k_assign(
                     for (int q = 0; q < ASSIGN_PPT; q++) {
                         const size_t p = p0 + (size_t)q * stride;
                         const double xv =
-                            (p < npix) ? (double)ld_px(img, dtype, (size_t)b * npix + p) : 0.0;
+                            (p < npix) ? (double)ld_t<DT>(img, (size_t)b * npix + p) : 0.0;
                         d[q] = __builtin_fma(xv, c, d[q]);
                     }
                 }
@@ -120,9 +120,9 @@ static int launch_assign(shp_ctx *ctx, const void *d_img, int dtype, int nb, siz
     const double *m2c = bp<double>(ctx->cen), *cn = m2c + (size_t)k * nb;
     const unsigned grid = grid_for((npix + ASSIGN_PPT - 1) / ASSIGN_PPT, 256, 256u * 16u);
 #define LA(NBT)                                                                                  \
-    hipLaunchKernelGGL(HIP_KERNEL_NAME(k_assign<NBT>), dim3(grid), dim3(256), 0, ctx->stream,    \
-                       d_img, dtype, npix, nb, m2c, cn, k, has_null, (long long)null_val,        \
-                       d_clus16, d_clus32)
+    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(HIP_KERNEL_NAME(k_assign<NBT, DT>), dim3(grid),     \
+                                             dim3(256), 0, ctx->stream, d_img, npix, nb, m2c, cn, \
+                                             k, has_null, (long long)null_val, d_clus16, d_clus32))
     const int ps = prof_begin(ctx, PROF_ASSIGN);
     switch (nb) {
     case 1: LA(1); break;
@@ -445,21 +445,34 @@ static int run_kmeans_fit(shp_ctx *ctx, const double *xin, int64_t nrows, int nb
                             (long long)nrows, k);
     const uint32_t n = (uint32_t)nrows;
     const int kn = k * nb;
-    // centre the data on the host (one pass; sklearn: X -= X.mean(axis=0))
-    std::vector<double> mu(nb, 0.0), X((size_t)n * nb);
-    for (int b = 0; b < nb; b++) {
-        double s = 0.0;
-        for (uint32_t i = 0; i < n; i++) s += xin[(size_t)i * nb + b];
-        mu[b] = s / (double)n;
+    // centre the data on the host (sklearn: X -= X.mean(axis=0)); rows outer / bands inner keeps
+    // each band's additions in row order while nb independent chains are in flight.  X lives in
+    // a pinned, grow-only buffer of the context: no page faults after the first call and the
+    // upload runs at full PCIe speed.
+    const size_t xbytes = (size_t)n * nb * 8;
+    if (ctx->h_fit_cap < xbytes) {
+        if (ctx->h_fit) hipHostFree(ctx->h_fit);
+        ctx->h_fit = nullptr; ctx->h_fit_cap = 0;
+        if (hipHostMalloc((void **)&ctx->h_fit, xbytes + xbytes / 8, hipHostMallocDefault) != hipSuccess)
+            SHP_FAIL(ctx, SHP_ERR_NOMEM, "hipHostMalloc(%zu) failed", xbytes);
+        ctx->h_fit_cap = xbytes + xbytes / 8;
     }
+    double *X = ctx->h_fit;
+    std::vector<double> mu(nb, 0.0), acc(nb, 0.0), acc2(nb, 0.0);
+    for (uint32_t i = 0; i < n; i++)
+        for (int b = 0; b < nb; b++) acc[b] += xin[(size_t)i * nb + b];
+    for (int b = 0; b < nb; b++) { mu[b] = acc[b] / (double)n; acc[b] = 0.0; }
+    for (uint32_t i = 0; i < n; i++)
+        for (int b = 0; b < nb; b++) {
+            const double xv = xin[(size_t)i * nb + b] - mu[b];
+            X[(size_t)i * nb + b] = xv;
+            acc[b] += xv;
+        }
+    for (int b = 0; b < nb; b++) acc[b] /= (double)n;
+    for (uint32_t i = 0; i < n; i++)
+        for (int b = 0; b < nb; b++) { const double d = X[(size_t)i * nb + b] - acc[b]; acc2[b] += d * d; }
     double tol = 0.0;
-    for (int b = 0; b < nb; b++) {
-        double m = 0.0, v = 0.0;
-        for (uint32_t i = 0; i < n; i++) { X[(size_t)i * nb + b] = xin[(size_t)i * nb + b] - mu[b]; m += X[(size_t)i * nb + b]; }
-        m /= (double)n;
-        for (uint32_t i = 0; i < n; i++) { const double d = X[(size_t)i * nb + b] - m; v += d * d; }
-        tol += v / (double)n;
-    }
+    for (int b = 0; b < nb; b++) tol += acc2[b] / (double)n;
     tol = tol / nb * tol_rel;
     std::vector<double> C(kn), Cn(kn), w(k), hm((size_t)kn + k);
     for (int t = 0; t < kn; t++) C[t] = init[t] - mu[t % nb];
@@ -491,7 +504,7 @@ static int run_kmeans_fit(shp_ctx *ctx, const double *xin, int64_t nrows, int nb
     double *pin_up = (double *)(ctx->h_pinned + 16);
     double *pin_dn = pin_up + (2 * kn + k);
     HIPCHK(ctx, hipStreamSynchronize(st));           // earlier users of the staging area are done
-    HIPCHK(ctx, hipMemcpyAsync(dX, X.data(), (size_t)n * nb * 8, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemcpyAsync(dX, X, xbytes, hipMemcpyHostToDevice, st));
     HIPCHK(ctx, hipMemsetAsync(dlabB, 0xff, (size_t)n * 4, st));        // labels_old = -1
     const unsigned g = grid_for(n, 256);
     auto upload_centres = [&](const std::vector<double> &cc) -> int {

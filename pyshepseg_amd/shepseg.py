@@ -113,18 +113,27 @@ def doShepherdSegmentation(img, numClusters=60, clusterSubsamplePcnt=1,
     return segResult
 
 
-def _sample_rows(img, subsamplePcnt, imgNullVal):
+def _sample_rows(img, subsamplePcnt, imgNullVal, wantMinMax=False):
     """The rows sklearn is fitted on in the reference (shepseg.py:283-299): non-null pixels
-    in raster order, every skip-th one."""
+    in raster order, every skip-th one.  With wantMinMax also the per-band (min, max) of those
+    rows, taken on the band-planar form where the reduction runs over contiguous memory."""
     (nBands, nRows, nCols) = img.shape
     flat = img.reshape(nBands, nRows * nCols)
     skip = int(round(100. / subsamplePcnt))
     if imgNullVal is not None:
         nonNull = (flat != imgNullVal).all(axis=0)
         idx = numpy.flatnonzero(nonNull)[::skip]
+        planar = flat[:, idx]
+    elif skip == 1:
+        planar = flat
     else:
-        idx = numpy.arange(0, nRows * nCols, skip)
-    return numpy.ascontiguousarray(flat[:, idx].T)
+        planar = flat[:, ::skip]
+    xSample = numpy.ascontiguousarray(planar.T)
+    if wantMinMax:
+        if planar.shape[1] == 0:
+            return xSample, None
+        return xSample, (planar.min(axis=1), planar.max(axis=1))
+    return xSample
 
 
 def _kmeans_plusplus(x, k, rng):
@@ -172,9 +181,9 @@ def fitSpectralClusters(img, numClusters, subsamplePcnt, imgNullVal, fixedKMeans
     (reference shepseg.py:252-314).  Lloyd iterations run on the GPU (shp_kmeans_fit).
     Returns a fitted :class:`KMeansModel`."""
     img = numpy.asarray(img)
-    xSample = _sample_rows(img, subsamplePcnt, imgNullVal)
+    xSample, minmax = _sample_rows(img, subsamplePcnt, imgNullVal, wantMinMax=True)
     if fixedKMeansInit:
-        init = diagonalClusterCentres(xSample, numClusters)
+        init = diagonalClusterCentres(xSample, numClusters, minmax)
         return _fit(xSample, init)
     best = None
     rng = numpy.random.RandomState()
@@ -206,12 +215,16 @@ def applySpectralClusters(kmeansObj, img, imgNullVal):
     return _assign(_centres_of(kmeansObj), img, imgNullVal)
 
 
-def diagonalClusterCentres(xSample, numClusters):
+def diagonalClusterCentres(xSample, numClusters, _minmax=None):
     """Initial centres evenly spaced along the diagonal of the data's bounding box, cast to
-    the sample's integer dtype (reference shepseg.py:364-397)."""
+    the sample's integer dtype (reference shepseg.py:364-397).  _minmax: per-band (min, max)
+    of xSample when the caller already has them."""
     (numPoints, numBands) = xSample.shape
-    bandMin = xSample.min(axis=0)
-    bandMax = xSample.max(axis=0)
+    if _minmax is not None:
+        (bandMin, bandMax) = _minmax
+    else:
+        bandMin = xSample.min(axis=0)
+        bandMax = xSample.max(axis=0)
     centres = numpy.empty((numClusters, numBands), dtype=xSample.dtype)
     step = (bandMax - bandMin) / (numClusters + 1)
     for i in range(numClusters):
