@@ -493,18 +493,24 @@ API int shp_dev_subsample(shp_ctx *ctx, const void *d_img, int dtype, int nbands
     return 0;
 }
 
-// copy window (x, y, xs, ys) of every band of a device raster into a contiguous tile image
-__global__ __launch_bounds__(256) void k_window(const void *__restrict__ img, int esize, int nb,
+// copy window (x, y, xs, ys) of every band of a device raster into a contiguous tile image:
+// blockIdx.x = (band, window row), a thread moves 16 bytes of the row (one vector load / store
+// when both ends are 16-byte aligned, element by element otherwise)
+__global__ __launch_bounds__(256) void k_window(const uint8_t *__restrict__ img, uint32_t esize,
                                                 uint32_t rows, uint32_t cols, uint32_t x, uint32_t y,
-                                                uint32_t xs, uint32_t ys, void *__restrict__ out)
+                                                uint32_t xs, uint32_t ys, uint8_t *__restrict__ out)
 {
-    const size_t total = (size_t)nb * ys * xs;
-    for (size_t i = (size_t)blockIdx.x * 256u + threadIdx.x; i < total; i += (size_t)gridDim.x * 256u) {
-        const size_t b = i / ((size_t)ys * xs), r = (i / xs) % ys, c = i % xs;
-        const size_t src = b * (size_t)rows * cols + (size_t)(y + r) * cols + (x + c);
-        if (esize == 1) ((uint8_t *)out)[i] = ((const uint8_t *)img)[src];
-        else if (esize == 2) ((uint16_t *)out)[i] = ((const uint16_t *)img)[src];
-        else ((uint32_t *)out)[i] = ((const uint32_t *)img)[src];
+    const uint32_t br = blockIdx.x, b = br / ys, r = br - b * ys;
+    const size_t rowbytes = (size_t)xs * esize;
+    const size_t c0 = ((size_t)blockIdx.y * 256u + threadIdx.x) * 16u;         // byte offset in the row
+    if (c0 >= rowbytes) return;
+    const uint8_t *src = img + (((size_t)b * rows + (y + r)) * cols + x) * esize + c0;
+    uint8_t *dst = out + (size_t)br * rowbytes + c0;
+    if (c0 + 16u <= rowbytes && ((((uintptr_t)src) | ((uintptr_t)dst)) & 15u) == 0u) {
+        *(uint4 *)dst = *(const uint4 *)src;
+    } else {
+        const uint32_t nbytes = rowbytes - c0 < 16u ? (uint32_t)(rowbytes - c0) : 16u;
+        for (uint32_t i = 0; i < nbytes; i++) dst[i] = src[i];
     }
 }
 
@@ -533,9 +539,11 @@ API int shp_segment_window_dev(shp_ctx *ctx, const void *d_img, int dtype, int n
     if (!(x == 0 && y == 0 && xs == img_cols && ys == img_rows)) {
         const size_t total = (size_t)nbands * n;
         CHK(buf_ensure(ctx, ctx->img, total * dtype_size(dtype)));
-        hipLaunchKernelGGL(k_window, dim3(grid_for(total, 256, 256u * 32u)), dim3(256), 0, ctx->stream, d_img,
-                           (int)dtype_size(dtype), nbands, (uint32_t)img_rows, (uint32_t)img_cols, (uint32_t)x,
-                           (uint32_t)y, (uint32_t)xs, (uint32_t)ys, ctx->img.p);
+        const size_t rowbytes = (size_t)xs * dtype_size(dtype);
+        hipLaunchKernelGGL(k_window, dim3((unsigned)nbands * (unsigned)ys, grid_for((rowbytes + 15) / 16, 256)),
+                           dim3(256), 0, ctx->stream, (const uint8_t *)d_img, (uint32_t)dtype_size(dtype),
+                           (uint32_t)img_rows, (uint32_t)img_cols, (uint32_t)x, (uint32_t)y, (uint32_t)xs,
+                           (uint32_t)ys, (uint8_t *)ctx->img.p);
         KCHK(ctx);
         tile_img = ctx->img.p;
     }

@@ -624,6 +624,7 @@ static std::mutex g_small_mu;
 static std::condition_variable g_small_cv;
 static int g_small_running = 0;
 #define SMALL_MAX_CONCURRENT 16
+static const int g_small_max = getenv("SHEPSEG_SMALL_MAX") ? atoi(getenv("SHEPSEG_SMALL_MAX")) : SMALL_MAX_CONCURRENT;
 
 static inline int bits_for(uint32_t maxval)
 {
@@ -729,7 +730,7 @@ static int run_eliminate_small(shp_ctx *ctx, const void *d_img, int dtype, int n
     args.nb = nb; args.four = four; args.thr2 = thr2;
     {
         std::unique_lock<std::mutex> lk(g_small_mu);
-        g_small_cv.wait(lk, [] { return g_small_running < SMALL_MAX_CONCURRENT; });
+        g_small_cv.wait(lk, [] { return g_small_running < g_small_max; });
         g_small_running++;
     }
     hipLaunchKernelGGL(k_small_loop, dim3(SMALL_BLOCKS), dim3(256), 0, st, args);
