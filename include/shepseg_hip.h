@@ -194,6 +194,16 @@ int shp_segstats_dev(shp_ctx *ctx, const uint32_t *d_seg, const void *d_band, in
                      const uint32_t *stats_sel, int nstats, int64_t missing,
                      int64_t *intcols_out, float *floatcols_out);
 
+/* Multi-GPU split of the statistics: a segment that straddles two ranks' rows needs its
+ * pixels from both.  Writes (segment id, band value) of every pixel whose segment id s has
+ * flags[s] != 0 (flags: max_seg_id+1 bytes, host) to the host arrays, in no particular order;
+ * *count_out = number of such pixels (when it exceeds cap only the first cap pairs are stored).
+ * Plays the part of the per-segment dictionaries the reference keeps alive across tiles until
+ * checkSegComplete sees the whole segment (tilingstats.py:518-553). */
+int shp_gather_flagged_dev(shp_ctx *ctx, const uint32_t *d_seg, const void *d_band, int dtype,
+                           int64_t npix, uint32_t max_seg_id, const uint8_t *flags, int64_t cap,
+                           uint32_t *seg_out, int64_t *val_out, int64_t *count_out);
+
 #ifdef __cplusplus
 }
 #endif

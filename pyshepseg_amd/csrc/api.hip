@@ -9,6 +9,7 @@
 #include "elim_small.h"
 #include "synth.h"
 #include "stitch.h"
+static int read_u32(shp_ctx *ctx, const uint32_t *d, uint32_t *h);
 #include "segstats.h"
 
 #define API extern "C" __attribute__((visibility("default")))
@@ -714,4 +715,18 @@ API int shp_segstats(shp_ctx *ctx, const uint32_t *seg, const void *band, int dt
     }
     return run_segstats(ctx, bp<uint32_t>(ctx->seg), ctx->img.p, dtype, (uint32_t)npix, max_seg_id,
                         has_null, null_val, stats_sel, nstats, missing, intcols_out, floatcols_out);
+}
+
+API int shp_gather_flagged_dev(shp_ctx *ctx, const uint32_t *d_seg, const void *d_band, int dtype,
+                               int64_t npix, uint32_t max_seg_id, const uint8_t *flags,
+                               int64_t cap, uint32_t *seg_out, int64_t *val_out, int64_t *count_out)
+{
+    CHK(enter(ctx));
+    if (!d_seg || !d_band || !flags || !count_out || dtype_size(dtype) == 0 || cap < 0 ||
+        (cap > 0 && (!seg_out || !val_out)))
+        SHP_FAIL(ctx, SHP_ERR_ARG, "bad argument");
+    if (npix < 0 || npix >= 0xffffffffll || cap >= 0xffffffffll)
+        SHP_FAIL(ctx, SHP_ERR_ARG, "raster too large (%lld px)", (long long)npix);
+    return run_gather_flagged(ctx, d_seg, d_band, dtype, (uint32_t)npix, max_seg_id, flags, (uint32_t)cap,
+                              seg_out, val_out, count_out);
 }

@@ -172,3 +172,77 @@ static int run_segstats(shp_ctx *ctx, const uint32_t *d_seg, const void *d_band,
     HIPCHK(ctx, hipStreamSynchronize(st));
     return 0;
 }
+
+// ---- multi-GPU split: the pixels of segments that straddle a rank boundary ------------------
+// (seg id, band value) of every pixel whose segment is flagged, compacted (any order) with one
+// global atomic per 4096 pixels.  count may exceed cap: only the first cap pairs are stored.
+__global__ __launch_bounds__(256) void k_gather_flagged(const uint32_t *__restrict__ seg,
+                                                        const void *__restrict__ band, int dtype,
+                                                        uint32_t n, uint32_t S,
+                                                        const uint8_t *__restrict__ flags,
+                                                        uint32_t *__restrict__ out_seg,
+                                                        long long *__restrict__ out_val,
+                                                        uint32_t cap, uint32_t *count)
+{
+    __shared__ uint32_t s_buf[4096];
+    __shared__ uint32_t s_cnt, s_base;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    const unsigned lane = lane_id();
+    for (uint32_t it = 0; it < 16u; it++) {
+        const uint32_t p = blockIdx.x * 4096u + it * 256u + threadIdx.x;
+        bool take = false;
+        if (p < n) {
+            const uint32_t sg = seg[p];
+            take = sg != 0u && sg <= S && flags[sg] != 0;
+        }
+        const unsigned long long m = __ballot(take);
+        if (m != 0ull) {
+            uint32_t wbase = 0;
+            if (lane == 0) wbase = atomicAdd(&s_cnt, (uint32_t)__popcll(m));
+            wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wbase);
+            if (take) s_buf[wbase + (uint32_t)__popcll(m & lanemask_lt())] = p;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) s_base = s_cnt ? atomicAdd(count, s_cnt) : 0u;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < s_cnt; i += 256u) {
+        const uint32_t o = s_base + i;
+        if (o < cap) {
+            const uint32_t p = s_buf[i];
+            out_seg[o] = seg[p];
+            out_val[o] = ld_px(band, dtype, p);
+        }
+    }
+}
+
+static int run_gather_flagged(shp_ctx *ctx, const uint32_t *d_seg, const void *d_band, int dtype,
+                              uint32_t n, uint32_t S, const uint8_t *flags_host, uint32_t cap,
+                              uint32_t *seg_out, int64_t *val_out, int64_t *count_out)
+{
+    hipStream_t st = ctx->stream;
+    const size_t ns = (size_t)S + 1;
+    CHK(buf_ensure(ctx, ctx->small, ns + 64));
+    CHK(buf_ensure(ctx, ctx->aux, (size_t)cap * 4 + 64));
+    CHK(buf_ensure(ctx, ctx->aux2, (size_t)cap * 8 + 64));
+    uint8_t *d_flags = bp<uint8_t>(ctx->small) + 64;
+    uint32_t *d_count = bp<uint32_t>(ctx->small);
+    HIPCHK(ctx, hipMemcpyAsync(d_flags, flags_host, ns, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemsetAsync(d_count, 0, 4, st));
+    if (n) {
+        hipLaunchKernelGGL(k_gather_flagged, dim3(grid_for(n, 4096)), dim3(256), 0, st, d_seg, d_band, dtype,
+                           n, S, d_flags, bp<uint32_t>(ctx->aux), (long long *)ctx->aux2.p, cap, d_count);
+        KCHK(ctx);
+    }
+    uint32_t cnt = 0;
+    CHK(read_u32(ctx, d_count, &cnt));
+    const uint32_t take = cnt < cap ? cnt : cap;
+    if (take) {
+        HIPCHK(ctx, hipMemcpyAsync(seg_out, ctx->aux.p, (size_t)take * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipMemcpyAsync(val_out, ctx->aux2.p, (size_t)take * 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+    }
+    *count_out = (int64_t)cnt;
+    return 0;
+}

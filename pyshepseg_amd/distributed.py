@@ -238,6 +238,51 @@ def runDistributed(engine, comm, nRows, nCols, tileSize, overlapSize, minSegment
     return res
 
 
+def calcPerSegmentStatsDistributed(engine, comm, hist, imgbandnum, statsSelection,
+                                   missingStatsValue=-9999, imgNullVal=None):
+    """Per-segment statistics of one image band against the stitched label raster that
+    runDistributed left sharded by rows over the ranks (reference tilingstats.py:85-216; SURVEY
+    8e).  ``hist`` is the global histogram of the labels (DistResult.hist), which plays the part
+    of the reference's segSize: a segment whose local pixel count equals hist[id] is complete on
+    this rank and its statistics are final (checkSegComplete, tilingstats.py:518-553).  The
+    pixels of the few segments that straddle a rank boundary are gathered as (id, value) pairs,
+    all-gathered, and their statistics computed once (rank 0) with the same kernel.  Finished
+    rows are disjoint between ranks, so one integer all-reduce assembles the columns.
+    Returns (intcols int64 (nInt, maxSegId+1), floatcols float32 (nFloat, maxSegId+1),
+    statsSelection_fast) on every rank -- bit-identical to the single-GPU result."""
+    from . import tilingstats
+    hist = numpy.asarray(hist).astype(numpy.int64)
+    S = len(hist) - 1
+    (fast, nInt, nFloat) = tilingstats.makeFastStatsSelection(
+        list(range(len(statsSelection))), statsSelection)
+    lh = numpy.asarray(engine.histogram(S)).astype(numpy.int64)
+    lh[0] = 0
+    complete = (lh == hist) & (lh > 0)
+    strad = (lh > 0) & (lh < hist)
+    (ic, fc) = engine.localStats(imgbandnum, S, fast, nInt, nFloat, missingStatsValue, imgNullVal)
+    keep = complete.copy()
+    if comm.rank == 0:
+        keep |= (hist == 0)                 # ids nobody holds (and row 0): "missing" rows, once
+    ic[:, ~keep] = 0
+    fc[:, ~keep] = 0
+    pairs = engine.gatherFlagged(imgbandnum, S, strad.astype(numpy.uint8), int(lh[strad].sum()))
+    allPairs = comm.allgather_obj(pairs)
+    if comm.rank == 0:
+        segs = numpy.concatenate([p[0] for p in allPairs])
+        vals = numpy.concatenate([p[1] for p in allPairs])
+        if len(segs):
+            (ids, compact) = numpy.unique(segs, return_inverse=True)
+            (ic2, fc2) = engine.statsOfPairs((compact + 1).astype(numpy.uint32), vals, len(ids), fast,
+                                             nInt, nFloat, missingStatsValue, imgNullVal)
+            ic[:, ids] = ic2[:, 1:]
+            fc[:, ids] = fc2[:, 1:]
+    if comm.world > 1:
+        ic = comm.allreduce_sum_i64(ic.reshape(-1)).reshape(nInt, S + 1)
+        fbits = comm.allreduce_sum_i64(fc.view(numpy.int32).reshape(-1).astype(numpy.int64))
+        fc = fbits.astype(numpy.int32).view(numpy.float32).reshape(nFloat, S + 1)
+    return ic, fc, fast
+
+
 # ------------------------------------------------------------------------------------------
 # HIP engine: this rank's GPU
 # ------------------------------------------------------------------------------------------
@@ -388,6 +433,50 @@ class HipEngine(object):
                                               (self.outHi - self.outLo) * self.nCols, maxSegId,
                                               _lib.ptr(hist)))
         return hist
+
+    def _bandPtr(self, imgbandnum):
+        """Device address of this rank's OUTPUT rows of one image band (1-based band number)."""
+        (nb, rows, cols) = self.ras.shape
+        isz = numpy.dtype(self.ras.dtype).itemsize
+        return self.ras.ptr + (((imgbandnum - 1) * rows + (self.outLo - self.yLo)) * cols) * isz
+
+    def localStats(self, imgbandnum, S, fast, nInt, nFloat, missing, imgNullVal):
+        n = (self.outHi - self.outLo) * self.nCols
+        ic = numpy.zeros((nInt, S + 1), dtype=numpy.int64)
+        fc = numpy.zeros((nFloat, S + 1), dtype=numpy.float32)
+        if n > 0:
+            self.c.check(self.L.shp_segstats_dev(
+                self.c.handle, self._lastOut, ctypes.c_void_p(self._bandPtr(imgbandnum)),
+                _lib.SHP_DTYPES[self.ras.dtype], n, S, int(imgNullVal is not None),
+                0 if imgNullVal is None else int(imgNullVal), _lib.ptr(fast), fast.shape[0],
+                int(missing), _lib.ptr(ic), _lib.ptr(fc)))
+        return ic, fc
+
+    def gatherFlagged(self, imgbandnum, S, flags, count):
+        n = (self.outHi - self.outLo) * self.nCols
+        segs = numpy.empty(max(count, 1), dtype=numpy.uint32)
+        vals = numpy.empty(max(count, 1), dtype=numpy.int64)
+        got = ctypes.c_int64(0)
+        if n > 0 and count > 0:
+            self.c.check(self.L.shp_gather_flagged_dev(
+                self.c.handle, self._lastOut, ctypes.c_void_p(self._bandPtr(imgbandnum)),
+                _lib.SHP_DTYPES[self.ras.dtype], n, S, _lib.ptr(flags), count, _lib.ptr(segs),
+                _lib.ptr(vals), ctypes.byref(got)))
+            if got.value != count:
+                raise tiling.PyShepSegTilingError(
+                    "straddling-segment gather found %d pixels, histogram says %d" % (got.value, count))
+        return segs[:count], vals[:count]
+
+    def statsOfPairs(self, segs, vals, K, fast, nInt, nFloat, missing, imgNullVal):
+        """Statistics of a list of (compact id 1..K, value) pairs: the same kernel on a 1 x M raster."""
+        band = vals.astype(self.ras.dtype if self.ras is not None else numpy.uint16)
+        ic = numpy.zeros((nInt, K + 1), dtype=numpy.int64)
+        fc = numpy.zeros((nFloat, K + 1), dtype=numpy.float32)
+        self.c.check(self.L.shp_segstats(
+            self.c.handle, _lib.ptr(segs), _lib.ptr(band), _lib.SHP_DTYPES[band.dtype], len(segs), K,
+            int(imgNullVal is not None), 0 if imgNullVal is None else int(imgNullVal),
+            _lib.ptr(fast), fast.shape[0], int(missing), _lib.ptr(ic), _lib.ptr(fc)))
+        return ic, fc
 
     def localOutput(self):
         out = numpy.empty((self.outHi - self.outLo, self.nCols), dtype=numpy.uint32)

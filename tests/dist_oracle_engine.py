@@ -94,3 +94,28 @@ class OracleEngine(object):
 
     def finish(self):
         pass
+
+    # ---- per-segment statistics (calcPerSegmentStatsDistributed) ----
+    _NAMES = {0: 'min', 1: 'max', 2: 'mean', 3: 'stddev', 4: 'median', 5: 'mode', 6: 'percentile',
+              7: 'pixcount'}
+
+    def _sel(self, fast):
+        return [('c%d' % i, self._NAMES[int(r[1])], int(r[4])) if int(r[1]) == 6
+                else ('c%d' % i, self._NAMES[int(r[1])]) for i, r in enumerate(fast)]
+
+    def _band(self, imgbandnum):
+        return np.ascontiguousarray(self.img[imgbandnum - 1, self.outLo:self.outHi])
+
+    def localStats(self, imgbandnum, S, fast, nInt, nFloat, missing, imgNullVal):
+        return self.orc.segstats(self.out, self._band(imgbandnum), self._sel(fast), imgNullVal,
+                                 missing, max_seg_id=S)
+
+    def gatherFlagged(self, imgbandnum, S, flags, count):
+        m = flags[self.out] != 0
+        m &= self.out != 0
+        assert int(m.sum()) == count
+        return self.out[m].astype(np.uint32), self._band(imgbandnum)[m].astype(np.int64)
+
+    def statsOfPairs(self, segs, vals, K, fast, nInt, nFloat, missing, imgNullVal):
+        return self.orc.segstats(segs, vals.astype(self.img.dtype), self._sel(fast), imgNullVal,
+                                 missing, max_seg_id=K)

@@ -24,6 +24,11 @@ def main():
     r = distributed.runDistributed(eng, comm, img.shape[1], img.shape[2], tile, ov,
                                    minSegmentSize=12, numClusters=8, fixedKMeansInit=True,
                                    simpleTileRecode=bool(simple))
+    sel = [('a', 'min'), ('b', 'max'), ('c', 'mean'), ('d', 'stddev'), ('e', 'median'),
+           ('f', 'mode'), ('g', 'percentile', 25), ('h', 'pixcount')]
+    ic, fc, _fast = distributed.calcPerSegmentStatsDistributed(eng, comm, r.hist, 2, sel,
+                                                               imgNullVal=65535)
+    np.savez(os.path.join(outdir, 'stats%d.npz' % comm.rank), ic=ic, fc=fc)
     np.savez(os.path.join(outdir, 'rank%d.npz' % comm.rank), out=eng.out, outLo=r.outRows[0],
              outHi=r.outRows[1], maxSegId=r.maxSegId, hist=r.hist,
              centres=r.kmeans.cluster_centers_, msd=r.maxSpectralDiff, rows=np.array(r.rowRange))

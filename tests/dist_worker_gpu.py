@@ -31,6 +31,10 @@ def main():
     r = distributed.runDistributed(eng, comm, nr, nc, 512, 128, minSegmentSize=50, numClusters=30,
                                    fixedKMeansInit=True)
     out = eng.localOutput()
+    sel = [('a', 'min'), ('b', 'max'), ('c', 'mean'), ('d', 'stddev'), ('e', 'median'),
+           ('f', 'mode'), ('g', 'percentile', 90), ('h', 'pixcount')]
+    ic, fc, _fast = distributed.calcPerSegmentStatsDistributed(eng, comm, r.hist, 3, sel)
+    np.savez(os.path.join(outdir, 'stats%d.npz' % comm.rank), ic=ic, fc=fc)
     eng.releaseOutput()
     np.savez(os.path.join(outdir, 'rank%d.npz' % comm.rank), out=out, outLo=r.outRows[0],
              outHi=r.outRows[1], maxSegId=r.maxSegId, hist=r.hist,

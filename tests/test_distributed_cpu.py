@@ -72,3 +72,11 @@ def test_two_rank_chain_matches_single_process(world, simple, tmp_path, oracle):
         assert np.array_equal(q['hist'], hist)
     assert covered == 330
     assert np.array_equal(got, want)
+    # per-segment statistics sharded the same way == the oracle on the whole raster, on every rank
+    sel = [('a', 'min'), ('b', 'max'), ('c', 'mean'), ('d', 'stddev'), ('e', 'median'),
+           ('f', 'mode'), ('g', 'percentile', 25), ('h', 'pixcount')]
+    wic, wfc = oracle.segstats(want, np.ascontiguousarray(img[1]), sel, 65535, -9999, max_seg_id=mx)
+    for r in range(world):
+        st = np.load(tmp_path / ('stats%d.npz' % r))
+        assert np.array_equal(st['ic'], wic)
+        assert np.array_equal(st['fc'].view(np.uint32), wfc.view(np.uint32))

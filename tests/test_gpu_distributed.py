@@ -33,6 +33,8 @@ def test_hip_engine_chain_matches_single_process(world, tmp_path):
     p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
     parts = [np.load(tmp_path / ('rank%d.npz' % r)) for r in range(world)]
+    from pyshepseg_amd import tilingstats
+    from oracle import oracle
     ras = tiling.DeviceRaster.synth(11, 6, 1500, 1300)
     try:
         cfg = tiling.SegmentationConcurrencyConfig(concurrencyType=tiling.CONC_THREADS, numWorkers=3)
@@ -48,3 +50,12 @@ def test_hip_engine_chain_matches_single_process(world, tmp_path):
         assert int(q['maxSegId']) == ref.maxSegId
         assert np.array_equal(q['hist'], ref.hist)
     assert np.array_equal(got, ref.segimg)
+    # statistics sharded over the ranks == the single-GPU statistics of the whole raster
+    sel = [('a', 'min'), ('b', 'max'), ('c', 'mean'), ('d', 'stddev'), ('e', 'median'),
+           ('f', 'mode'), ('g', 'percentile', 90), ('h', 'pixcount')]
+    band = oracle.synthimg(11, 6, 1500, 1300)[2]
+    wic, wfc, _f = tilingstats.calcPerSegmentStats(ref.segimg, band, sel, maxSegId=ref.maxSegId)
+    for r in range(world):
+        st = np.load(tmp_path / ('stats%d.npz' % r))
+        assert np.array_equal(st['ic'], wic)
+        assert np.array_equal(st['fc'].view(np.uint32), wfc.view(np.uint32))
