@@ -1,0 +1,125 @@
+"""GPU, BASELINE.json's full sizes.
+
+C2 (8192 x 8192 x 6, one call): the oracle still finishes in seconds, so labels are compared
+bit for bit.  C3 (40000 x 40000 x 6 tiled): the oracle cannot run the whole job, so the run is
+checked through size-independent properties -- the histogram accounts for every pixel, ids are
+1..maxSegId, two runs agree exactly, the sharded driver (world size 1) agrees with the in-process
+driver, per-segment pixel counts from the statistics kernel equal the histogram -- and one of its
+interior 4096 x 4096 tile windows is compared with the oracle bit for bit."""
+import ctypes
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _segment_window(ras, x, y, xs, ys, centres, minseg, msd, four=True):
+    """Local labels of one window of a DeviceRaster (the worker's call, tiling.py)."""
+    from pyshepseg_amd import _lib
+    c = _lib.ctx()
+    n = xs * ys
+    d = ctypes.c_void_p()
+    c.check(c._L.shp_dev_alloc(c.handle, n * 4, ctypes.byref(d)))
+    try:
+        mx, s1, s2, ncl = ctypes.c_uint32(0), ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_uint32(0)
+        c.check(c._L.shp_segment_window_dev(
+            c.handle, ctypes.c_void_p(ras.ptr), _lib.SHP_DTYPES[ras.dtype], ras.shape[0], ras.shape[1],
+            ras.shape[2], x, y, xs, ys, _lib.ptr(centres), centres.shape[0], 0, 0, int(four), minseg,
+            float(msd), d, ctypes.byref(mx), ctypes.byref(s1), ctypes.byref(s2), ctypes.byref(ncl)))
+        out = np.empty((ys, xs), dtype=np.uint32)
+        c.check(c._L.shp_dev_download(c.handle, _lib.ptr(out), d, n * 4))
+    finally:
+        c.check(c._L.shp_dev_free(c.handle, d))
+    return out, mx.value, s1.value, s2.value, ncl.value
+
+
+def test_c2_single_call_vs_oracle(oracle):
+    """BASELINE configs[1]: synthimg(5, 6, 8192, 8192), k = 60, minSeg = 50, fixed init, 1 %
+    sample; the model is fitted on the device, labels are compared for that model."""
+    from pyshepseg_amd import shepseg, tiling
+    img = oracle.synthimg(5, 6, 8192, 8192)
+    km = shepseg.fitSpectralClusters(img, 60, 1, None, True)
+    centres = np.ascontiguousarray(km.cluster_centers_, dtype=np.float64)
+    msd = float(shepseg.autoMaxSpectralDiff(km, 'auto', 50))
+    got = shepseg.doShepherdSegmentation(img, numClusters=60, minSegmentSize=50, kmeansObj=km)
+    want = oracle.segment_tile(img, centres, 50, msd, None, True)
+    assert np.array_equal(got.segimg, want['segimg'])
+    assert got.singlePixelsEliminated == want['singlePixelsEliminated']
+    assert got.smallSegmentsEliminated == want['smallSegmentsEliminated']
+    # the same image resident on the device, one window = the whole raster
+    ras = tiling.DeviceRaster.fromArray(img)
+    try:
+        seg, mx, _s1, _s2, _ncl = _segment_window(ras, 0, 0, 8192, 8192, centres, 50, msd)
+    finally:
+        ras.free()
+    assert mx == int(want['segimg'].max())
+    assert np.array_equal(seg, want['segimg'])
+
+
+def test_c3_fullsize_properties(oracle):
+    """BASELINE configs[2]: 40000 x 40000 x 6, tile 4096 / overlap 1024, k = 60, minSeg = 50."""
+    from pyshepseg_amd import tiling, tilingstats, _lib
+    N = 40000
+    ras = tiling.DeviceRaster.synth(11, 6, N, N)
+    cfg = tiling.SegmentationConcurrencyConfig(concurrencyType=tiling.CONC_THREADS, numWorkers=16)
+    try:
+        runs = []
+        for _rep in range(2):
+            r = tiling.doTiledShepherdSegmentation(
+                ras, tiling._KEEP_ON_DEVICE, tileSize=4096, overlapSize=1024, minSegmentSize=50,
+                numClusters=60, fixedKMeansInit=True, concurrencyCfg=cfg)
+            hist = np.asarray(r.hist).astype(np.int64)
+            runs.append((int(r.maxSegId), hist, r.kmeans.cluster_centers_.copy(),
+                         float(r.maxSpectralDiff)))
+            if _rep == 0:
+                # per-segment pixel counts by the statistics kernel == the stitch's histogram
+                c = _lib.ctx()
+                sel = [('n', 'pixcount'), ('lo', 'min'), ('hi', 'max')]
+                (fast, nInt, nFloat) = tilingstats.makeFastStatsSelection([0, 1, 2], sel)
+                ic = np.zeros((nInt, r.maxSegId + 1), dtype=np.int64)
+                fc = np.zeros((max(nFloat, 1), r.maxSegId + 1), dtype=np.float32)
+                c.check(c._L.shp_segstats_dev(
+                    c.handle, ctypes.c_void_p(r.outDev[0]), ctypes.c_void_p(ras.ptr), _lib.SHP_DTYPES[ras.dtype],
+                    N * N, r.maxSegId, 0, 0, _lib.ptr(fast), 3, -9999, _lib.ptr(ic), _lib.ptr(fc)))
+                assert np.array_equal(ic[fast[0, 3], 1:], hist[1:])
+                assert (ic[fast[1, 3], 1:] <= ic[fast[2, 3], 1:]).all()
+            tiling.freeDeviceOutput(r)
+        (mx, hist, centres, msd) = runs[0]
+        assert mx == len(hist) - 1
+        assert hist[0] == 0 and int(hist.sum()) == N * N          # no nulls: every pixel labelled
+        assert r.numTileRows == 12 and r.numTileCols == 12
+        # the reference's stitch can leave a few ids empty; flag and histogram agree
+        assert bool(r.hasEmptySegments) == bool((hist[1:] == 0).any())
+        assert (hist[1:] == 0).sum() < 1e-3 * mx
+        # deterministic run to run: same model, same ids, same histogram
+        assert runs[1][0] == mx and np.array_equal(runs[1][1], hist)
+        assert np.array_equal(runs[1][2], centres) and runs[1][3] == msd
+
+        # the sharded (multi-GPU) driver at world size 1 is a second implementation of the chain
+        from pyshepseg_amd import distributed
+        eng = distributed.HipEngine(lambda yLo, yHi: tiling.DeviceRaster.synth(11, 6, yHi - yLo, N, y0=yLo),
+                                    numWorkers=16)
+        d = distributed.runDistributed(eng, distributed.Comm(None), N, N, 4096, 1024, minSegmentSize=50,
+                                       numClusters=60, fixedKMeansInit=True)
+        eng.ras.free()
+        assert d.maxSegId == mx and np.array_equal(np.asarray(d.hist).astype(np.int64), hist)
+        assert np.array_equal(d.kmeans.cluster_centers_, centres)
+
+        # one interior tile window at full tile size against the oracle
+        ti = tiling.getTilesForFile(ras, 4096, 1024)
+        (x, y, xs, ys) = ti.getTile(5, 6)
+        assert xs == 4096 and ys == 4096
+        seg, _mx, s1, s2, ncl = _segment_window(ras, x, y, xs, ys, centres, 50, msd)
+        idx_y = np.arange(y, y + ys, dtype=np.uint32)
+        idx_x = np.arange(x, x + xs, dtype=np.uint32)
+        sub = np.empty((6, ys, xs), dtype=np.uint16)
+        c = _lib.ctx()
+        c.check(c._L.shp_dev_subsample(c.handle, ctypes.c_void_p(ras.ptr), 2, 6, N, N,
+                                       _lib.ptr(idx_y), ys, _lib.ptr(idx_x), xs, _lib.ptr(sub)))
+        assert np.array_equal(sub, oracle.synthimg(11, 6, ys, xs, y0=y, x0=x))
+        want = oracle.segment_tile(sub, centres, 50, msd, None, True)
+        assert np.array_equal(seg, want['segimg'])
+        assert s1 == want['singlePixelsEliminated'] and s2 == want['smallSegmentsEliminated']
+    finally:
+        ras.free()
