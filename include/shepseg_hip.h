@@ -204,6 +204,27 @@ int shp_gather_flagged_dev(shp_ctx *ctx, const uint32_t *d_seg, const void *d_ba
                            int64_t npix, uint32_t max_seg_id, const uint8_t *flags, int64_t cap,
                            uint32_t *seg_out, int64_t *val_out, int64_t *count_out);
 
+/* ---- subset --------------------------------------------------------------------------
+ * replaces the tile loop of subset.subsetImage (subset.py:124-166) and its njit kernel
+ * processSubsetTile (subset.py:366-425): the window (tlx, tly, xs, ys) of a label raster is
+ * recoded to ids 1..n in first-seen order, the window being visited in tiles of tile_size x
+ * tile_size (the reference uses tiling.TILESIZE = 1024), tile rows outer, raster order inside a
+ * tile; pixels that are null (0) or masked out (mask byte == 0; mask may be NULL) become 0.
+ * out: xs*ys labels; orig_out[new id] = old id (row 0 = 0) is the reference's recodeDict
+ * inverted -- the row gather that copySubsettedSegmentsToNew (:232-266) applies to every RAT
+ * column and the optional origSegIdColName column (:207-226); hist_out[new id] = pixel count
+ * (histogramDict).  orig_out / hist_out hold cap rows (n + 1 are written); *n_new_out = n.
+ * Error "Requested subset is not within input image" as subset.py:86-88. */
+int shp_subset_recode(shp_ctx *ctx, const uint32_t *seg, int64_t img_rows, int64_t img_cols,
+                      int64_t tlx, int64_t tly, int64_t xs, int64_t ys, const uint8_t *mask,
+                      int tile_size, uint32_t max_seg_id, uint32_t *out, uint32_t *orig_out,
+                      uint32_t *hist_out, int64_t cap, uint32_t *n_new_out);
+/* same with the label raster, the mask and the output window in device memory */
+int shp_subset_recode_dev(shp_ctx *ctx, const uint32_t *d_seg, int64_t img_rows, int64_t img_cols,
+                          int64_t tlx, int64_t tly, int64_t xs, int64_t ys, const uint8_t *d_mask,
+                          int tile_size, uint32_t max_seg_id, uint32_t *d_out, uint32_t *orig_out,
+                          uint32_t *hist_out, int64_t cap, uint32_t *n_new_out);
+
 #ifdef __cplusplus
 }
 #endif

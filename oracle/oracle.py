@@ -262,3 +262,22 @@ def segstats(seg, band, stats_selection, null_val=None, missing=-9999, max_seg_i
                             len(stats_selection), ctypes.c_int64(int(missing)), _p(ic), _p(fc))
     assert rc == 0
     return ic, fc
+
+
+def subset_recode(seg, tlx, tly, xs, ys, mask=None, tile_size=1024):
+    """subset.subsetImage's recode: (out (ys, xs) uint32, orig ids per new id, histogram per new id)."""
+    seg = np.ascontiguousarray(seg, dtype=np.uint32)
+    assert 0 <= tlx and 0 <= tly and tlx + xs <= seg.shape[1] and tly + ys <= seg.shape[0]
+    if mask is not None:
+        mask = np.ascontiguousarray(mask != 0, dtype=np.uint8)
+        assert mask.shape == (ys, xs)
+    out = np.zeros((ys, xs), dtype=np.uint32)
+    orig = np.zeros(xs * ys + 1, dtype=np.uint32)
+    hist = np.zeros(xs * ys + 1, dtype=np.uint32)
+    f = lib().orc_subset_recode
+    f.restype = ctypes.c_uint32
+    n = f(_p(seg), ctypes.c_int64(seg.shape[1]), ctypes.c_int64(tlx), ctypes.c_int64(tly),
+          ctypes.c_int64(xs), ctypes.c_int64(ys), _p(mask) if mask is not None else None,
+          ctypes.c_int64(tile_size), ctypes.c_uint32(int(seg.max()) if seg.size else 0), _p(out),
+          _p(orig), _p(hist))
+    return out, orig[:n + 1].copy(), hist[:n + 1].copy()

@@ -827,3 +827,42 @@ ORC_API int orc_segstats(const uint32_t *seg, const void *band, int dtype, int64
     free(off); free(vals); free(fill);
     return 0;
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * subset.subsetImage's recode (reference subset.py:124-166 tile loop + processSubsetTile
+ * :366-425): the window (tlx, tly, xs, ys) of a label raster is visited tile by tile
+ * (tile_size x tile_size, row-major over tiles, raster order inside a tile); masked-out
+ * (mask == 0) and null pixels give 0, every other id gets the next new id the first time it is
+ * seen.  orig_out[new id] = old id (orig_out[0] = 0), hist_out[new id] = pixel count; both must
+ * hold xs*ys + 1 entries.  Returns the number of new ids.
+ * ------------------------------------------------------------------------------------------- */
+ORC_API uint32_t orc_subset_recode(const uint32_t *seg, int64_t img_cols, int64_t tlx, int64_t tly, int64_t xs,
+                           int64_t ys, const uint8_t *mask, int64_t tile_size, uint32_t max_seg_id,
+                           uint32_t *out, uint32_t *orig_out, uint32_t *hist_out)
+{
+    uint32_t *lut = (uint32_t *)calloc((size_t)max_seg_id + 1, sizeof(uint32_t));
+    uint32_t nnew = 0;
+    orig_out[0] = 0; hist_out[0] = 0;
+    for (int64_t ty = 0; ty < ys; ty += tile_size)
+        for (int64_t tx = 0; tx < xs; tx += tile_size) {
+            const int64_t th = ys - ty < tile_size ? ys - ty : tile_size;
+            const int64_t tw = xs - tx < tile_size ? xs - tx : tile_size;
+            for (int64_t y = ty; y < ty + th; y++)
+                for (int64_t x = tx; x < tx + tw; x++) {
+                    const uint32_t s = seg[(size_t)(tly + y) * img_cols + (tlx + x)];
+                    uint32_t v = 0;
+                    if (!(mask && mask[(size_t)y * xs + x] == 0) && s != 0) {
+                        if (lut[s] == 0) {
+                            lut[s] = ++nnew;
+                            orig_out[nnew] = s;
+                            hist_out[nnew] = 0;
+                        }
+                        v = lut[s];
+                        hist_out[v]++;
+                    }
+                    out[(size_t)y * xs + x] = v;
+                }
+        }
+    free(lut);
+    return nnew;
+}

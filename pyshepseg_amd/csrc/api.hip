@@ -11,6 +11,7 @@
 #include "stitch.h"
 static int read_u32(shp_ctx *ctx, const uint32_t *d, uint32_t *h);
 #include "segstats.h"
+#include "subset.h"
 
 #define API extern "C" __attribute__((visibility("default")))
 
@@ -729,4 +730,63 @@ API int shp_gather_flagged_dev(shp_ctx *ctx, const uint32_t *d_seg, const void *
         SHP_FAIL(ctx, SHP_ERR_ARG, "raster too large (%lld px)", (long long)npix);
     return run_gather_flagged(ctx, d_seg, d_band, dtype, (uint32_t)npix, max_seg_id, flags, (uint32_t)cap,
                               seg_out, val_out, count_out);
+}
+
+// ---- subset ---------------------------------------------------------------------
+static int subset_check(shp_ctx *ctx, int64_t img_rows, int64_t img_cols, int64_t tlx, int64_t tly,
+                        int64_t xs, int64_t ys, int tile_size)
+{
+    if (img_rows < 0 || img_cols < 0 || tlx < 0 || tly < 0 || xs < 0 || ys < 0 || tile_size < 1)
+        SHP_FAIL(ctx, SHP_ERR_ARG, "bad argument");
+    if (tlx + xs > img_cols || tly + ys > img_rows)
+        SHP_FAIL(ctx, SHP_ERR_ARG, "Requested subset is not within input image");      // subset.py:86-88
+    if ((uint64_t)xs * (uint64_t)ys >= 0xffffffffull || img_cols >= 0xffffffffll)
+        SHP_FAIL(ctx, SHP_ERR_ARG, "subset too large");
+    return 0;
+}
+
+API int shp_subset_recode_dev(shp_ctx *ctx, const uint32_t *d_seg, int64_t img_rows, int64_t img_cols,
+                              int64_t tlx, int64_t tly, int64_t xs, int64_t ys, const uint8_t *d_mask,
+                              int tile_size, uint32_t max_seg_id, uint32_t *d_out, uint32_t *orig_out,
+                              uint32_t *hist_out, int64_t cap, uint32_t *n_new_out)
+{
+    CHK(enter(ctx));
+    if (!d_seg || !d_out || !orig_out || !hist_out || !n_new_out || cap < 1)
+        SHP_FAIL(ctx, SHP_ERR_ARG, "NULL argument");
+    CHK(subset_check(ctx, img_rows, img_cols, tlx, tly, xs, ys, tile_size));
+    return run_subset_recode(ctx, d_seg, (uint32_t)img_cols, (uint32_t)tlx, (uint32_t)tly, (uint32_t)xs,
+                             (uint32_t)ys, d_mask, (uint32_t)tile_size, max_seg_id, d_out, orig_out,
+                             hist_out, cap, n_new_out);
+}
+
+API int shp_subset_recode(shp_ctx *ctx, const uint32_t *seg, int64_t img_rows, int64_t img_cols,
+                          int64_t tlx, int64_t tly, int64_t xs, int64_t ys, const uint8_t *mask,
+                          int tile_size, uint32_t max_seg_id, uint32_t *out, uint32_t *orig_out,
+                          uint32_t *hist_out, int64_t cap, uint32_t *n_new_out)
+{
+    CHK(enter(ctx));
+    if (!seg || !out || !orig_out || !hist_out || !n_new_out || cap < 1)
+        SHP_FAIL(ctx, SHP_ERR_ARG, "NULL argument");
+    CHK(subset_check(ctx, img_rows, img_cols, tlx, tly, xs, ys, tile_size));
+    const size_t n = (size_t)xs * (size_t)ys;
+    *n_new_out = 0;
+    if (n == 0) return 0;
+    // only the window travels: rows of xs labels out of a raster of img_cols
+    CHK(buf_ensure(ctx, ctx->seg, n * 4));
+    CHK(buf_ensure(ctx, ctx->lab, n * 4));
+    HIPCHK(ctx, hipMemcpy2DAsync(ctx->seg.p, (size_t)xs * 4, seg + (size_t)tly * img_cols + tlx,
+                                 (size_t)img_cols * 4, (size_t)xs * 4, (size_t)ys, hipMemcpyHostToDevice,
+                                 ctx->stream));
+    uint8_t *d_mask = nullptr;
+    if (mask) {
+        CHK(buf_ensure(ctx, ctx->clus, n));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->clus.p, mask, n, hipMemcpyHostToDevice, ctx->stream));
+        d_mask = (uint8_t *)ctx->clus.p;
+    }
+    CHK(run_subset_recode(ctx, bp<uint32_t>(ctx->seg), (uint32_t)xs, 0u, 0u, (uint32_t)xs, (uint32_t)ys,
+                          d_mask, (uint32_t)tile_size, max_seg_id, bp<uint32_t>(ctx->lab), orig_out, hist_out,
+                          cap, n_new_out));
+    HIPCHK(ctx, hipMemcpyAsync(out, ctx->lab.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
 }

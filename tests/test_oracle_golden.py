@@ -105,3 +105,15 @@ def test_host_sample_and_diagonal_init(golden):
     xs2 = shepseg._sample_rows(img2, 1, 65535)
     full = np.transpose(img2, (1, 2, 0)).reshape(-1, 6)
     assert np.array_equal(xs2, full[(full != 65535).all(axis=1)][::100])
+
+
+def test_subset_recode_vs_reference(golden, oracle):
+    """subset.subsetImage's recode (reference processSubsetTile driven tile by tile)."""
+    g = golden('subset_recode')
+    for name, masked in (('a', False), ('b', True), ('c', False), ('d', True)):
+        (tlx, tly, xs, ys, tile) = [int(v) for v in g[name + '_win']]
+        out, orig, hist = oracle.subset_recode(g['seg'], tlx, tly, xs, ys,
+                                               g['mask'] if masked else None, tile)
+        assert np.array_equal(out, g[name + '_out'])
+        assert np.array_equal(orig, g[name + '_orig'])
+        assert np.array_equal(hist, g[name + '_hist'])
