@@ -225,6 +225,27 @@ int shp_subset_recode_dev(shp_ctx *ctx, const uint32_t *d_seg, int64_t img_rows,
                           int tile_size, uint32_t max_seg_id, uint32_t *d_out, uint32_t *orig_out,
                           uint32_t *hist_out, int64_t cap, uint32_t *n_new_out);
 
+/* ---- spatial statistics --------------------------------------------------------------
+ * replaces the tile loop of tilingstats.calcPerSegmentSpatialStatsTiled (tilingstats.py:1262-1390)
+ * for the reference's built-in user functions, func = 0 userFuncMeanCoord (:1098-1142; params =
+ * the six GDAL geotransform numbers; float columns 0, 1 = mean easting, northing), 1
+ * userFuncNumEdgePixels (:1146-1216; params[0] = fourConnected; int column 0), 2 userFuncVariogram
+ * (:1037-1094; params[0] = maxDist in 1..255; float columns 0..maxDist-1).  Only a segment's pixels
+ * whose band value differs from null_val count (accumulateSegSpatial :1686-1699; the reference
+ * insists on a nodata value, :1325-1333).  nint / nflt = number of integer / real columns of
+ * colNamesAndTypes; intcols_out: nint x (max_seg_id+1) int64, floatcols_out: nflt x
+ * (max_seg_id+1) float32; entries the function does not set, and segments without a valid pixel,
+ * hold `missing`; row 0 is zero.  Arbitrary njit callbacks are not supported. */
+int shp_spatialstats(shp_ctx *ctx, const uint32_t *seg, const void *band, int dtype, int64_t nrows,
+                     int64_t ncols, uint32_t max_seg_id, int64_t null_val, int func,
+                     const double *params, int64_t missing, int nint, int nflt,
+                     int64_t *intcols_out, float *floatcols_out);
+/* same with the label raster and the band already in device memory */
+int shp_spatialstats_dev(shp_ctx *ctx, const uint32_t *d_seg, const void *d_band, int dtype,
+                         int64_t nrows, int64_t ncols, uint32_t max_seg_id, int64_t null_val,
+                         int func, const double *params, int64_t missing, int nint, int nflt,
+                         int64_t *intcols_out, float *floatcols_out);
+
 #ifdef __cplusplus
 }
 #endif

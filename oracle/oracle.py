@@ -281,3 +281,29 @@ def subset_recode(seg, tlx, tly, xs, ys, mask=None, tile_size=1024):
           ctypes.c_int64(tile_size), ctypes.c_uint32(int(seg.max()) if seg.size else 0), _p(out),
           _p(orig), _p(hist))
     return out, orig[:n + 1].copy(), hist[:n + 1].copy()
+
+
+SPATIAL_FUNCS = {'meancoord': 0, 'numedge': 1, 'variogram': 2}
+
+
+def spatialstats(seg, band, func, param, null_val, nint, nflt, missing=-9999, tile_size=1024,
+                 max_seg_id=None):
+    """calcPerSegmentSpatialStatsTiled with a built-in user function: (intcols (nint, S+1) int64,
+    floatcols (nflt, S+1) float32)."""
+    seg = np.ascontiguousarray(seg, dtype=np.uint32)
+    band = np.ascontiguousarray(band)
+    assert band.dtype in DTYPES and band.shape == seg.shape and seg.ndim == 2
+    if max_seg_id is None:
+        max_seg_id = int(seg.max()) if seg.size else 0
+    params = np.zeros(6, dtype=np.float64)
+    pv = np.atleast_1d(np.asarray(param, dtype=np.float64))
+    params[:len(pv)] = pv
+    ic = np.zeros((max(nint, 1), max_seg_id + 1), dtype=np.int64)
+    fc = np.zeros((max(nflt, 1), max_seg_id + 1), dtype=np.float32)
+    rc = lib().orc_spatialstats(_p(seg), _p(band), DTYPES[band.dtype], ctypes.c_int64(seg.shape[0]),
+                                ctypes.c_int64(seg.shape[1]), ctypes.c_uint32(max_seg_id),
+                                ctypes.c_int64(int(null_val)), SPATIAL_FUNCS[func], _p(params),
+                                ctypes.c_int64(tile_size), ctypes.c_int64(int(missing)), nint, nflt,
+                                _p(ic), _p(fc))
+    assert rc == 0
+    return ic[:nint], fc[:nflt]

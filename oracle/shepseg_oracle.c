@@ -866,3 +866,130 @@ ORC_API uint32_t orc_subset_recode(const uint32_t *seg, int64_t img_cols, int64_
     free(lut);
     return nnew;
 }
+
+/* ---------------------------------------------------------------------------------------------
+ * calcPerSegmentSpatialStatsTiled with the reference's three built-in user functions
+ * (tilingstats.py:1262-1390 driver, accumulateSegSpatial :1652-1699, userFuncVariogram :1037-1094,
+ * userFuncMeanCoord :1098-1142, userFuncNumEdgePixels :1146-1216).  A segment's point list holds
+ * its non-nodata pixels in the order the tiles (tile_size x tile_size, row-major) deliver them,
+ * raster order inside a tile.  func 0 = mean coordinates (params = GDAL transform[6]; float
+ * columns 0, 1), 1 = number of edge pixels (params[0] = fourConnected; int column 0; the
+ * 8-connected test omits (y-1, x+1) exactly as the reference does), 2 = variogram (params[0] =
+ * maxDist; float columns 0..maxDist-1).  userFunc outputs: intArr int32, floatArr float64, stored
+ * into int64 / float32 page columns; unset entries and segments without valid pixels hold
+ * `missing`; row 0 is zero.
+ * ------------------------------------------------------------------------------------------- */
+ORC_API int orc_spatialstats(const uint32_t *seg, const void *band, int dtype, int64_t nrows,
+                             int64_t ncols, uint32_t max_seg_id, int64_t null_val, int func,
+                             const double *params, int64_t tile_size, int64_t missing, int nint,
+                             int nflt, int64_t *intcols_out, float *floatcols_out)
+{
+    const size_t ns = (size_t)max_seg_id + 1;
+    const size_t n = (size_t)nrows * (size_t)ncols;
+    size_t *off = (size_t *)calloc(ns + 1, sizeof(size_t));
+    size_t *fill = (size_t *)calloc(ns, sizeof(size_t));
+    uint8_t *present = (uint8_t *)calloc(ns, 1);
+    for (size_t p = 0; p < n; p++) {
+        const uint32_t s = seg[p];
+        if (s == 0 || s > max_seg_id) continue;
+        present[s] = 1;
+        if (px_get(band, dtype, p) != null_val) off[s + 1]++;
+    }
+    for (size_t s = 0; s < ns; s++) off[s + 1] += off[s];
+    uint32_t *px = (uint32_t *)malloc((off[ns] + 1) * sizeof(uint32_t));
+    uint32_t *py = (uint32_t *)malloc((off[ns] + 1) * sizeof(uint32_t));
+    int64_t *pv = (int64_t *)malloc((off[ns] + 1) * sizeof(int64_t));
+    for (int64_t ty = 0; ty < nrows; ty += tile_size)
+        for (int64_t tx = 0; tx < ncols; tx += tile_size) {
+            const int64_t th = nrows - ty < tile_size ? nrows - ty : tile_size;
+            const int64_t tw = ncols - tx < tile_size ? ncols - tx : tile_size;
+            for (int64_t y = ty; y < ty + th; y++)
+                for (int64_t x = tx; x < tx + tw; x++) {
+                    const size_t p = (size_t)y * ncols + x;
+                    const uint32_t s = seg[p];
+                    if (s == 0 || s > max_seg_id) continue;
+                    const int64_t v = px_get(band, dtype, p);
+                    if (v == null_val) continue;
+                    const size_t k = off[s] + fill[s]++;
+                    px[k] = (uint32_t)x; py[k] = (uint32_t)y; pv[k] = v;
+                }
+        }
+    for (int c = 0; c < nint; c++) for (size_t s = 0; s < ns; s++) intcols_out[(size_t)c * ns + s] = s ? missing : 0;
+    for (int c = 0; c < nflt; c++) for (size_t s = 0; s < ns; s++) floatcols_out[(size_t)c * ns + s] = s ? (float)missing : 0.0f;
+    for (size_t s = 1; s < ns; s++) {
+        const size_t m = off[s + 1] - off[s];
+        if (m == 0) continue;
+        const uint32_t *X = px + off[s], *Y = py + off[s];
+        const int64_t *V = pv + off[s];
+        if (func == 0) {
+            double sumx = 0.0, sumy = 0.0;
+            for (size_t i = 0; i < m; i++) {
+                const double geox = params[0] + params[1] * (double)X[i] + params[2] * (double)Y[i];
+                const double geoy = params[3] + params[4] * (double)X[i] + params[5] * (double)Y[i];
+                sumx += geox; sumy += geoy;
+            }
+            if (nflt > 0) floatcols_out[s] = (float)(sumx / (double)m);
+            if (nflt > 1) floatcols_out[ns + s] = (float)(sumy / (double)m);
+            continue;
+        }
+        uint32_t xmin = X[0], xmax = X[0], ymin = Y[0], ymax = Y[0];
+        for (size_t i = 1; i < m; i++) {
+            if (X[i] < xmin) xmin = X[i]; else if (X[i] > xmax) xmax = X[i];
+            if (Y[i] < ymin) ymin = Y[i]; else if (Y[i] > ymax) ymax = Y[i];
+        }
+        const int64_t W = (int64_t)xmax - xmin + 1, H = (int64_t)ymax - ymin + 1;
+        if (func == 1) {
+            uint8_t *mask = (uint8_t *)calloc((size_t)W * H, 1);
+            for (size_t i = 0; i < m; i++) mask[(size_t)(Y[i] - ymin) * W + (X[i] - xmin)] = 1;
+            const int four = params[0] != 0.0;
+            int32_t total_edge = 0;
+#define MK(yy, xx) ((int)mask[(size_t)(yy) * W + (xx)])
+            for (int64_t y = 0; y < H; y++)
+                for (int64_t x = 0; x < W; x++) {
+                    if (!MK(y, x)) continue;
+                    if (y == 0 || x == 0 || y == H - 1 || x == W - 1) { total_edge++; continue; }
+                    int tot;
+                    if (four) {
+                        tot = MK(y - 1, x) + MK(y + 1, x) + MK(y, x - 1) + MK(y, x + 1);
+                        if (tot != 4) total_edge++;
+                    } else {                 /* sic: (y+1, x+1) twice, (y-1, x+1) never */
+                        tot = MK(y - 1, x - 1) + MK(y - 1, x) + MK(y + 1, x + 1) + MK(y, x - 1) + MK(y, x + 1) +
+                              MK(y + 1, x - 1) + MK(y + 1, x) + MK(y + 1, x + 1);
+                        if (tot != 8) total_edge++;
+                    }
+                }
+#undef MK
+            free(mask);
+            if (nint > 0) intcols_out[s] = (int64_t)total_edge;
+        } else {
+            const int64_t maxd = (int64_t)params[0];
+            int64_t *tile = (int64_t *)malloc((size_t)W * H * sizeof(int64_t));
+            for (size_t i = 0; i < (size_t)W * H; i++) tile[i] = null_val;
+            for (size_t i = 0; i < m; i++) tile[(size_t)(Y[i] - ymin) * W + (X[i] - xmin)] = V[i];
+            uint32_t *counts = (uint32_t *)calloc((size_t)maxd + 1, sizeof(uint32_t));
+            double *sums = (double *)calloc((size_t)maxd + 1, sizeof(double));
+            for (int64_t y = 0; y < H; y++)
+                for (int64_t x = 0; x < W; x++) {
+                    const int64_t val = tile[(size_t)y * W + x];
+                    if (val == null_val) continue;
+                    for (int64_t yo = 1; yo <= maxd; yo++)
+                        for (int64_t xo = 1; xo <= maxd; xo++) {
+                            if (y + yo >= H || x + xo >= W) continue;
+                            const int64_t val2 = tile[(size_t)(y + yo) * W + (x + xo)];
+                            if (val2 == null_val) continue;
+                            const int64_t dist = (int64_t)sqrt((double)(yo * yo + xo * xo));
+                            if (dist <= maxd && dist > 0) {
+                                counts[dist - 1]++;
+                                sums[dist - 1] += (double)((val - val2) * (val - val2));
+                            }
+                        }
+                }
+            for (int64_t d = 0; d < maxd && d < nflt; d++)
+                if (counts[d] > 0) floatcols_out[(size_t)d * ns + s] = (float)sqrt(sums[d] / (double)counts[d]);
+            free(tile); free(counts); free(sums);
+        }
+    }
+    (void)present;
+    free(off); free(fill); free(present); free(px); free(py); free(pv);
+    return 0;
+}

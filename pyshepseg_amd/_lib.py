@@ -100,6 +100,12 @@ _SIGS = {
     'shp_subset_recode_dev': (_c.c_int, [_vp, _vp, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64,
                                          _c.c_int64, _c.c_int64, _vp, _c.c_int, _c.c_uint32, _vp, _vp,
                                          _vp, _c.c_int64, _vp]),
+    'shp_spatialstats': (_c.c_int, [_vp, _vp, _vp, _c.c_int, _c.c_int64, _c.c_int64, _c.c_uint32,
+                                    _c.c_int64, _c.c_int, _vp, _c.c_int64, _c.c_int, _c.c_int, _vp,
+                                    _vp]),
+    'shp_spatialstats_dev': (_c.c_int, [_vp, _vp, _vp, _c.c_int, _c.c_int64, _c.c_int64, _c.c_uint32,
+                                        _c.c_int64, _c.c_int, _vp, _c.c_int64, _c.c_int, _c.c_int,
+                                        _vp, _vp]),
     'shp_gather_flagged_dev': (_c.c_int, [_vp, _vp, _vp, _c.c_int, _c.c_int64, _c.c_uint32, _vp,
                                           _c.c_int64, _vp, _vp, _vp]),
 }

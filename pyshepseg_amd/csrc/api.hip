@@ -12,6 +12,7 @@
 static int read_u32(shp_ctx *ctx, const uint32_t *d, uint32_t *h);
 #include "segstats.h"
 #include "subset.h"
+#include "spatial.h"
 
 #define API extern "C" __attribute__((visibility("default")))
 
@@ -789,4 +790,50 @@ API int shp_subset_recode(shp_ctx *ctx, const uint32_t *seg, int64_t img_rows, i
     HIPCHK(ctx, hipMemcpyAsync(out, ctx->lab.p, n * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
+}
+
+// ---- spatial statistics ------------------------------------------------------------
+static int spatial_check(shp_ctx *ctx, int dtype, int64_t nrows, int64_t ncols, int func,
+                         const double *params, int nint, int nflt)
+{
+    if (dtype_size(dtype) == 0 || nrows < 0 || ncols < 0 || !params || nint < 0 || nflt < 0 || nint + nflt < 1)
+        SHP_FAIL(ctx, SHP_ERR_ARG, "bad argument");
+    if (func < 0 || func > 2) SHP_FAIL(ctx, SHP_ERR_ARG, "unknown built-in spatial function %d", func);
+    if ((uint64_t)nrows * (uint64_t)ncols >= 0xffffffffull) SHP_FAIL(ctx, SHP_ERR_ARG, "raster too large");
+    return 0;
+}
+
+API int shp_spatialstats_dev(shp_ctx *ctx, const uint32_t *d_seg, const void *d_band, int dtype,
+                             int64_t nrows, int64_t ncols, uint32_t max_seg_id, int64_t null_val,
+                             int func, const double *params, int64_t missing, int nint, int nflt,
+                             int64_t *intcols_out, float *floatcols_out)
+{
+    CHK(enter(ctx));
+    if (!d_seg || !d_band || (nint && !intcols_out) || (nflt && !floatcols_out))
+        SHP_FAIL(ctx, SHP_ERR_ARG, "NULL argument");
+    CHK(spatial_check(ctx, dtype, nrows, ncols, func, params, nint, nflt));
+    return run_spatialstats(ctx, d_seg, d_band, dtype, (uint32_t)nrows, (uint32_t)ncols, max_seg_id,
+                            null_val, func, params, missing, nint, nflt, intcols_out, floatcols_out);
+}
+
+API int shp_spatialstats(shp_ctx *ctx, const uint32_t *seg, const void *band, int dtype, int64_t nrows,
+                         int64_t ncols, uint32_t max_seg_id, int64_t null_val, int func,
+                         const double *params, int64_t missing, int nint, int nflt,
+                         int64_t *intcols_out, float *floatcols_out)
+{
+    CHK(enter(ctx));
+    if (!seg || !band || (nint && !intcols_out) || (nflt && !floatcols_out))
+        SHP_FAIL(ctx, SHP_ERR_ARG, "NULL argument");
+    CHK(spatial_check(ctx, dtype, nrows, ncols, func, params, nint, nflt));
+    const size_t npix = (size_t)nrows * (size_t)ncols;
+    CHK(buf_ensure(ctx, ctx->seg, npix * 4));
+    CHK(buf_ensure(ctx, ctx->img, npix * dtype_size(dtype)));
+    if (npix) {
+        HIPCHK(ctx, hipMemcpyAsync(ctx->seg.p, seg, npix * 4, hipMemcpyHostToDevice, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->img.p, band, npix * dtype_size(dtype), hipMemcpyHostToDevice,
+                                   ctx->stream));
+    }
+    return run_spatialstats(ctx, bp<uint32_t>(ctx->seg), ctx->img.p, dtype, (uint32_t)nrows, (uint32_t)ncols,
+                            max_seg_id, null_val, func, params, missing, nint, nflt, intcols_out,
+                            floatcols_out);
 }

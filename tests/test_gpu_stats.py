@@ -65,3 +65,69 @@ def test_stats_errors():
     with pytest.raises(tilingstats.PyShepSegStatsError):
         tilingstats.calcPerSegmentStats(np.ones((4, 4), np.uint32), np.ones((4, 5), np.uint16),
                                         [('m', 'mean')])
+
+
+def _spatial_cases(g):
+    from pyshepseg_amd import tilingstats as ts
+    R, I = ts.GFT_Real, ts.GFT_Integer
+    return [('mean_fc', ts.userFuncMeanCoord, g['transform'], [('e', R), ('n', R)]),
+            ('meanrot_fc', ts.userFuncMeanCoord, g['rot'], [('e', R), ('n', R)]),
+            ('edge4_ic', ts.userFuncNumEdgePixels, True, [('edges', I)]),
+            ('edge8_ic', ts.userFuncNumEdgePixels, False, [('edges', I)]),
+            ('vario_fc', ts.userFuncVariogram, 4, [('v%d' % i, R) for i in range(4)])]
+
+
+def test_golden_spatial_stats(golden):
+    """Built-in spatial user functions against the reference's own njit code (goldens)."""
+    from pyshepseg_amd import tilingstats as ts
+    g = golden('spatial_stats')
+    for key, fn, prm, cols in _spatial_cases(g):
+        r = ts.calcPerSegmentSpatialStatsTiled(g['band'], 1, g['seg'], cols, fn, prm, imgNullVal=0)
+        got = np.stack([r.columns[n] for (n, _t) in cols])
+        want = g[key]
+        if key.startswith('mean'):
+            # float64 sums of transformed coordinates are re-associated on the device (n*t0 +
+            # t1*sum(x) + t2*sum(y)): within 1e-6 relative (north_star), almost always bit-equal
+            assert np.allclose(got, want, rtol=1e-6, atol=0)
+            assert (got.view(np.uint32) == want.view(np.uint32)).mean() > 0.99
+        elif got.dtype == np.float32:
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+        else:
+            assert np.array_equal(got, want)
+
+
+def test_spatial_stats_vs_oracle_large(oracle):
+    """2000 x 1800, default 1024 tiles in the oracle's point order, several dtypes' worth of values."""
+    from pyshepseg_amd import tilingstats as ts
+    rng = np.random.RandomState(4)
+    base = rng.permutation(np.arange(1, 30 * 25 + 1)).reshape(30, 25).astype(np.uint32)
+    seg = np.kron(base, np.ones((70, 75), dtype=np.uint32))[:2000, :1800]
+    seg[rng.rand(*seg.shape) < 0.02] = 0
+    band = (oracle.synthimg(8, 1, 2000, 1800)[0]).astype(np.uint16)
+    band[rng.rand(*band.shape) < 0.05] = 65535
+    S = int(seg.max())
+    tr = np.array([300000.0, 10.0, 0.0, 7000000.0, 0.0, -10.0])
+    R, I = ts.GFT_Real, ts.GFT_Integer
+    ic, fc = ts.calcPerSegmentSpatialStats(seg, band, [R, R], ts.userFuncMeanCoord, tr, 65535)
+    _wi, wf = oracle.spatialstats(seg, band, 'meancoord', tr, 65535, 0, 2, max_seg_id=S)
+    assert np.array_equal(fc.view(np.uint32), wf.view(np.uint32))     # integer-valued transform: exact sums
+    for four in (True, False):
+        ic, fc = ts.calcPerSegmentSpatialStats(seg, band, [I, I], ts.userFuncNumEdgePixels, four, 65535)
+        wi, _wf = oracle.spatialstats(seg, band, 'numedge', int(four), 65535, 2, 0, max_seg_id=S)
+        assert np.array_equal(ic, wi)                                  # second int column stays missing
+    ic, fc = ts.calcPerSegmentSpatialStats(seg, band, [R] * 7, ts.userFuncVariogram, 6, 65535)
+    _wi, wf = oracle.spatialstats(seg, band, 'variogram', 6, 65535, 0, 7, max_seg_id=S)
+    assert np.array_equal(fc.view(np.uint32), wf.view(np.uint32))
+
+
+def test_spatial_stats_errors():
+    from pyshepseg_amd import tilingstats as ts
+    seg = np.ones((8, 8), np.uint32)
+    img = np.ones((8, 8), np.uint16)
+    with pytest.raises(ts.PyShepSegStatsError, match='NoData value must be set'):
+        ts.calcPerSegmentSpatialStatsTiled(img, 1, seg, [('a', ts.GFT_Real)], ts.userFuncMeanCoord, [0] * 6)
+    with pytest.raises(ts.PyShepSegStatsError, match='one or more columns'):
+        ts.calcPerSegmentSpatialStatsTiled(img, 1, seg, [], ts.userFuncMeanCoord, [0] * 6, imgNullVal=0)
+    with pytest.raises(ts.PyShepSegStatsError, match='built-in user functions'):
+        ts.calcPerSegmentSpatialStatsTiled(img, 1, seg, [('a', ts.GFT_Real)], lambda *a: None, None,
+                                           imgNullVal=0)

@@ -27,3 +27,22 @@ def test_oracle_segstats(name, golden, oracle):
     assert done[1:].all()                       # every id of these fixtures has pixels
     assert np.array_equal(ic[:, done], g['intcols'][:, done])
     assert np.array_equal(fc[:, done], g['floatcols'][:, done])      # bit-exact float32
+
+
+def test_spatial_stats_vs_reference(golden, oracle):
+    """Built-in user functions of calcPerSegmentSpatialStatsTiled (reference njit code driven by
+    oracle/refgen/gen_golden_spatial.py): the oracle restatement is bit-identical."""
+    g = golden('spatial_stats')
+    seg, band, tile = g['seg'], g['band'], int(g['tile'])
+    _ic, fc = oracle.spatialstats(seg, band, 'meancoord', g['transform'], 0, 0, 2, tile_size=tile)
+    assert np.array_equal(fc.view(np.uint32), g['mean_fc'].view(np.uint32))
+    _ic, fc = oracle.spatialstats(seg, band, 'meancoord', g['rot'], 0, 0, 2, tile_size=tile)
+    assert np.array_equal(fc.view(np.uint32), g['meanrot_fc'].view(np.uint32))
+    ic, _fc = oracle.spatialstats(seg, band, 'numedge', 1, 0, 1, 0, tile_size=tile)
+    assert np.array_equal(ic, g['edge4_ic'])
+    ic, _fc = oracle.spatialstats(seg, band, 'numedge', 0, 0, 1, 0, tile_size=tile)
+    assert np.array_equal(ic, g['edge8_ic'])
+    _ic, fc = oracle.spatialstats(seg, band, 'variogram', 4, 0, 0, 4, tile_size=tile)
+    assert np.array_equal(fc.view(np.uint32), g['vario_fc'].view(np.uint32))
+    # the fixture exercises the corners: an all-nodata segment and unset variogram bins stay missing
+    assert (g['mean_fc'][0, 1:] == -9999).any() and (g['edge4_ic'][0, 1:] > 0).any()
