@@ -147,18 +147,79 @@ __global__ __launch_bounds__(256) void k_big_list(const uint32_t *__restrict__ l
 
 // Bounding box (min col, max col, max row; the min row is the root's) of every cut-able
 // component.  Only corner pixels can hold an extreme (the topmost pixel of the leftmost column
-// has no member above or to its left, ...), which leaves a handful of candidates per component
-// instead of one per row: atomics on one address serialise at L2.
+// has no member above or to its left, ...); their candidates are combined per 32 x 64 patch in
+// LDS (AggTable, keyed by root) and flushed with one pruned global atomic per (patch, component,
+// field): atomics on one address serialise at L2.
 __global__ __launch_bounds__(256) void k_big_bbox(const uint32_t *__restrict__ lab,
-                                                  const uint32_t *__restrict__ csize, uint32_t n,
+                                                  const uint32_t *__restrict__ csize, uint32_t nrows,
                                                   uint32_t ncols, BigInfo *big,
                                                   const uint32_t *__restrict__ bigbits)
+{
+    __shared__ AggTable tab;
+    agg_init(tab, 0xFFFFFFFFu, 0u, 0u);             // min col | max col + 1 | max row + 1
+    __syncthreads();
+    const unsigned lane = lane_id(), wv = threadIdx.x >> 6;
+    const uint32_t c = blockIdx.x * 64u + lane;
+    const uint32_t r0 = blockIdx.y * AGG_ROWS + wv * (AGG_ROWS / 4u);
+    const bool cin = c < ncols;
+    uint32_t above = (cin && r0 > 0u && r0 <= nrows) ? lab[(size_t)(r0 - 1u) * ncols + c] : NULL_LAB;
+    uint32_t cur = (cin && r0 < nrows) ? lab[(size_t)r0 * ncols + c] : NULL_LAB;
+    for (uint32_t i = 0; i < AGG_ROWS / 4u; i++) {
+        const uint32_t row = r0 + i;
+        if (row >= nrows) break;                             // uniform per wavefront
+        const uint32_t below = (cin && row + 1u < nrows) ? lab[(size_t)(row + 1u) * ncols + c] : NULL_LAB;
+        const uint32_t r = cur;
+        uint32_t lf = __shfl_up(r, 1, 64), rt = __shfl_down(r, 1, 64);
+        if (lane == 0) lf = (cin && c > 0u) ? lab[(size_t)row * ncols + c - 1u] : NULL_LAB;
+        if (lane == 63) rt = (c + 1u < ncols) ? lab[(size_t)row * ncols + c + 1u] : NULL_LAB;
+        if (cin && c + 1u == ncols) rt = NULL_LAB;
+        if (r != NULL_LAB && ((bigbits[r >> 5] >> (r & 31u)) & 1u)) {    // 2 MB bitmap, not a 4N-byte gather
+            const bool ldiff = lf != r, rdiff = rt != r, udiff = above != r, ddiff = below != r;
+            const bool cminc = ldiff && udiff, cmaxc = rdiff && udiff, cmaxr = ddiff && ldiff;
+            if (cminc || cmaxc || cmaxr) {
+                const int h = agg_slot(tab, r + 1u);                     // key 0 means empty
+                if (h >= 0) {
+                    if (cminc) atomicMin(&tab.v[0][h], c);
+                    if (cmaxc) atomicMax(&tab.v[1][h], c + 1u);
+                    if (cmaxr) atomicMax(&tab.v[2][h], row + 1u);
+                } else {
+                    const uint32_t cs = csize[r];
+                    if (cs & VIS_FLAG) {
+                        const uint32_t bi = cs & ~VIS_FLAG;
+                        if (cminc) atomicMin(&big[bi].minc, c);
+                        if (cmaxc) atomicMax(&big[bi].maxc, c);
+                        if (cmaxr) atomicMax(&big[bi].maxr, row);
+                    }
+                }
+            }
+        }
+        above = cur;
+        cur = below;
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < AGG_SLOTS; i += 256u) {
+        if (tab.key[i] == 0u) continue;
+        const uint32_t cs = csize[tab.key[i] - 1u];
+        if (!(cs & VIS_FLAG)) continue;
+        const uint32_t bi = cs & ~VIS_FLAG;
+        const uint32_t mn = tab.v[0][i], mx = tab.v[1][i], mr = tab.v[2][i];
+        if (mn != 0xFFFFFFFFu && mn < big[bi].minc) atomicMin(&big[bi].minc, mn);
+        if (mx != 0u && mx - 1u > big[bi].maxc) atomicMax(&big[bi].maxc, mx - 1u);
+        if (mr != 0u && mr - 1u > big[bi].maxr) atomicMax(&big[bi].maxr, mr - 1u);
+    }
+}
+
+// timing probe (SHEPSEG_PROBE=1): k_big_bbox without its atomics
+__global__ __launch_bounds__(256) void k_probe_bbox(const uint32_t *__restrict__ lab,
+                                                    const uint32_t *__restrict__ csize, uint32_t n,
+                                                    uint32_t ncols, BigInfo *big,
+                                                    const uint32_t *__restrict__ bigbits, uint32_t *sink, uint32_t magic)
 {
     const uint32_t p = blockIdx.x * 256u + threadIdx.x;
     if (p >= n) return;
     const uint32_t r = lab[p];
     if (r == NULL_LAB) return;
-    if (!((bigbits[r >> 5] >> (r & 31u)) & 1u)) return;     // 2 MB bitmap instead of a 4N-byte gather
+    if (!((bigbits[r >> 5] >> (r & 31u)) & 1u)) return;
     const uint32_t row = p / ncols, col = p - row * ncols;
     const bool ldiff = col == 0 || lab[p - 1] != r;
     const bool udiff = p < ncols || lab[p - ncols] != r;
@@ -169,9 +230,11 @@ __global__ __launch_bounds__(256) void k_big_bbox(const uint32_t *__restrict__ l
     const uint32_t c = csize[r];
     if (!(c & VIS_FLAG)) return;
     const uint32_t bi = c & ~VIS_FLAG;
-    if (cminc && col < big[bi].minc) atomicMin(&big[bi].minc, col);
-    if (cmaxc && col > big[bi].maxc) atomicMax(&big[bi].maxc, col);
-    if (cmaxr && row > big[bi].maxr) atomicMax(&big[bi].maxr, row);
+    uint32_t acc = 0;
+    if (cminc && col < big[bi].minc) acc += 1;
+    if (cmaxc && col > big[bi].maxc) acc += 2;
+    if (cmaxr && row > big[bi].maxr) acc += 4;
+    if (acc == magic) *sink = 1;
 }
 
 // One wavefront per cut-able component: exact replay of shepseg.py:490-539 restricted to the
@@ -578,7 +641,13 @@ static int run_clump(shp_ctx *ctx, const uint16_t *d_clus, uint32_t nrows, uint3
     HIPCHK(ctx, hipMemsetAsync(bigbits, 0, ((size_t)n / 32 + 1) * 4, st));
     HIPCHK(ctx, hipMemsetAsync(d_segsz, 0, 4, st));         // only the null count accumulates
     hipLaunchKernelGGL(k_big_list, dim3(g), dim3(256), 0, st, lab, csize, n, ncols, big, counters, bigbits); KCHK(ctx);
-    hipLaunchKernelGGL(k_big_bbox, dim3(g), dim3(256), 0, st, lab, csize, n, ncols, big, bigbits); KCHK(ctx);
+    hipLaunchKernelGGL(k_big_bbox, dim3(grid_for(ncols, 64), grid_for(nrows, AGG_ROWS)), dim3(256), 0, st, lab,
+                       csize, nrows, ncols, big, bigbits); KCHK(ctx);
+    static const int probe = getenv("SHEPSEG_PROBE") ? atoi(getenv("SHEPSEG_PROBE")) : 0;
+    if (probe) {
+        hipLaunchKernelGGL(k_probe_bbox, dim3(g), dim3(256), 0, st, lab, csize, n, ncols, big, bigbits, counters + 3, 0xFFFFFFFFu);
+        KCHK(ctx);
+    }
     ps = prof_begin(ctx, PROF_DFS);
     uint32_t *order = (uint32_t *)((char *)ctx->big.p + (size_t)maxbig * sizeof(BigInfo) + 64);
     hipLaunchKernelGGL(k_big_order, dim3(grid_for(maxbig, 256)), dim3(256), 0, st, big, counters, order); KCHK(ctx);

@@ -193,6 +193,36 @@ template <int DT> __device__ __forceinline__ long long ld_t(const void *__restri
     default: { constexpr int DT = SHP_U32; __VA_ARGS__; } break;             \
     }
 
+// ---- workgroup-local aggregation of per-id minima / maxima ---------------------------------------
+// Atomics on one address serialise at L2, and the pixels that update one id's bounding box sit
+// close together.  Kernels that reduce per-id extremes therefore walk 2-D patches (AGG_ROWS x 64
+// pixels per 256-thread workgroup, a wavefront per image row so loads stay coalesced), combine
+// candidates in a small LDS hash table with LDS atomics, and issue one global atomic per
+// (workgroup, id, field).  A full table sends the candidate straight to global memory.
+#define AGG_SLOTS 128u
+#define AGG_ROWS 32u
+struct AggTable {
+    uint32_t key[AGG_SLOTS];        // 0 = empty
+    uint32_t v[3][AGG_SLOTS];
+};
+__device__ __forceinline__ void agg_init(AggTable &t, uint32_t i0, uint32_t i1, uint32_t i2)
+{
+    for (uint32_t i = threadIdx.x; i < AGG_SLOTS; i += 256u) {
+        t.key[i] = 0u; t.v[0][i] = i0; t.v[1][i] = i1; t.v[2][i] = i2;
+    }
+}
+// slot of `key` (claimed if new) or -1 when the table is full
+__device__ __forceinline__ int agg_slot(AggTable &t, uint32_t key)
+{
+    uint32_t h = (key * 2654435761u) >> 25;
+    for (uint32_t probe = 0; probe < AGG_SLOTS; probe++) {
+        const uint32_t old = atomicCAS(&t.key[h], 0u, key);
+        if (old == 0u || old == key) return (int)h;
+        h = (h + 1u) & (AGG_SLOTS - 1u);
+    }
+    return -1;
+}
+
 __device__ __forceinline__ unsigned lane_id() { return threadIdx.x & 63u; }
 __device__ __forceinline__ unsigned long long lanemask_lt()
 {

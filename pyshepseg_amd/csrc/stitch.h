@@ -295,29 +295,78 @@ __global__ __launch_bounds__(256) void k_meta_cross(const uint32_t *__restrict__
     if (mn[s] < mid && mx[s] >= mid + 1u) flags[s] |= bit;
 }
 
-// bounding-box corner of every segment + "has a pixel in the trimmed window"
+// bounding-box corner of every segment + "has a pixel in the trimmed window".
+// Only corner pixels act (see k_strip_minmax): the top row and the left column of a segment are
+// both found on pixels that have neither the segment above nor to the left, and the topmost-
+// leftmost pixel of (segment n window) has the same property relative to the window.  Their
+// candidates are combined per 32 x 64 patch in LDS (AggTable) before touching global memory.
 __global__ __launch_bounds__(256) void k_meta_pixels(const uint32_t *__restrict__ tile, uint32_t ys,
                                                      uint32_t xs, uint32_t top, uint32_t bottom,
                                                      uint32_t left, uint32_t right, uint32_t *segtop,
                                                      uint32_t *segleft, uint32_t *flags)
 {
+    __shared__ AggTable tab;
+    agg_init(tab, 0xFFFFFFFFu, 0xFFFFFFFFu, 0u);
+    __syncthreads();
+    const unsigned lane = lane_id(), wv = threadIdx.x >> 6;
+    const uint32_t c = blockIdx.x * 64u + lane;
+    const uint32_t r0 = blockIdx.y * AGG_ROWS + wv * (AGG_ROWS / 4u);
+    const bool cin = c < xs;
+    uint32_t above = (cin && r0 > 0u && r0 <= ys) ? tile[(size_t)(r0 - 1u) * xs + c] : 0u;
+    for (uint32_t i = 0; i < AGG_ROWS / 4u; i++) {
+        const uint32_t r = r0 + i;
+        if (r >= ys) break;                                  // uniform per wavefront
+        const uint32_t s = cin ? tile[(size_t)r * xs + c] : 0u;
+        uint32_t lf = __shfl_up(s, 1, 64);
+        if (lane == 0) lf = (cin && c > 0u) ? tile[(size_t)r * xs + c - 1u] : 0u;
+        if (s != 0u) {
+            const bool ldiff = c == 0u || lf != s;
+            const bool udiff = r == 0u || above != s;
+            const bool corner = ldiff && udiff;
+            const bool inwin = r >= top && r < bottom && c >= left && c < right;
+            const bool wcorner = inwin && (ldiff || c == left) && (udiff || r == top);
+            if (corner || wcorner) {
+                const int h = agg_slot(tab, s);
+                if (h >= 0) {
+                    if (corner) { atomicMin(&tab.v[0][h], r); atomicMin(&tab.v[1][h], c); }
+                    if (wcorner) tab.v[2][h] = 1u;
+                } else {
+                    if (corner) { atomicMin(&segtop[s], r); atomicMin(&segleft[s], c); }
+                    if (wcorner) atomicOr(&flags[s], META_IN_TRIM);
+                }
+            }
+        }
+        above = s;
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < AGG_SLOTS; i += 256u) {
+        const uint32_t s = tab.key[i];
+        if (s == 0u) continue;
+        // plain pre-reads prune most of what is left (a stale value only costs a redundant atomic)
+        if (tab.v[0][i] < segtop[s]) atomicMin(&segtop[s], tab.v[0][i]);
+        if (tab.v[1][i] < segleft[s]) atomicMin(&segleft[s], tab.v[1][i]);
+        if (tab.v[2][i] && !(flags[s] & META_IN_TRIM)) atomicOr(&flags[s], META_IN_TRIM);
+    }
+}
+
+// timing probe (SHEPSEG_PROBE=1): k_meta_pixels without its atomics
+__global__ __launch_bounds__(256) void k_probe_meta(const uint32_t *__restrict__ tile, uint32_t ys,
+                                                    uint32_t xs, uint32_t top, uint32_t bottom,
+                                                    uint32_t left, uint32_t right, uint32_t *segtop,
+                                                    uint32_t *segleft, uint32_t *flags, uint32_t *sink, uint32_t magic)
+{
     const uint32_t p = blockIdx.x * 256u + threadIdx.x;
     if (p >= ys * xs) return;
     const uint32_t s = tile[p];
     if (s == 0) return;
-    // Only corner pixels act (see k_strip_minmax): the top row and the left column of a segment
-    // are both found on pixels that have neither the segment above nor to the left, and the
-    // topmost-leftmost pixel of (segment n window) has the same property relative to the window.
     const uint32_t r = p / xs, c = p - r * xs;
     const bool ldiff = c == 0 || tile[p - 1] != s;
     const bool udiff = r == 0 || tile[p - xs] != s;
-    if (ldiff && udiff) {
-        if (r < segtop[s]) atomicMin(&segtop[s], r);
-        if (c < segleft[s]) atomicMin(&segleft[s], c);
-    }
+    uint32_t acc = 0;
+    if (ldiff && udiff) { if (r < segtop[s]) acc += 1; if (c < segleft[s]) acc += 2; }
     const bool inwin = r >= top && r < bottom && c >= left && c < right;
-    if (inwin && (ldiff || c == left) && (udiff || r == top) && !(flags[s] & META_IN_TRIM))
-        atomicOr(&flags[s], META_IN_TRIM);
+    if (inwin && (ldiff || c == left) && (udiff || r == top) && !(flags[s] & META_IN_TRIM)) acc += 4;
+    if (acc == magic) *sink = 1;
 }
 
 static int run_stitch_prepare(shp_ctx *ctx, const uint32_t *d_tile, uint32_t ys, uint32_t xs,
@@ -347,8 +396,13 @@ static int run_stitch_prepare(shp_ctx *ctx, const uint32_t *d_tile, uint32_t ys,
                            (horizontal ? srows : scols) / 2u, nseg,
                            horizontal ? META_CROSS_TOP : META_CROSS_LEFT, flags); KCHK(ctx);
     }
-    hipLaunchKernelGGL(k_meta_pixels, dim3(grid_for(n, 256)), dim3(256), 0, st, d_tile, ys, xs, top, bottom,
-                       left, right, segtop, segleft, flags); KCHK(ctx);
+    hipLaunchKernelGGL(k_meta_pixels, dim3(grid_for(xs, 64), grid_for(ys, AGG_ROWS)), dim3(256), 0, st, d_tile,
+                       ys, xs, top, bottom, left, right, segtop, segleft, flags); KCHK(ctx);
+    static const int probe = getenv("SHEPSEG_PROBE") ? atoi(getenv("SHEPSEG_PROBE")) : 0;
+    if (probe) {
+        hipLaunchKernelGGL(k_probe_meta, dim3(grid_for(n, 256)), dim3(256), 0, st, d_tile, ys, xs, top, bottom,
+                           left, right, segtop, segleft, flags, flags, 0xFFFFFFFFu); KCHK(ctx);
+    }
     return 0;
 }
 

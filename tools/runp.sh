@@ -5,4 +5,3 @@ rm -rf gpurun_out/prof_w1
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_w1 -o run -- python bench.py --size 12288 --steps 2 --warmup 1 --cpu-sample 0 --workers 1 > gpurun_out/prof_w1.log 2>&1
 rm -f gpurun_out/prof_w1/*kernel_trace.csv gpurun_out/prof_w1/*/*kernel_trace.csv
 timeout -k 10 400 python bench.py --cpu-sample 0 > gpurun_out/bd.log 2>&1; tail -1 gpurun_out/bd.log | cut -c1-400
-timeout -k 10 200 python tools/perf_fit.py 2>&1 | tail -2
