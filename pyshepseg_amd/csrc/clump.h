@@ -45,67 +45,159 @@ __device__ __forceinline__ void uf_merge(uint32_t *lab, uint32_t a, uint32_t b)
     }
 }
 
-// lab[p] = first pixel of p's horizontal run inside this wavefront's 64-pixel span
-// and the size accumulator of every run head (a superset of the final roots) is zeroed
-__global__ __launch_bounds__(256) void k_ccl_init(const uint16_t *__restrict__ clus,
-                                                  uint32_t *__restrict__ lab, uint32_t n,
-                                                  uint32_t ncols, uint32_t *__restrict__ csize)
+// ---- union-find CCL, patch-local first ------------------------------------------------------------
+// The image is cut into 32 x 64 patches (one 256-thread workgroup each, a wavefront per image row
+// so loads stay coalesced).  k_ccl_local labels a patch entirely in LDS (run heads by ballot, the
+// pruned vertical / diagonal links as LDS atomicMin hooks), counts the size of every patch-local
+// component in LDS and writes, per pixel, lab = global index of its local root and csize = that
+// local size at local roots, 0 elsewhere.  k_ccl_border then hooks the links that cross a patch
+// border with global atomics (~10 % of the pixels), and k_ccl_flatten resolves every pixel to its
+// global root and moves the size of each local component that is not its own global root to that
+// root -- one global atomic per such component instead of one per run of pixels, none at all for
+// the majority of components that live inside one patch.
+// Link rule for pixel p of cluster c (L, U, UL, UR = that neighbour exists and has cluster c):
+//   horizontal runs are linked to their head; U is linked unless L and UL (then p-1's U link and
+//   the row runs already imply it); 8-connectivity adds, only when U is absent, UL unless L, and UR.
+#define CCL_ROWS 32u
+__device__ __forceinline__ uint32_t lds_find(const uint32_t *L, uint32_t x)
 {
-    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
-    const bool inb = p < n;
-    const unsigned lane = lane_id();
-    const uint32_t c = inb ? clus[p] : 0u;
-    const uint32_t col = p % ncols;
-    const uint32_t cl = __shfl_up(c, 1, 64);
-    const bool leftsame = inb && lane > 0 && col > 0 && c != 0 && cl == c;
-    const unsigned long long heads = __ballot(!leftsame);
-    const unsigned long long m = heads & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
-    const unsigned start = 63u - (unsigned)__clzll(m);
-    if (inb) lab[p] = (c == 0) ? NULL_LAB : p - (lane - start);
-    if (inb && c != 0 && start == lane) csize[p] = 0u;
+    uint32_t p = L[x];
+    while (p != x) { x = p; p = L[x]; }
+    return x;
 }
-
-__global__ __launch_bounds__(256) void k_ccl_merge(const uint16_t *__restrict__ clus,
-                                                   uint32_t *lab, uint32_t n, uint32_t nrows,
-                                                   uint32_t ncols, int four)
+__device__ __forceinline__ void lds_merge(uint32_t *L, uint32_t a, uint32_t b)
 {
-    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
-    if (p >= n) return;
-    const uint32_t c = clus[p];
-    if (c == 0) return;
-    const uint32_t row = p / ncols, col = p - row * ncols;
-    const bool L = col > 0 && clus[p - 1] == c;
-    const bool U = row > 0 && clus[p - ncols] == c;
-    const bool UL = row > 0 && col > 0 && clus[p - ncols - 1] == c;
-    if (L && lane_id() == 0) uf_merge(lab, p, p - 1);        // runs cut at a wavefront boundary
-    if (U) {
-        if (!(L && UL)) uf_merge(lab, p, p - ncols);
-    } else if (!four) {
-        if (UL && !L) uf_merge(lab, p, p - ncols - 1);
-        const bool UR = row > 0 && col + 1 < ncols && clus[p - ncols + 1] == c;
-        if (UR) uf_merge(lab, p, p - ncols + 1);
+    a = lds_find(L, a);
+    b = lds_find(L, b);
+    while (a != b) {
+        if (a < b) { uint32_t t = a; a = b; b = t; }
+        const uint32_t old = atomicMin(&L[a], b);
+        if (old == a) break;
+        a = lds_find(L, old);
+        b = lds_find(L, b);
     }
 }
 
-// lab[p] = root, and the component sizes in the same pass: csize[root] += run length, one atomic
-// per run of equal roots per wavefront
+__global__ __launch_bounds__(256) void k_ccl_local(const uint16_t *__restrict__ clus,
+                                                   uint32_t *__restrict__ lab,
+                                                   uint32_t *__restrict__ csize, uint32_t nrows,
+                                                   uint32_t ncols, int four)
+{
+    __shared__ uint32_t L[CCL_ROWS * 64u];
+    __shared__ uint32_t sz[CCL_ROWS * 64u];
+    __shared__ uint16_t cl[CCL_ROWS * 64u];
+    const unsigned lane = lane_id(), wv = threadIdx.x >> 6;
+    const uint32_t c = blockIdx.x * 64u + lane;
+    const uint32_t prow0 = blockIdx.y * CCL_ROWS;
+    const bool cin = c < ncols;
+    uint32_t cv[CCL_ROWS / 4u];
+#pragma unroll
+    for (uint32_t i = 0; i < CCL_ROWS / 4u; i++) {
+        const uint32_t lr = wv * (CCL_ROWS / 4u) + i, r = prow0 + lr;
+        const uint32_t v = (cin && r < nrows) ? clus[(size_t)r * ncols + c] : 0u;
+        cv[i] = v;
+        cl[lr * 64u + lane] = (uint16_t)v;
+        sz[lr * 64u + lane] = 0u;
+        // row-run heads by ballot
+        const uint32_t vl = __shfl_up(v, 1, 64);
+        const bool leftsame = lane > 0 && v != 0u && vl == v;
+        const unsigned long long heads = __ballot(!leftsame);
+        const unsigned long long m = heads & ((lane == 63) ? ~0ull : ((2ull << lane) - 1ull));
+        const unsigned start = 63u - (unsigned)__clzll(m);
+        L[lr * 64u + lane] = lr * 64u + start;          // null pixels: their own (unused) singleton
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t i = 0; i < CCL_ROWS / 4u; i++) {
+        const uint32_t lr = wv * (CCL_ROWS / 4u) + i;
+        const uint32_t v = cv[i];
+        if (v == 0u || lr == 0u) continue;
+        const uint32_t x = lr * 64u + lane;
+        const bool Lk = lane > 0 && cl[x - 1u] == v;
+        const bool U = cl[x - 64u] == v;
+        const bool UL = lane > 0 && cl[x - 65u] == v;
+        if (U) {
+            if (!(Lk && UL)) lds_merge(L, x, x - 64u);
+        } else if (!four) {
+            if (UL && !Lk) lds_merge(L, x, x - 65u);
+            if (lane < 63 && cl[x - 63u] == v) lds_merge(L, x, x - 63u);
+        }
+    }
+    __syncthreads();
+    uint32_t root[CCL_ROWS / 4u];
+#pragma unroll
+    for (uint32_t i = 0; i < CCL_ROWS / 4u; i++) {
+        const uint32_t x = (wv * (CCL_ROWS / 4u) + i) * 64u + lane;
+        root[i] = cv[i] ? lds_find(L, x) : 0xFFFFFFFFu;
+        // one LDS atomic per run of equal roots in the row
+        const uint32_t pr = __shfl_up(root[i], 1, 64);
+        const bool head = lane == 0 || pr != root[i];
+        const unsigned long long heads = __ballot(head);
+        if (head && cv[i]) {
+            const unsigned long long nxt = (lane == 63) ? 0ull : (heads & ~((2ull << lane) - 1ull));
+            atomicAdd(&sz[root[i]], (nxt ? (unsigned)__builtin_ctzll(nxt) : 64u) - lane);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t i = 0; i < CCL_ROWS / 4u; i++) {
+        const uint32_t lr = wv * (CCL_ROWS / 4u) + i, r = prow0 + lr;
+        if (!cin || r >= nrows) continue;
+        const size_t p = (size_t)r * ncols + c;
+        if (cv[i] == 0u) { lab[p] = NULL_LAB; csize[p] = 0u; continue; }
+        const uint32_t rt = root[i];
+        lab[p] = (prow0 + (rt >> 6)) * ncols + blockIdx.x * 64u + (rt & 63u);
+        csize[p] = (rt == lr * 64u + lane) ? sz[rt] : 0u;
+    }
+}
+
+// links that cross a patch border (same rule as inside the patches).  Only border pixels are
+// launched: first every pixel of the patches' top rows, then the first / last column of every
+// patch for the remaining rows.
+__global__ __launch_bounds__(256) void k_ccl_border(const uint16_t *__restrict__ clus, uint32_t *lab,
+                                                    uint32_t nrows, uint32_t ncols, int four,
+                                                    uint32_t ntop, uint32_t npc)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    uint32_t row, col;
+    if (i < ntop * ncols) {
+        row = (i / ncols) * CCL_ROWS;
+        col = i % ncols;
+    } else {
+        const uint32_t j = i - ntop * ncols;
+        row = j / (2u * npc);
+        const uint32_t k = j - row * (2u * npc);
+        col = (k >> 1) * 64u + ((k & 1u) ? 63u : 0u);
+        if (row >= nrows || col >= ncols || (row % CCL_ROWS) == 0u) return;
+    }
+    const uint32_t p = row * ncols + col;
+    const bool topb = (row % CCL_ROWS) == 0u, leftb = (col & 63u) == 0u, rightb = (col & 63u) == 63u;
+    const uint32_t v = clus[p];
+    if (v == 0u) return;
+    const bool L = col > 0 && clus[p - 1] == v;
+    const bool U = row > 0 && clus[p - ncols] == v;
+    const bool UL = row > 0 && col > 0 && clus[p - ncols - 1] == v;
+    if (L && leftb) uf_merge(lab, p, p - 1);                       // row runs cut at a patch column
+    if (U) {
+        if (topb && !(L && UL)) uf_merge(lab, p, p - ncols);
+    } else if (!four) {
+        if (UL && !L && (topb || leftb)) uf_merge(lab, p, p - ncols - 1);
+        const bool UR = row > 0 && col + 1 < ncols && clus[p - ncols + 1] == v;
+        if (UR && (topb || rightb)) uf_merge(lab, p, p - ncols + 1);
+    }
+}
+
+// lab[p] = global root; a patch-local component that is not its own global root hands its size
+// (csize at its local root, 0 at every other pixel) to that root
 __global__ __launch_bounds__(256) void k_ccl_flatten(uint32_t *lab, uint32_t n, uint32_t *csize)
 {
     const uint32_t p = blockIdx.x * 256u + threadIdx.x;
-    const bool inb = p < n;
-    const unsigned lane = lane_id();
-    uint32_t r = NULL_LAB;
-    if (inb && lab[p] != NULL_LAB) {
-        r = uf_find(lab, p);
-        lab[p] = r;
-    }
-    const uint32_t pr = __shfl_up(r, 1, 64);
-    const bool head = lane == 0 || pr != r || !inb;
-    const unsigned long long heads = __ballot(head);
-    if (head && r != NULL_LAB) {
-        const unsigned long long nxt = (lane == 63) ? 0ull : (heads & ~((2ull << lane) - 1ull));
-        const unsigned nl = nxt ? (unsigned)__builtin_ctzll(nxt) : 64u;
-        atomicAdd(&csize[r], nl - lane);
+    if (p >= n || lab[p] == NULL_LAB) return;
+    const uint32_t r = uf_find(lab, p);
+    lab[p] = r;
+    if (r != p) {
+        const uint32_t s = csize[p];
+        if (s) atomicAdd(&csize[r], s);
     }
 }
 
@@ -632,8 +724,14 @@ static int run_clump(shp_ctx *ctx, const uint16_t *d_clus, uint32_t nrows, uint3
     const unsigned g = grid_for(n, 256);
     hipStream_t st = ctx->stream;
     int ps = prof_begin(ctx, PROF_CCL);
-    hipLaunchKernelGGL(k_ccl_init, dim3(g), dim3(256), 0, st, d_clus, lab, n, ncols, csize); KCHK(ctx);
-    hipLaunchKernelGGL(k_ccl_merge, dim3(g), dim3(256), 0, st, d_clus, lab, n, nrows, ncols, four); KCHK(ctx);
+    hipLaunchKernelGGL(k_ccl_local, dim3(grid_for(ncols, 64), grid_for(nrows, CCL_ROWS)), dim3(256), 0, st, d_clus,
+                       lab, csize, nrows, ncols, four); KCHK(ctx);
+    {
+        const uint32_t ntop = (nrows + CCL_ROWS - 1u) / CCL_ROWS, npc = (ncols + 63u) / 64u;
+        const size_t nborder = (size_t)ntop * ncols + (size_t)nrows * 2u * npc;
+        hipLaunchKernelGGL(k_ccl_border, dim3(grid_for(nborder, 256)), dim3(256), 0, st, d_clus, lab, nrows, ncols,
+                           four, ntop, npc); KCHK(ctx);
+    }
     hipLaunchKernelGGL(k_ccl_flatten, dim3(g), dim3(256), 0, st, lab, n, csize); KCHK(ctx);
     prof_end(ctx, ps);
     HIPCHK(ctx, hipMemsetAsync(counters, 0, 16, st));

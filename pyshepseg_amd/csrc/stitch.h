@@ -23,33 +23,60 @@ __device__ __forceinline__ uint32_t hash64(unsigned long long k)
     return (uint32_t)k;
 }
 
-// strip geometry: pixel i of the strip -> (r, c) of the tile, r < srows, c < scols
+// Per segment of a strip (rows < srows, cols < scols of the tile): min and max+1 of the row index
+// (horizontal) or of the column index (vertical); mx = 0 means absent.
+// Only corner pixels can hold an extreme: the topmost pixel of a segment's leftmost column has
+// neither the segment above it nor to its left, and so on for the other extremes.  That leaves a
+// handful of candidates per segment; they are combined per 32 x 64 patch in LDS (AggTable) and
+// flushed with one pruned global atomic per (patch, segment, field).
 __global__ __launch_bounds__(256) void k_strip_minmax(const uint32_t *__restrict__ tile, uint32_t xs,
                                                       uint32_t srows, uint32_t scols, int horizontal,
                                                       uint32_t *mn, uint32_t *mx)
 {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= srows * scols) return;
-    const uint32_t r = i / scols, c = i - r * scols;
-    const uint32_t s = tile[r * xs + c];
-    if (s == 0) return;
-    // Only corner pixels can hold an extreme: the topmost pixel of a segment's leftmost column has
-    // neither the segment above it nor to its left, and so on for the other three extremes.  That
-    // leaves a handful of candidates per segment, so the atomics no longer pile up on one address
-    // (rows of a segment are processed concurrently, pre-reads alone cannot prune them).
-    const uint32_t q = r * xs + c;
-    const bool ldiff = c == 0 || tile[q - 1] != s;
-    const bool udiff = r == 0 || tile[q - xs] != s;
-    if (horizontal) {
-        if (!ldiff) return;
-        const bool ddiff = r + 1u == srows || tile[q + xs] != s;
-        if (udiff && r < mn[s]) atomicMin(&mn[s], r);
-        if (ddiff && r + 1u > mx[s]) atomicMax(&mx[s], r + 1u);     // mx holds max+1 (0 = absent)
-    } else {
-        if (!udiff) return;
-        const bool rdiff = c + 1u == scols || tile[q + 1] != s;
-        if (ldiff && c < mn[s]) atomicMin(&mn[s], c);
-        if (rdiff && c + 1u > mx[s]) atomicMax(&mx[s], c + 1u);
+    __shared__ AggTable tab;
+    agg_init(tab, 0xFFFFFFFFu, 0u, 0u);
+    __syncthreads();
+    const unsigned lane = lane_id(), wv = threadIdx.x >> 6;
+    const uint32_t c = blockIdx.x * 64u + lane;
+    const uint32_t r0 = blockIdx.y * AGG_ROWS + wv * (AGG_ROWS / 4u);
+    const bool cin = c < scols;
+    uint32_t above = (cin && r0 > 0u && r0 <= srows) ? tile[(size_t)(r0 - 1u) * xs + c] : 0u;
+    uint32_t cur = (cin && r0 < srows) ? tile[(size_t)r0 * xs + c] : 0u;
+    for (uint32_t i = 0; i < AGG_ROWS / 4u; i++) {
+        const uint32_t r = r0 + i;
+        if (r >= srows) break;                               // uniform per wavefront
+        const uint32_t below = (cin && r + 1u < srows) ? tile[(size_t)(r + 1u) * xs + c] : 0u;
+        const uint32_t s = cur;
+        uint32_t lf = __shfl_up(s, 1, 64), rt = __shfl_down(s, 1, 64);
+        if (lane == 0) lf = (cin && c > 0u) ? tile[(size_t)r * xs + c - 1u] : 0u;
+        if (lane == 63) rt = (c + 1u < scols) ? tile[(size_t)r * xs + c + 1u] : 0u;
+        if (cin && c + 1u == scols) rt = 0u;                 // the strip ends here
+        if (s != 0u) {
+            const bool ldiff = lf != s, udiff = above != s;
+            bool lo, hi;
+            uint32_t v;
+            if (horizontal) { v = r; lo = ldiff && udiff; hi = ldiff && below != s; }
+            else            { v = c; lo = ldiff && udiff; hi = udiff && rt != s; }
+            if (lo || hi) {
+                const int h = agg_slot(tab, s);
+                if (h >= 0) {
+                    if (lo) atomicMin(&tab.v[0][h], v);
+                    if (hi) atomicMax(&tab.v[1][h], v + 1u);
+                } else {
+                    if (lo) atomicMin(&mn[s], v);
+                    if (hi) atomicMax(&mx[s], v + 1u);
+                }
+            }
+        }
+        above = cur;
+        cur = below;
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < AGG_SLOTS; i += 256u) {
+        const uint32_t s = tab.key[i];
+        if (s == 0u) continue;
+        if (tab.v[0][i] < mn[s]) atomicMin(&mn[s], tab.v[0][i]);
+        if (tab.v[1][i] > mx[s]) atomicMax(&mx[s], tab.v[1][i]);
     }
 }
 
@@ -204,7 +231,7 @@ static int stitch_strip(shp_ctx *ctx, const uint32_t *tile, uint32_t xs, uint32_
     HIPCHK(ctx, hipMemsetAsync(keys, 0, (size_t)hsize * 8, st));
     HIPCHK(ctx, hipMemsetAsync(cnts, 0, (size_t)hsize * 4, st));
     const unsigned g = grid_for(npx, 256);
-    hipLaunchKernelGGL(k_strip_minmax, dim3(g), dim3(256), 0, st, tile, xs, srows, scols, horizontal, mn, mx); KCHK(ctx);
+    hipLaunchKernelGGL(k_strip_minmax, dim3(grid_for(scols, 64), grid_for(srows, AGG_ROWS)), dim3(256), 0, st, tile, xs, srows, scols, horizontal, mn, mx); KCHK(ctx);
     hipLaunchKernelGGL(k_pair_count, dim3(g), dim3(256), 0, st, tile, xs, srows, scols, B, bpitch, mn, mx,
                        mid, keys, cnts, hsize - 1u); KCHK(ctx);
     hipLaunchKernelGGL(k_pair_best, dim3(grid_for(hsize, 256)), dim3(256), 0, st, keys, cnts, hsize, best); KCHK(ctx);
@@ -390,8 +417,8 @@ static int run_stitch_prepare(shp_ctx *ctx, const uint32_t *d_tile, uint32_t ys,
         if (srows * scols == 0) continue;
         HIPCHK(ctx, hipMemsetAsync(mn, 0xff, (size_t)nseg * 4, st));
         HIPCHK(ctx, hipMemsetAsync(mx, 0, (size_t)nseg * 4, st));
-        hipLaunchKernelGGL(k_strip_minmax, dim3(grid_for(srows * scols, 256)), dim3(256), 0, st, d_tile, xs,
-                           srows, scols, horizontal, mn, mx); KCHK(ctx);
+        hipLaunchKernelGGL(k_strip_minmax, dim3(grid_for(scols, 64), grid_for(srows, AGG_ROWS)), dim3(256), 0, st,
+                           d_tile, xs, srows, scols, horizontal, mn, mx); KCHK(ctx);
         hipLaunchKernelGGL(k_meta_cross, dim3(grid_for(nseg, 256)), dim3(256), 0, st, mn, mx,
                            (horizontal ? srows : scols) / 2u, nseg,
                            horizontal ? META_CROSS_TOP : META_CROSS_LEFT, flags); KCHK(ctx);
