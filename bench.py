@@ -25,7 +25,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 # must be in the environment before the HIP runtime starts (torch initialises it first when N > 1)
-os.environ.setdefault('GPU_MAX_HW_QUEUES', '20')
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '24')
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
@@ -39,7 +39,7 @@ def parse():
     ap.add_argument('--bands', type=int, default=6)
     ap.add_argument('--tile', type=int, default=4096)
     ap.add_argument('--overlap', type=int, default=1024)
-    ap.add_argument('--workers', type=int, default=int(os.environ.get('SHEPSEG_WORKERS', '16')))
+    ap.add_argument('--workers', type=int, default=int(os.environ.get('SHEPSEG_WORKERS', '20')))
     ap.add_argument('--simple-recode', type=int, default=0, help='diagnostic: simpleTileRecode')
     ap.add_argument('--cpu-sample', type=int, default=9216,
                     help='window edge of the cpu_baseline sample (0 = skip)')

@@ -10,7 +10,7 @@ import threading
 
 # more hardware queues than ROCm's default of 4, so that the per-tile worker streams do not
 # queue behind each other's long-running kernels (must be set before the HIP runtime starts)
-os.environ.setdefault('GPU_MAX_HW_QUEUES', '20')
+os.environ.setdefault('GPU_MAX_HW_QUEUES', '24')
 
 import numpy
 

@@ -107,7 +107,7 @@ static inline void prof_collect(shp_ctx *ctx)
 #define KCHK(ctx) HIPCHK(ctx, hipGetLastError())
 
 // the side stream is only created when a call really forks: every stream costs a slot in the
-// 16 hardware queues the worker streams are spread over
+// hardware queues (GPU_MAX_HW_QUEUES, 24 by default here) the worker streams are spread over
 static inline int ensure_stream2(shp_ctx *ctx)
 {
     if (ctx->stream2) return 0;

@@ -623,7 +623,7 @@ __global__ __launch_bounds__(256) void k_small_loop(SmallArgs a)
 static std::mutex g_small_mu;
 static std::condition_variable g_small_cv;
 static int g_small_running = 0;
-#define SMALL_MAX_CONCURRENT 16
+#define SMALL_MAX_CONCURRENT 20
 static const int g_small_max = getenv("SHEPSEG_SMALL_MAX") ? atoi(getenv("SHEPSEG_SMALL_MAX")) : SMALL_MAX_CONCURRENT;
 
 static inline int bits_for(uint32_t maxval)
@@ -733,7 +733,8 @@ static int run_eliminate_small(shp_ctx *ctx, const void *d_img, int dtype, int n
         g_small_cv.wait(lk, [] { return g_small_running < g_small_max; });
         g_small_running++;
     }
-    hipLaunchKernelGGL(k_small_loop, dim3(SMALL_BLOCKS), dim3(256), 0, st, args);
+    static const unsigned small_blocks = getenv("SHEPSEG_SMALL_BLOCKS") ? (unsigned)atoi(getenv("SHEPSEG_SMALL_BLOCKS")) : SMALL_BLOCKS;
+    hipLaunchKernelGGL(k_small_loop, dim3(small_blocks), dim3(256), 0, st, args);
     hipError_t lerr = hipGetLastError();
     hipError_t cerr = hipMemcpyAsync(pin, ctl, sizeof(SmallCtl), hipMemcpyDeviceToHost, st);
     hipError_t serr = hipStreamSynchronize(st);
