@@ -261,9 +261,11 @@ __global__ __launch_bounds__(256) void k_small_init(const uint32_t *__restrict__
 
 // ---------------------------------------------------------------------------------------------
 // The find/merge pass loop of eliminateSmallSegments (shepseg.py:970-997) as ONE persistent
-// kernel per tile.  A pass needs six grid-wide dependencies (find -> mark -> alloc -> fill ->
-// rank -> apply); as separate launches that was ~400 tiny dispatches per tile, each costing
-// 0.1-0.3 ms once 16 tiles share the GPU.  Here SMALL_BLOCKS workgroups stay resident and
+// kernel per tile.  A pass needs three grid-wide dependencies (find -> link sources to targets
+// in ascending id + relabel pixels -> apply); as separate launches that was hundreds of tiny
+// dispatches per tile, each costing 0.1-0.3 ms once 16 tiles share the GPU (an earlier version
+// built the per-target source lists with count / allocate / fill / rank phases: six barriers;
+// a lock-free sorted insert does it in one).  Here SMALL_BLOCKS workgroups stay resident and
 // meet at software grid barriers (agent-scope release / acquire as MI355X_MICROARCH.md and
 // cdna_hip_programming.md Guideline 16 prescribe: every storing wave drains vmcnt, workgroup
 // barrier, one lane's release fence, arrive; poll; one lane's acquire fence, drain, workgroup
@@ -506,23 +508,29 @@ __global__ __launch_bounds__(256) void k_small_loop(SmallArgs a)
         }
         if (!small_grid_barrier(ctl, G)) return;
         const uint32_t nsrc = cnt->nsrc;
-        // ---- merge step 1: count sources per target and list the targets (thread per source,
-        //      one counter atomic per wavefront), then relabel the sources' pixels (wave per
-        //      source; doMerge :1107-1109) ----
-        for (uint32_t i0 = 0; i0 < nsrc; i0 += gthreads) {
-            const uint32_t i = i0 + gtid;
-            uint32_t t = 0;
-            bool first = false;
-            if (i < nsrc) {
-                t = a.mergeto[a.srclist[i]];
-                if (t != 0) first = atomicAdd(&a.tcount[t], 1u) == 0u;
-            }
-            const unsigned long long mf = __ballot(first);
-            if (mf != 0ull) {
-                uint32_t base = 0;
-                if (lane == 0) base = atomicAdd(&cnt->ntgt, (uint32_t)__popcll(mf));
-                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-                if (first) a.tgtlist[base + (uint32_t)__popcll(mf & lanemask_lt())] = t;
+        // ---- merge step 1: every source links itself into its target's list, kept in ascending
+        //      source id by a lock-free sorted insert (head in tfill[t], links in tlist[s]; inserts
+        //      only, so a failed CAS simply retries), the first one to arrive registers the
+        //      target; then the sources' pixels are relabelled (wave per source; doMerge
+        //      :1107-1109).  One phase instead of count / allocate / fill / rank. ----
+        for (uint32_t i = gtid; i < nsrc; i += gthreads) {
+            const uint32_t s = a.srclist[i];
+            const uint32_t t = a.mergeto[s];
+            if (t == 0) continue;
+            for (uint32_t tries = 0;; tries++) {
+                uint32_t prev = 0, cur = L2LOAD(&a.tfill[t]);
+                while (cur != 0 && cur < s) { prev = cur; cur = L2LOAD(&a.tlist[cur]); }
+                __hip_atomic_store(&a.tlist[s], cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");      // link visible before s is
+                uint32_t *slot = prev ? &a.tlist[prev] : &a.tfill[t];
+                if (atomicCAS(slot, cur, s) == cur) {
+                    if (prev == 0 && cur == 0) a.tgtlist[atomicAdd(&cnt->ntgt, 1u)] = t;   // list was empty
+                    break;
+                }
+                if (tries > SMALL_SPIN_LIMIT) {
+                    __hip_atomic_store(&ctl->fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
             }
         }
         for (uint32_t i = gwave; i < nsrc; i += gwaves) {
@@ -537,42 +545,6 @@ __global__ __launch_bounds__(256) void k_small_loop(SmallArgs a)
         }
         if (!small_grid_barrier(ctl, G)) return;
         const uint32_t ntgt = cnt->ntgt;
-        // ---- storage for each target's source list (wave prefix sum, one bump atomic/wave) ----
-        for (uint32_t i0 = 0; i0 < ntgt; i0 += gthreads) {
-            const uint32_t i = i0 + gtid;
-            const uint32_t t = (i < ntgt) ? a.tgtlist[i] : 0u;
-            const uint32_t c = (i < ntgt) ? a.tcount[t] : 0u;
-            uint32_t incl = c;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) {
-                const uint32_t o = __shfl_up(incl, d, 64);
-                if (lane >= (unsigned)d) incl += o;
-            }
-            const uint32_t tot = __shfl(incl, 63, 64);
-            uint32_t base = 0;
-            if (lane == 0 && tot) base = atomicAdd(&cnt->bump, tot);
-            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-            if (i < ntgt) a.toff[t] = base + incl - c;
-        }
-        if (!small_grid_barrier(ctl, G)) return;
-        for (uint32_t i = gtid; i < nsrc; i += gthreads) {
-            const uint32_t s = a.srclist[i];
-            const uint32_t t = a.mergeto[s];
-            if (t == 0) continue;
-            a.tlist[a.toff[t] + atomicAdd(&a.tfill[t], 1u)] = s;
-        }
-        if (!small_grid_barrier(ctl, G)) return;
-        // ---- rank of every source inside its target's list (ascending id) ----
-        for (uint32_t i = gtid; i < nsrc; i += gthreads) {
-            const uint32_t s = a.srclist[i];
-            const uint32_t t = a.mergeto[s];
-            if (t == 0) continue;
-            const uint32_t base = a.toff[t], n = a.tcount[t];
-            uint32_t rank = 0;
-            for (uint32_t j = 0; j < n; j++) rank += (a.tlist[base + j] < s) ? 1u : 0u;
-            a.tsorted[base + rank] = s;
-        }
-        if (!small_grid_barrier(ctl, G)) return;
         // ---- merge step 2: each target absorbs its sources in ascending id (doMerge :1112-1123)
         //      size-histogram updates go through LDS, numElim through a wave reduction ----
         for (uint32_t b = threadIdx.x; b < 256u; b += 256u) lhist[b] = 0;
@@ -580,11 +552,10 @@ __global__ __launch_bounds__(256) void k_small_loop(SmallArgs a)
         uint32_t my_elim = 0;
         for (uint32_t i0 = gtid; i0 < ntgt; i0 += gthreads) {
             const uint32_t t = a.tgtlist[i0];
-            const uint32_t n = a.tcount[t], base = a.toff[t];
             const uint32_t a0 = a.segsz[t];
-            uint32_t sz = a0, tail = a.chtail[t];
-            for (uint32_t i = 0; i < n; i++) {
-                const uint32_t s = a.tsorted[base + i];
+            uint32_t sz = a0, tail = a.chtail[t], n = 0;
+            for (uint32_t s = a.tfill[t]; s != 0;) {
+                const uint32_t nxt = a.tlist[s];
                 for (int b = 0; b < a.nb; b++) {
                     a.ssum[(size_t)t * a.nb + b] = a.ssum[(size_t)t * a.nb + b] + a.ssum[(size_t)s * a.nb + b];
                     a.ssum[(size_t)s * a.nb + b] = 0.0f;
@@ -594,10 +565,11 @@ __global__ __launch_bounds__(256) void k_small_loop(SmallArgs a)
                 a.chnext[tail] = s;
                 tail = a.chtail[s];
                 a.mergeto[s] = 0;
+                n++;
+                s = nxt;
             }
             a.segsz[t] = sz;
             a.chtail[t] = tail;
-            a.tcount[t] = 0;
             a.tfill[t] = 0;
             my_elim += n;
             // histogram of sizes < min_seg: bins < 256 via LDS (signed deltas as uint32 wrap)
