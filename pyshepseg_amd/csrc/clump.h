@@ -451,11 +451,12 @@ __device__ __forceinline__ void dfs_split_global(uint32_t *lab, const BigInfo &B
 #define DFS_BMW_SMALL 6144u  // class A bitmap words (196608 bounding-box pixels, 24 KiB)
 #define DFS_BMW_LARGE 16384u // class B bitmap words (524288 bounding-box pixels, 64 KiB)
 
+// The bitmap carries a one-bit border of zeros on every side, so the walk needs no bounds checks.
 __device__ __forceinline__ unsigned long long dfs_bitmap_words(const BigInfo &B, uint32_t ncols)
 {
     const uint32_t minr = B.root / ncols;
     const uint32_t H = B.maxr - minr + 1u, W = B.maxc - B.minc + 1u;
-    return (unsigned long long)H * ((W + 31u) >> 5);
+    return (unsigned long long)(H + 2u) * ((W + 2u + 31u) >> 5);
 }
 
 __device__ __forceinline__ void dfs_split_lds(uint32_t *lab, const BigInfo &B, uint32_t *bm,
@@ -468,18 +469,21 @@ __device__ __forceinline__ void dfs_split_lds(uint32_t *lab, const BigInfo &B, u
     const unsigned lane = lane_id();
     const unsigned long long lt = lanemask_lt();
     const uint32_t minr = root / ncols, minc = B.minc;
-    const uint32_t H = B.maxr - minr + 1u, W = B.maxc - minc + 1u, wpr = (W + 31u) >> 5;
-    const uint32_t nwords = H * wpr;
+    const uint32_t H = B.maxr - minr + 1u, W = B.maxc - minc + 1u, wpr = (W + 2u + 31u) >> 5;
+    const uint32_t nwords = (H + 2u) * wpr;
+    // padded coordinates: member (y, x) of the box sits at row y + 1, bit column x + 1;
+    // its pixel index is gbase + (y + 1) * ncols + (x + 1)   (mod 2^32)
+    const uint32_t gbase = (minr - 1u) * ncols + minc - 1u;
     // ---- build the member bitmap from the flattened CCL labels ----
-    for (uint32_t r = 0; r < H; r++) {
-        const uint32_t rowbase = (minr + r) * ncols + minc;
-        for (uint32_t c0 = 0; c0 < W; c0 += 64u) {
-            const uint32_t c = c0 + lane;
-            const bool mem = c < W && lab[rowbase + c] == root;
+    for (uint32_t pr = 0; pr < H + 2u; pr++) {
+        const bool rin = pr >= 1u && pr <= H;
+        for (uint32_t c0 = 0; c0 < wpr * 32u; c0 += 64u) {
+            const uint32_t bc = c0 + lane;
+            const bool mem = rin && bc >= 1u && bc <= W && lab[gbase + pr * ncols + bc] == root;
             const unsigned long long m = __ballot(mem);
             if (lane == 0) {
-                bm[r * wpr + (c0 >> 5)] = (uint32_t)m;
-                if ((c0 >> 5) + 1u < wpr) bm[r * wpr + (c0 >> 5) + 1u] = (uint32_t)(m >> 32);
+                bm[pr * wpr + (c0 >> 5)] = (uint32_t)m;
+                if ((c0 >> 5) + 1u < wpr) bm[pr * wpr + (c0 >> 5) + 1u] = (uint32_t)(m >> 32);
             }
         }
     }
@@ -494,6 +498,7 @@ __device__ __forceinline__ void dfs_split_lds(uint32_t *lab, const BigInfo &B, u
         dx = (l8 < 3u) ? -1 : (l8 < 5u) ? 0 : 1;
         dy = (l8 == 0u || l8 == 3u || l8 == 5u) ? -1 : (l8 == 1u || l8 == 6u) ? 0 : 1;
     }
+    const bool qlane = lane < nq;
     uint32_t wcur = 0;                           // first word that can still hold a set bit
     for (;;) {
         // ---- next seed = first set bit in raster order ----
@@ -512,7 +517,7 @@ __device__ __forceinline__ void dfs_split_lds(uint32_t *lab, const BigInfo &B, u
         if (sword == 0xFFFFFFFFu) break;
         wcur = sword;
         const uint32_t sy = sword / wpr, sx = ((sword - sy * wpr) << 5) + (uint32_t)__builtin_ctz(sbits);
-        const uint32_t seed = (minr + sy) * ncols + minc + sx;
+        const uint32_t seed = gbase + sy * ncols + sx;
         const uint32_t FL = seed | VIS_FLAG;
         if (lane == 0) {
             lab[seed] = FL;
@@ -524,15 +529,15 @@ __device__ __forceinline__ void dfs_split_lds(uint32_t *lab, const BigInfo &B, u
         bool have = true;
         uint32_t cnt = 0;
         while (have && cnt < MAX_CLUMP_SIZE) {
-            const int ny = (int)ty + dy, nx = (int)tx + dx;
-            const bool valid = lane < nq && ny >= 0 && nx >= 0 && ny < (int)H && nx < (int)W;
-            const uint32_t wi = (uint32_t)ny * wpr + ((uint32_t)nx >> 5);
-            const uint32_t bit = 1u << ((uint32_t)nx & 31u);
-            const bool avail = valid && (bm[valid ? wi : 0u] & bit) != 0u;
+            // no bounds checks: the border bits are zero.  24-bit multiplies are full rate.
+            const uint32_t ny = ty + (uint32_t)dy, nx = tx + (uint32_t)dx;
+            const uint32_t wi = qlane ? __umul24(ny, wpr) + (nx >> 5) : 0u;
+            const uint32_t bit = 1u << (nx & 31u);
+            const bool avail = qlane && (bm[wi] & bit) != 0u;
             const unsigned long long m = __ballot(avail);
             if (avail) {
                 atomicAnd(&bm[wi], ~bit);
-                lab[(minr + (uint32_t)ny) * ncols + minc + (uint32_t)nx] = FL;
+                lab[gbase + __umul24(ny, ncols) + nx] = FL;
             }
             const uint32_t npush = (uint32_t)__popcll(m);
             if (npush == 0) {
@@ -565,7 +570,7 @@ __device__ __forceinline__ void dfs_split_lds(uint32_t *lab, const BigInfo &B, u
                     __builtin_amdgcn_wave_barrier();
                 }
                 const unsigned last = 63u - (unsigned)__clzll(m);
-                const uint32_t packed = ((uint32_t)ny << 16) | (uint32_t)nx;
+                const uint32_t packed = (ny << 16) | nx;
                 if (avail && lane != last) sw[sp_l + (uint32_t)__popcll(m & lt)] = packed;
                 sp_l += npush - 1u;
                 const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)packed, (int)last);
