@@ -533,7 +533,8 @@ __device__ __forceinline__ void dfs_split_lds(uint32_t *lab, const BigInfo &B, u
             const uint32_t ny = ty + (uint32_t)dy, nx = tx + (uint32_t)dx;
             const uint32_t wi = qlane ? __umul24(ny, wpr) + (nx >> 5) : 0u;
             const uint32_t bit = 1u << (nx & 31u);
-            const bool avail = qlane && (bm[wi] & bit) != 0u;
+            const uint32_t word = bm[wi];                   // unconditional: no exec-mask detour
+            const bool avail = qlane & ((word & bit) != 0u);
             const unsigned long long m = __ballot(avail);
             if (avail) {
                 atomicAnd(&bm[wi], ~bit);
