@@ -448,7 +448,7 @@ __device__ __forceinline__ void dfs_split_global(uint32_t *lab, const BigInfo &B
 // in LDS (64 KiB), so a pop costs one LDS round trip instead of a dependent HBM/L2 access, and the walk
 // no longer suffers when other streams pollute L2.  Labels are still written to `lab` with
 // fire-and-forget stores.  Components that do not fit take dfs_split_global.
-#define DFS_BMW_SMALL 6144u  // class A bitmap words (196608 bounding-box pixels, 24 KiB)
+#define DFS_BMW_SMALL 10240u // class A bitmap words (327680 padded bounding-box pixels, 40 KiB)
 #define DFS_BMW_LARGE 16384u // class B bitmap words (524288 bounding-box pixels, 64 KiB)
 
 // The bitmap carries a one-bit border of zeros on every side, so the walk needs no bounds checks.
@@ -605,11 +605,14 @@ __global__ __launch_bounds__(256) void k_big_order(const BigInfo *__restrict__ b
     order[rank] = i;
 }
 
-// Two launches per tile share this kernel: class A (bitmap <= 24 KiB: ~90 % of the components,
-// 30 KiB of LDS per workgroup so five fit a CU and other kernels still find LDS) and class B
-// (<= 64 KiB bitmap, or no bitmap at all -> global path).  Keeping the footprint small matters:
-// with 80 KiB per workgroup the replays of 16 concurrent tiles filled every CU's LDS and
-// starved every other kernel that needs a few KiB of it.
+// Two launches per tile share this kernel: class A (bitmap <= 40 KiB: nearly all components,
+// 46 KiB of LDS per workgroup so three fit a CU and other kernels still find LDS) and class B
+// (<= 64 KiB bitmap, or no bitmap at all -> global path).  The two launches run one after the
+// other in the tile's stream, so the tile waits for the longest walk of EACH class: the
+// boundary sits where class B is nearly empty (24 KiB: 16.8 + 12.6 ms per tile, 40 KiB: 7.6 +
+// 16.0 ms).  Keeping the footprint below half a CU's LDS matters: with 80 KiB per workgroup
+// the replays of 16 concurrent tiles filled every CU's LDS and starved every other kernel that
+// needs a few KiB of it; forking the classes onto two streams oversubscribes the hardware queues.
 __global__ __launch_bounds__(64) void k_dfs_split(uint32_t *lab, const BigInfo *__restrict__ big,
                                                   const uint32_t *__restrict__ counters,
                                                   uint32_t *stackbuf, uint32_t nrows,
@@ -765,11 +768,12 @@ static int run_clump(shp_ctx *ctx, const uint16_t *d_clus, uint32_t nrows, uint3
         HIPCHK(ctx, hipEventRecord(ctx->evfork, st));
         HIPCHK(ctx, hipStreamWaitEvent(ctx->stream2, ctx->evfork, 0));
     }
+    static const uint32_t bmw_small = getenv("SHEPSEG_DFS_SMALL") ? (uint32_t)atoi(getenv("SHEPSEG_DFS_SMALL")) : DFS_BMW_SMALL;
     hipLaunchKernelGGL(k_dfs_split, dim3(maxbig), dim3(64), (DFS_SWN + DFS_BMW_LARGE) * 4, st, lab, big,
-                       counters, bp<uint32_t>(ctx->stack), nrows, ncols, four, DFS_BMW_SMALL,
+                       counters, bp<uint32_t>(ctx->stack), nrows, ncols, four, bmw_small,
                        DFS_BMW_LARGE, 1, d_singles, d_nsingles, order, csize); KCHK(ctx);
-    hipLaunchKernelGGL(k_dfs_split, dim3(maxbig), dim3(64), (DFS_SWN + DFS_BMW_SMALL) * 4, st2, lab,
-                       big, counters, bp<uint32_t>(ctx->stack), nrows, ncols, four, 0u, DFS_BMW_SMALL, 0,
+    hipLaunchKernelGGL(k_dfs_split, dim3(maxbig), dim3(64), (DFS_SWN + bmw_small) * 4, st2, lab,
+                       big, counters, bp<uint32_t>(ctx->stack), nrows, ncols, four, 0u, bmw_small, 0,
                        d_singles, d_nsingles, order, csize);
     KCHK(ctx);
     if (fork2) {
