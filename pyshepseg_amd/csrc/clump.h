@@ -301,34 +301,6 @@ __global__ __launch_bounds__(256) void k_big_bbox(const uint32_t *__restrict__ l
     }
 }
 
-// timing probe (SHEPSEG_PROBE=1): k_big_bbox without its atomics
-__global__ __launch_bounds__(256) void k_probe_bbox(const uint32_t *__restrict__ lab,
-                                                    const uint32_t *__restrict__ csize, uint32_t n,
-                                                    uint32_t ncols, BigInfo *big,
-                                                    const uint32_t *__restrict__ bigbits, uint32_t *sink, uint32_t magic)
-{
-    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
-    if (p >= n) return;
-    const uint32_t r = lab[p];
-    if (r == NULL_LAB) return;
-    if (!((bigbits[r >> 5] >> (r & 31u)) & 1u)) return;
-    const uint32_t row = p / ncols, col = p - row * ncols;
-    const bool ldiff = col == 0 || lab[p - 1] != r;
-    const bool udiff = p < ncols || lab[p - ncols] != r;
-    const bool rdiff = col + 1u == ncols || lab[p + 1] != r;
-    const bool ddiff = p + ncols >= n || lab[p + ncols] != r;
-    const bool cminc = ldiff && udiff, cmaxc = rdiff && udiff, cmaxr = ddiff && ldiff;
-    if (!(cminc || cmaxc || cmaxr)) return;
-    const uint32_t c = csize[r];
-    if (!(c & VIS_FLAG)) return;
-    const uint32_t bi = c & ~VIS_FLAG;
-    uint32_t acc = 0;
-    if (cminc && col < big[bi].minc) acc += 1;
-    if (cmaxc && col > big[bi].maxc) acc += 2;
-    if (cmaxr && row > big[bi].maxr) acc += 4;
-    if (acc == magic) *sink = 1;
-}
-
 // One wavefront per cut-able component: exact replay of shepseg.py:490-539 restricted to the
 // component (unvisited member pixels are exactly those with lab == root).
 //   * the explicit LIFO stack lives in an LDS window (oldest half spilled to / refilled from
@@ -750,11 +722,6 @@ static int run_clump(shp_ctx *ctx, const uint16_t *d_clus, uint32_t nrows, uint3
     hipLaunchKernelGGL(k_big_list, dim3(g), dim3(256), 0, st, lab, csize, n, ncols, big, counters, bigbits); KCHK(ctx);
     hipLaunchKernelGGL(k_big_bbox, dim3(grid_for(ncols, 64), grid_for(nrows, AGG_ROWS)), dim3(256), 0, st, lab,
                        csize, nrows, ncols, big, bigbits); KCHK(ctx);
-    static const int probe = getenv("SHEPSEG_PROBE") ? atoi(getenv("SHEPSEG_PROBE")) : 0;
-    if (probe) {
-        hipLaunchKernelGGL(k_probe_bbox, dim3(g), dim3(256), 0, st, lab, csize, n, ncols, big, bigbits, counters + 3, 0xFFFFFFFFu);
-        KCHK(ctx);
-    }
     ps = prof_begin(ctx, PROF_DFS);
     uint32_t *order = (uint32_t *)((char *)ctx->big.p + (size_t)maxbig * sizeof(BigInfo) + 64);
     hipLaunchKernelGGL(k_big_order, dim3(grid_for(maxbig, 256)), dim3(256), 0, st, big, counters, order); KCHK(ctx);

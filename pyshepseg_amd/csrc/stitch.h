@@ -376,26 +376,6 @@ __global__ __launch_bounds__(256) void k_meta_pixels(const uint32_t *__restrict_
     }
 }
 
-// timing probe (SHEPSEG_PROBE=1): k_meta_pixels without its atomics
-__global__ __launch_bounds__(256) void k_probe_meta(const uint32_t *__restrict__ tile, uint32_t ys,
-                                                    uint32_t xs, uint32_t top, uint32_t bottom,
-                                                    uint32_t left, uint32_t right, uint32_t *segtop,
-                                                    uint32_t *segleft, uint32_t *flags, uint32_t *sink, uint32_t magic)
-{
-    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
-    if (p >= ys * xs) return;
-    const uint32_t s = tile[p];
-    if (s == 0) return;
-    const uint32_t r = p / xs, c = p - r * xs;
-    const bool ldiff = c == 0 || tile[p - 1] != s;
-    const bool udiff = r == 0 || tile[p - xs] != s;
-    uint32_t acc = 0;
-    if (ldiff && udiff) { if (r < segtop[s]) acc += 1; if (c < segleft[s]) acc += 2; }
-    const bool inwin = r >= top && r < bottom && c >= left && c < right;
-    if (inwin && (ldiff || c == left) && (udiff || r == top) && !(flags[s] & META_IN_TRIM)) acc += 4;
-    if (acc == magic) *sink = 1;
-}
-
 static int run_stitch_prepare(shp_ctx *ctx, const uint32_t *d_tile, uint32_t ys, uint32_t xs,
                               uint32_t overlap, int has_top, int has_left, uint32_t max_local,
                               uint32_t top, uint32_t bottom, uint32_t left, uint32_t right,
@@ -425,11 +405,6 @@ static int run_stitch_prepare(shp_ctx *ctx, const uint32_t *d_tile, uint32_t ys,
     }
     hipLaunchKernelGGL(k_meta_pixels, dim3(grid_for(xs, 64), grid_for(ys, AGG_ROWS)), dim3(256), 0, st, d_tile,
                        ys, xs, top, bottom, left, right, segtop, segleft, flags); KCHK(ctx);
-    static const int probe = getenv("SHEPSEG_PROBE") ? atoi(getenv("SHEPSEG_PROBE")) : 0;
-    if (probe) {
-        hipLaunchKernelGGL(k_probe_meta, dim3(grid_for(n, 256)), dim3(256), 0, st, d_tile, ys, xs, top, bottom,
-                           left, right, segtop, segleft, flags, flags, 0xFFFFFFFFu); KCHK(ctx);
-    }
     return 0;
 }
 
