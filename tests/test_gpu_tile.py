@@ -194,3 +194,55 @@ def test_default_kmeanspp_path_runs(shepseg, oracle):
     assert r.kmeans.cluster_centers_.shape == (8, 3) and r.kmeans.inertia_ > 0
     want = oracle.segment_tile(img, r.kmeans.cluster_centers_, 15, float(r.maxSpectralDiff), None, True)
     assert np.array_equal(r.segimg, want['segimg'])
+
+
+def test_many_sources_one_target(shepseg, oracle):
+    """Hundreds of equal-size small segments merge into ONE target in the same pass: the sources
+    must be absorbed in ascending id (the float32 spectral sums depend on the order), which the
+    pass loop gets from a lock-free sorted insert under heavy contention."""
+    rng = np.random.RandomState(12)
+    nb, nr, nc = 3, 300, 400
+    img = np.empty((nb, nr, nc), dtype=np.uint16)
+    img[:] = np.array([20000, 30000, 40000], dtype=np.uint16)[:, None, None]       # the background
+    blobs = 0
+    for y in range(4, nr - 4, 6):
+        for x in range(4, nc - 4, 7):
+            v = np.array([20000, 30000, 40000]) + rng.randint(3000, 9000, size=nb)    # distinct values
+            img[:, y, x:x + 3] = v[:, None].astype(np.uint16)                      # 3-pixel blobs
+            blobs += 1
+    km = shepseg.KMeansModel(np.array([[20000., 30000., 40000.], [26000., 36000., 46000.]]))
+    elim = []
+    for minseg, msd in ((10, 1e9), (10, 11000.0)):
+        r = shepseg.doShepherdSegmentation(img, kmeansObj=km, minSegmentSize=minseg, maxSpectralDiff=msd)
+        want = oracle.segment_tile(img, km.cluster_centers_, minseg, msd, None, True)
+        assert np.array_equal(r.segimg, want['segimg'])
+        assert r.smallSegmentsEliminated == want['smallSegmentsEliminated']
+        elim.append(want['smallSegmentsEliminated'])
+    # every blob joins the background when nothing is too different; only some with a threshold
+    assert blobs > 2000 and elim[0] >= blobs and 0 < elim[1] < blobs
+
+
+@pytest.mark.parametrize('four', [True, False])
+def test_tiny_min_segment_size_patch_tables(four, shepseg, oracle):
+    """minSegmentSize 2 on noise leaves hundreds of segments per 32 x 64 patch: the per-patch
+    LDS aggregation tables overflow and their direct-to-global path is taken (stitch prepare),
+    odd image sizes exercise the ragged patches of the patch-local CCL."""
+    from pyshepseg_amd import tiling
+    rng = np.random.RandomState(3)
+    img = rng.randint(0, 4, size=(2, 333, 517)).astype(np.uint8) * 60
+    km = shepseg.KMeansModel(np.array([[0., 0.], [60., 60.], [120., 120.], [180., 180.]]))
+    r = shepseg.doShepherdSegmentation(img, kmeansObj=km, minSegmentSize=2, fourConnected=four)
+    want = oracle.segment_tile(img, km.cluster_centers_, 2, float(r.maxSpectralDiff), None, four)
+    assert np.array_equal(r.segimg, want['segimg'])
+    # the tiled driver on the same image: stitch tables with > 128 segments per patch
+    cfg = tiling.SegmentationConcurrencyConfig(concurrencyType=tiling.CONC_THREADS, numWorkers=2)
+    t = tiling.doTiledShepherdSegmentation(img, None, tileSize=160, overlapSize=48, minSegmentSize=2,
+                                           kmeansObj=km, fourConnected=four, concurrencyCfg=cfg)
+    tiles, ntc, ntr = oracle.get_tiles(333, 517, 160, 48)
+    local = {}
+    for (c, rr), (x, y, xs, ys) in tiles.items():
+        sub = np.ascontiguousarray(img[:, y:y + ys, x:x + xs])
+        local[(c, rr)] = oracle.segment_tile(sub, km.cluster_centers_, 2, float(t.maxSpectralDiff),
+                                             None, four)['segimg']
+    wt, mx, hist = oracle.stitch_tiles(local, tiles, ntc, ntr, 333, 517, 48)
+    assert t.maxSegId == mx and np.array_equal(t.segimg, wt) and np.array_equal(t.hist, hist)
