@@ -4,15 +4,19 @@ xGMI on the GPU box, gloo in the CPU tests).
 What shards and what does not
 -----------------------------
 * Tiles are independent once the global k-means model is known (reference tiling.py:1430-1453),
-  so tile ROWS are dealt to ranks in contiguous blocks balanced by area; every rank holds only
-  its slice of the raster and of the stitched output.  No collective on that path.
+  so the tiles, in row-major order, are dealt to ranks in contiguous ranges balanced by area
+  (whole tile rows when there are too few tiles per rank); every rank holds only the rows of the
+  raster its tiles need and the rows of the stitched output they write.  No collective on that
+  path.
 * The cross-tile stitch is specified sequentially (reference stitchTiles, tiling.py:979-1043:
   every tile's new ids start after the largest id of all earlier tiles, and shared segments
   take the id the tile above / to the left already gave them).  It is kept exactly that way:
-  rank r stitches its rows as soon as it has received, from the rank holding the rows above,
-  the running maxSegId and the recoded bottom overlap strips of that rank's last tile row --
-  the one real exchange step (point-to-point send/recv, <= 25 MB per strip) -- and passes its
-  own on.  A final all-reduce sums the per-rank histograms.
+  rank r stitches its tiles as soon as it has received, from the rank holding the tiles before,
+  the running maxSegId, the recoded bottom overlap strips of that rank's last ncols tiles (the
+  top neighbours of this rank's first tiles) and, when this rank starts in the middle of a tile
+  row, the right strip of the tile before -- the one real exchange step (point-to-point
+  send/recv, <= 25 MB per strip) -- and passes its own on.  A final all-reduce sums the
+  per-rank histograms.
 * The k-means fit runs on rank 0 from the sub-sample gathered from every rank's slice; the
   centres (k x nBands float64) are broadcast.
 
@@ -69,6 +73,67 @@ def shardTileRows(tileInfo, world):
         last = max(i for i, (a, b) in enumerate(out) if b > a)
         out[last] = (out[last][0], nrows)
     return out
+
+
+def shardTiles(tileInfo, world):
+    """Contiguous ranges [t0, t1) of tiles (row-major index row * ncols + col) per rank, balanced
+    by pixel area.  Every rank that has a successor holds at least ncols tiles, so a tile's top
+    neighbour is either local or in the previous rank; with fewer than ncols tiles per rank the
+    ranges are whole tile rows (shardTileRows), which has the same property."""
+    (ncols, nrows) = (tileInfo.ncols, tileInfo.nrows)
+    nt = ncols * nrows
+    if world <= 1:
+        return [(0, nt)]
+    if nt // world < ncols:
+        return [(a * ncols, b * ncols) for (a, b) in shardTileRows(tileInfo, world)]
+    weights = []
+    for r in range(nrows):
+        for c in range(ncols):
+            (_x, _y, xs, ys) = tileInfo.getTile(c, r)
+            weights.append(xs * ys)
+    total = float(sum(weights))
+    out = []
+    i = 0
+    acc = 0.0
+    for k in range(world):
+        i0 = i
+        later = world - k - 1
+        if k == world - 1:
+            i = nt
+        else:
+            target = total * (k + 1) / world
+            while i < nt - later * ncols:
+                if i - i0 >= ncols and abs(acc + weights[i] - target) > abs(acc - target):
+                    break
+                acc += weights[i]
+                i += 1
+        out.append((i0, i))
+    return out
+
+
+def boundaryPlan(tileInfo, shards, p, overlapSize):
+    """What rank p hands to the next rank that has tiles: a list of (kind, col, row, h, w) --
+    'b' the recoded bottom strip (h x w) of a tile that is the top neighbour of one of the next
+    rank's tiles, 'r' the right strip of rank p's last tile when the next rank starts in the
+    middle of that tile row.  Both sides derive it from the shard table alone."""
+    ncols = tileInfo.ncols
+    nonEmpty = [i for i, (a, b) in enumerate(shards) if b > a]
+    pos = nonEmpty.index(p)
+    if pos + 1 >= len(nonEmpty):
+        return []
+    (p0, p1) = shards[p]
+    (q0, q1) = shards[nonEmpty[pos + 1]]
+    plan = []
+    for t in range(max(p0, q0 - ncols), p1):
+        if t + ncols < q1:                     # its bottom neighbour belongs to the next rank
+            (col, row) = (t % ncols, t // ncols)
+            (_x, _y, xs, ys) = tileInfo.getTile(col, row)
+            plan.append(('b', col, row, min(overlapSize, ys), xs))
+    if q0 % ncols != 0:
+        (col, row) = ((p1 - 1) % ncols, (p1 - 1) // ncols)
+        (_x, _y, xs, ys) = tileInfo.getTile(col, row)
+        plan.append(('r', col, row, ys, min(overlapSize, xs)))
+    return plan
 
 
 class Comm(object):
@@ -135,31 +200,46 @@ def runDistributed(engine, comm, nRows, nCols, tileSize, overlapSize, minSegment
                    numClusters=60, subsamplePcnt=None, maxSpectralDiff='auto', imgNullVal=None,
                    fixedKMeansInit=True, fourConnected=True, simpleTileRecode=False,
                    spectDistPcntile=50, kmeansObj=None):
-    """Tiled segmentation of an (nRows x nCols) raster sharded by tile rows over comm.world
-    ranks.  ``engine`` owns this rank's slice of the raster and of the output (see HipEngine).
-    Returns a DistResult with maxSegId, hist (global), kmeans, maxSpectralDiff, rowRange (tile
-    rows of this rank) and outRows (image rows of the output held by this rank)."""
+    """Tiled segmentation of an (nRows x nCols) raster, its tiles sharded over comm.world ranks.
+    ``engine`` owns this rank's slice of the raster and of the output (see HipEngine).  Returns a
+    DistResult with maxSegId, hist (global), kmeans, maxSpectralDiff, tileRange (row-major tile
+    indices of this rank), rowRange (the tile rows they touch) and outRows (image rows of the
+    output buffer this rank holds: its tiles' trimmed windows are written, the rest is 0)."""
     if (overlapSize % 2) != 0:
         raise tiling.PyShepSegTilingError("Overlap size must be an even number")
 
     class _Ds(object):
         RasterXSize, RasterYSize = nCols, nRows
     tileInfo = tiling.getTilesForFile(_Ds(), tileSize, overlapSize)
-    shards = shardTileRows(tileInfo, comm.world)
-    (r0, r1) = shards[comm.rank]
-    myRows = list(range(r0, r1))
-    haveTiles = r1 > r0
-    jobs, total = tiling.makeTileJobs(tileInfo, rows=set(myRows))
-    # image rows this rank needs (its tiles) and owns in the output (their trimmed windows)
+    ncolsT = tileInfo.ncols
+    shards = shardTiles(tileInfo, comm.world)
+    (t0, t1) = shards[comm.rank]
+    haveTiles = t1 > t0
+    myTiles = [(t % ncolsT, t // ncolsT) for t in range(t0, t1)]
+    (r0, r1) = (t0 // ncolsT, (t1 - 1) // ncolsT + 1) if haveTiles else (0, 0)
+    jobs, total = tiling.makeTileJobs(tileInfo, tiles=set(myTiles))
+
+    def _winOf(col, row):
+        return tiling.trimmedWindow(tileInfo, col, row, *tileInfo.getTile(col, row), overlapSize)
+    # image rows this rank needs (its tiles) and writes in the output (their trimmed windows)
     if haveTiles:
-        yLo = tileInfo.getTile(0, r0)[1]
-        lastT = tileInfo.getTile(0, r1 - 1)
-        yHi = lastT[1] + lastT[3]
-        w0 = tiling.trimmedWindow(tileInfo, 0, r0, *tileInfo.getTile(0, r0), overlapSize)
-        w1 = tiling.trimmedWindow(tileInfo, 0, r1 - 1, *lastT, overlapSize)
-        outLo, outHi = w0[5], w1[5] + (w1[1] - w1[0])
+        yLo = min(tileInfo.getTile(c, r)[1] for (c, r) in myTiles)
+        yHi = max(tileInfo.getTile(c, r)[1] + tileInfo.getTile(c, r)[3] for (c, r) in myTiles)
+        wins = [_winOf(c, r) for (c, r) in myTiles]
+        outLo = min(w[5] for w in wins)
+        outHi = max(w[5] + (w[1] - w[0]) for w in wins)
     else:
         yLo = yHi = outLo = outHi = 0
+    # a disjoint split of the image rows for the k-means sample: from the first output row of this
+    # rank's first tile to that of the next rank's first tile (inside both ranks' slices)
+    nonEmpty = [i for i, (a, b) in enumerate(shards) if b > a]
+    firstRow = {i: _winOf(shards[i][0] % ncolsT, shards[i][0] // ncolsT)[5] for i in nonEmpty}
+    if haveTiles:
+        pos = nonEmpty.index(comm.rank)
+        sLo = 0 if pos == 0 else firstRow[comm.rank]
+        sHi = nRows if pos + 1 == len(nonEmpty) else max(sLo, firstRow[nonEmpty[pos + 1]])
+    else:
+        sLo = sHi = 0
     engine.setup(tileInfo, jobs, total, yLo, yHi, outLo, outHi, nCols, overlapSize)
 
     # ---- one global k-means model (reference tiling.py:154-226) ----
@@ -172,7 +252,7 @@ def runDistributed(engine, comm, nRows, nCols, tileSize, overlapSize, minSegment
         skip = int(round(1. / subsampleProp))
         ry = tiling._subsample_indices(nRows, skip)
         rx = tiling._subsample_indices(nCols, skip)
-        mine = ry[(ry >= outLo) & (ry < outHi)] if haveTiles else ry[:0]
+        mine = ry[(ry >= sLo) & (ry < sHi)]
         part = engine.subsample(mine, rx)                      # (nBands, len(mine), len(rx))
         parts = comm.allgather_obj(part)
         centres = None
@@ -189,34 +269,34 @@ def runDistributed(engine, comm, nRows, nCols, tileSize, overlapSize, minSegment
     engine.startSegmentation(centres, msd, imgNullVal, fourConnected, minSegmentSize)
 
     # ---- the stitch chain ----
-    nonEmpty = [i for i, (a, b) in enumerate(shards) if b > a]
     maxSegId = 0
     if haveTiles:
         pos = nonEmpty.index(comm.rank)
         prevRank = nonEmpty[pos - 1] if pos > 0 else None
         nextRank = nonEmpty[pos + 1] if pos + 1 < len(nonEmpty) else None
-        topStrips = {}
+        fromPrev = {}
         if prevRank is not None:
-            maxSegId, topStrips = engine.recvBoundary(comm, prevRank, tileInfo, r0 - 1)
+            maxSegId, fromPrev = engine.recvBoundary(
+                comm, prevRank, boundaryPlan(tileInfo, shards, prevRank, overlapSize))
         engine.setMaxSegId(maxSegId)
         jobmap = {(j.col, j.row): j for j in jobs}
         for j in jobs:
             engine.waitTile(j)
-            win = tiling.trimmedWindow(tileInfo, j.col, j.row, j.xpos, j.ypos, j.xsize, j.ysize,
-                                       overlapSize)
+            win = _winOf(j.col, j.row)
             top = left = None
             if not simpleTileRecode:
-                if j.row > r0:
-                    top = engine.bottomStripOf(jobmap[(j.col, j.row - 1)])
-                elif j.row > 0:
-                    top = topStrips[j.col]
+                if j.row > 0:
+                    a = jobmap.get((j.col, j.row - 1))
+                    top = engine.bottomStripOf(a) if a is not None else fromPrev[('b', j.col, j.row - 1)]
                 if j.col > 0:
-                    left = engine.rightStripOf(jobmap[(j.col - 1, j.row)])
+                    a = jobmap.get((j.col - 1, j.row))
+                    left = engine.rightStripOf(a) if a is not None else fromPrev[('r', j.col - 1, j.row)]
             engine.stitchTile(j, top, left, win, simpleTileRecode)
         maxSegId = engine.getMaxSegId()
         if nextRank is not None:
+            plan = boundaryPlan(tileInfo, shards, comm.rank, overlapSize)
             engine.sendBoundary(comm, nextRank, maxSegId,
-                                [jobmap[(c, r1 - 1)] for c in range(tileInfo.ncols)])
+                                [(kind, jobmap[(c, r)], h, w) for (kind, c, r, h, w) in plan])
     # final maxSegId lives on the last rank that has tiles
     vals = comm.allgather_obj(int(maxSegId))
     maxSegId = vals[nonEmpty[-1]] if nonEmpty else 0
@@ -232,6 +312,7 @@ def runDistributed(engine, comm, nRows, nCols, tileSize, overlapSize, minSegment
     res.maxSpectralDiff = msd
     res.subsamplePcnt = subsamplePcnt
     res.rowRange = (r0, r1)
+    res.tileRange = (t0, t1)
     res.outRows = (outLo, outHi)
     res.numTileRows, res.numTileCols = tileInfo.nrows, tileInfo.ncols
     res.hasEmptySegments = bool((hist[1:] == 0).any())
@@ -314,6 +395,8 @@ class HipEngine(object):
         self.nbOut = max((outHi - outLo) * nCols, 1) * 4
         self.d_tiles = tiling._devAlloc(self.c, self.nbTiles)
         self.d_out = tiling._devAlloc(self.c, self.nbOut)
+        # other ranks' tiles share these rows: what this rank does not write must read as null
+        self.c.check(self.L.shp_dev_memset(self.c.handle, self.d_out, 0, self.nbOut))
         self.d_scal = tiling._devAlloc(self.c, 256)
         self.c.check(self.L.shp_dev_memset(self.c.handle, self.d_scal, 0, 256))
         self.nbStrips = max(tiling.layoutStrips(jobs, overlapSize), 1) * 4
@@ -385,16 +468,17 @@ class HipEngine(object):
     def _onGpu(comm):
         return comm.device is not None and str(comm.device).startswith('cuda')
 
-    def sendBoundary(self, comm, dst, maxSegId, lastRowJobs):
+    def sendBoundary(self, comm, dst, maxSegId, items):
+        """items: (kind, job, h, w) from boundaryPlan; strips are dense h x w blocks."""
         import torch
         self.c.check(self.L.shp_sync(self.c.handle))
         gpu = self._onGpu(comm)
         hdr = torch.tensor([maxSegId], dtype=torch.int64, device=comm.device)
         comm.send(hdr, dst)
-        for a in lastRowJobs:
-            n = self.overlap * a.xsize
+        for (kind, a, h, w) in items:
+            n = h * w
             buf = torch.empty(n, dtype=torch.int32, device=comm.device)
-            (ptr, _pitch) = self.bottomStripOf(a)
+            (ptr, _pitch) = self.bottomStripOf(a) if kind == 'b' else self.rightStripOf(a)
             if gpu:      # device-to-device into the RCCL send buffer
                 self.c.check(self.L.shp_dev_copy(self.c.handle, ctypes.c_void_p(buf.data_ptr()),
                                                  ctypes.c_void_p(ptr), n * 4))
@@ -403,26 +487,25 @@ class HipEngine(object):
                                                      ctypes.c_void_p(ptr), n * 4))
             comm.send(buf, dst)
 
-    def recvBoundary(self, comm, src, tileInfo, aboveRow):
+    def recvBoundary(self, comm, src, plan):
         import torch
         gpu = self._onGpu(comm)
         hdr = torch.zeros(1, dtype=torch.int64, device=comm.device)
         comm.recv(hdr, src)
         strips = {}
-        for col in range(tileInfo.ncols):
-            xsize = tileInfo.getTile(col, aboveRow)[2]
-            n = self.overlap * xsize
+        for (kind, col, row, h, w) in plan:
+            n = h * w
             buf = torch.empty(n, dtype=torch.int32, device=comm.device)
             comm.recv(buf, src)
             if gpu:
                 self.recvBufs.append(buf)                # keep alive until finish()
-                strips[col] = (buf.data_ptr(), xsize)
+                strips[(kind, col, row)] = (buf.data_ptr(), w)
             else:
                 d = tiling._devAlloc(self.c, n * 4)
                 self.c.check(self.L.shp_dev_upload(self.c.handle, d, ctypes.c_void_p(buf.data_ptr()),
                                                    n * 4))
                 self.recvDev.append((d, n * 4))
-                strips[col] = (d.value, xsize)
+                strips[(kind, col, row)] = (d.value, w)
         if gpu:
             torch.cuda.synchronize()
         return int(hdr.cpu()[0]), strips

@@ -445,13 +445,16 @@ def trimmedWindow(tileInfo, col, row, xpos, ypos, xsize, ysize, overlapSize):
     return (top, bottom, left, right, xout, yout)
 
 
-def makeTileJobs(tileInfo, rows=None):
-    """Row-major list of tile jobs (optionally only the given tile rows) with their offsets in
-    one contiguous label block; returns (jobs, total pixels)."""
+def makeTileJobs(tileInfo, rows=None, tiles=None):
+    """Row-major list of tile jobs (optionally only the given tile rows, or only the given set of
+    (col, row) tiles) with their offsets in one contiguous label block; returns (jobs, total
+    pixels)."""
     jobs = []
     total = 0
     for (col, row) in sorted(tileInfo.tiles.keys(), key=lambda x: (x[1], x[0])):
         if rows is not None and row not in rows:
+            continue
+        if tiles is not None and (col, row) not in tiles:
             continue
         j = _TileJob()
         (j.col, j.row) = (col, row)

@@ -70,23 +70,24 @@ class OracleEngine(object):
                  xout:xout + trimmed.shape[1]] = trimmed
         self.maxSeg = max(self.maxSeg, int(trimmed.max()))
 
-    def sendBoundary(self, comm, dst, maxSegId, lastRowJobs):
+    def sendBoundary(self, comm, dst, maxSegId, items):
         import torch
         comm.send(torch.tensor([maxSegId], dtype=torch.int64), dst)
-        for a in lastRowJobs:
-            s = np.ascontiguousarray(self.bottomStripOf(a)).view(np.int32).reshape(-1)
+        for (kind, a, h, w) in items:
+            s = self.bottomStripOf(a) if kind == 'b' else self.rightStripOf(a)
+            assert s.shape == (h, w)
+            s = np.ascontiguousarray(s).view(np.int32).reshape(-1)
             comm.send(torch.from_numpy(s.copy()), dst)
 
-    def recvBoundary(self, comm, src, tileInfo, aboveRow):
+    def recvBoundary(self, comm, src, plan):
         import torch
         hdr = torch.zeros(1, dtype=torch.int64)
         comm.recv(hdr, src)
         strips = {}
-        for col in range(tileInfo.ncols):
-            xsize = tileInfo.getTile(col, aboveRow)[2]
-            buf = torch.empty(self.ov * xsize, dtype=torch.int32)
+        for (kind, col, row, h, w) in plan:
+            buf = torch.empty(h * w, dtype=torch.int32)
             comm.recv(buf, src)
-            strips[col] = buf.numpy().view(np.uint32).reshape(self.ov, xsize)
+            strips[(kind, col, row)] = buf.numpy().view(np.uint32).reshape(h, w)
         return int(hdr[0]), strips
 
     def histogram(self, maxSegId):

@@ -30,6 +30,27 @@ def test_shard_tile_rows():
     assert max(b - a for (a, b) in sh) <= 2
 
 
+def test_shard_tiles():
+    from pyshepseg_amd import tiling, distributed
+    ti = tiling.getTilesForFile(_Ds(40000, 40000), 4096, 1024)
+    nt = ti.ncols * ti.nrows
+    for world in (1, 2, 3, 4, 5, 8, 12, 16, 200):
+        sh = distributed.shardTiles(ti, world)
+        assert len(sh) == world
+        assert [t for (a, b) in sh for t in range(a, b)] == list(range(nt))       # contiguous, complete
+        ne = [(a, b) for (a, b) in sh if b > a]
+        assert all(b - a >= ti.ncols for (a, b) in ne[:-1])         # top neighbours: local or previous rank
+        for p, (a, b) in enumerate(sh):
+            if b > a:
+                for (kind, col, row, h, w) in distributed.boundaryPlan(ti, sh, p, 1024):
+                    assert a <= row * ti.ncols + col < b
+    sh = distributed.shardTiles(ti, 8)                               # 144 tiles, balanced by pixel area
+    area = [sum(ti.getTile(t % 12, t // 12)[2] * ti.getTile(t % 12, t // 12)[3] for t in range(a, b))
+            for (a, b) in sh]
+    assert max(area) < 1.06 * min(area)
+    assert [b - a for (a, b) in distributed.shardTiles(ti, 16)].count(12) == 12     # whole rows
+
+
 def _free_port():
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
@@ -38,9 +59,10 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize('world,simple', [(2, 0), (3, 0), (2, 1)])
-def test_two_rank_chain_matches_single_process(world, simple, tmp_path, oracle):
-    img = oracle.synthimg(31, 3, 330, 260)
+@pytest.mark.parametrize('world,simple,NR', [(2, 0, 330), (3, 0, 330), (2, 1, 330), (3, 0, 150)])
+def test_two_rank_chain_matches_single_process(world, simple, NR, tmp_path, oracle):
+    # NR = 150: two tile rows for three ranks -> whole-row shards and a rank without tiles
+    img = oracle.synthimg(31, 3, NR, 260)
     img[:, :4, :] = 65535                      # a null border row band (nulls are not given here)
     np.save(tmp_path / 'img.npy', img)
     tile, ov = 96, 32
@@ -56,21 +78,21 @@ def test_two_rank_chain_matches_single_process(world, simple, tmp_path, oracle):
     centres, msd = parts[0]['centres'], float(parts[0]['msd'])
     for q in parts[1:]:
         assert np.array_equal(q['centres'], centres)
-    tiles, ntc, ntr = oracle.get_tiles(330, 260, tile, ov)
+    tiles, ntc, ntr = oracle.get_tiles(NR, 260, tile, ov)
     local = {}
     for (c, r), (x, y, xs, ys) in tiles.items():
         sub = np.ascontiguousarray(img[:, y:y + ys, x:x + xs])
         local[(c, r)] = oracle.segment_tile(sub, centres, 12, msd, None, True)['segimg']
-    want, mx, hist = oracle.stitch_tiles(local, tiles, ntc, ntr, 330, 260, ov, simple=bool(simple))
+    want, mx, hist = oracle.stitch_tiles(local, tiles, ntc, ntr, NR, 260, ov, simple=bool(simple))
     got = np.zeros_like(want)
-    covered = 0
+    cover = np.zeros(NR, dtype=bool)
     for q in parts:
         lo, hi = int(q['outLo']), int(q['outHi'])
-        got[lo:hi] = q['out']
-        covered += hi - lo
+        got[lo:hi] = np.maximum(got[lo:hi], q['out'])          # a rank writes only its tiles' windows
+        cover[lo:hi] = True
         assert int(q['maxSegId']) == mx
         assert np.array_equal(q['hist'], hist)
-    assert covered == 330
+    assert cover.all()
     assert np.array_equal(got, want)
     # per-segment statistics sharded the same way == the oracle on the whole raster, on every rank
     sel = [('a', 'min'), ('b', 'max'), ('c', 'mean'), ('d', 'stddev'), ('e', 'median'),
