@@ -122,8 +122,11 @@ def main():
     c = _lib.ctx()
     c.check(c._L.shp_sync(c.handle))
     t0 = time.time()
+    step_s = []
     for _ in range(args.steps):
+        ts = time.time()
         r = step()
+        step_s.append(round(time.time() - ts, 4))
     c.check(c._L.shp_sync(c.handle))
     dt = (time.time() - t0) / max(args.steps, 1)
     prof = prof_totals(_lib.pool_contexts())
@@ -176,6 +179,7 @@ def main():
                      "device_ms_by_kernel": {names[i]: round(prof.get(i, (0, 0))[0] / max(args.steps, 1), 1)
                                              for i in names}},
     }
+    out["config"]["step_s"] = step_s
     out["config"]["host_timers_s"] = {k: round(v['total'], 3)
                                        for k, v in r.timings.makeSummaryDict().items()}
     if args.cpu_sample > 0:

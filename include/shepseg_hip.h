@@ -46,6 +46,11 @@ int shp_version(void);
 int shp_device_count(void);                      /* number of usable HIP devices (0 = none) */
 int shp_ctx_create(int device, shp_ctx **out);   /* owns one HIP stream + device workspace */
 int shp_ctx_create_priority(int device, shp_ctx **out);  /* same, highest stream priority */
+/* Grow the context's (grow-only) workspace for tiles of up to npix pixels of this type now, instead
+ * of in the middle of a run when the first such tile arrives.  The reference has no counterpart
+ * (numpy allocates per call); the tiled drivers call it once per worker thread
+ * (SegThreadsMgr.worker, tiling.py:1560-1600) with the job's largest tile. */
+int shp_ctx_reserve(shp_ctx *ctx, int dtype, int nbands, int64_t npix);
 void shp_ctx_destroy(shp_ctx *ctx);
 const char *shp_last_error(const shp_ctx *ctx);  /* valid until the next call on ctx */
 /* device-time (HIP events on the ctx stream) of the stages of the last shp_segment_tile /

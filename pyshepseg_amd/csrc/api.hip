@@ -837,3 +837,37 @@ API int shp_spatialstats(shp_ctx *ctx, const uint32_t *seg, const void *band, in
                             max_seg_id, null_val, func, params, missing, nint, nflt, intcols_out,
                             floatcols_out);
 }
+
+// Grow the context's workspace for tiles of up to npix pixels now (the buffers are grow-only and
+// a regrow synchronises and reallocates in the middle of a run): the tiled drivers call this once
+// per worker with the largest tile of the job, so that a pooled context does not keep growing
+// until it has met that tile itself.
+API int shp_ctx_reserve(shp_ctx *ctx, int dtype, int nbands, int64_t npix)
+{
+    CHK(enter(ctx));
+    if (dtype_size(dtype) == 0 || nbands < 1 || npix < 0 || npix >= 0x7fffffffll)
+        SHP_FAIL(ctx, SHP_ERR_ARG, "bad argument");
+    const size_t n = (size_t)npix, ns = n / 4 + 2;
+    const uint32_t maxbig = (uint32_t)(n / (MAX_CLUMP_SIZE + 2u) + 1u);
+    const size_t nblk = (n + SORT_TILE - 1) / SORT_TILE, nh = (size_t)256 * (nblk ? nblk : 1);
+    CHK(buf_ensure(ctx, ctx->img, (size_t)nbands * n * dtype_size(dtype)));
+    CHK(buf_ensure(ctx, ctx->clus, n * 2));
+    DevBuf *perpix[] = {&ctx->lab, &ctx->aux, &ctx->aux2, &ctx->stack, &ctx->sort_k0, &ctx->sort_k1,
+                        &ctx->sort_v1, &ctx->pix};
+    for (DevBuf *b : perpix) CHK(buf_ensure(ctx, *b, n * 4));
+    CHK(buf_ensure(ctx, ctx->segsz, (n + 2) * 4));
+    CHK(buf_ensure(ctx, ctx->singles, (n + 2) * 4));
+    CHK(buf_ensure(ctx, ctx->bigbits, (n / 32 + 2) * 4));
+    CHK(buf_ensure(ctx, ctx->big, (size_t)maxbig * (sizeof(BigInfo) + 4) + 128));
+    CHK(buf_ensure(ctx, ctx->sort_hist, 2 * nh * 4));
+    CHK(buf_ensure(ctx, ctx->scan_tmp, scan_tmp_bytes(n > nh ? n : nh)));
+    DevBuf *perseg[] = {&ctx->origsz, &ctx->chnext, &ctx->chtail, &ctx->mergeto, &ctx->tcount,
+                        &ctx->tfill, &ctx->tsorted, &ctx->srclist, &ctx->tgtlist};
+    for (DevBuf *b : perseg) CHK(buf_ensure(ctx, *b, ns * 4));
+    CHK(buf_ensure(ctx, ctx->off, ns * 4 + 16));
+    CHK(buf_ensure(ctx, ctx->toff, ns * 4 + 16));
+    CHK(buf_ensure(ctx, ctx->tlist, (ns + 32) * 4));
+    CHK(buf_ensure(ctx, ctx->ssum, ns * (size_t)nbands * 4));
+    CHK(buf_ensure(ctx, ctx->small, 8192));
+    return 0;
+}

@@ -509,7 +509,13 @@ def startSegmentationWorkers(src, jobs, d_tiles, centres, msd, imgNullVal, fourC
                     jj.error = e
                 jj.done.set()
 
+    maxTilePx = max([jj.xsize * jj.ysize for jj in jobs] or [0])
+
     def worker_loop(c):
+        if onDevice and maxTilePx > 0:
+            # size the pooled context for the job's largest tile now: a grow-only workspace that
+            # regrows when it first meets that tile stalls the device in the middle of the run
+            c.check(L.shp_ctx_reserve(c.handle, dtcode, nBandsAll, maxTilePx))
         while not forceExit.is_set():
             try:
                 j = inQue.get_nowait()
