@@ -685,7 +685,6 @@ static int run_eliminate_small(shp_ctx *ctx, const void *d_img, int dtype, int n
 #undef SPECTRA_LAUNCH
     KCHK(ctx);
     prof_end(ctx, ps);
-    ps = prof_begin(ctx, PROF_SMALL_LOOP);
 
     const double thr2 = max_spectral_diff * max_spectral_diff;       // float64 square (N8)
     // one persistent kernel runs every pass (see k_small_loop)
@@ -706,8 +705,10 @@ static int run_eliminate_small(shp_ctx *ctx, const void *d_img, int dtype, int n
         g_small_running++;
     }
     static const unsigned small_blocks = getenv("SHEPSEG_SMALL_BLOCKS") ? (unsigned)atoi(getenv("SHEPSEG_SMALL_BLOCKS")) : SMALL_BLOCKS;
+    ps = prof_begin(ctx, PROF_SMALL_LOOP);           // events hug the kernel: no copies, no host waits
     hipLaunchKernelGGL(k_small_loop, dim3(small_blocks), dim3(256), 0, st, args);
     hipError_t lerr = hipGetLastError();
+    prof_end(ctx, ps);
     hipError_t cerr = hipMemcpyAsync(pin, ctl, sizeof(SmallCtl), hipMemcpyDeviceToHost, st);
     hipError_t serr = hipStreamSynchronize(st);
     {
@@ -719,7 +720,6 @@ static int run_eliminate_small(shp_ctx *ctx, const void *d_img, int dtype, int n
     if (pin->fail || !pin->done)
         SHP_FAIL(ctx, SHP_ERR_STATE, "small-segment loop: grid barrier timed out (fail=%u done=%u)",
                  pin->fail, pin->done);
-    prof_end(ctx, ps);
     *num_elim = (int64_t)pin->nelim;
     uint32_t new_max = 0;
     CHK(run_relabel(ctx, d_seg, n, segsz, S, &new_max));
