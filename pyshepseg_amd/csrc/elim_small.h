@@ -436,9 +436,8 @@ __device__ __forceinline__ void find_merge_wave(uint32_t s, uint32_t target, con
 
 __global__ __launch_bounds__(256) void k_small_loop(SmallArgs a)
 {
-    __shared__ uint32_t lsrc[256];
     __shared__ uint32_t wpix[4][64];
-    __shared__ uint32_t lcnt, s_target, s_done;
+    __shared__ uint32_t s_target, s_done;
     __shared__ uint32_t lhist[256];
     SmallCtl *ctl = a.ctl;
     __builtin_amdgcn_s_setprio(2);
@@ -446,7 +445,6 @@ __global__ __launch_bounds__(256) void k_small_loop(SmallArgs a)
     const uint32_t gtid = blockIdx.x * 256u + threadIdx.x, gthreads = G * 256u;
     const uint32_t gwave = gtid >> 6, gwaves = gthreads >> 6;
     const unsigned lane = lane_id(), w = threadIdx.x >> 6;
-    const uint32_t nchunks = (a.S + 255u) / 256u;       // segment ids 1..S in chunks of 256
     for (uint32_t slot = 0;; slot++) {
         const uint32_t par = slot & 1u;
         // ---- loop control (identical in every workgroup; shepseg.py:970-997) ----
@@ -477,34 +475,34 @@ __global__ __launch_bounds__(256) void k_small_loop(SmallArgs a)
         if (s_done) break;
         const uint32_t target = s_target;
         SmallCnt *cnt = &ctl->cnt[par];
-        // ---- find phase: sources = segments of the target size ----
-        for (uint32_t ch = blockIdx.x; ch < nchunks; ch += G) {
-            if (threadIdx.x == 0) lcnt = 0;
-            __syncthreads();
-            const uint32_t s = ch * 256u + threadIdx.x + 1u;
-            const bool is = s <= a.S && a.segsz[s] == target;
-            const unsigned long long m = __ballot(is);
-            if (m != 0ull) {
-                uint32_t lbase = 0, gbase = 0;
-                if (lane == 0) {
-                    lbase = atomicAdd(&lcnt, (uint32_t)__popcll(m));
-                    gbase = atomicAdd(&cnt->nsrc, (uint32_t)__popcll(m));
+        // ---- find phase: sources = segments of the target size.  Every wavefront scans its own
+        //      64-id slices of the size table (four slices in flight: the scan of ~2.5 M ids is
+        //      repeated every pass and is pure load latency) and handles the sources it finds. ----
+        {
+            const uint32_t stride = gwaves * 64u;
+            for (uint32_t base = gwave * 64u; base < a.S; base += 4u * stride) {
+                uint32_t sz[4];
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    const uint32_t sid = base + (uint32_t)u * stride + lane + 1u;
+                    sz[u] = sid <= a.S ? a.segsz[sid] : 0xFFFFFFFFu;
                 }
-                lbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)lbase);
-                gbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)gbase);
-                if (is) {
-                    const uint32_t r = (uint32_t)__popcll(m & lanemask_lt());
-                    lsrc[lbase + r] = s;
-                    a.srclist[gbase + r] = s;
+#pragma unroll
+                for (int u = 0; u < 4; u++) {
+                    unsigned long long m = __ballot(sz[u] == target);
+                    if (m == 0ull) continue;
+                    const uint32_t b0 = base + (uint32_t)u * stride;
+                    uint32_t gbase = 0;
+                    if (lane == 0) gbase = atomicAdd(&cnt->nsrc, (uint32_t)__popcll(m));
+                    gbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)gbase);
+                    if (sz[u] == target) a.srclist[gbase + (uint32_t)__popcll(m & lanemask_lt())] = b0 + lane + 1u;
+                    while (m) {
+                        const uint32_t src = b0 + (uint32_t)__builtin_ctzll(m) + 1u;
+                        m &= m - 1ull;
+                        find_merge_wave(src, target, a, wpix[w]);
+                    }
                 }
             }
-            __syncthreads();
-            const uint32_t n = lcnt;
-            for (uint32_t i = w; i < n; i += 4u) {
-                const uint32_t src = (uint32_t)__builtin_amdgcn_readfirstlane((int)lsrc[i]);
-                find_merge_wave(src, target, a, wpix[w]);
-            }
-            __syncthreads();
         }
         if (!small_grid_barrier(ctl, G)) return;
         const uint32_t nsrc = cnt->nsrc;
