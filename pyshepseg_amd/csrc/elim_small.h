@@ -285,6 +285,7 @@ struct SmallCtl {
     SmallCnt cnt[2];         // double-buffered per-pass counters
     uint32_t bar_count, bar_gen;
     uint32_t nelim, fail, done, slots;
+    unsigned long long tphase[4];   // SHEPSEG_SMALL_TIMING: wall_clock64 ticks spent in control+find / link / apply
 };
 
 struct SmallArgs {
@@ -445,6 +446,7 @@ __global__ __launch_bounds__(256) void k_small_loop(SmallArgs a)
     const uint32_t gtid = blockIdx.x * 256u + threadIdx.x, gthreads = G * 256u;
     const uint32_t gwave = gtid >> 6, gwaves = gthreads >> 6;
     const unsigned lane = lane_id(), w = threadIdx.x >> 6;
+    unsigned long long tmark = wall_clock64();
     for (uint32_t slot = 0;; slot++) {
         const uint32_t par = slot & 1u;
         // ---- loop control (identical in every workgroup; shepseg.py:970-997) ----
@@ -505,6 +507,7 @@ __global__ __launch_bounds__(256) void k_small_loop(SmallArgs a)
             }
         }
         if (!small_grid_barrier(ctl, G)) return;
+        if (gtid == 0) { const unsigned long long t = wall_clock64(); ctl->tphase[0] += t - tmark; tmark = t; }
         const uint32_t nsrc = cnt->nsrc;
         // ---- merge step 1: every source links itself into its target's list, kept in ascending
         //      source id by a lock-free sorted insert (head in tfill[t], links in tlist[s]; inserts
@@ -542,6 +545,7 @@ __global__ __launch_bounds__(256) void k_small_loop(SmallArgs a)
             }
         }
         if (!small_grid_barrier(ctl, G)) return;
+        if (gtid == 0) { const unsigned long long t = wall_clock64(); ctl->tphase[1] += t - tmark; tmark = t; }
         const uint32_t ntgt = cnt->ntgt;
         // ---- merge step 2: each target absorbs its sources in ascending id (doMerge :1112-1123)
         //      size-histogram updates go through LDS, numElim through a wave reduction ----
@@ -584,6 +588,7 @@ __global__ __launch_bounds__(256) void k_small_loop(SmallArgs a)
         if (threadIdx.x < a.min_seg && lhist[threadIdx.x] != 0u)
             atomicAdd(&a.hist[threadIdx.x], lhist[threadIdx.x]);          // wrapping add of the delta
         if (!small_grid_barrier(ctl, G)) return;
+        if (gtid == 0) { const unsigned long long t = wall_clock64(); ctl->tphase[2] += t - tmark; tmark = t; ctl->tphase[3] += 1; }
     }
 }
 
@@ -629,7 +634,7 @@ static int run_eliminate_small(shp_ctx *ctx, const void *d_img, int dtype, int n
     CHK(buf_ensure(ctx, ctx->tsorted, ns * 4));
     CHK(buf_ensure(ctx, ctx->srclist, ns * 4));
     CHK(buf_ensure(ctx, ctx->tgtlist, ns * 4));
-    CHK(buf_ensure(ctx, ctx->small, ((size_t)min_seg + 64) * 4));
+    CHK(buf_ensure(ctx, ctx->small, ((size_t)min_seg + 96) * 4));
     CHK(buf_ensure(ctx, ctx->scan_tmp, scan_tmp_bytes(ns > n ? ns : n)));
     uint32_t *segsz = bp<uint32_t>(ctx->segsz), *origsz = bp<uint32_t>(ctx->origsz);
     uint32_t *off = bp<uint32_t>(ctx->off), *chnext = bp<uint32_t>(ctx->chnext);
@@ -718,6 +723,9 @@ static int run_eliminate_small(shp_ctx *ctx, const void *d_img, int dtype, int n
     if (pin->fail || !pin->done)
         SHP_FAIL(ctx, SHP_ERR_STATE, "small-segment loop: grid barrier timed out (fail=%u done=%u)",
                  pin->fail, pin->done);
+    if (getenv("SHEPSEG_SMALL_TIMING"))
+        fprintf(stderr, "small loop: passes %llu  find %.2f ms  link+relabel %.2f ms  apply %.2f ms (S=%u)\n",
+                pin->tphase[3], pin->tphase[0] / 1e5, pin->tphase[1] / 1e5, pin->tphase[2] / 1e5, S);
     *num_elim = (int64_t)pin->nelim;
     uint32_t new_max = 0;
     CHK(run_relabel(ctx, d_seg, n, segsz, S, &new_max));
