@@ -522,7 +522,10 @@ __global__ __launch_bounds__(256) void k_small_loop(SmallArgs a)
                 uint32_t prev = 0, cur = L2LOAD(&a.tfill[t]);
                 while (cur != 0 && cur < s) { prev = cur; cur = L2LOAD(&a.tlist[cur]); }
                 __hip_atomic_store(&a.tlist[s], cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");      // link visible before s is
+                // the link must have reached the coherent level before s becomes reachable: both are
+                // agent-scope atomics, so draining this lane's stores is enough (a release fence
+                // would also write back the XCD's whole L2, once per source)
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 uint32_t *slot = prev ? &a.tlist[prev] : &a.tfill[t];
                 if (atomicCAS(slot, cur, s) == cur) {
                     if (prev == 0 && cur == 0) a.tgtlist[atomicAdd(&cnt->ntgt, 1u)] = t;   // list was empty
