@@ -261,3 +261,24 @@ def test_kmeans_fit_vs_oracle_shapes(k, n, shepseg, oracle):
     assert km.n_iter_ == want_n
     assert np.allclose(km.cluster_centers_, want_c, rtol=0, atol=1e-8)
     assert np.array_equal(km.labels_, want_l)
+
+
+@pytest.mark.parametrize('four', [True, False])
+def test_cut_components_both_connectivities(four, shepseg, oracle):
+    """Components far above the 10001-pixel cap, 4- and 8-connected: a few large smooth blobs with
+    diagonal-only bridges (8-connected merges them, 4-connected does not), so the replay kernel's
+    LDS path (both size classes) and its neighbour order are exercised for both connectivities."""
+    rng = np.random.RandomState(21)
+    nr, nc = 700, 900
+    cl = np.ones((nr, nc), dtype=np.int32)
+    yy, xx = np.mgrid[0:nr, 0:nc]
+    for _i in range(14):
+        cy, cx, ry, rx = rng.randint(50, nr - 50), rng.randint(50, nc - 50), rng.randint(40, 160), rng.randint(40, 200)
+        cl[((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 < 1.0] = rng.randint(2, 5)
+    cl[(yy + xx) % 97 == 0] = 5                         # thin diagonal lines: 8-connected only
+    cl[rng.rand(nr, nc) < 0.01] = 0                     # some nulls
+    seg, nxt = shepseg.clump(cl, 0, fourConnected=four)
+    oseg, onxt = oracle.clump(cl, 0, four, 1)
+    assert nxt == onxt and np.array_equal(seg, oseg)
+    sizes = np.bincount(oseg.ravel())[1:]
+    assert (sizes >= 10001).sum() >= 10                 # many capped pieces
