@@ -282,3 +282,19 @@ def test_cut_components_both_connectivities(four, shepseg, oracle):
     assert nxt == onxt and np.array_equal(seg, oseg)
     sizes = np.bincount(oseg.ravel())[1:]
     assert (sizes >= 10001).sum() >= 10                 # many capped pieces
+
+
+@pytest.mark.parametrize('four', [True, False])
+def test_uniform_region_global_replay(four, shepseg, oracle):
+    """One component whose bounding box (1200 x 1100) does not fit the 64 KiB LDS bitmap: the
+    global-memory replay path, with deep stacks (uniform region) that spill out of the LDS window."""
+    cl = np.full((1200, 1100), 3, dtype=np.int32)
+    cl[400:420, 300:900] = 0                            # a null bar inside
+    seg, nxt = shepseg.clump(cl, 0, fourConnected=four)
+    oseg, onxt = oracle.clump(cl, 0, four, 1)
+    assert nxt == onxt and np.array_equal(seg, oseg)
+    # and one that does fit the LDS bitmap but still spills its stack window
+    cl = np.full((500, 900), 2, dtype=np.int32)
+    seg, nxt = shepseg.clump(cl, 0, fourConnected=four)
+    oseg, onxt = oracle.clump(cl, 0, four, 1)
+    assert nxt == onxt and np.array_equal(seg, oseg)
