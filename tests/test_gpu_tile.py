@@ -298,3 +298,40 @@ def test_uniform_region_global_replay(four, shepseg, oracle):
     seg, nxt = shepseg.clump(cl, 0, fourConnected=four)
     oseg, onxt = oracle.clump(cl, 0, four, 1)
     assert nxt == onxt and np.array_equal(seg, oseg)
+
+
+def test_random_shapes_vs_oracle(shepseg, oracle):
+    """Forty random small tiles (ragged against the 32 x 64 patches and the 64-pixel wavefront rows
+    in every way: 1 x N, N x 1, widths just below / above 64 ...), random band counts, dtypes,
+    nulls, connectivity and minimum sizes: fused pipeline and clump stage against the oracle."""
+    rng = np.random.RandomState(2024)
+    shapes = [(1, 1), (1, 257), (300, 1), (2, 63), (33, 64), (32, 65), (65, 129), (31, 191)]
+    while len(shapes) < 40:
+        shapes.append((int(rng.randint(1, 220)), int(rng.randint(1, 330))))
+    for i, (nr, nc) in enumerate(shapes):
+        nb = int(rng.randint(1, 5))
+        dtype = [np.uint8, np.uint16, np.int16][i % 3]
+        levels = int(rng.randint(2, 6))
+        base = rng.randint(0, levels, size=(nb, (nr + 7) // 8, (nc + 7) // 8))
+        img = np.kron(base, np.ones((1, 8, 8), dtype=np.int64))[:, :nr, :nc] * 40 + rng.randint(0, 12, size=(nb, nr, nc))
+        img = img.astype(dtype)
+        null = None
+        if i % 4 == 1:
+            null = 255 if dtype == np.uint8 else 999
+            img[:, rng.rand(nr, nc) < 0.05] = null
+        four = bool(i % 2)
+        minseg = int(rng.randint(2, 30))
+        k = levels
+        centres = (np.arange(k, dtype=np.float64)[:, None] * 40 + 6) * np.ones((1, nb))
+        km = shepseg.KMeansModel(centres)
+        msd = float(rng.choice([15.0, 60.0, 1e6]))
+        got = shepseg.doShepherdSegmentation(img, kmeansObj=km, minSegmentSize=minseg, maxSpectralDiff=msd,
+                                             imgNullVal=null, fourConnected=four)
+        want = oracle.segment_tile(img, centres, minseg, msd, null, four)
+        assert np.array_equal(got.segimg, want['segimg']), (i, nr, nc, nb, dtype, null, four, minseg, msd)
+        assert got.singlePixelsEliminated == want['singlePixelsEliminated']
+        assert got.smallSegmentsEliminated == want['smallSegmentsEliminated']
+        cl = oracle.kmeans_assign(img, centres, null)
+        seg, nxt = shepseg.clump(cl, 0, fourConnected=four)
+        oseg, onxt = oracle.clump(cl, 0, four, 1)
+        assert nxt == onxt and np.array_equal(seg, oseg), (i, nr, nc)
