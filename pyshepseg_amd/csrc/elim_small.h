@@ -278,11 +278,12 @@ __global__ __launch_bounds__(256) void k_small_init(const uint32_t *__restrict__
 #define SMALL_BLOCKS 64u
 #define SMALL_SPIN_LIMIT (1u << 25)
 
-struct SmallCnt { uint32_t nsrc, ntgt, bump, pad; };
+struct SmallCnt { uint32_t nsrc, ntgt, nmerge, pad; };    // nmerge: sources that found a target
 struct SmallState { uint32_t target; int32_t prev; uint32_t passes; uint32_t pad; };
 struct SmallCtl {
     SmallState st[2];        // double-buffered loop state (slot parity)
-    SmallCnt cnt[2];         // double-buffered per-pass counters
+    SmallCnt cnt[3];         // per-pass counters, ring of three: a pass without merges skips its last two
+                             // barriers, so a workgroup can be one pass ahead when it zeroes the next slot
     uint32_t bar_count, bar_gen;
     uint32_t nelim, fail, done, slots;
     unsigned long long tphase[4];   // SHEPSEG_SMALL_TIMING: wall_clock64 ticks spent in control+find / link / apply
@@ -353,7 +354,7 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
 // the FIRST strict minimum in (k, ii outer, jj inner) order (N7) == the lexicographic minimum
 // of (distSqr, k, position): one 64-bit wave reduction (distSqr >= +0, so its float32 bit
 // pattern orders like the value).
-__device__ __forceinline__ void find_merge_wave(uint32_t s, uint32_t target, const SmallArgs &a,
+__device__ __forceinline__ bool find_merge_wave(uint32_t s, uint32_t target, const SmallArgs &a,
                                                 uint32_t *wpix)
 {
     const unsigned lane = lane_id();
@@ -428,11 +429,12 @@ __device__ __forceinline__ void find_merge_wave(uint32_t s, uint32_t target, con
         if (c == 0) break;
     }
     const unsigned long long wmin = wave_min_u64(best);
-    if (wmin == ~0ull) { if (lane == 0) a.mergeto[s] = 0; return; }
-    if (best == wmin) {                      // unique: (k, position) differs between lanes
-        const float bd = __uint_as_float((uint32_t)(wmin >> 32));
-        a.mergeto[s] = ((double)bd > a.thr2) ? 0u : bestnb;
-    }
+    if (wmin == ~0ull) { if (lane == 0) a.mergeto[s] = 0; return false; }
+    const float bd = __uint_as_float((uint32_t)(wmin >> 32));
+    const bool merges = !((double)bd > a.thr2);
+    if (best == wmin)                        // unique: (k, position) differs between lanes
+        a.mergeto[s] = merges ? bestnb : 0u;
+    return merges;                           // wave-uniform: does s merge in this pass?
 }
 
 __global__ __launch_bounds__(256) void k_small_loop(SmallArgs a)
@@ -469,19 +471,21 @@ __global__ __launch_bounds__(256) void k_small_loop(SmallArgs a)
             if (blockIdx.x == 0) {
                 ctl->st[par ^ 1u].target = target; ctl->st[par ^ 1u].prev = prev;
                 ctl->st[par ^ 1u].passes = passes;
-                ctl->cnt[par ^ 1u].nsrc = 0; ctl->cnt[par ^ 1u].ntgt = 0; ctl->cnt[par ^ 1u].bump = 0;
+                SmallCnt *nx = &ctl->cnt[(slot + 1u) % 3u];
+                nx->nsrc = 0; nx->ntgt = 0; nx->nmerge = 0;
                 if (done) { ctl->done = 1; ctl->slots = slot; }
             }
         }
         __syncthreads();
         if (s_done) break;
         const uint32_t target = s_target;
-        SmallCnt *cnt = &ctl->cnt[par];
+        SmallCnt *cnt = &ctl->cnt[slot % 3u];
         // ---- find phase: sources = segments of the target size.  Every wavefront scans its own
         //      64-id slices of the size table (four slices in flight: the scan of ~2.5 M ids is
         //      repeated every pass and is pure load latency) and handles the sources it finds. ----
         {
             const uint32_t stride = gwaves * 64u;
+            uint32_t wmerges = 0;
             for (uint32_t base = gwave * 64u; base < a.S; base += 4u * stride) {
                 uint32_t sz[4];
 #pragma unroll
@@ -501,14 +505,21 @@ __global__ __launch_bounds__(256) void k_small_loop(SmallArgs a)
                     while (m) {
                         const uint32_t src = b0 + (uint32_t)__builtin_ctzll(m) + 1u;
                         m &= m - 1ull;
-                        find_merge_wave(src, target, a, wpix[w]);
+                        wmerges += find_merge_wave(src, target, a, wpix[w]) ? 1u : 0u;
                     }
                 }
             }
+            if (wmerges && lane == 0) atomicAdd(&cnt->nmerge, wmerges);
         }
         if (!small_grid_barrier(ctl, G)) return;
         if (gtid == 0) { const unsigned long long t = wall_clock64(); ctl->tphase[0] += t - tmark; tmark = t; }
         const uint32_t nsrc = cnt->nsrc;
+        if (cnt->nmerge == 0u) {
+            // nobody merges (every candidate was further than maxSpectralDiff, or had no larger
+            // neighbour): nothing to link, relabel or absorb, the size histogram is unchanged
+            if (gtid == 0) ctl->tphase[3] += 1;
+            continue;
+        }
         // ---- merge step 1: every source links itself into its target's list, kept in ascending
         //      source id by a lock-free sorted insert (head in tfill[t], links in tlist[s]; inserts
         //      only, so a failed CAS simply retries), the first one to arrive registers the
