@@ -276,7 +276,7 @@ __global__ __launch_bounds__(256) void k_small_init(const uint32_t *__restrict__
 // that all their workgroups are co-resident.
 // ---------------------------------------------------------------------------------------------
 #define SMALL_BLOCKS 64u
-#define SMALL_SPIN_LIMIT (1u << 25)
+#define SMALL_SPIN_LIMIT (1u << 23)
 
 struct SmallCnt { uint32_t nsrc, ntgt, nmerge, pad; };    // nmerge: sources that found a target
 struct SmallState { uint32_t target; int32_t prev; uint32_t passes; uint32_t pad; };
@@ -299,9 +299,10 @@ struct SmallArgs {
     uint32_t S, min_seg, nrows, ncols;
     int nb, four;
     double thr2;
+    int poll;           // s_sleep(8) repetitions between two polls of a grid barrier
 };
 
-__device__ __forceinline__ bool small_grid_barrier(SmallCtl *ctl, uint32_t nblocks)
+__device__ __forceinline__ bool small_grid_barrier(SmallCtl *ctl, uint32_t nblocks, int poll = 4)
 {
     __shared__ uint32_t s_ok;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's stores have left
@@ -320,10 +321,13 @@ __device__ __forceinline__ bool small_grid_barrier(SmallCtl *ctl, uint32_t nbloc
             __hip_atomic_fetch_add(&ctl->bar_gen, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
             uint32_t spins = 0;
+            // poll gently: 1280 workgroups of 20 concurrent loops polling device-coherent lines is
+            // fabric traffic every other kernel pays for; the fail flag is looked at now and then
             while (__hip_atomic_load(&ctl->bar_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) {
-                __builtin_amdgcn_s_sleep(8);
+                for (int q = 0; q < poll; q++) __builtin_amdgcn_s_sleep(8);
                 if (++spins > SMALL_SPIN_LIMIT ||
-                    __hip_atomic_load(&ctl->fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                    ((spins & 15u) == 0u &&
+                     __hip_atomic_load(&ctl->fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
                     __hip_atomic_store(&ctl->fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     ok = 0;
                     break;
@@ -511,7 +515,7 @@ __global__ __launch_bounds__(256) void k_small_loop(SmallArgs a)
             }
             if (wmerges && lane == 0) atomicAdd(&cnt->nmerge, wmerges);
         }
-        if (!small_grid_barrier(ctl, G)) return;
+        if (!small_grid_barrier(ctl, G, a.poll)) return;
         if (gtid == 0) { const unsigned long long t = wall_clock64(); ctl->tphase[0] += t - tmark; tmark = t; }
         const uint32_t nsrc = cnt->nsrc;
         if (cnt->nmerge == 0u) {
@@ -558,7 +562,7 @@ __global__ __launch_bounds__(256) void k_small_loop(SmallArgs a)
                 for (uint32_t j = lane; j < m; j += 64u) a.seg[a.pix[o + j]] = t;
             }
         }
-        if (!small_grid_barrier(ctl, G)) return;
+        if (!small_grid_barrier(ctl, G, a.poll)) return;
         if (gtid == 0) { const unsigned long long t = wall_clock64(); ctl->tphase[1] += t - tmark; tmark = t; }
         const uint32_t ntgt = cnt->ntgt;
         // ---- merge step 2: each target absorbs its sources in ascending id (doMerge :1112-1123)
@@ -601,7 +605,7 @@ __global__ __launch_bounds__(256) void k_small_loop(SmallArgs a)
         __syncthreads();
         if (threadIdx.x < a.min_seg && lhist[threadIdx.x] != 0u)
             atomicAdd(&a.hist[threadIdx.x], lhist[threadIdx.x]);          // wrapping add of the delta
-        if (!small_grid_barrier(ctl, G)) return;
+        if (!small_grid_barrier(ctl, G, a.poll)) return;
         if (gtid == 0) { const unsigned long long t = wall_clock64(); ctl->tphase[2] += t - tmark; tmark = t; ctl->tphase[3] += 1; }
     }
 }
@@ -716,6 +720,8 @@ static int run_eliminate_small(shp_ctx *ctx, const void *d_img, int dtype, int n
     args.tlist = tlist; args.tsorted = tsorted; args.srclist = srclist; args.tgtlist = tgtlist;
     args.S = S; args.min_seg = min_seg; args.nrows = nrows; args.ncols = ncols;
     args.nb = nb; args.four = four; args.thr2 = thr2;
+    static const int poll_env = getenv("SHEPSEG_SMALL_POLL") ? atoi(getenv("SHEPSEG_SMALL_POLL")) : 4;
+    args.poll = poll_env < 1 ? 1 : poll_env;
     {
         std::unique_lock<std::mutex> lk(g_small_mu);
         g_small_cv.wait(lk, [] { return g_small_running < g_small_max; });
