@@ -35,9 +35,10 @@ __global__ __launch_bounds__(256) void k_assign(
             best[q] = 0;
             bestd[q] = 0.0;
             if (NB > 0) {
+                const size_t pc = p < npix ? p : npix - 1;      // clamped: the loads need no branch
 #pragma unroll
                 for (int b = 0; b < NB; b++) {
-                    long long v = (p < npix) ? ld_t<DT>(img, (size_t)b * npix + p) : 0;
+                    const long long v = ld_t<DT>(img, (size_t)b * npix + pc);
                     if (has_null && v == null_val) isnull[q] = true;
                     x[q][b] = (double)v;
                 }
@@ -72,9 +73,15 @@ __global__ __launch_bounds__(256) void k_assign(
                     }
                 }
             }
+            // first minimum wins: the index moves only on a strict improvement, the value is a min
 #pragma unroll
-            for (int q = 0; q < ASSIGN_PPT; q++)
-                if (j == 0 || d[q] < bestd[q]) { bestd[q] = d[q]; best[q] = j; }
+            for (int q = 0; q < ASSIGN_PPT; q++) {
+                if (j == 0) { bestd[q] = d[q]; best[q] = 0; }
+                else {
+                    best[q] = d[q] < bestd[q] ? j : best[q];
+                    bestd[q] = __builtin_fmin(d[q], bestd[q]);
+                }
+            }
         }
 #pragma unroll
         for (int q = 0; q < ASSIGN_PPT; q++) {
