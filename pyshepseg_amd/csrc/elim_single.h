@@ -13,39 +13,55 @@
 
 #define NO_TARGET 0xFFFFFFFFu
 
-// nearest spectrally-similar neighbouring pixel in a segment of size > 1 (shepseg.py:677-736)
-__device__ __forceinline__ uint32_t single_target(const void *__restrict__ img, int dtype, int nb,
+// nearest spectrally-similar neighbouring pixel in a segment of size > 1 (shepseg.py:677-736).
+// The 3 x 3 window is walked in the reference's order (rows outer, columns inner; first strict
+// minimum wins) but evaluated without branches around the loads: neighbour ids, then their
+// segment sizes, then the band values of all nine positions are fetched as independent loads
+// (an excluded position re-reads the centre pixel and is ignored), so one candidate costs three
+// memory round trips instead of 3 + 2 * nBands.  DT = pixel type (see ld_t).
+template <int DT>
+__device__ __forceinline__ uint32_t single_target(const void *__restrict__ img, int nb,
                                                   const uint32_t *__restrict__ seg,
                                                   const uint32_t *__restrict__ segsz, uint32_t p,
                                                   uint32_t n, uint32_t nrows, uint32_t ncols, int four)
 {
-    uint32_t out = NO_TARGET;
     const uint32_t i = p / ncols, j = p - i * ncols;
-    const uint32_t i0 = i > 0 ? i - 1 : 0, i1 = (i + 1 < nrows) ? i + 1 : nrows - 1;
-    const uint32_t j0 = j > 0 ? j - 1 : 0, j1 = (j + 1 < ncols) ? j + 1 : ncols - 1;
-    long long mind = -1;
-    for (uint32_t a = i0; a <= i1; a++)
-        for (uint32_t b = j0; b <= j1; b++) {
-            if (four && a != i && b != j) continue;
-            const uint32_t q = a * ncols + b;
-            const uint32_t sn = seg[q];
-            if (segsz[sn] > 1u) {
-                long long d = 0;
-                for (int k = 0; k < nb; k++) {
-                    const long long t = ld_px(img, dtype, (size_t)k * n + p) -
-                                        ld_px(img, dtype, (size_t)k * n + q);
-                    d += t * t;
-                }
-                if (mind < 0 || d < mind) { mind = d; out = sn; }
-            }
+    uint32_t q[9], sn[9];
+    bool ok[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+        const int da = k / 3 - 1, db = k % 3 - 1;
+        const int a = (int)i + da, b = (int)j + db;
+        ok[k] = k != 4 && a >= 0 && b >= 0 && a < (int)nrows && b < (int)ncols && !(four && da != 0 && db != 0);
+        q[k] = ok[k] ? (uint32_t)a * ncols + (uint32_t)b : p;
+        sn[k] = seg[q[k]];
+    }
+#pragma unroll
+    for (int k = 0; k < 9; k++) ok[k] = ok[k] && segsz[sn[k]] > 1u;
+    long long d[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) d[k] = 0;
+    for (int b = 0; b < nb; b++) {
+        const long long vp = ld_t<DT>(img, (size_t)b * n + p);
+#pragma unroll
+        for (int k = 0; k < 9; k++) {
+            const long long t = vp - ld_t<DT>(img, (size_t)b * n + q[k]);
+            d[k] += t * t;
         }
+    }
+    uint32_t out = NO_TARGET;
+    long long mind = -1;
+#pragma unroll
+    for (int k = 0; k < 9; k++)
+        if (ok[k] && (mind < 0 || d[k] < mind)) { mind = d[k]; out = sn[k]; }
     return out;
 }
 
 // first pass: every pixel.  Single pixels that find no target yet are appended to `rest`
 // (they are the only candidates of the later passes: sizes never shrink to 1).
+template <int DT>
 __global__ __launch_bounds__(256) void k_single_scan(
-    const void *__restrict__ img, int dtype, int nb, const uint32_t *__restrict__ seg,
+    const void *__restrict__ img, int nb, const uint32_t *__restrict__ seg,
     const uint32_t *__restrict__ segsz, uint32_t *__restrict__ tgt, uint32_t n, uint32_t nrows,
     uint32_t ncols, int four, uint32_t *__restrict__ rest, uint32_t *nrest)
 {
@@ -54,7 +70,7 @@ __global__ __launch_bounds__(256) void k_single_scan(
     bool keep = false;
     if (p < n) {
         if (segsz[seg[p]] == 1u) {
-            out = single_target(img, dtype, nb, seg, segsz, p, n, nrows, ncols, four);
+            out = single_target<DT>(img, nb, seg, segsz, p, n, nrows, ncols, four);
             keep = out == NO_TARGET;
         }
         tgt[p] = out;
@@ -85,8 +101,9 @@ __global__ __launch_bounds__(256) void k_single_apply(uint32_t *__restrict__ seg
 }
 
 // later passes: only the remaining single pixels
+template <int DT>
 __global__ __launch_bounds__(256) void k_single_scan_list(
-    const void *__restrict__ img, int dtype, int nb, const uint32_t *__restrict__ seg,
+    const void *__restrict__ img, int nb, const uint32_t *__restrict__ seg,
     const uint32_t *__restrict__ segsz, uint32_t *__restrict__ tgt_l, uint32_t n, uint32_t nrows,
     uint32_t ncols, int four, const uint32_t *__restrict__ rest, const uint32_t *__restrict__ nrest)
 {
@@ -94,7 +111,7 @@ __global__ __launch_bounds__(256) void k_single_scan_list(
     if (i >= *nrest) return;
     const uint32_t p = rest[i];
     uint32_t out = NO_TARGET;
-    if (segsz[seg[p]] == 1u) out = single_target(img, dtype, nb, seg, segsz, p, n, nrows, ncols, four);
+    if (segsz[seg[p]] == 1u) out = single_target<DT>(img, nb, seg, segsz, p, n, nrows, ncols, four);
     tgt_l[i] = out;
 }
 
@@ -220,8 +237,9 @@ static int run_eliminate_single(shp_ctx *ctx, const void *d_img, int dtype, int 
         HIPCHK(ctx, hipMemcpyAsync(nelim, ctx->h_pinned + 8, 8, hipMemcpyHostToDevice, st));
     } else {
         HIPCHK(ctx, hipMemsetAsync(nelim, 0, 8, st));
-        hipLaunchKernelGGL(k_single_scan, dim3(g), dim3(256), 0, st, d_img, dtype, nb, d_seg, segsz, tgt, n,
-                           nrows, ncols, four, rest, nrest); KCHK(ctx);
+        DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_single_scan<DT>, dim3(g), dim3(256), 0, st, d_img, nb, d_seg,
+                                                 segsz, tgt, n, nrows, ncols, four, rest, nrest));
+        KCHK(ctx);
         hipLaunchKernelGGL(k_single_apply, dim3(g), dim3(256), 0, st, d_seg, segsz, tgt, n, nelim); KCHK(ctx);
         HIPCHK(ctx, hipMemcpyAsync(ctx->h_pinned, nelim, 8, hipMemcpyDeviceToHost, st));
         HIPCHK(ctx, hipStreamSynchronize(st));
@@ -232,8 +250,9 @@ static int run_eliminate_single(shp_ctx *ctx, const void *d_img, int dtype, int 
     while (merged != 0 && nr != 0) {
         const unsigned gl = grid_for(nr, 256);
         HIPCHK(ctx, hipMemsetAsync(nelim, 0, 4, st));
-        hipLaunchKernelGGL(k_single_scan_list, dim3(gl), dim3(256), 0, st, d_img, dtype, nb, d_seg, segsz,
-                           tgt, n, nrows, ncols, four, rest, nrest); KCHK(ctx);
+        DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_single_scan_list<DT>, dim3(gl), dim3(256), 0, st, d_img, nb,
+                                                 d_seg, segsz, tgt, n, nrows, ncols, four, rest, nrest));
+        KCHK(ctx);
         hipLaunchKernelGGL(k_single_apply_list, dim3(gl), dim3(256), 0, st, d_seg, segsz, tgt, rest, nrest,
                            nelim); KCHK(ctx);
         HIPCHK(ctx, hipMemcpyAsync(ctx->h_pinned, nelim, 4, hipMemcpyDeviceToHost, st));
