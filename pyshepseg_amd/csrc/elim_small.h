@@ -46,7 +46,7 @@ __device__ __forceinline__ float f32_acc(float acc, long long v)
 // WIDE = 32-bit pixel types, whose values need the float64 form of the reference's
 // `float32 + pixel` (N5); for 8/16-bit types a float32 add is the same correctly rounded sum.
 #define SPECTRA_BG 8        // bands per pass
-#define SPECTRA_GRID 1024   // workgroups of the persistent k_spectra_big
+#define SPECTRA_GRID 4096   // workgroups of the persistent k_spectra_big (latency-bound: fill the wave slots)
 template <typename T> __device__ __forceinline__ T wave_sum_t(T v)
 {
 #pragma unroll
