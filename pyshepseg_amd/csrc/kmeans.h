@@ -176,6 +176,7 @@ struct FitCtl {
     double shift;
 };
 
+#define FIT_RPT 4        // sample rows per thread in the E-step (independent fma chains in flight)
 template <int NB>
 __global__ __launch_bounds__(256) void k_fit_assign(const double *__restrict__ X, uint32_t n, int nb_rt,
                                                     const double *__restrict__ m2c,
@@ -186,31 +187,66 @@ __global__ __launch_bounds__(256) void k_fit_assign(const double *__restrict__ X
 {
     if (ctl && ctl->stop) return;               // the loop has ended: the rest of the batch is a no-op
     const int nb = (NB > 0) ? NB : nb_rt;
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    bool diff = false;
-    if (i < n) {
-        double x[(NB > 0) ? NB : 1];
-        if (NB > 0) {
+    const uint32_t i0 = blockIdx.x * (256u * FIT_RPT) + threadIdx.x;
+    uint32_t ndiff = 0;
+    if (NB > 0) {
+        double x[FIT_RPT][(NB > 0) ? NB : 1], bestd[FIT_RPT];
+        int best[FIT_RPT];
 #pragma unroll
-            for (int b = 0; b < NB; b++) x[b] = X[(size_t)i * NB + b];
+        for (int r = 0; r < FIT_RPT; r++) {
+            const uint32_t i = i0 + (uint32_t)r * 256u;
+            const uint32_t ic = i < n ? i : n - 1u;      // clamped: branch-free loads
+#pragma unroll
+            for (int b = 0; b < NB; b++) x[r][b] = X[(size_t)ic * NB + b];
+            best[r] = 0; bestd[r] = 0.0;
         }
-        int best = 0;
-        double bestd = 0.0;
         for (int j = 0; j < k; j++) {
-            double d = cnorm[j];
-            if (NB > 0) {
+            const double cn = cnorm[j];
+            double d[FIT_RPT];
 #pragma unroll
-                for (int b = 0; b < NB; b++) d = __builtin_fma(x[b], m2c[j * NB + b], d);
-            } else {
-                for (int b = 0; b < nb; b++) d = __builtin_fma(X[(size_t)i * nb + b], m2c[j * nb + b], d);
+            for (int r = 0; r < FIT_RPT; r++) d[r] = cn;
+#pragma unroll
+            for (int b = 0; b < NB; b++) {
+                const double c = m2c[j * NB + b];
+#pragma unroll
+                for (int r = 0; r < FIT_RPT; r++) d[r] = __builtin_fma(x[r][b], c, d[r]);
             }
-            if (j == 0 || d < bestd) { bestd = d; best = j; }
+#pragma unroll
+            for (int r = 0; r < FIT_RPT; r++) {
+                if (j == 0) { bestd[r] = d[r]; best[r] = 0; }
+                else {
+                    best[r] = d[r] < bestd[r] ? j : best[r];
+                    bestd[r] = __builtin_fmin(d[r], bestd[r]);
+                }
+            }
         }
-        lab[i] = best;
-        diff = lab_old && lab_old[i] != best;
+#pragma unroll
+        for (int r = 0; r < FIT_RPT; r++) {
+            const uint32_t i = i0 + (uint32_t)r * 256u;
+            if (i < n) {
+                lab[i] = best[r];
+                if (lab_old && lab_old[i] != best[r]) ndiff++;
+            }
+        }
+    } else {
+        for (int r = 0; r < FIT_RPT; r++) {
+            const uint32_t i = i0 + (uint32_t)r * 256u;
+            if (i >= n) continue;
+            int best = 0;
+            double bestd = 0.0;
+            for (int j = 0; j < k; j++) {
+                double d = cnorm[j];
+                for (int b = 0; b < nb; b++) d = __builtin_fma(X[(size_t)i * nb + b], m2c[j * nb + b], d);
+                if (j == 0 || d < bestd) { bestd = d; best = j; }
+            }
+            lab[i] = best;
+            if (lab_old && lab_old[i] != best) ndiff++;
+        }
     }
-    const unsigned long long m = __ballot(diff);
-    if (m != 0ull && lane_id() == 0) atomicAdd(&ctl->ndiff, (uint32_t)__popcll(m));
+    // one atomic per wavefront
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) ndiff += __shfl_xor(ndiff, s, 64);
+    if (ndiff != 0u && lane_id() == 0 && ctl) atomicAdd(&ctl->ndiff, ndiff);
 }
 
 static void launch_fit_assign(shp_ctx *ctx, unsigned g, const double *dX, uint32_t n, int nb,
@@ -513,7 +549,7 @@ static int run_kmeans_fit(shp_ctx *ctx, const double *xin, int64_t nrows, int nb
     HIPCHK(ctx, hipStreamSynchronize(st));           // earlier users of the staging area are done
     HIPCHK(ctx, hipMemcpyAsync(dX, X, xbytes, hipMemcpyHostToDevice, st));
     HIPCHK(ctx, hipMemsetAsync(dlabB, 0xff, (size_t)n * 4, st));        // labels_old = -1
-    const unsigned g = grid_for(n, 256);
+    const unsigned g = grid_for(n, 256u * FIT_RPT);
     auto upload_centres = [&](const std::vector<double> &cc) -> int {
         kmeans_prepare_host(cc.data(), k, nb, pin_up, pin_up + kn);        // m2c | cnorm
         memcpy(pin_up + kn + k, cc.data(), (size_t)kn * 8);              // C  (dC follows dcn)
@@ -569,7 +605,7 @@ static int run_kmeans_fit(shp_ctx *ctx, const double *xin, int64_t nrows, int nb
         int32_t *dlab = (it & 1) ? dlabA : dlabB;
         HIPCHK(ctx, hipMemcpyAsync(pin_dn, dS, (size_t)(kn + k) * 8, hipMemcpyDeviceToHost, st));
         HIPCHK(ctx, hipMemcpyAsync(pin_up, dC, (size_t)kn * 8, hipMemcpyDeviceToHost, st));
-        hipLaunchKernelGGL(k_fit_dist, dim3(g), dim3(256), 0, st, dX, n, nb, dlab, dC, ddist); KCHK(ctx);
+        hipLaunchKernelGGL(k_fit_dist, dim3(grid_for(n, 256)), dim3(256), 0, st, dX, n, nb, dlab, dC, ddist); KCHK(ctx);
         std::vector<double> dist(n);
         std::vector<int32_t> hl(n);
         HIPCHK(ctx, hipMemcpyAsync(dist.data(), ddist, (size_t)n * 8, hipMemcpyDeviceToHost, st));
