@@ -12,6 +12,7 @@
 #pragma once
 #include "common.h"
 #include <algorithm>
+#include <chrono>
 
 #define ASSIGN_PPT 4   // pixels per thread (amortises the scalar centroid loads)
 
@@ -488,6 +489,7 @@ static int run_kmeans_fit(shp_ctx *ctx, const double *xin, int64_t nrows, int nb
                             (long long)nrows, k);
     const uint32_t n = (uint32_t)nrows;
     const int kn = k * nb;
+    const auto t_begin = std::chrono::steady_clock::now();
     // centre the data on the host (sklearn: X -= X.mean(axis=0)); rows outer / bands inner keeps
     // each band's additions in row order while nb independent chains are in flight.  X lives in
     // a pinned, grow-only buffer of the context: no page faults after the first call and the
@@ -567,6 +569,7 @@ static int run_kmeans_fit(shp_ctx *ctx, const double *xin, int64_t nrows, int nb
     // kernels still queued behind it return at once.  Iteration `it` writes its labels to buffer
     // A when it is odd, B when even, and compares them with the other buffer (labels_old).
     const bool sorted = k <= FIT_SORT_MAXK;
+    const auto t_prep = std::chrono::steady_clock::now();
     bool strict = false, finished = false;
     int it_done = 0;
     CHK(upload_centres(C));
@@ -667,5 +670,11 @@ static int run_kmeans_fit(shp_ctx *ctx, const double *xin, int64_t nrows, int nb
     HIPCHK(ctx, hipStreamSynchronize(st));
     for (int t = 0; t < kn; t++) centres_out[t] = C[t] + mu[t % nb];
     if (n_iter_out) *n_iter_out = it;
+    if (getenv("SHEPSEG_FIT_TIMING")) {
+        const auto t_end = std::chrono::steady_clock::now();
+        fprintf(stderr, "kmeans fit: n=%u k=%d iterations=%d  host prep + upload %.2f ms  Lloyd %.2f ms\n", n, k, it,
+                std::chrono::duration<double, std::milli>(t_prep - t_begin).count(),
+                std::chrono::duration<double, std::milli>(t_end - t_prep).count());
+    }
     return 0;
 }
