@@ -64,10 +64,14 @@ static inline size_t scan_tmp_bytes(size_t n)
 
 // out[i] = sum_{j<i} f(j); *total_dev (optional, device pointer) = sum of all.
 // tmp: device scratch of scan_tmp_bytes(n).
+// lazy_boff (optional): the add-back pass is skipped and *lazy_boff receives the per-block offsets
+// (nullptr when there is a single block): the consumer adds lazy_boff[i / SCAN_ITEMS] to out[i]
+// itself, one launch less on a stream where every launch queues behind other tiles' kernels.
 template <class F>
 static int scan_exclusive(shp_ctx *ctx, F f, uint32_t n, uint32_t *out, uint32_t *total_dev,
-                          uint32_t *tmp)
+                          uint32_t *tmp, const uint32_t **lazy_boff = nullptr)
 {
+    if (lazy_boff) *lazy_boff = nullptr;
     if (n == 0) {
         if (total_dev) HIPCHK(ctx, hipMemsetAsync(total_dev, 0, 4, ctx->stream));
         return 0;
@@ -85,6 +89,7 @@ static int scan_exclusive(shp_ctx *ctx, F f, uint32_t n, uint32_t *out, uint32_t
     }
     ArrFn g{bsum};
     CHK(scan_exclusive(ctx, g, nb, boff, total_dev, tmp + 2 * (size_t)nb + 2));
+    if (lazy_boff) { *lazy_boff = boff; return 0; }
     hipLaunchKernelGGL(k_scan_add, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, out, n, boff);
     KCHK(ctx);
     return 0;

@@ -43,7 +43,7 @@ __device__ __forceinline__ unsigned long long match_digit(uint32_t d, bool valid
 __global__ __launch_bounds__(256) void k_sort_scatter(
     const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
     uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, uint32_t n, int shift,
-    const uint32_t *__restrict__ histscan, uint32_t nblk)
+    const uint32_t *__restrict__ histscan, uint32_t nblk, const uint32_t *__restrict__ boff)
 {
     __shared__ uint32_t wcount[4][256];
     const unsigned w = threadIdx.x >> 6, lane = lane_id();
@@ -68,7 +68,8 @@ __global__ __launch_bounds__(256) void k_sort_scatter(
     }
     __syncthreads();
     {
-        uint32_t run = histscan[(size_t)threadIdx.x * nblk + blockIdx.x];
+        const size_t hi = (size_t)threadIdx.x * nblk + blockIdx.x;
+        uint32_t run = histscan[hi] + (boff ? boff[hi / SCAN_ITEMS] : 0u);      // lazy add-back of the scan
 #pragma unroll
         for (int i = 0; i < 4; i++) {
             const uint32_t c = wcount[i][threadIdx.x];
@@ -126,9 +127,10 @@ static int sort_pairs(shp_ctx *ctx, const uint32_t *keys_in, const uint32_t *val
                            nblk);
         KCHK(ctx);
         ArrFn f{hist};
-        CHK(scan_exclusive(ctx, f, (uint32_t)nh, hscan, nullptr, bp<uint32_t>(ctx->scan_tmp)));
+        const uint32_t *boff = nullptr;
+        CHK(scan_exclusive(ctx, f, (uint32_t)nh, hscan, nullptr, bp<uint32_t>(ctx->scan_tmp), &boff));
         hipLaunchKernelGGL(k_sort_scatter, dim3(nblk), dim3(256), 0, ctx->stream, kin, vin, kout,
-                           vout, n, p * 8, hscan, nblk);
+                           vout, n, p * 8, hscan, nblk, boff);
         KCHK(ctx);
         kin = kout; vin = vout;
     }
