@@ -51,6 +51,35 @@ def test_shard_tiles():
     assert [b - a for (a, b) in distributed.shardTiles(ti, 16)].count(12) == 12     # whole rows
 
 
+def test_shard_plan_random_grids():
+    """Random rasters / tile sizes / world sizes: every tile's top and left neighbours are either
+    in the same shard or delivered by the previous shard's boundary plan."""
+    from pyshepseg_amd import tiling, distributed
+    rng = np.random.RandomState(7)
+    for _case in range(200):
+        (nr, nc) = (int(rng.randint(50, 3000)), int(rng.randint(50, 3000)))
+        tile = int(rng.randint(32, 700))
+        ov = 2 * int(rng.randint(1, max(2, tile // 4)))
+        ti = tiling.getTilesForFile(_Ds(nr, nc), tile, ov)
+        world = int(rng.randint(1, 12))
+        sh = distributed.shardTiles(ti, world)
+        nt = ti.ncols * ti.nrows
+        assert [t for (a, b) in sh for t in range(a, b)] == list(range(nt))
+        ne = [i for i, (a, b) in enumerate(sh) if b > a]
+        for pos, r in enumerate(ne):
+            (a, b) = sh[r]
+            got = set()
+            if pos > 0:
+                got = {(k, col, row) for (k, col, row, _h, _w) in
+                       distributed.boundaryPlan(ti, sh, ne[pos - 1], ov)}
+            for t in range(a, b):
+                (col, row) = (t % ti.ncols, t // ti.ncols)
+                if row > 0 and not (a <= t - ti.ncols < b):
+                    assert ('b', col, row - 1) in got
+                if col > 0 and not (a <= t - 1 < b):
+                    assert ('r', col - 1, row) in got
+
+
 def _free_port():
     s = socket.socket()
     s.bind(('127.0.0.1', 0))
