@@ -127,9 +127,43 @@ def calcPerSegmentStatsTiled(imgfile, imgbandnum, segfile, statsSelection,
     (columnName, statName[, parameter]) with statName in 'min', 'max', 'mean', 'stddev',
     'median', 'mode', 'percentile', 'pixcount'.  Returns a TiledStatsResult; with GDAL files the
     columns are also written to the segfile's RAT.
+
+    Both rasters may already live in HBM: ``imgfile`` a ``tiling.DeviceRaster`` and ``segfile``
+    the result of ``doTiledShepherdSegmentation(..., outfile=tiling._KEEP_ON_DEVICE)``; nothing
+    is copied then but the result columns.
     """
     timings = Timers()
     gdalSeg = None
+    from . import tiling as _tiling
+    if isinstance(imgfile, _tiling.DeviceRaster) and getattr(segfile, 'outDev', None):
+        (dptr, nrows, ncols, _nbytes) = segfile.outDev
+        (nb, ir, ic) = imgfile.shape
+        if (ir, ic) != (nrows, ncols):
+            raise PyShepSegStatsError("Images are different sizes")
+        if not (1 <= imgbandnum <= nb):
+            raise PyShepSegStatsError("band %d not in image" % imgbandnum)
+        if imgNullVal is None:
+            imgNullVal = imgfile.nullVal
+        maxSegId = int(segfile.maxSegId)
+        (fast, nInt, nFloat) = makeFastStatsSelection(list(range(len(statsSelection))), statsSelection)
+        intcols = numpy.zeros((max(nInt, 1), maxSegId + 1), dtype=numpy.int64)
+        floatcols = numpy.zeros((max(nFloat, 1), maxSegId + 1), dtype=numpy.float32)
+        c = _lib.ctx()
+        band = imgfile.ptr + (imgbandnum - 1) * nrows * ncols * imgfile.dtype.itemsize
+        with timings.interval('accumulation'):
+            c.check(c._L.shp_segstats_dev(
+                c.handle, ctypes.c_void_p(dptr), ctypes.c_void_p(band), _lib.SHP_DTYPES[imgfile.dtype],
+                nrows * ncols, maxSegId, int(imgNullVal is not None),
+                0 if imgNullVal is None else int(imgNullVal), _lib.ptr(fast), len(statsSelection),
+                int(missingStatsValue), _lib.ptr(intcols), _lib.ptr(floatcols)))
+        cols = {}
+        for i, sel in enumerate(statsSelection):
+            src = floatcols if fast[i, STATSEL_COLTYPE] == STAT_DTYPE_FLOAT else intcols
+            cols[sel[0]] = src[fast[i, STATSEL_COLARRAYINDEX]]
+        rtn = TiledStatsResult()
+        rtn.timings = timings
+        rtn.columns = cols
+        return rtn
     with timings.interval('reading'):
         seg = _loadArray(segfile)
         img = _loadArray(imgfile, imgbandnum)

@@ -131,3 +131,28 @@ def test_spatial_stats_errors():
     with pytest.raises(ts.PyShepSegStatsError, match='built-in user functions'):
         ts.calcPerSegmentSpatialStatsTiled(img, 1, seg, [('a', ts.GFT_Real)], lambda *a: None, None,
                                            imgNullVal=0)
+
+
+def test_stats_on_device_resident_rasters(oracle):
+    """Segmentation kept in HBM -> statistics without a copy == statistics of the downloaded arrays."""
+    from pyshepseg_amd import tiling, tilingstats as ts
+    ras = tiling.DeviceRaster.synth(3, 4, 700, 900)
+    try:
+        cfg = tiling.SegmentationConcurrencyConfig(concurrencyType=tiling.CONC_THREADS, numWorkers=3)
+        kw = dict(tileSize=256, overlapSize=64, minSegmentSize=30, numClusters=12, fixedKMeansInit=True,
+                  concurrencyCfg=cfg)
+        rd = tiling.doTiledShepherdSegmentation(ras, tiling._KEEP_ON_DEVICE, **kw)
+        sel = [('m', 'mean'), ('s', 'stddev'), ('p', 'percentile', 75), ('n', 'pixcount'), ('mo', 'mode')]
+        got = ts.calcPerSegmentStatsTiled(ras, 2, rd, sel)
+        tiling.freeDeviceOutput(rd)
+        rh = tiling.doTiledShepherdSegmentation(ras, None, **kw)
+        img = ras.toArray()
+    finally:
+        ras.free()
+    want = ts.calcPerSegmentStatsTiled(img, 2, rh.segimg, sel)
+    wi, wf = oracle.segstats(rh.segimg, img[1], sel, max_seg_id=rh.maxSegId)
+    for name in ('m', 's'):
+        assert np.array_equal(got.columns[name].view(np.uint32), want.columns[name].view(np.uint32))
+    for name in ('p', 'n', 'mo'):
+        assert np.array_equal(got.columns[name], want.columns[name])
+    assert np.array_equal(got.columns['n'], wi[1]) and np.array_equal(got.columns['m'].view(np.uint32), wf[0].view(np.uint32))
