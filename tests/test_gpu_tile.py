@@ -335,3 +335,27 @@ def test_random_shapes_vs_oracle(shepseg, oracle):
         seg, nxt = shepseg.clump(cl, 0, fourConnected=four)
         oseg, onxt = oracle.clump(cl, 0, four, 1)
         assert nxt == onxt and np.array_equal(seg, oseg), (i, nr, nc)
+
+
+def test_ctx_reserve_and_argument_errors(shepseg):
+    """shp_ctx_reserve grows the workspace up front; bad arguments come back as errors, not crashes."""
+    import ctypes
+    from pyshepseg_amd import _lib
+    c = _lib.Context()
+    try:
+        assert c._L.shp_ctx_reserve(c.handle, _lib.SHP_DTYPES[np.dtype(np.uint16)], 6, 1 << 20) == 0
+        assert c._L.shp_ctx_reserve(c.handle, 99, 6, 1 << 20) != 0            # unknown dtype
+        assert b'bad argument' in c._L.shp_last_error(c.handle)
+        assert c._L.shp_ctx_reserve(c.handle, 2, 0, 1 << 20) != 0             # no bands
+        assert c._L.shp_ctx_reserve(c.handle, 2, 6, -5) != 0
+        # a context that has reserved still segments correctly
+        img = (np.arange(3 * 40 * 50).reshape(3, 40, 50) % 7 * 30).astype(np.uint16)
+        seg = np.empty((40, 50), np.uint32)
+        cen = np.array([[0., 0, 0], [90, 90, 90], [180, 180, 180]])
+        mx, s1, s2, ncl = ctypes.c_uint32(), ctypes.c_int64(), ctypes.c_int64(), ctypes.c_uint32()
+        rc = c._L.shp_segment_tile(c.handle, _lib.ptr(img), 2, 3, 40, 50, _lib.ptr(cen), 3, 0, 0, 1, 5,
+                                   ctypes.c_double(1e9), _lib.ptr(seg), ctypes.byref(mx), ctypes.byref(s1),
+                                   ctypes.byref(s2), ctypes.byref(ncl))
+        assert rc == 0 and mx.value == seg.max() and seg.min() >= 1
+    finally:
+        c.close()
