@@ -497,21 +497,24 @@ __device__ __forceinline__ void dfs_split_lds(uint32_t *lab, const BigInfo &B, u
         }
         __builtin_amdgcn_wave_barrier();
         uint32_t sp_l = 0, sp_g = 0;
-        uint32_t ty = sy, tx = sx;
         bool have = true;
         uint32_t cnt = 0;
+        // Neighbour probe of the current position: every lane fetches the bitmap word of its own
+        // neighbour.  No bounds checks (the border bits are zero); 24-bit multiplies are full rate.
+        // The probe of the NEXT position is issued as soon as that position is known, before the
+        // stack bookkeeping of the current step, so the LDS round trip overlaps it.
+        uint32_t ny, nx, wi, bit, word;
+#define DFS_PROBE(PY, PX)                                                  \
+        do {                                                               \
+            ny = (PY) + (uint32_t)dy; nx = (PX) + (uint32_t)dx;            \
+            wi = qlane ? __umul24(ny, wpr) + (nx >> 5) : 0u;               \
+            bit = 1u << (nx & 31u);                                        \
+            word = bm[wi];                                                 \
+        } while (0)
+        DFS_PROBE(sy, sx);
         while (have && cnt < MAX_CLUMP_SIZE) {
-            // no bounds checks: the border bits are zero.  24-bit multiplies are full rate.
-            const uint32_t ny = ty + (uint32_t)dy, nx = tx + (uint32_t)dx;
-            const uint32_t wi = qlane ? __umul24(ny, wpr) + (nx >> 5) : 0u;
-            const uint32_t bit = 1u << (nx & 31u);
-            const uint32_t word = bm[wi];                   // unconditional: no exec-mask detour
             const bool avail = qlane & ((word & bit) != 0u);
             const unsigned long long m = __ballot(avail);
-            if (avail) {
-                atomicAnd(&bm[wi], ~bit);
-                lab[gbase + __umul24(ny, ncols) + nx] = FL;
-            }
             const uint32_t npush = (uint32_t)__popcll(m);
             if (npush == 0) {
                 if (sp_l == 0 && sp_g > 0) {
@@ -523,11 +526,19 @@ __device__ __forceinline__ void dfs_split_lds(uint32_t *lab, const BigInfo &B, u
                 }
                 if (sp_l > 0) {
                     const uint32_t e = sw[--sp_l];
-                    ty = e >> 16; tx = e & 0xffffu;
+                    DFS_PROBE(e >> 16, e & 0xffffu);
                 } else {
                     have = false;
                 }
             } else {
+                // this step's neighbours: label them, clear their bits (before the next probe reads)
+                const uint32_t packed = (ny << 16) | nx;
+                const uint32_t gidx = gbase + __umul24(ny, ncols) + nx;
+                if (avail) atomicAnd(&bm[wi], ~bit);
+                const unsigned last = 63u - (unsigned)__clzll(m);
+                const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)packed, (int)last);
+                DFS_PROBE(e >> 16, e & 0xffffu);             // the last one pushed is popped next
+                if (avail) lab[gidx] = FL;
                 if (sp_l + 8u > DFS_SWN) {
                     for (uint32_t i = lane; i < DFS_SWN / 2u; i += 64u) gstack[sp_g + i] = sw[i];
                     __builtin_amdgcn_wave_barrier();
@@ -542,16 +553,13 @@ __device__ __forceinline__ void dfs_split_lds(uint32_t *lab, const BigInfo &B, u
                     sp_l -= DFS_SWN / 2u;
                     __builtin_amdgcn_wave_barrier();
                 }
-                const unsigned last = 63u - (unsigned)__clzll(m);
-                const uint32_t packed = (ny << 16) | nx;
                 if (avail && lane != last) sw[sp_l + (uint32_t)__popcll(m & lt)] = packed;
                 sp_l += npush - 1u;
-                const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)packed, (int)last);
-                ty = e >> 16; tx = e & 0xffffu;
                 cnt += npush;
                 __builtin_amdgcn_wave_barrier();
             }
         }
+#undef DFS_PROBE
         if (lane == 0) {
             csize[seed] = cnt + 1u;
             if (cnt == 0 && singles) singles[atomicAdd(nsingles, 1u)] = seed;
