@@ -507,13 +507,13 @@ __device__ __forceinline__ void dfs_split_lds(uint32_t *lab, const BigInfo &B, u
 #define DFS_PROBE(PY, PX)                                                  \
         do {                                                               \
             ny = (PY) + (uint32_t)dy; nx = (PX) + (uint32_t)dx;            \
-            wi = qlane ? __umul24(ny, wpr) + (nx >> 5) : 0u;               \
-            bit = 1u << (nx & 31u);                                        \
+            wi = __umul24(ny, wpr) + (nx >> 5);      /* idle lanes: a valid neighbour word too */ \
+            bit = qlane ? 1u << (nx & 31u) : 0u;     /* ... but no bit to test */                   \
             word = bm[wi];                                                 \
         } while (0)
         DFS_PROBE(sy, sx);
         while (have && cnt < MAX_CLUMP_SIZE) {
-            const bool avail = qlane & ((word & bit) != 0u);
+            const bool avail = (word & bit) != 0u;
             const unsigned long long m = __ballot(avail);
             const uint32_t npush = (uint32_t)__popcll(m);
             if (npush == 0) {
