@@ -286,6 +286,8 @@ struct SmallCtl {
                              // barriers, so a workgroup can be one pass ahead when it zeroes the next slot
     uint32_t bar_count, bar_gen;
     uint32_t nelim, fail, done, slots;
+    uint32_t xcd_n[16];             // workgroups of this launch per XCD (counted at kernel start)
+    uint32_t xcd_cnt[16];           // per-XCD arrival counters of the two-level grid barrier
     unsigned long long tphase[4];   // SHEPSEG_SMALL_TIMING: wall_clock64 ticks spent in control+find / link / apply
 };
 
@@ -300,6 +302,7 @@ struct SmallArgs {
     int nb, four;
     double thr2;
     int poll;           // s_sleep(8) repetitions between two polls of a grid barrier
+    int bar2;           // two-level (per-XCD) grid barrier
 };
 
 __device__ __forceinline__ bool small_grid_barrier(SmallCtl *ctl, uint32_t nblocks, int poll = 4)
@@ -340,6 +343,57 @@ __device__ __forceinline__ bool small_grid_barrier(SmallCtl *ctl, uint32_t nbloc
     }
     __syncthreads();
     return s_ok != 0;
+}
+
+// Two-level form of the grid barrier.  MI355X has eight XCDs, each with its own L2: the release
+// side of an agent-scope barrier is an L2 write-back (buffer_wbl2) of the whole XCD -- the data of
+// every other kernel running there included -- and the one-level barrier above executes it once per
+// workgroup (65 per barrier, ~150 barriers per tile, 20 tiles in flight).  Here the workgroups of
+// one XCD first meet on a per-XCD counter (their stores have drained into that XCD's L2 by then) and
+// only the last one to arrive writes the L2 back and goes on to the global counter: 8 write-backs
+// per barrier.  The acquire side (invalidate) stays per workgroup.
+#define SMALL_GETREG_XCC_ID ((3u << 11) | 20u)      // s_getreg_b32 hwreg(HW_REG_XCC_ID, 0, 4)
+struct SmallBar { uint32_t xcd, nx, nactive; int poll; };
+
+__device__ __forceinline__ bool small_grid_barrier2(SmallCtl *ctl, const SmallBar &b)
+{
+    __shared__ uint32_t s_ok2;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's stores are in this XCD's L2
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t ok = 1;
+        const uint32_t gen = __hip_atomic_load(&ctl->bar_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t a = __hip_atomic_fetch_add(&ctl->xcd_cnt[b.xcd], 1u, __ATOMIC_RELAXED,
+                                                  __HIP_MEMORY_SCOPE_AGENT) + 1u;
+        if (a == b.nx) {                                      // last workgroup of this XCD
+            __hip_atomic_store(&ctl->xcd_cnt[b.xcd], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");                // one L2 write-back per XCD
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const uint32_t g = __hip_atomic_fetch_add(&ctl->bar_count, 1u, __ATOMIC_RELAXED,
+                                                      __HIP_MEMORY_SCOPE_AGENT) + 1u;
+            if (g == b.nactive) {
+                __hip_atomic_store(&ctl->bar_count, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __hip_atomic_fetch_add(&ctl->bar_gen, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
+        uint32_t spins = 0;
+        while (__hip_atomic_load(&ctl->bar_gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gen) {
+            for (int q = 0; q < b.poll; q++) __builtin_amdgcn_s_sleep(8);
+            if (++spins > SMALL_SPIN_LIMIT ||
+                ((spins & 15u) == 0u &&
+                 __hip_atomic_load(&ctl->fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) {
+                __hip_atomic_store(&ctl->fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = 0;
+                break;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        s_ok2 = ok;
+    }
+    __syncthreads();
+    return s_ok2 != 0;
 }
 
 __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
@@ -452,6 +506,25 @@ __global__ __launch_bounds__(256) void k_small_loop(SmallArgs a)
     const uint32_t gtid = blockIdx.x * 256u + threadIdx.x, gthreads = G * 256u;
     const uint32_t gwave = gtid >> 6, gwaves = gthreads >> 6;
     const unsigned lane = lane_id(), w = threadIdx.x >> 6;
+    // where does this workgroup run?  count the launch's workgroups per XCD, meet once with the
+    // one-level barrier so that everybody sees the final counts, then use the two-level barrier
+    __shared__ SmallBar s_bar;
+    if (threadIdx.x == 0) {
+        const uint32_t x = (uint32_t)__builtin_amdgcn_s_getreg(SMALL_GETREG_XCC_ID) & 15u;
+        s_bar.xcd = x;
+        __hip_atomic_fetch_add(&ctl->xcd_n[x], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (!small_grid_barrier(ctl, G, a.poll)) return;
+    if (threadIdx.x == 0) {
+        uint32_t nact = 0;
+        for (int i = 0; i < 16; i++)
+            nact += __hip_atomic_load(&ctl->xcd_n[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) ? 1u : 0u;
+        s_bar.nx = __hip_atomic_load(&ctl->xcd_n[s_bar.xcd], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_bar.nactive = nact;
+        s_bar.poll = a.poll;
+    }
+    __syncthreads();
+    const SmallBar bar = s_bar;
     unsigned long long tmark = wall_clock64();
     for (uint32_t slot = 0;; slot++) {
         const uint32_t par = slot & 1u;
@@ -515,7 +588,7 @@ __global__ __launch_bounds__(256) void k_small_loop(SmallArgs a)
             }
             if (wmerges && lane == 0) atomicAdd(&cnt->nmerge, wmerges);
         }
-        if (!small_grid_barrier(ctl, G, a.poll)) return;
+        if (!(a.bar2 ? small_grid_barrier2(ctl, bar) : small_grid_barrier(ctl, G, a.poll))) return;
         if (gtid == 0) { const unsigned long long t = wall_clock64(); ctl->tphase[0] += t - tmark; tmark = t; }
         const uint32_t nsrc = cnt->nsrc;
         if (cnt->nmerge == 0u) {
@@ -562,7 +635,7 @@ __global__ __launch_bounds__(256) void k_small_loop(SmallArgs a)
                 for (uint32_t j = lane; j < m; j += 64u) a.seg[a.pix[o + j]] = t;
             }
         }
-        if (!small_grid_barrier(ctl, G, a.poll)) return;
+        if (!(a.bar2 ? small_grid_barrier2(ctl, bar) : small_grid_barrier(ctl, G, a.poll))) return;
         if (gtid == 0) { const unsigned long long t = wall_clock64(); ctl->tphase[1] += t - tmark; tmark = t; }
         const uint32_t ntgt = cnt->ntgt;
         // ---- merge step 2: each target absorbs its sources in ascending id (doMerge :1112-1123)
@@ -605,7 +678,7 @@ __global__ __launch_bounds__(256) void k_small_loop(SmallArgs a)
         __syncthreads();
         if (threadIdx.x < a.min_seg && lhist[threadIdx.x] != 0u)
             atomicAdd(&a.hist[threadIdx.x], lhist[threadIdx.x]);          // wrapping add of the delta
-        if (!small_grid_barrier(ctl, G, a.poll)) return;
+        if (!(a.bar2 ? small_grid_barrier2(ctl, bar) : small_grid_barrier(ctl, G, a.poll))) return;
         if (gtid == 0) { const unsigned long long t = wall_clock64(); ctl->tphase[2] += t - tmark; tmark = t; ctl->tphase[3] += 1; }
     }
 }
@@ -652,7 +725,7 @@ static int run_eliminate_small(shp_ctx *ctx, const void *d_img, int dtype, int n
     CHK(buf_ensure(ctx, ctx->tsorted, ns * 4));
     CHK(buf_ensure(ctx, ctx->srclist, ns * 4));
     CHK(buf_ensure(ctx, ctx->tgtlist, ns * 4));
-    CHK(buf_ensure(ctx, ctx->small, ((size_t)min_seg + 96) * 4));
+    CHK(buf_ensure(ctx, ctx->small, ((size_t)min_seg + 160) * 4));
     CHK(buf_ensure(ctx, ctx->scan_tmp, scan_tmp_bytes(ns > n ? ns : n)));
     uint32_t *segsz = bp<uint32_t>(ctx->segsz), *origsz = bp<uint32_t>(ctx->origsz);
     uint32_t *off = bp<uint32_t>(ctx->off), *chnext = bp<uint32_t>(ctx->chnext);
@@ -722,6 +795,8 @@ static int run_eliminate_small(shp_ctx *ctx, const void *d_img, int dtype, int n
     args.nb = nb; args.four = four; args.thr2 = thr2;
     static const int poll_env = getenv("SHEPSEG_SMALL_POLL") ? atoi(getenv("SHEPSEG_SMALL_POLL")) : 4;
     args.poll = poll_env < 1 ? 1 : poll_env;
+    static const int bar2_env = getenv("SHEPSEG_SMALL_BAR2") ? atoi(getenv("SHEPSEG_SMALL_BAR2")) : 1;
+    args.bar2 = bar2_env;
     {
         std::unique_lock<std::mutex> lk(g_small_mu);
         g_small_cv.wait(lk, [] { return g_small_running < g_small_max; });
@@ -746,6 +821,11 @@ static int run_eliminate_small(shp_ctx *ctx, const void *d_img, int dtype, int n
     if (getenv("SHEPSEG_SMALL_TIMING"))
         fprintf(stderr, "small loop: passes %llu  find %.2f ms  link+relabel %.2f ms  apply %.2f ms (S=%u)\n",
                 pin->tphase[3], pin->tphase[0] / 1e5, pin->tphase[1] / 1e5, pin->tphase[2] / 1e5, S);
+    if (getenv("SHEPSEG_SMALL_TIMING")) {
+        fprintf(stderr, "  workgroups per XCD:");
+        for (int i = 0; i < 16; i++) fprintf(stderr, " %u", pin->xcd_n[i]);
+        fprintf(stderr, "\n");
+    }
     *num_elim = (int64_t)pin->nelim;
     uint32_t new_max = 0;
     CHK(run_relabel(ctx, d_seg, n, segsz, S, &new_max));
