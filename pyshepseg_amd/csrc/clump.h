@@ -81,8 +81,14 @@ __device__ __forceinline__ void lds_merge(uint32_t *L, uint32_t a, uint32_t b)
 __global__ __launch_bounds__(256) void k_ccl_local(const uint16_t *__restrict__ clus,
                                                    uint32_t *__restrict__ lab,
                                                    uint32_t *__restrict__ csize, uint32_t nrows,
-                                                   uint32_t ncols, int four)
+                                                   uint32_t ncols, int four, uint32_t *zero4,
+                                                   uint32_t *zero_a, uint32_t *zero_b)
 {
+    // the scalars of the later clump kernels are zeroed here instead of by memset launches
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 4u) {
+        zero4[threadIdx.x] = 0u;
+        if (threadIdx.x == 0) { if (zero_a) *zero_a = 0u; if (zero_b) *zero_b = 0u; }
+    }
     __shared__ uint32_t L[CCL_ROWS * 64u];
     __shared__ uint32_t sz[CCL_ROWS * 64u];
     __shared__ uint16_t cl[CCL_ROWS * 64u];
@@ -189,9 +195,11 @@ __global__ __launch_bounds__(256) void k_ccl_border(const uint16_t *__restrict__
 
 // lab[p] = global root; a patch-local component that is not its own global root hands its size
 // (csize at its local root, 0 at every other pixel) to that root
-__global__ __launch_bounds__(256) void k_ccl_flatten(uint32_t *lab, uint32_t n, uint32_t *csize)
+__global__ __launch_bounds__(256) void k_ccl_flatten(uint32_t *lab, uint32_t n, uint32_t *csize,
+                                                     uint32_t *__restrict__ bigbits)
 {
     const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (p < n && (p & 31u) == 0u) bigbits[p >> 5] = 0u;      // the cut-able-root bitmap starts empty
     if (p >= n || lab[p] == NULL_LAB) return;
     const uint32_t r = uf_find(lab, p);
     lab[p] = r;
@@ -714,26 +722,22 @@ static int run_clump(shp_ctx *ctx, const uint16_t *d_clus, uint32_t nrows, uint3
     hipStream_t st = ctx->stream;
     int ps = prof_begin(ctx, PROF_CCL);
     hipLaunchKernelGGL(k_ccl_local, dim3(grid_for(ncols, 64), grid_for(nrows, CCL_ROWS)), dim3(256), 0, st, d_clus,
-                       lab, csize, nrows, ncols, four); KCHK(ctx);
+                       lab, csize, nrows, ncols, four, counters, d_segsz, d_nsingles); KCHK(ctx);
     {
         const uint32_t ntop = (nrows + CCL_ROWS - 1u) / CCL_ROWS, npc = (ncols + 63u) / 64u;
         const size_t nborder = (size_t)ntop * ncols + (size_t)nrows * 2u * npc;
         hipLaunchKernelGGL(k_ccl_border, dim3(grid_for(nborder, 256)), dim3(256), 0, st, d_clus, lab, nrows, ncols,
                            four, ntop, npc); KCHK(ctx);
     }
-    hipLaunchKernelGGL(k_ccl_flatten, dim3(g), dim3(256), 0, st, lab, n, csize); KCHK(ctx);
-    prof_end(ctx, ps);
-    HIPCHK(ctx, hipMemsetAsync(counters, 0, 16, st));
     uint32_t *bigbits = bp<uint32_t>(ctx->bigbits), *rank = bp<uint32_t>(ctx->aux2);
-    HIPCHK(ctx, hipMemsetAsync(bigbits, 0, ((size_t)n / 32 + 1) * 4, st));
-    HIPCHK(ctx, hipMemsetAsync(d_segsz, 0, 4, st));         // only the null count accumulates
+    hipLaunchKernelGGL(k_ccl_flatten, dim3(g), dim3(256), 0, st, lab, n, csize, bigbits); KCHK(ctx);
+    prof_end(ctx, ps);
     hipLaunchKernelGGL(k_big_list, dim3(g), dim3(256), 0, st, lab, csize, n, ncols, big, counters, bigbits); KCHK(ctx);
     hipLaunchKernelGGL(k_big_bbox, dim3(grid_for(ncols, 64), grid_for(nrows, AGG_ROWS)), dim3(256), 0, st, lab,
                        csize, nrows, ncols, big, bigbits); KCHK(ctx);
     ps = prof_begin(ctx, PROF_DFS);
     uint32_t *order = (uint32_t *)((char *)ctx->big.p + (size_t)maxbig * sizeof(BigInfo) + 64);
     hipLaunchKernelGGL(k_big_order, dim3(grid_for(maxbig, 256)), dim3(256), 0, st, big, counters, order); KCHK(ctx);
-    if (d_nsingles) HIPCHK(ctx, hipMemsetAsync(d_nsingles, 0, 4, st));
     // fork: the two size classes touch disjoint components, so they can run on two streams
     static const int fork_env = getenv("SHEPSEG_DFS_FORK") ? atoi(getenv("SHEPSEG_DFS_FORK")) : -1;
     const int fork2 = fork_env >= 0 ? fork_env : ctx->dfs_fork;

@@ -105,9 +105,11 @@ template <int DT>
 __global__ __launch_bounds__(256) void k_single_scan_list(
     const void *__restrict__ img, int nb, const uint32_t *__restrict__ seg,
     const uint32_t *__restrict__ segsz, uint32_t *__restrict__ tgt_l, uint32_t n, uint32_t nrows,
-    uint32_t ncols, int four, const uint32_t *__restrict__ rest, const uint32_t *__restrict__ nrest)
+    uint32_t ncols, int four, const uint32_t *__restrict__ rest, const uint32_t *__restrict__ nrest,
+    uint32_t *nelim)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i == 0) *nelim = 0u;                 // the apply kernel of this pass raises it (no memset launch)
     if (i >= *nrest) return;
     const uint32_t p = rest[i];
     uint32_t out = NO_TARGET;
@@ -249,9 +251,8 @@ static int run_eliminate_single(shp_ctx *ctx, const void *d_img, int dtype, int 
     // later passes touch only the single pixels that could not merge in the first one
     while (merged != 0 && nr != 0) {
         const unsigned gl = grid_for(nr, 256);
-        HIPCHK(ctx, hipMemsetAsync(nelim, 0, 4, st));
         DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_single_scan_list<DT>, dim3(gl), dim3(256), 0, st, d_img, nb,
-                                                 d_seg, segsz, tgt, n, nrows, ncols, four, rest, nrest));
+                                                 d_seg, segsz, tgt, n, nrows, ncols, four, rest, nrest, nelim));
         KCHK(ctx);
         hipLaunchKernelGGL(k_single_apply_list, dim3(gl), dim3(256), 0, st, d_seg, segsz, tgt, rest, nrest,
                            nelim); KCHK(ctx);

@@ -313,13 +313,28 @@ static int run_stitch_tile(shp_ctx *ctx, uint32_t *d_tile, uint32_t ys, uint32_t
 #define META_CROSS_LEFT 2u
 #define META_IN_TRIM 4u
 
-__global__ __launch_bounds__(256) void k_meta_cross(const uint32_t *__restrict__ mn,
-                                                    const uint32_t *__restrict__ mx, uint32_t mid,
-                                                    uint32_t nseg, uint32_t bit, uint32_t *flags)
+// every per-segment table of the prepare stage in one launch (memsets are launches too, and every
+// launch boundary is a cache write-back / invalidate for the whole device)
+__global__ __launch_bounds__(256) void k_meta_init(uint32_t nseg, uint32_t *__restrict__ flags,
+                                                   uint32_t *__restrict__ segtop,
+                                                   uint32_t *__restrict__ segleft,
+                                                   uint32_t *__restrict__ mn, uint32_t *__restrict__ mx)
 {
     const uint32_t s = blockIdx.x * 256u + threadIdx.x;
-    if (s >= nseg || s == 0) return;
-    if (mn[s] < mid && mx[s] >= mid + 1u) flags[s] |= bit;
+    if (s >= nseg) return;
+    flags[s] = 0u; segtop[s] = 0xFFFFFFFFu; segleft[s] = 0xFFFFFFFFu;
+    if (mn) { mn[s] = 0xFFFFFFFFu; mx[s] = 0u; }
+}
+
+// crossesMidline for every segment of the strip; leaves mn / mx reset for the next strip
+__global__ __launch_bounds__(256) void k_meta_cross(uint32_t *__restrict__ mn, uint32_t *__restrict__ mx,
+                                                    uint32_t mid, uint32_t nseg, uint32_t bit,
+                                                    uint32_t *flags)
+{
+    const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+    if (s >= nseg) return;
+    if (s != 0 && mn[s] < mid && mx[s] >= mid + 1u) flags[s] |= bit;
+    mn[s] = 0xFFFFFFFFu; mx[s] = 0u;
 }
 
 // bounding-box corner of every segment + "has a pixel in the trimmed window".
@@ -384,19 +399,17 @@ static int run_stitch_prepare(shp_ctx *ctx, const uint32_t *d_tile, uint32_t ys,
     hipStream_t st = ctx->stream;
     const uint32_t n = ys * xs, nseg = max_local + 1u;
     uint32_t *flags = d_meta, *segtop = d_meta + nseg, *segleft = d_meta + 2 * (size_t)nseg;
-    HIPCHK(ctx, hipMemsetAsync(flags, 0, (size_t)nseg * 4, st));
-    HIPCHK(ctx, hipMemsetAsync(segtop, 0xff, (size_t)nseg * 8, st));
-    if (n == 0) return 0;
     CHK(buf_ensure(ctx, ctx->aux, (size_t)nseg * 8 + 64));
     uint32_t *mn = bp<uint32_t>(ctx->aux), *mx = mn + nseg;
+    hipLaunchKernelGGL(k_meta_init, dim3(grid_for(nseg, 256)), dim3(256), 0, st, nseg, flags, segtop, segleft,
+                       mn, mx); KCHK(ctx);
+    if (n == 0) return 0;
     const uint32_t an_rows = overlap < ys ? overlap : ys, an_cols = overlap < xs ? overlap : xs;
     for (int pass = 0; pass < 2; pass++) {
         const int horizontal = pass == 0;
         if (horizontal ? !has_top : !has_left) continue;
         const uint32_t srows = horizontal ? an_rows : ys, scols = horizontal ? xs : an_cols;
         if (srows * scols == 0) continue;
-        HIPCHK(ctx, hipMemsetAsync(mn, 0xff, (size_t)nseg * 4, st));
-        HIPCHK(ctx, hipMemsetAsync(mx, 0, (size_t)nseg * 4, st));
         hipLaunchKernelGGL(k_strip_minmax, dim3(grid_for(scols, 64), grid_for(srows, AGG_ROWS)), dim3(256), 0, st,
                            d_tile, xs, srows, scols, horizontal, mn, mx); KCHK(ctx);
         hipLaunchKernelGGL(k_meta_cross, dim3(grid_for(nseg, 256)), dim3(256), 0, st, mn, mx,
