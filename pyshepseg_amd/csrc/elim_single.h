@@ -105,12 +105,11 @@ template <int DT>
 __global__ __launch_bounds__(256) void k_single_scan_list(
     const void *__restrict__ img, int nb, const uint32_t *__restrict__ seg,
     const uint32_t *__restrict__ segsz, uint32_t *__restrict__ tgt_l, uint32_t n, uint32_t nrows,
-    uint32_t ncols, int four, const uint32_t *__restrict__ rest, const uint32_t *__restrict__ nrest,
-    uint32_t *nelim)
+    uint32_t ncols, int four, const uint32_t *__restrict__ rest, uint32_t nrest, uint32_t *nelim)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i == 0) *nelim = 0u;                 // the apply kernel of this pass raises it (no memset launch)
-    if (i >= *nrest) return;
+    if (i >= nrest) return;
     const uint32_t p = rest[i];
     uint32_t out = NO_TARGET;
     if (segsz[seg[p]] == 1u) out = single_target<DT>(img, nb, seg, segsz, p, n, nrows, ncols, four);
@@ -120,11 +119,11 @@ __global__ __launch_bounds__(256) void k_single_scan_list(
 __global__ __launch_bounds__(256) void k_single_apply_list(uint32_t *__restrict__ seg, uint32_t *segsz,
                                                            const uint32_t *__restrict__ tgt_l,
                                                            const uint32_t *__restrict__ rest,
-                                                           const uint32_t *__restrict__ nrest,
+                                                           uint32_t nrest,
                                                            uint32_t *nelim)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= *nrest) return;
+    if (i >= nrest) return;
     const uint32_t t = tgt_l[i];
     if (t == NO_TARGET) return;
     const uint32_t p = rest[i];
@@ -234,9 +233,6 @@ static int run_eliminate_single(shp_ctx *ctx, const void *d_img, int dtype, int 
         rest = bp<uint32_t>(ctx->singles);
         nr = nsingles;
         merged = 1;
-        uint32_t hn[2] = {0u, nsingles};
-        ctx->h_pinned[8] = hn[0]; ctx->h_pinned[9] = hn[1];
-        HIPCHK(ctx, hipMemcpyAsync(nelim, ctx->h_pinned + 8, 8, hipMemcpyHostToDevice, st));
     } else {
         HIPCHK(ctx, hipMemsetAsync(nelim, 0, 8, st));
         DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_single_scan<DT>, dim3(g), dim3(256), 0, st, d_img, nb, d_seg,
@@ -252,9 +248,9 @@ static int run_eliminate_single(shp_ctx *ctx, const void *d_img, int dtype, int 
     while (merged != 0 && nr != 0) {
         const unsigned gl = grid_for(nr, 256);
         DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_single_scan_list<DT>, dim3(gl), dim3(256), 0, st, d_img, nb,
-                                                 d_seg, segsz, tgt, n, nrows, ncols, four, rest, nrest, nelim));
+                                                 d_seg, segsz, tgt, n, nrows, ncols, four, rest, nr, nelim));
         KCHK(ctx);
-        hipLaunchKernelGGL(k_single_apply_list, dim3(gl), dim3(256), 0, st, d_seg, segsz, tgt, rest, nrest,
+        hipLaunchKernelGGL(k_single_apply_list, dim3(gl), dim3(256), 0, st, d_seg, segsz, tgt, rest, nr,
                            nelim); KCHK(ctx);
         HIPCHK(ctx, hipMemcpyAsync(ctx->h_pinned, nelim, 4, hipMemcpyDeviceToHost, st));
         HIPCHK(ctx, hipStreamSynchronize(st));

@@ -1,40 +1,53 @@
 // scan.h -- exclusive prefix sum of uint32 values produced by a device functor.
-// Three-phase (block-local scan, recursive scan of block totals, add-back); 1024 items per
+// Three-phase (block-local scan, recursive scan of block totals, add-back); 8192 items per
 // 256-thread workgroup.  HBM-bound: 4 B read (whatever the functor reads) + 4 B written/item.
 #pragma once
 #include "common.h"
 
-#define SCAN_ITEMS 1024u
+#define SCAN_SUB 1024u                       // items per inner step of a workgroup (4 per thread)
+#define SCAN_STEPS 8u
+#define SCAN_ITEMS (SCAN_SUB * SCAN_STEPS)   // items per workgroup: two levels cover 67 M items, so the
+                                             // scans of a tile need 2 + 1 launches instead of 3 + 2
 
+// block-local exclusive scan of SCAN_ITEMS items in SCAN_STEPS coalesced sub-tiles with a running
+// carry; bsum[block] = the block's total; total_out (optional, single-block grids) = the total
 template <class F>
 __global__ __launch_bounds__(256) void k_scan_local(F f, uint32_t n, uint32_t *__restrict__ out,
-                                                    uint32_t *__restrict__ bsum)
+                                                    uint32_t *__restrict__ bsum, uint32_t *total_out)
 {
     __shared__ uint32_t wsum[4];
-    const uint32_t base = blockIdx.x * SCAN_ITEMS + threadIdx.x * 4u;
-    uint32_t v[4];
+    const unsigned lane = lane_id(), w = threadIdx.x >> 6;
+    uint32_t carry = 0;
+    for (uint32_t st = 0; st < SCAN_STEPS; st++) {
+        const uint32_t base = blockIdx.x * SCAN_ITEMS + st * SCAN_SUB + threadIdx.x * 4u;
+        if (st * SCAN_SUB + blockIdx.x * SCAN_ITEMS >= n) break;          // uniform: nothing left
+        uint32_t v[4];
 #pragma unroll
-    for (int i = 0; i < 4; i++) v[i] = (base + i < n) ? f(base + i) : 0u;
-    const uint32_t tsum = v[0] + v[1] + v[2] + v[3];
-    uint32_t incl = tsum;
-    const unsigned lane = lane_id();
+        for (int i = 0; i < 4; i++) v[i] = (base + i < n) ? f(base + i) : 0u;
+        const uint32_t tsum = v[0] + v[1] + v[2] + v[3];
+        uint32_t incl = tsum;
 #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        uint32_t t = __shfl_up(incl, d, 64);
-        if (lane >= (unsigned)d) incl += t;
+        for (int d = 1; d < 64; d <<= 1) {
+            uint32_t t = __shfl_up(incl, d, 64);
+            if (lane >= (unsigned)d) incl += t;
+        }
+        __syncthreads();                                       // wsum of the previous step was read
+        if (lane == 63) wsum[w] = incl;
+        __syncthreads();
+        uint32_t woff = carry;
+        for (unsigned i = 0; i < w; i++) woff += wsum[i];
+        uint32_t run = woff + incl - tsum;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            if (base + i < n) out[base + i] = run;
+            run += v[i];
+        }
+        carry += wsum[0] + wsum[1] + wsum[2] + wsum[3];
     }
-    const unsigned w = threadIdx.x >> 6;
-    if (lane == 63) wsum[w] = incl;
-    __syncthreads();
-    uint32_t woff = 0;
-    for (unsigned i = 0; i < w; i++) woff += wsum[i];
-    uint32_t run = woff + incl - tsum;
-#pragma unroll
-    for (int i = 0; i < 4; i++) {
-        if (base + i < n) out[base + i] = run;
-        run += v[i];
+    if (threadIdx.x == 0) {
+        bsum[blockIdx.x] = carry;
+        if (total_out && gridDim.x == 1) *total_out = carry;
     }
-    if (threadIdx.x == 255) bsum[blockIdx.x] = woff + incl;
 }
 
 __global__ __launch_bounds__(256) void k_scan_add(uint32_t *__restrict__ out, uint32_t n,
@@ -80,13 +93,9 @@ static int scan_exclusive(shp_ctx *ctx, F f, uint32_t n, uint32_t *out, uint32_t
     uint32_t *bsum = tmp;
     uint32_t *boff = tmp + nb + 1;
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_local<F>), dim3(nb), dim3(256), 0, ctx->stream, f, n,
-                       out, bsum);
+                       out, bsum, nb == 1 ? total_dev : (uint32_t *)nullptr);
     KCHK(ctx);
-    if (nb == 1) {
-        if (total_dev)
-            HIPCHK(ctx, hipMemcpyAsync(total_dev, bsum, 4, hipMemcpyDeviceToDevice, ctx->stream));
-        return 0;
-    }
+    if (nb == 1) return 0;                   // the kernel wrote the total itself
     ArrFn g{bsum};
     CHK(scan_exclusive(ctx, g, nb, boff, total_dev, tmp + 2 * (size_t)nb + 2));
     if (lazy_boff) { *lazy_boff = boff; return 0; }
