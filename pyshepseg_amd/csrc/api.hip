@@ -308,9 +308,8 @@ static int segment_device(shp_ctx *ctx, const void *d_img, uint32_t *d_seg, int 
     CHK(buf_ensure(ctx, ctx->singles, ((size_t)n + 2) * 4));
     CHK(run_clump(ctx, bp<uint16_t>(ctx->clus), nrows, ncols, four, d_seg, scal + 2, bp<uint32_t>(ctx->segsz),
                   bp<uint32_t>(ctx->singles), scal + 3));
-    // read back: number of clumps, number of one-pixel clumps, null-pixel count
-    HIPCHK(ctx, hipMemcpyAsync(ctx->h_pinned, scal + 2, 8, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(ctx->h_pinned + 2, ctx->segsz.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+    // read back: number of clumps, number of one-pixel clumps, null-pixel count (scal[2..4])
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_pinned, scal + 2, 12, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     const uint32_t nclumps = ctx->h_pinned[0], nsingles = ctx->h_pinned[1], nnull = ctx->h_pinned[2];
     hipEventRecord(ctx->ev[3], ctx->stream);

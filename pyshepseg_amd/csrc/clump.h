@@ -87,7 +87,7 @@ __global__ __launch_bounds__(256) void k_ccl_local(const uint16_t *__restrict__ 
     // the scalars of the later clump kernels are zeroed here instead of by memset launches
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 4u) {
         zero4[threadIdx.x] = 0u;
-        if (threadIdx.x == 0) { if (zero_a) *zero_a = 0u; if (zero_b) *zero_b = 0u; }
+        if (threadIdx.x == 0) { if (zero_a) *zero_a = 0u; if (zero_b) { zero_b[0] = 0u; zero_b[1] = 0u; } }
     }
     __shared__ uint32_t L[CCL_ROWS * 64u];
     __shared__ uint32_t sz[CCL_ROWS * 64u];
@@ -683,7 +683,10 @@ __global__ __launch_bounds__(256) void k_clump_final(const uint32_t *__restrict_
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        if (s_null) atomicAdd(&segsz[0], s_null);
+        if (s_null) {
+            atomicAdd(&segsz[0], s_null);
+            if (nsingles) atomicAdd(&nsingles[1], s_null);      // mirror: one read-back gets all three
+        }
         s_base = s_cnt ? atomicAdd(nsingles, s_cnt) : 0u;
     }
     __syncthreads();

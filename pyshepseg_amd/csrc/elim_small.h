@@ -228,21 +228,30 @@ __global__ __launch_bounds__(256) void k_spectra_big(
     }
 }
 
-__global__ __launch_bounds__(256) void k_small_init(const uint32_t *__restrict__ segsz,
-                                                    uint32_t *__restrict__ origsz,
+// per-segment state of the pass loop; sizes come from `src` (segsz itself, or origsz when the
+// single-pixel stage left them there: then this is also the copy), and thread 0 sets up the loop
+// control block -- neither needs a copy launch of its own
+__global__ __launch_bounds__(256) void k_small_init(const uint32_t *src, uint32_t *segsz,
+                                                    uint32_t *origsz,
                                                     uint32_t *__restrict__ chnext,
                                                     uint32_t *__restrict__ chtail,
                                                     uint32_t *__restrict__ mergeto,
                                                     uint32_t *__restrict__ tcount,
                                                     uint32_t *__restrict__ tfill, uint32_t *hist,
-                                                    uint32_t S, uint32_t min_seg, uint32_t *tlist)
+                                                    uint32_t S, uint32_t min_seg, uint32_t *tlist,
+                                                    uint32_t *ctlwords, uint32_t nctlwords)
 {
     __shared__ uint32_t lh[256];            // block-local histogram of sizes 1..255
     lh[threadIdx.x] = 0;
     __syncthreads();
     const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+    if (blockIdx.x == 0) {                  // SmallCtl: all zero but st[0] = {target 1, prev -1, ...}
+        for (uint32_t i = threadIdx.x; i < nctlwords; i += 256u)
+            ctlwords[i] = (i == 0u) ? 1u : (i == 1u) ? 0xFFFFFFFFu : 0u;
+    }
     if (s <= S) {
-        const uint32_t m = segsz[s];
+        const uint32_t m = src[s];
+        segsz[s] = m;
         origsz[s] = m;
         chnext[s] = 0;
         chtail[s] = s;
@@ -739,10 +748,8 @@ static int run_eliminate_small(shp_ctx *ctx, const void *d_img, int dtype, int n
     SmallCtl *ctl = (SmallCtl *)(hist + ((min_seg + 4u + 3u) & ~3u));
     hipStream_t st = ctx->stream;
 
-    if (sizes_in_origsz)
-        HIPCHK(ctx, hipMemcpyAsync(segsz, origsz, ((size_t)S + 1) * 4, hipMemcpyDeviceToDevice, st));
-    else
-        CHK(run_seg_size(ctx, d_seg, n, S, segsz));
+    const uint32_t *sizes = sizes_in_origsz ? origsz : segsz;      // k_small_init copies them to both
+    if (!sizes_in_origsz) CHK(run_seg_size(ctx, d_seg, n, S, segsz));
     if (n == 0 || S == 0) return 0;
     // CSR: pixels grouped by segment id, raster order inside (stable sort of (seg, index))
     uint32_t *ksorted = nullptr, *pix = nullptr;
@@ -750,12 +757,14 @@ static int run_eliminate_small(shp_ctx *ctx, const void *d_img, int dtype, int n
     CHK(sort_pairs(ctx, d_seg, nullptr, n, bits_for(S), &ksorted, &pix));
     prof_end(ctx, ps);
     uint32_t *stmp = bp<uint32_t>(ctx->scan_tmp);      // (fetched after sort_pairs: it may regrow)
-    ArrFn szf{segsz};
+    ArrFn szf{sizes};
     CHK(scan_exclusive(ctx, szf, S + 1u, off, nullptr, stmp));
     const unsigned gs = grid_for((size_t)S + 1, 256);
     HIPCHK(ctx, hipMemsetAsync(hist, 0, ((size_t)min_seg + 2) * 4, st));
-    hipLaunchKernelGGL(k_small_init, dim3(gs), dim3(256), 0, st, segsz, origsz, chnext, chtail,
-                       mergeto, tcount, tfill, hist, S, min_seg, tlist); KCHK(ctx);
+    static_assert(sizeof(SmallCtl) % 4 == 0 && offsetof(SmallCtl, st) == 0, "SmallCtl layout");
+    hipLaunchKernelGGL(k_small_init, dim3(gs), dim3(256), 0, st, sizes, segsz, origsz, chnext, chtail,
+                       mergeto, tcount, tfill, hist, S, min_seg, tlist, (uint32_t *)ctl,
+                       (uint32_t)(sizeof(SmallCtl) / 4)); KCHK(ctx);
     ps = prof_begin(ctx, PROF_SPECTRA);
     uint32_t *biglist = tlist;          // free until the pass loop starts
     hipLaunchKernelGGL(k_big_seg_list, dim3(grid_for((size_t)S, 4096)), dim3(256), 0, st, segsz, S, biglist);
@@ -782,10 +791,7 @@ static int run_eliminate_small(shp_ctx *ctx, const void *d_img, int dtype, int n
 
     const double thr2 = max_spectral_diff * max_spectral_diff;       // float64 square (N8)
     // one persistent kernel runs every pass (see k_small_loop)
-    SmallCtl *pin = (SmallCtl *)(ctx->h_pinned + 16);
-    memset(pin, 0, sizeof(SmallCtl));
-    pin->st[0].target = 1; pin->st[0].prev = -1;
-    HIPCHK(ctx, hipMemcpyAsync(ctl, pin, sizeof(SmallCtl), hipMemcpyHostToDevice, st));
+    SmallCtl *pin = (SmallCtl *)(ctx->h_pinned + 16);            // (the kernel above initialised ctl)
     SmallArgs args;
     args.ctl = ctl; args.hist = hist; args.seg = d_seg; args.segsz = segsz; args.ssum = ssum;
     args.pix = pix; args.off = off; args.origsz = origsz; args.chnext = chnext; args.chtail = chtail;
