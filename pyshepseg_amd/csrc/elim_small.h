@@ -752,9 +752,9 @@ static int run_eliminate_small(shp_ctx *ctx, const void *d_img, int dtype, int n
     if (!sizes_in_origsz) CHK(run_seg_size(ctx, d_seg, n, S, segsz));
     if (n == 0 || S == 0) return 0;
     // CSR: pixels grouped by segment id, raster order inside (stable sort of (seg, index))
-    uint32_t *ksorted = nullptr, *pix = nullptr;
+    uint32_t *pix = nullptr;
     int ps = prof_begin(ctx, PROF_SORT);
-    CHK(sort_pairs(ctx, d_seg, nullptr, n, bits_for(S), &ksorted, &pix));
+    CHK(sort_pairs(ctx, d_seg, nullptr, n, bits_for(S), nullptr, &pix));
     prof_end(ctx, ps);
     uint32_t *stmp = bp<uint32_t>(ctx->scan_tmp);      // (fetched after sort_pairs: it may regrow)
     ArrFn szf{sizes};

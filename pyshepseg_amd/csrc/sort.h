@@ -19,10 +19,20 @@ __global__ __launch_bounds__(256) void k_sort_hist(const uint32_t *__restrict__ 
     __syncthreads();
     const unsigned w = threadIdx.x >> 6, lane = lane_id();
     const uint32_t base = blockIdx.x * SORT_TILE + w * SORT_ROWS * 64u + lane;
+    uint32_t d[SORT_ROWS];
 #pragma unroll
     for (unsigned r = 0; r < SORT_ROWS; r++) {
         const uint32_t idx = base + r * 64u;
-        if (idx < n) atomicAdd(&h[(keys[idx] >> shift) & 255u], 1u);
+        d[r] = (idx < n) ? ((keys[idx] >> shift) & 255u) : 256u;
+    }
+#pragma unroll
+    for (unsigned r = 0; r < SORT_ROWS; r++) {
+        // label rasters come in runs: the lanes that share the first lane's digit add once (64
+        // LDS atomics on one address would serialise), the others one by one
+        const uint32_t d0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)d[r]);
+        const unsigned long long same = __ballot(d[r] == d0);
+        if (d0 < 256u && lane == 0) atomicAdd(&h[d0], (uint32_t)__popcll(same));
+        if (d[r] != d0 && d[r] < 256u) atomicAdd(&h[d[r]], 1u);
     }
     __syncthreads();
     hist[(size_t)threadIdx.x * nblk + blockIdx.x] = h[threadIdx.x];
@@ -59,12 +69,21 @@ __global__ __launch_bounds__(256) void k_sort_scatter(
     for (int i = 0; i < 4; i++) wcount[i][threadIdx.x] = 0;
     __syncthreads();
     const unsigned long long lt = lanemask_lt();
+    // per row: the lanes sharing this lane's digit (peers) and how many items of that digit the
+    // wave's earlier rows hold (rowbase); the leader of each group bumps the wave's digit count
+    unsigned long long peers[SORT_ROWS];
+    uint32_t rowbase[SORT_ROWS];
 #pragma unroll
     for (unsigned r = 0; r < SORT_ROWS; r++) {
         const bool valid = (base + r * 64u) < n;
         const uint32_t d = (k[r] >> shift) & 255u;
-        const unsigned long long peers = match_digit(d, valid);
-        if (valid && (peers & lt) == 0ull) wcount[w][d] += (uint32_t)__popcll(peers);
+        peers[r] = match_digit(d, valid);
+        uint32_t rb = 0;
+        if (valid) rb = wcount[w][d];
+        __builtin_amdgcn_wave_barrier();
+        if (valid && (peers[r] & lt) == 0ull) wcount[w][d] = rb + (uint32_t)__popcll(peers[r]);
+        __builtin_amdgcn_wave_barrier();
+        rowbase[r] = rb;
     }
     __syncthreads();
     {
@@ -82,24 +101,19 @@ __global__ __launch_bounds__(256) void k_sort_scatter(
     for (unsigned r = 0; r < SORT_ROWS; r++) {
         const bool valid = (base + r * 64u) < n;
         const uint32_t d = (k[r] >> shift) & 255u;
-        const unsigned long long peers = match_digit(d, valid);
-        uint32_t off = 0;
-        if (valid) off = wcount[w][d];
-        __builtin_amdgcn_wave_barrier();
         if (valid) {
-            const uint32_t pos = off + (uint32_t)__popcll(peers & lt);
-            keys_out[pos] = k[r];
+            const uint32_t pos = wcount[w][d] + rowbase[r] + (uint32_t)__popcll(peers[r] & lt);
+            if (keys_out) keys_out[pos] = k[r];
             vals_out[pos] = v[r];
-            if ((peers & lt) == 0ull) wcount[w][d] = off + (uint32_t)__popcll(peers);
         }
-        __builtin_amdgcn_wave_barrier();
     }
 }
 
 // Sort n pairs by the low `bits` bits of the key.  vals_in == nullptr means value = index.
 // Uses ctx->sort_k0/sort_k1/sort_v1/pix as ping-pong storage and ctx->sort_hist/scan_tmp as
 // scratch.  On return *keys_sorted / *vals_sorted point at the buffers holding the result
-// (vals always end up in ctx->pix or ctx->sort_v1).
+// (vals always end up in ctx->pix or ctx->sort_v1).  keys_sorted == nullptr: the caller only wants
+// the values, the last pass does not write the keys.
 static int sort_pairs(shp_ctx *ctx, const uint32_t *keys_in, const uint32_t *vals_in, uint32_t n,
                       int bits, uint32_t **keys_sorted, uint32_t **vals_sorted)
 {
@@ -120,9 +134,9 @@ static int sort_pairs(shp_ctx *ctx, const uint32_t *keys_in, const uint32_t *val
     if (passes & 1) { vbuf[0] = bp<uint32_t>(ctx->pix); vbuf[1] = bp<uint32_t>(ctx->sort_v1); }
     else            { vbuf[0] = bp<uint32_t>(ctx->sort_v1); vbuf[1] = bp<uint32_t>(ctx->pix); }
     const uint32_t *kin = keys_in, *vin = vals_in;
-    if (n == 0) { *keys_sorted = kbuf[0]; *vals_sorted = bp<uint32_t>(ctx->pix); return 0; }
+    if (n == 0) { if (keys_sorted) *keys_sorted = kbuf[0]; *vals_sorted = bp<uint32_t>(ctx->pix); return 0; }
     for (int p = 0; p < passes; p++) {
-        uint32_t *kout = kbuf[p & 1], *vout = vbuf[p & 1];
+        uint32_t *kout = (!keys_sorted && p == passes - 1) ? nullptr : kbuf[p & 1], *vout = vbuf[p & 1];
         hipLaunchKernelGGL(k_sort_hist, dim3(nblk), dim3(256), 0, ctx->stream, kin, n, p * 8, hist,
                            nblk);
         KCHK(ctx);
@@ -134,7 +148,7 @@ static int sort_pairs(shp_ctx *ctx, const uint32_t *keys_in, const uint32_t *val
         KCHK(ctx);
         kin = kout; vin = vout;
     }
-    *keys_sorted = (uint32_t *)kin;
+    if (keys_sorted) *keys_sorted = (uint32_t *)kin;
     *vals_sorted = (uint32_t *)vin;
     return 0;
 }
