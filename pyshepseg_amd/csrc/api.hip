@@ -536,6 +536,8 @@ API int shp_segment_window_dev(shp_ctx *ctx, const void *d_img, int dtype, int n
     if (num_clumps_out) *num_clumps_out = 0;
     if (n == 0) return 0;
     ctx->dfs_fork = 0;      // many tiles in flight: one stream per worker is enough
+    FillScope fs(ctx, 1);
+    fill_acquire(ctx, 0);
     hipEventRecord(ctx->ev[0], ctx->stream);
     const void *tile_img = d_img;
     if (!(x == 0 && y == 0 && xs == img_cols && ys == img_rows)) {
@@ -576,8 +578,10 @@ API int shp_segment_tile_to_dev(shp_ctx *ctx, const void *img, int dtype, int nb
     if (num_clumps_out) *num_clumps_out = 0;
     if (n == 0) return 0;
     ctx->dfs_fork = 0;
+    FillScope fs(ctx, 1);
     hipEventRecord(ctx->ev[0], ctx->stream);
-    CHK(upload_img(ctx, img, dtype, nbands, n));
+    CHK(upload_img(ctx, img, dtype, nbands, n));          // (PCIe: outside the gate)
+    fill_acquire(ctx, 0);
     CHK(segment_device(ctx, ctx->img.p, d_seg_out, dtype, nbands, nrows, ncols, centres, k, has_null,
                        null_val, four_connected, min_seg_size, max_spectral_diff, max_seg_id_out,
                        singles_elim_out, small_elim_out, num_clumps_out));
@@ -620,6 +624,8 @@ API int shp_stitch_prepare_dev(shp_ctx *ctx, const uint32_t *d_tile, int ys, int
     if (!d_tile || !d_meta || ys < 0 || xs < 0 || overlap < 0) SHP_FAIL(ctx, SHP_ERR_ARG, "bad argument");
     if (top < 0 || left < 0 || bottom > ys || right > xs || top > bottom || left > right)
         SHP_FAIL(ctx, SHP_ERR_ARG, "bad trimmed window");
+    FillScope fs(ctx, 1);
+    fill_acquire(ctx, 3);
     CHK(run_stitch_prepare(ctx, d_tile, (uint32_t)ys, (uint32_t)xs, (uint32_t)overlap, has_top, has_left,
                            max_local, (uint32_t)top, (uint32_t)bottom, (uint32_t)left, (uint32_t)right,
                            d_meta));

@@ -741,6 +741,7 @@ static int run_clump(shp_ctx *ctx, const uint16_t *d_clus, uint32_t nrows, uint3
     ps = prof_begin(ctx, PROF_DFS);
     uint32_t *order = (uint32_t *)((char *)ctx->big.p + (size_t)maxbig * sizeof(BigInfo) + 64);
     hipLaunchKernelGGL(k_big_order, dim3(grid_for(maxbig, 256)), dim3(256), 0, st, big, counters, order); KCHK(ctx);
+    fill_release(ctx, true);            // the replay is a latency-bound phase: outside the fill gate
     // fork: the two size classes touch disjoint components, so they can run on two streams
     static const int fork_env = getenv("SHEPSEG_DFS_FORK") ? atoi(getenv("SHEPSEG_DFS_FORK")) : -1;
     const int fork2 = fork_env >= 0 ? fork_env : ctx->dfs_fork;
@@ -763,6 +764,10 @@ static int run_clump(shp_ctx *ctx, const uint16_t *d_clus, uint32_t nrows, uint3
         HIPCHK(ctx, hipStreamWaitEvent(st, ctx->evjoin, 0));
     }
     prof_end(ctx, ps);
+    if (fill_gating(ctx)) {
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        fill_acquire(ctx, 1);
+    }
     ps = prof_begin(ctx, PROF_LABEL);
     // seed rank -> clump id
     SeedFn sf{lab};

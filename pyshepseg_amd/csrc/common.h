@@ -7,6 +7,8 @@
 #include <string.h>
 #include <string>
 #include <vector>
+#include <mutex>
+#include <condition_variable>
 #include "../../include/shepseg_hip.h"
 
 #define WAVE 64
@@ -50,6 +52,61 @@ struct shp_ctx {
     int prof_id[PROF_POOL] = {};
     int prof_used = 0;
     int dfs_fork = 1;   // run the two DFS size classes on two streams (single-tile latency)
+    int gated = 0;      // this call takes part in the fill gate (tiled driver's worker calls)
+    bool fill_held = false;
+};
+
+// Fill gate.  A tile alternates between phases that fill the GPU (HBM-bound passes over the whole
+// tile: ~3.4 ms of device time) and phases that are one long dependent chain on a few wavefronts
+// (the depth-first replay, the pass loop: ~35 ms).  Twenty worker streams started together stay
+// in step -- every tile fills at once, then every tile waits at once, and the filling capacity
+// idles a quarter of the time.  The gate lets only a few tiles be in a filling phase at any time
+// (the others queue on the host), which staggers them: while some fill, the rest are in their
+// chains.  Phases nearer the end of a tile go first.  SHEPSEG_FILL_MAX = 0 switches it off.
+#define FILL_MAX_DEFAULT 4
+#define FILL_PRIOS 4
+struct FillGate {
+    std::mutex mu;
+    std::condition_variable cv;
+    int running = 0;
+    int waiting[FILL_PRIOS] = {};
+};
+static FillGate g_fill;
+static const int g_fill_max = getenv("SHEPSEG_FILL_MAX") ? atoi(getenv("SHEPSEG_FILL_MAX")) : FILL_MAX_DEFAULT;
+
+static inline bool fill_gating(const shp_ctx *ctx) { return g_fill_max > 0 && ctx->gated; }
+static inline void fill_acquire(shp_ctx *ctx, int prio)
+{
+    if (!fill_gating(ctx) || ctx->fill_held) return;
+    std::unique_lock<std::mutex> lk(g_fill.mu);
+    g_fill.waiting[prio]++;
+    g_fill.cv.wait(lk, [&] {
+        if (g_fill.running >= g_fill_max) return false;
+        for (int p = prio + 1; p < FILL_PRIOS; p++)
+            if (g_fill.waiting[p]) return false;
+        return true;
+    });
+    g_fill.waiting[prio]--;
+    g_fill.running++;
+    ctx->fill_held = true;
+    if (g_fill.running < g_fill_max) g_fill.cv.notify_all();
+}
+// sync: wait until the phase's kernels have left the GPU before letting the next tile in
+static inline void fill_release(shp_ctx *ctx, bool sync)
+{
+    if (!ctx->fill_held) return;
+    if (sync) (void)hipStreamSynchronize(ctx->stream);
+    {
+        std::lock_guard<std::mutex> lk(g_fill.mu);
+        g_fill.running--;
+    }
+    ctx->fill_held = false;
+    g_fill.cv.notify_all();
+}
+struct FillScope {          // an API call never leaves with the gate held (error paths)
+    shp_ctx *ctx;
+    FillScope(shp_ctx *c, int gated) : ctx(c) { c->gated = gated; }
+    ~FillScope() { fill_release(ctx, false); ctx->gated = 0; }
 };
 
 // kernels whose launch durations bench.py reports against the roofline

@@ -803,6 +803,7 @@ static int run_eliminate_small(shp_ctx *ctx, const void *d_img, int dtype, int n
     args.poll = poll_env < 1 ? 1 : poll_env;
     static const int bar2_env = getenv("SHEPSEG_SMALL_BAR2") ? atoi(getenv("SHEPSEG_SMALL_BAR2")) : 1;
     args.bar2 = bar2_env;
+    fill_release(ctx, true);            // the pass loop is a latency-bound phase
     {
         std::unique_lock<std::mutex> lk(g_small_mu);
         g_small_cv.wait(lk, [] { return g_small_running < g_small_max; });
@@ -821,6 +822,7 @@ static int run_eliminate_small(shp_ctx *ctx, const void *d_img, int dtype, int n
     }
     g_small_cv.notify_one();
     HIPCHK(ctx, lerr); HIPCHK(ctx, cerr); HIPCHK(ctx, serr);
+    fill_acquire(ctx, 2);
     if (pin->fail || !pin->done)
         SHP_FAIL(ctx, SHP_ERR_STATE, "small-segment loop: grid barrier timed out (fail=%u done=%u)",
                  pin->fail, pin->done);
