@@ -130,13 +130,22 @@ int shp_dev_subsample(shp_ctx *ctx, const void *d_img, int dtype, int nbands, in
                       const uint32_t *row_idx, int ny, const uint32_t *col_idx, int nx,
                       void *out_host);
 /* doShepherdSegmentation on window (x, y, xs, ys) of a device raster; labels (ys*xs uint32,
- * local ids) are written to device memory d_seg_out.  Synchronous on return. */
+ * local ids) are written to device memory d_seg_out.  Synchronous on return.  d_clusmap: NULL, or
+ * the raster-wide cluster map whose window has been filled by shp_assign_rects_dev (the k-means
+ * predict step of shepseg.py:211 is then not repeated for the pixels tiles share). */
 int shp_segment_window_dev(shp_ctx *ctx, const void *d_img, int dtype, int nbands, int img_rows,
                            int img_cols, int x, int y, int xs, int ys, const double *centres, int k,
                            int has_null, int64_t null_val, int four_connected, int min_seg_size,
                            double max_spectral_diff, uint32_t *d_seg_out, uint32_t *max_seg_id_out,
                            int64_t *singles_elim_out, int64_t *small_elim_out,
-                           uint32_t *num_clumps_out);
+                           uint32_t *num_clumps_out, const uint16_t *d_clusmap);
+/* km.predict (shepseg.py:211, with the null mask of :205-207) on rectangles of a device raster:
+ * d_clusmap[y][x] (uint16, img_rows x img_cols) = 0 for a null pixel, else cluster + 1.
+ * rects = nrects x (x, y, xs, ys).  The model is global (tiling.py:154-226), so the tiled driver
+ * assigns every pixel once instead of once per overlapping tile. */
+int shp_assign_rects_dev(shp_ctx *ctx, const void *d_img, int dtype, int nbands, int img_rows,
+                         int img_cols, const int32_t *rects, int nrects, const double *centres,
+                         int k, int has_null, int64_t null_val, uint16_t *d_clusmap);
 /* same with the tile image handed over as a host buffer (read -> H2D -> segment) */
 int shp_segment_tile_to_dev(shp_ctx *ctx, const void *img, int dtype, int nbands, int nrows,
                             int ncols, const double *centres, int k, int has_null, int64_t null_val,

@@ -73,7 +73,9 @@ _SIGS = {
                                           _c.c_int, _c.c_int, _c.c_int, _c.c_int, _vp, _c.c_int,
                                           _c.c_int, _c.c_int64, _c.c_int, _c.c_int, _c.c_double,
                                           _vp, _c.POINTER(_c.c_uint32), _c.POINTER(_c.c_int64),
-                                          _c.POINTER(_c.c_int64), _c.POINTER(_c.c_uint32)]),
+                                          _c.POINTER(_c.c_int64), _c.POINTER(_c.c_uint32), _vp]),
+    'shp_assign_rects_dev': (_c.c_int, [_vp, _vp, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _vp,
+                                        _c.c_int, _vp, _c.c_int, _c.c_int, _c.c_int64, _vp]),
     'shp_segment_tile_to_dev': (_c.c_int, [_vp, _vp, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _vp,
                                            _c.c_int, _c.c_int, _c.c_int64, _c.c_int, _c.c_int,
                                            _c.c_double, _vp, _c.POINTER(_c.c_uint32),

@@ -294,15 +294,16 @@ static int segment_device(shp_ctx *ctx, const void *d_img, uint32_t *d_seg, int 
                           uint32_t nrows, uint32_t ncols,
                           const double *centres, int k, int has_null, int64_t null_val, int four,
                           int min_seg_size, double msd, uint32_t *max_seg_id, int64_t *singles,
-                          int64_t *small, uint32_t *nclumps_out)
+                          int64_t *small, uint32_t *nclumps_out, bool have_clusters = false)
 {
     const uint32_t n = nrows * ncols;
     CHK(buf_ensure(ctx, ctx->clus, (size_t)n * 2));
     CHK(buf_ensure(ctx, ctx->small, 4096));
     uint32_t *scal = bp<uint32_t>(ctx->small);
     hipEventRecord(ctx->ev[1], ctx->stream);
-    CHK(launch_assign(ctx, d_img, dtype, nb, n, centres, k, has_null, null_val,
-                      bp<uint16_t>(ctx->clus), nullptr));
+    if (!have_clusters)         // (else ctx->clus already holds the tile's window of the cluster map)
+        CHK(launch_assign(ctx, d_img, dtype, nb, n, centres, k, has_null, null_val,
+                          bp<uint16_t>(ctx->clus), nullptr));
     hipEventRecord(ctx->ev[2], ctx->stream);
     CHK(buf_ensure(ctx, ctx->segsz, ((size_t)n + 2) * 4));
     CHK(buf_ensure(ctx, ctx->singles, ((size_t)n + 2) * 4));
@@ -521,7 +522,7 @@ API int shp_segment_window_dev(shp_ctx *ctx, const void *d_img, int dtype, int n
                                int has_null, int64_t null_val, int four_connected, int min_seg_size,
                                double max_spectral_diff, uint32_t *d_seg_out, uint32_t *max_seg_id_out,
                                int64_t *singles_elim_out, int64_t *small_elim_out,
-                               uint32_t *num_clumps_out)
+                               uint32_t *num_clumps_out, const uint16_t *d_clusmap)
 {
     CHK(enter(ctx));
     if (!d_img || !centres || !d_seg_out || dtype_size(dtype) == 0 || nbands < 1)
@@ -551,12 +552,47 @@ API int shp_segment_window_dev(shp_ctx *ctx, const void *d_img, int dtype, int n
         KCHK(ctx);
         tile_img = ctx->img.p;
     }
+    if (d_clusmap) {            // the window of the raster-wide cluster map (shp_assign_rects_dev)
+        CHK(buf_ensure(ctx, ctx->clus, (size_t)n * 2));
+        const size_t rowbytes = (size_t)xs * 2;
+        hipLaunchKernelGGL(k_window, dim3((unsigned)ys, grid_for((rowbytes + 15) / 16, 256)), dim3(256), 0,
+                           ctx->stream, (const uint8_t *)d_clusmap, 2u, (uint32_t)img_rows, (uint32_t)img_cols,
+                           (uint32_t)x, (uint32_t)y, (uint32_t)xs, (uint32_t)ys, (uint8_t *)ctx->clus.p);
+        KCHK(ctx);
+    }
     CHK(segment_device(ctx, tile_img, d_seg_out, dtype, nbands, ys, xs, centres, k, has_null, null_val,
                        four_connected, min_seg_size, max_spectral_diff, max_seg_id_out,
-                       singles_elim_out, small_elim_out, num_clumps_out));
+                       singles_elim_out, small_elim_out, num_clumps_out, d_clusmap != nullptr));
     hipEventRecord(ctx->ev[6], ctx->stream);
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     collect_timings(ctx);
+    return 0;
+}
+
+// Clusters of rectangles of a device raster into a raster-wide cluster map (uint16, the raster's
+// geometry): 0 = null pixel, else cluster index + 1, exactly what the per-tile assign step writes.
+// rects: nrects x (x, y, xs, ys).  Synchronous.
+API int shp_assign_rects_dev(shp_ctx *ctx, const void *d_img, int dtype, int nbands, int img_rows,
+                             int img_cols, const int32_t *rects, int nrects, const double *centres,
+                             int k, int has_null, int64_t null_val, uint16_t *d_clusmap)
+{
+    CHK(enter(ctx));
+    if (!d_img || !centres || !d_clusmap || dtype_size(dtype) == 0 || nbands < 1 || nrects < 0 ||
+        (nrects > 0 && !rects) || img_rows < 0 || img_cols < 0)
+        SHP_FAIL(ctx, SHP_ERR_ARG, "bad argument");
+    for (int r = 0; r < nrects; r++) {
+        const int32_t *q = rects + 4 * r;
+        if (q[0] < 0 || q[1] < 0 || q[2] < 0 || q[3] < 0 || (int64_t)q[0] + q[2] > img_cols ||
+            (int64_t)q[1] + q[3] > img_rows)
+            SHP_FAIL(ctx, SHP_ERR_ARG, "rectangle (%d,%d,%d,%d) outside the %d x %d raster", q[0], q[1], q[2],
+                     q[3], img_rows, img_cols);
+    }
+    if (nrects == 0) return 0;
+    FillScope fs(ctx, 1);
+    fill_acquire(ctx, 0);
+    CHK(launch_assign(ctx, d_img, dtype, nbands, (size_t)img_rows * (size_t)img_cols, centres, k, has_null,
+                      null_val, d_clusmap, nullptr, rects, nrects, (uint32_t)img_cols));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return 0;
 }
 

@@ -16,36 +16,54 @@
 
 #define ASSIGN_PPT 4   // pixels per thread (amortises the scalar centroid loads)
 
-template <int NB, int DT>
+// RECT: the pixels are a rectangle of a band-planar raster (x0, y0, w, h; `pitch` pixels per raster
+// row; `npix` = pixels per band of the whole raster) and the clusters go to the same position of a
+// cluster map with the raster's geometry -- the tiled driver assigns every pixel once, not once
+// per overlapping tile (the model is global, so a pixel's cluster does not depend on the tile).
+// Launched with a 2-D grid: x = columns / 256, y = rows / ASSIGN_PPT.
+struct AssignRect { uint32_t x0, y0, w, h, pitch; };
+
+template <int NB, int DT, bool RECT>
 __global__ __launch_bounds__(256) void k_assign(
     const void *__restrict__ img, size_t npix, int nb_rt,
     const double *__restrict__ m2c, const double *__restrict__ cnorm, int k, int has_null,
-    long long null_val, uint16_t *__restrict__ clus16, int32_t *__restrict__ clus32)
+    long long null_val, uint16_t *__restrict__ clus16, int32_t *__restrict__ clus32, AssignRect rc)
 {
     const int nb = (NB > 0) ? NB : nb_rt;
     const size_t stride = (size_t)gridDim.x * 256u;
-    for (size_t p0 = (size_t)blockIdx.x * 256u + threadIdx.x; p0 < npix; p0 += stride * ASSIGN_PPT) {
+    size_t p0 = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (!RECT && p0 >= npix) return;
+    for (;;) {
         double x[ASSIGN_PPT][(NB > 0) ? NB : 1];
-        bool isnull[ASSIGN_PPT];
+        bool isnull[ASSIGN_PPT], ok[ASSIGN_PPT];
+        size_t off[ASSIGN_PPT];          // clamped inside the data: the loads need no branch
         double bestd[ASSIGN_PPT];
         int best[ASSIGN_PPT];
 #pragma unroll
         for (int q = 0; q < ASSIGN_PPT; q++) {
-            const size_t p = p0 + (size_t)q * stride;
+            if (RECT) {
+                const uint32_t col = blockIdx.x * 256u + threadIdx.x, row = blockIdx.y * ASSIGN_PPT + q;
+                ok[q] = col < rc.w && row < rc.h;
+                const uint32_t cc = col < rc.w ? col : rc.w - 1u, rr = row < rc.h ? row : rc.h - 1u;
+                off[q] = (size_t)(rc.y0 + rr) * rc.pitch + rc.x0 + cc;
+            } else {
+                const size_t p = p0 + (size_t)q * stride;
+                ok[q] = p < npix;
+                off[q] = ok[q] ? p : npix - 1;
+            }
             isnull[q] = false;
             best[q] = 0;
             bestd[q] = 0.0;
             if (NB > 0) {
-                const size_t pc = p < npix ? p : npix - 1;      // clamped: the loads need no branch
 #pragma unroll
                 for (int b = 0; b < NB; b++) {
-                    const long long v = ld_t<DT>(img, (size_t)b * npix + pc);
+                    const long long v = ld_t<DT>(img, (size_t)b * npix + off[q]);
                     if (has_null && v == null_val) isnull[q] = true;
                     x[q][b] = (double)v;
                 }
             } else {
                 for (int b = 0; b < nb; b++) {
-                    long long v = (p < npix) ? ld_t<DT>(img, (size_t)b * npix + p) : 0;
+                    const long long v = ld_t<DT>(img, (size_t)b * npix + off[q]);
                     if (has_null && v == null_val) isnull[q] = true;
                 }
             }
@@ -67,9 +85,7 @@ __global__ __launch_bounds__(256) void k_assign(
                     const double c = m2c[j * nb + b];
 #pragma unroll
                     for (int q = 0; q < ASSIGN_PPT; q++) {
-                        const size_t p = p0 + (size_t)q * stride;
-                        const double xv =
-                            (p < npix) ? (double)ld_t<DT>(img, (size_t)b * npix + p) : 0.0;
+                        const double xv = (double)ld_t<DT>(img, (size_t)b * npix + off[q]);
                         d[q] = __builtin_fma(xv, c, d[q]);
                     }
                 }
@@ -86,13 +102,15 @@ __global__ __launch_bounds__(256) void k_assign(
         }
 #pragma unroll
         for (int q = 0; q < ASSIGN_PPT; q++) {
-            const size_t p = p0 + (size_t)q * stride;
-            if (p < npix) {
+            if (ok[q]) {
                 const int c = isnull[q] ? 0 : best[q] + 1;
-                if (clus16) clus16[p] = (uint16_t)c;
-                if (clus32) clus32[p] = c;
+                if (clus16) clus16[off[q]] = (uint16_t)c;
+                if (clus32) clus32[off[q]] = c;
             }
         }
+        if (RECT) break;
+        p0 += stride * ASSIGN_PPT;
+        if (p0 >= npix) break;
     }
 }
 
@@ -113,9 +131,12 @@ static inline void kmeans_prepare_host(const double *centres, int k, int nb, dou
 
 // centres (host) -> ctx->cen (device: m2c[k*nb] then cnorm[k]); launches the assign kernel
 // on the device image `d_img`; writes uint16 labels to d_clus16 and/or int32 to d_clus32.
+// rects != nullptr: d_img is a whole raster of npix pixels per band and `pitch` pixels per row,
+// the nrects rectangles (x, y, xs, ys each) are assigned into the cluster map d_clus16.
 static int launch_assign(shp_ctx *ctx, const void *d_img, int dtype, int nb, size_t npix,
                          const double *centres, int k, int has_null, int64_t null_val,
-                         uint16_t *d_clus16, int32_t *d_clus32)
+                         uint16_t *d_clus16, int32_t *d_clus32, const int32_t *rects = nullptr,
+                         int nrects = 0, uint32_t pitch = 0)
 {
     if (k < 1 || k > 65534) SHP_FAIL(ctx, SHP_ERR_ARG, "numClusters %d out of range", k);
     const size_t hn = (size_t)k * nb + k;
@@ -128,9 +149,23 @@ static int launch_assign(shp_ctx *ctx, const void *d_img, int dtype, int nb, siz
     const double *m2c = bp<double>(ctx->cen), *cn = m2c + (size_t)k * nb;
     const unsigned grid = grid_for((npix + ASSIGN_PPT - 1) / ASSIGN_PPT, 256, 256u * 16u);
 #define LA(NBT)                                                                                  \
-    DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(HIP_KERNEL_NAME(k_assign<NBT, DT>), dim3(grid),     \
-                                             dim3(256), 0, ctx->stream, d_img, npix, nb, m2c, cn, \
-                                             k, has_null, (long long)null_val, d_clus16, d_clus32))
+    do {                                                                                         \
+        if (!rects) {                                                                            \
+            DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(HIP_KERNEL_NAME(k_assign<NBT, DT, false>),  \
+                           dim3(grid), dim3(256), 0, ctx->stream, d_img, npix, nb, m2c, cn, k,   \
+                           has_null, (long long)null_val, d_clus16, d_clus32, AssignRect{}));    \
+        } else {                                                                                 \
+            for (int r = 0; r < nrects; r++) {                                                   \
+                const AssignRect rc{(uint32_t)rects[4 * r], (uint32_t)rects[4 * r + 1],          \
+                                    (uint32_t)rects[4 * r + 2], (uint32_t)rects[4 * r + 3], pitch}; \
+                if (rc.w == 0u || rc.h == 0u) continue;                                          \
+                const dim3 g2(grid_for(rc.w, 256), grid_for(rc.h, ASSIGN_PPT));                  \
+                DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(HIP_KERNEL_NAME(k_assign<NBT, DT, true>), \
+                               g2, dim3(256), 0, ctx->stream, d_img, npix, nb, m2c, cn, k,       \
+                               has_null, (long long)null_val, d_clus16, d_clus32, rc));          \
+            }                                                                                    \
+        }                                                                                        \
+    } while (0)
     const int ps = prof_begin(ctx, PROF_ASSIGN);
     switch (nb) {
     case 1: LA(1); break;

@@ -468,6 +468,71 @@ def makeTileJobs(tileInfo, rows=None, tiles=None):
     return jobs, total
 
 
+class _ClusterMap(object):
+    """Raster-wide map of k-means clusters (uint16, device) filled block by block on demand.  The
+    model is global, so a pixel's cluster does not depend on the tile: the overlapping tiles of
+    the reference each repeat km.predict (shepseg.py:211) for the 1.6x pixels they share; here
+    every block of the raster is assigned once, by the first worker whose window needs it, and
+    the tiles copy their windows.  Blocks are claimed under a lock; a worker assigns the blocks it
+    claimed (one call, one rectangle per run of blocks in a block row), then waits for the blocks
+    of its window that others claimed."""
+    BLOCK = 1024
+
+    def __init__(self, nRows, nCols, numWorkers):
+        self.c = _lib.ctx()
+        self.nRows, self.nCols = nRows, nCols
+        self.nbytes = max(nRows * nCols, 1) * 2
+        self.dptr = _devAlloc(self.c, self.nbytes)
+        B = self.BLOCK
+        self.state = numpy.zeros(((nRows + B - 1) // B, (nCols + B - 1) // B), dtype=numpy.int8)
+        self.cond = threading.Condition()
+        self.workersLeft = numWorkers
+
+    def ensureWindow(self, c, x, y, xs, ys, forceExit, assignRects):
+        """Returns the device address of the map once every block under the window is assigned."""
+        B = self.BLOCK
+        (by0, by1, bx0, bx1) = (y // B, (y + ys + B - 1) // B, x // B, (x + xs + B - 1) // B)
+        rects = []
+        with self.cond:
+            sub = self.state[by0:by1, bx0:bx1]
+            for r in range(sub.shape[0]):
+                free = numpy.flatnonzero(sub[r] == 0)
+                if free.size == 0:
+                    continue
+                sub[r, free] = 1                                   # claimed
+                runs = numpy.split(free, numpy.flatnonzero(numpy.diff(free) != 1) + 1)
+                for run in runs:
+                    (rx, ry) = ((bx0 + int(run[0])) * B, (by0 + r) * B)
+                    rects.append((rx, ry, min(int(run.size) * B, self.nCols - rx), min(B, self.nRows - ry)))
+        if rects:
+            arr = numpy.array(rects, dtype=numpy.int32)
+            try:
+                assignRects(arr)
+            except Exception:
+                forceExit.set()
+                with self.cond:
+                    self.cond.notify_all()
+                raise
+            with self.cond:
+                for (rx, ry, w, h) in rects:
+                    self.state[ry // B, rx // B:(rx + w + B - 1) // B] = 2
+                self.cond.notify_all()
+        with self.cond:
+            while not (self.state[by0:by1, bx0:bx1] == 2).all():
+                if forceExit.is_set():
+                    raise PyShepSegTilingError("cluster map: another worker failed")
+                self.cond.wait(timeout=1.0)
+        return self.dptr
+
+    def workerExit(self):
+        with self.cond:
+            self.workersLeft -= 1
+            last = self.workersLeft == 0
+        if last and self.dptr is not None:
+            _devRelease(self.c, self.dptr, self.nbytes)
+            self.dptr = None
+
+
 def startSegmentationWorkers(src, jobs, d_tiles, centres, msd, imgNullVal, fourConnected,
         minSegmentSize, numWorkers, timings, bands=None, yOrigin=0, maxConcurrentReads=20,
         verbose=False, stitchPrep=None):
@@ -497,6 +562,9 @@ def startSegmentationWorkers(src, jobs, d_tiles, centres, msd, imgNullVal, fourC
     for i in order:
         inQue.put(jobs[i])
     forceExit = threading.Event()
+    clusMap = None
+    if onDevice and jobs and os.environ.get('SHEPSEG_CLUSTER_MAP', '1') != '0':
+        clusMap = _ClusterMap(srcYsize, srcXsize, max(1, numWorkers))
 
     def worker():
         try:
@@ -508,6 +576,9 @@ def startSegmentationWorkers(src, jobs, d_tiles, centres, msd, imgNullVal, fourC
                 if jj.error is None and not jj.done.is_set():
                     jj.error = e
                 jj.done.set()
+        finally:
+            if clusMap is not None:
+                clusMap.workerExit()
 
     maxTilePx = max([jj.xsize * jj.ysize for jj in jobs] or [0])
 
@@ -529,12 +600,20 @@ def startSegmentationWorkers(src, jobs, d_tiles, centres, msd, imgNullVal, fourC
                 dseg = ctypes.c_void_p(d_tiles.value + 4 * j.offset)
                 if onDevice:
                     with timings.interval('segmentation'):
+                        dclus = None
+                        if clusMap is not None:
+                            dclus = clusMap.ensureWindow(
+                                c, j.xpos, j.ypos - yOrigin, j.xsize, j.ysize, forceExit,
+                                lambda rects: c.check(L.shp_assign_rects_dev(
+                                    c.handle, ctypes.c_void_p(src.ptr), dtcode, nBandsAll, srcYsize,
+                                    srcXsize, _lib.ptr(rects), rects.shape[0], _lib.ptr(centres),
+                                    centres.shape[0], nullFlag, nullV, clusMap.dptr)))
                         c.check(L.shp_segment_window_dev(
                             c.handle, ctypes.c_void_p(src.ptr), dtcode, nBandsAll, srcYsize,
                             srcXsize, j.xpos, j.ypos - yOrigin, j.xsize, j.ysize, _lib.ptr(centres),
                             centres.shape[0], nullFlag, nullV, int(bool(fourConnected)),
                             int(minSegmentSize), float(msd), dseg, ctypes.byref(mx),
-                            ctypes.byref(s1), ctypes.byref(s2), ctypes.byref(ncl)))
+                            ctypes.byref(s1), ctypes.byref(s2), ctypes.byref(ncl), dclus))
                 else:
                     with timings.interval('reading'):
                         with readSem:

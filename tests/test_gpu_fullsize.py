@@ -26,7 +26,7 @@ def _segment_window(ras, x, y, xs, ys, centres, minseg, msd, four=True):
         c.check(c._L.shp_segment_window_dev(
             c.handle, ctypes.c_void_p(ras.ptr), _lib.SHP_DTYPES[ras.dtype], ras.shape[0], ras.shape[1],
             ras.shape[2], x, y, xs, ys, _lib.ptr(centres), centres.shape[0], 0, 0, int(four), minseg,
-            float(msd), d, ctypes.byref(mx), ctypes.byref(s1), ctypes.byref(s2), ctypes.byref(ncl)))
+            float(msd), d, ctypes.byref(mx), ctypes.byref(s1), ctypes.byref(s2), ctypes.byref(ncl), None))
         out = np.empty((ys, xs), dtype=np.uint32)
         c.check(c._L.shp_dev_download(c.handle, _lib.ptr(out), d, n * 4))
     finally:
