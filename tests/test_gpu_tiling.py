@@ -80,3 +80,77 @@ def test_tiled_npy_roundtrip(tmp_path, oracle):
                                    float(r.maxSpectralDiff), None, True)
     assert np.array_equal(out, want) and r.maxSegId == mx
     assert np.array_equal(np.load(tmp_path / 'out_hist.npy'), hist)
+
+
+@pytest.mark.parametrize('dtype,null', [(np.uint16, None), (np.int16, -7), (np.uint8, 0), (np.int32, 123456)])
+def test_assign_rects_cluster_map_vs_oracle(dtype, null, oracle):
+    """shp_assign_rects_dev: rectangles of a device raster into the raster-wide cluster map ==
+    the oracle's km.predict of the same pixels (0 = null, else cluster + 1); pixels outside the
+    rectangles are not touched; bad rectangles are refused."""
+    import ctypes
+    from pyshepseg_amd import tiling, _lib
+    rng = np.random.default_rng(5)
+    (nb, nr, nc, k) = (3, 301, 517, 7)
+    info = np.iinfo(dtype)
+    img = rng.integers(max(info.min, -3000), min(info.max, 3000), size=(nb, nr, nc)).astype(dtype)
+    if null is not None:
+        img[:, rng.integers(0, nr, 400), rng.integers(0, nc, 400)] = null
+        img[1, 5, 5] = null                                           # null in one band only
+    centres = rng.uniform(img.min(), img.max(), size=(k, nb))
+    want = oracle.kmeans_assign(img, centres, null)               # 0 = null, else cluster + 1
+    ras = tiling.DeviceRaster.fromArray(img, nullVal=null)
+    c = _lib.ctx()
+    d = ctypes.c_void_p()
+    c.check(c._L.shp_dev_alloc(c.handle, nr * nc * 2, ctypes.byref(d)))
+    try:
+        c.check(c._L.shp_dev_memset(c.handle, d, 0xEE, nr * nc * 2))
+        rects = np.array([[0, 0, 257, 5], [300, 17, 217, 284], [0, 300, 517, 1], [10, 40, 1, 3],
+                          [20, 60, 0, 9]], dtype=np.int32)
+        c.check(c._L.shp_assign_rects_dev(
+            c.handle, ctypes.c_void_p(ras.ptr), _lib.SHP_DTYPES[np.dtype(dtype)], nb, nr, nc,
+            _lib.ptr(rects), rects.shape[0], _lib.ptr(centres), k, int(null is not None),
+            0 if null is None else int(null), d))
+        got = np.empty((nr, nc), dtype=np.uint16)
+        c.check(c._L.shp_dev_download(c.handle, _lib.ptr(got), d, got.nbytes))
+        touched = np.zeros((nr, nc), dtype=bool)
+        for (x, y, w, h) in rects:
+            touched[y:y + h, x:x + w] = True
+        assert np.array_equal(got[touched], want[touched].astype(np.uint16))
+        assert (got[~touched] == 0xEEEE).all()
+        bad = np.array([[500, 0, 18, 4]], dtype=np.int32)
+        rc = c._L.shp_assign_rects_dev(
+            c.handle, ctypes.c_void_p(ras.ptr), _lib.SHP_DTYPES[np.dtype(dtype)], nb, nr, nc,
+            _lib.ptr(bad), 1, _lib.ptr(centres), k, 0, 0, d)
+        assert rc != 0
+    finally:
+        c.check(c._L.shp_dev_free(c.handle, d))
+        ras.free()
+
+
+def test_tiled_device_raster_with_nulls_and_cluster_map(oracle, monkeypatch):
+    """Device raster with a null value (null pixels and a null border), 8-connected: the tiled run
+    through the raster-wide cluster map == the run with the per-tile assign step == the oracle."""
+    from pyshepseg_amd import tiling, shepseg
+    img = oracle.synthimg(3, 4, 700, 900)
+    img[:, :40, :] = 0
+    img[:, 300:340, 500:620] = 0
+    img[2, 650, 10] = 0
+    km = shepseg.fitSpectralClusters(img, 12, 5, 0, True)
+    cfg = tiling.SegmentationConcurrencyConfig(concurrencyType=tiling.CONC_THREADS, numWorkers=3)
+    outs = []
+    for flag in ('1', '0'):
+        monkeypatch.setenv('SHEPSEG_CLUSTER_MAP', flag)
+        ras = tiling.DeviceRaster.fromArray(img, nullVal=0)
+        try:
+            r = tiling.doTiledShepherdSegmentation(ras, None, tileSize=256, overlapSize=64,
+                                                   minSegmentSize=30, imgNullVal=0, kmeansObj=km,
+                                                   fourConnected=False, concurrencyCfg=cfg)
+        finally:
+            ras.free()
+        outs.append(r)
+    want, mx, hist = _oracle_tiled(oracle, img, km.cluster_centers_, 256, 64, 30,
+                                   float(outs[0].maxSpectralDiff), 0, False)
+    for r in outs:
+        assert r.maxSegId == mx
+        assert np.array_equal(r.segimg, want)
+        assert np.array_equal(r.hist, hist)
