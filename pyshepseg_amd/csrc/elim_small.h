@@ -22,6 +22,7 @@
 #include "common.h"
 #include "scan.h"
 #include "sort.h"
+#include "csr.h"
 #include "elim_single.h"
 #include <type_traits>
 
@@ -701,13 +702,6 @@ static int g_small_running = 0;
 #define SMALL_MAX_CONCURRENT 20
 static const int g_small_max = getenv("SHEPSEG_SMALL_MAX") ? atoi(getenv("SHEPSEG_SMALL_MAX")) : SMALL_MAX_CONCURRENT;
 
-static inline int bits_for(uint32_t maxval)
-{
-    int b = 1;
-    while (b < 32 && (maxval >> b) != 0) b++;
-    return b;
-}
-
 // d_seg in place; *max_id in: seg.max(); out: seg.max() after the final relabel.
 // sizes_in_origsz: ctx->origsz already holds makeSegSize(d_seg) (run_eliminate_single leaves it)
 static int run_eliminate_small(shp_ctx *ctx, const void *d_img, int dtype, int nb, uint32_t nrows,
@@ -754,7 +748,7 @@ static int run_eliminate_small(shp_ctx *ctx, const void *d_img, int dtype, int n
     // CSR: pixels grouped by segment id, raster order inside (stable sort of (seg, index))
     uint32_t *pix = nullptr;
     int ps = prof_begin(ctx, PROF_SORT);
-    CHK(sort_pairs(ctx, d_seg, nullptr, n, bits_for(S), nullptr, &pix));
+    CHK(build_segment_csr(ctx, d_seg, n, S, &pix));
     prof_end(ctx, ps);
     uint32_t *stmp = bp<uint32_t>(ctx->scan_tmp);      // (fetched after sort_pairs: it may regrow)
     ArrFn szf{sizes};

@@ -17,7 +17,7 @@
 #include "scan.h"
 #include "sort.h"
 #include "clump.h"      // k_run_count
-#include "elim_small.h" // bits_for
+#include "elim_small.h"
 
 __global__ __launch_bounds__(256) void k_stats_keys(const uint32_t *__restrict__ seg,
                                                     const void *__restrict__ band, int dtype,

@@ -109,6 +109,13 @@ __global__ __launch_bounds__(256) void k_sort_scatter(
     }
 }
 
+static inline int bits_for(uint32_t maxval)      // significant bits of the largest key
+{
+    int b = 1;
+    while (b < 32 && (maxval >> b) != 0) b++;
+    return b;
+}
+
 // Sort n pairs by the low `bits` bits of the key.  vals_in == nullptr means value = index.
 // Uses ctx->sort_k0/sort_k1/sort_v1/pix as ping-pong storage and ctx->sort_hist/scan_tmp as
 // scratch.  On return *keys_sorted / *vals_sorted point at the buffers holding the result
