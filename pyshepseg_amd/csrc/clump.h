@@ -642,7 +642,8 @@ __global__ __launch_bounds__(256) void k_clump_final(const uint32_t *__restrict_
                                                      const uint32_t *__restrict__ csize,
                                                      uint32_t *__restrict__ seg, uint32_t *segsz,
                                                      uint32_t n, uint32_t *__restrict__ singles,
-                                                     uint32_t *nsingles)
+                                                     uint32_t *nsingles,
+                                                     const uint32_t *__restrict__ rank_boff)
 {
     // one-pixel clumps and the null count are gathered in LDS over the workgroup's whole span and
     // flushed with ONE global atomic each: atomics on a single counter serialise at L2, a
@@ -662,7 +663,8 @@ __global__ __launch_bounds__(256) void k_clump_final(const uint32_t *__restrict_
             if (l == NULL_LAB) { seg[p] = 0u; isnull = true; }
             else {
                 const uint32_t seed = l & ~VIS_FLAG;
-                const uint32_t id = rank[seed] + 1u;
+                // (rank_boff: the seed scan's block offsets, added here instead of by a launch)
+                const uint32_t id = rank[seed] + (rank_boff ? rank_boff[seed / SCAN_ITEMS] : 0u) + 1u;
                 seg[p] = id;
                 if (seed == p) {
                     const uint32_t sz = csize[p];
@@ -771,9 +773,10 @@ static int run_clump(shp_ctx *ctx, const uint16_t *d_clus, uint32_t nrows, uint3
     ps = prof_begin(ctx, PROF_LABEL);
     // seed rank -> clump id
     SeedFn sf{lab};
-    CHK(scan_exclusive(ctx, sf, n, rank, nclumps_dev, bp<uint32_t>(ctx->scan_tmp)));
+    const uint32_t *rank_boff = nullptr;
+    CHK(scan_exclusive(ctx, sf, n, rank, nclumps_dev, bp<uint32_t>(ctx->scan_tmp), &rank_boff));
     hipLaunchKernelGGL(k_clump_final, dim3(grid_for(n, 256u * FINAL_SPAN)), dim3(256), 0, st, lab, rank, csize, d_seg, d_segsz, n,
-                       d_singles, d_nsingles); KCHK(ctx);
+                       d_singles, d_nsingles, rank_boff); KCHK(ctx);
     prof_end(ctx, ps);
     return 0;
 }

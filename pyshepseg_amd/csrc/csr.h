@@ -21,9 +21,12 @@ struct RunLenFn {
 };
 
 __global__ __launch_bounds__(256) void k_run_tile_count(const uint32_t *__restrict__ seg, uint32_t n,
-                                                        uint32_t *__restrict__ bcount)
+                                                        uint32_t *__restrict__ bcount,
+                                                        uint32_t *zero, uint32_t nzero)
 {
     __shared__ uint32_t wc[4];
+    if (blockIdx.x == 0)                    // a caller's small array to clear (saves a fill launch)
+        for (uint32_t q = threadIdx.x; q < nzero; q += 256u) zero[q] = 0u;
     const unsigned w = threadIdx.x >> 6, lane = lane_id();
     const uint32_t base = blockIdx.x * RUN_TILE + w * (RUN_ROWS * 64u) + lane;
     uint32_t s[RUN_ROWS];
@@ -114,11 +117,13 @@ __global__ __launch_bounds__(256) void k_run_expand(const uint32_t *__restrict__
 
 // *pix_out: n pixel indices grouped by segment id (0..S), raster order inside.  Uses ctx->aux /
 // aux2 (runs), the sort workspaces and scan_tmp; the result lives in ctx->sort_v1.
+// zero[0..nzero) is cleared on the way.
 static int build_segment_csr(shp_ctx *ctx, const uint32_t *d_seg, uint32_t n, uint32_t S,
-                             uint32_t **pix_out)
+                             uint32_t **pix_out, uint32_t *zero = nullptr, uint32_t nzero = 0)
 {
     static const int runs_env = getenv("SHEPSEG_CSR_RUNS") ? atoi(getenv("SHEPSEG_CSR_RUNS")) : 1;
     if (!runs_env || n == 0 || n > (1u << RUN_POS_BITS)) {
+        if (nzero) HIPCHK(ctx, hipMemsetAsync(zero, 0, (size_t)nzero * 4, ctx->stream));
         CHK(sort_pairs(ctx, d_seg, nullptr, n, bits_for(S), nullptr, pix_out));
         return 0;
     }
@@ -132,7 +137,7 @@ static int build_segment_csr(shp_ctx *ctx, const uint32_t *d_seg, uint32_t n, ui
     CHK(buf_ensure(ctx, ctx->scan_tmp, scan_tmp_bytes(n)));
     uint32_t *bcount = bp<uint32_t>(ctx->sort_hist), *boff = bcount + nblk, *tot = boff + nblk;
     uint32_t *rkeys = bp<uint32_t>(ctx->aux), *rvals = bp<uint32_t>(ctx->aux2);
-    hipLaunchKernelGGL(k_run_tile_count, dim3(nblk), dim3(256), 0, st, d_seg, n, bcount); KCHK(ctx);
+    hipLaunchKernelGGL(k_run_tile_count, dim3(nblk), dim3(256), 0, st, d_seg, n, bcount, zero, nzero); KCHK(ctx);
     ArrFn bf{bcount};
     CHK(scan_exclusive(ctx, bf, nblk, boff, tot, bp<uint32_t>(ctx->scan_tmp)));
     HIPCHK(ctx, hipMemcpyAsync(ctx->h_pinned, tot, 4, hipMemcpyDeviceToHost, st));

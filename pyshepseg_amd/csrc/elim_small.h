@@ -240,7 +240,8 @@ __global__ __launch_bounds__(256) void k_small_init(const uint32_t *src, uint32_
                                                     uint32_t *__restrict__ tcount,
                                                     uint32_t *__restrict__ tfill, uint32_t *hist,
                                                     uint32_t S, uint32_t min_seg, uint32_t *tlist,
-                                                    uint32_t *ctlwords, uint32_t nctlwords)
+                                                    uint32_t *ctlwords, uint32_t nctlwords,
+                                                    uint32_t *off, const uint32_t *__restrict__ off_boff)
 {
     __shared__ uint32_t lh[256];            // block-local histogram of sizes 1..255
     lh[threadIdx.x] = 0;
@@ -260,6 +261,7 @@ __global__ __launch_bounds__(256) void k_small_init(const uint32_t *src, uint32_
         tcount[s] = 0;
         tfill[s] = 0;
         if (s == 0u) tlist[0] = 0u;             // counter of k_big_seg_list
+        if (off_boff) off[s] += off_boff[s / SCAN_ITEMS];     // second level of the offset scan
         if (s >= 1u && m < min_seg) {
             if (m < 256u) atomicAdd(&lh[m], 1u);
             else atomicAdd(&hist[m], 1u);
@@ -748,17 +750,17 @@ static int run_eliminate_small(shp_ctx *ctx, const void *d_img, int dtype, int n
     // CSR: pixels grouped by segment id, raster order inside (stable sort of (seg, index))
     uint32_t *pix = nullptr;
     int ps = prof_begin(ctx, PROF_SORT);
-    CHK(build_segment_csr(ctx, d_seg, n, S, &pix));
+    CHK(build_segment_csr(ctx, d_seg, n, S, &pix, hist, min_seg + 2u));    // (also zeroes hist)
     prof_end(ctx, ps);
     uint32_t *stmp = bp<uint32_t>(ctx->scan_tmp);      // (fetched after sort_pairs: it may regrow)
     ArrFn szf{sizes};
-    CHK(scan_exclusive(ctx, szf, S + 1u, off, nullptr, stmp));
+    const uint32_t *off_boff = nullptr;
+    CHK(scan_exclusive(ctx, szf, S + 1u, off, nullptr, stmp, &off_boff));
     const unsigned gs = grid_for((size_t)S + 1, 256);
-    HIPCHK(ctx, hipMemsetAsync(hist, 0, ((size_t)min_seg + 2) * 4, st));
     static_assert(sizeof(SmallCtl) % 4 == 0 && offsetof(SmallCtl, st) == 0, "SmallCtl layout");
     hipLaunchKernelGGL(k_small_init, dim3(gs), dim3(256), 0, st, sizes, segsz, origsz, chnext, chtail,
                        mergeto, tcount, tfill, hist, S, min_seg, tlist, (uint32_t *)ctl,
-                       (uint32_t)(sizeof(SmallCtl) / 4)); KCHK(ctx);
+                       (uint32_t)(sizeof(SmallCtl) / 4), off, off_boff); KCHK(ctx);
     ps = prof_begin(ctx, PROF_SPECTRA);
     uint32_t *biglist = tlist;          // free until the pass loop starts
     hipLaunchKernelGGL(k_big_seg_list, dim3(grid_for((size_t)S, 4096)), dim3(256), 0, st, segsz, S, biglist);
