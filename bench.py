@@ -134,8 +134,8 @@ def main():
     npix = args.size * args.size
     value = npix / dt / 1e6
     # dominant kernel by accumulated device time
-    names = {0: 'k_assign', 1: 'ccl (k_ccl_local+k_ccl_border+k_ccl_flatten)', 2: 'k_dfs_split',
-             3: 'radix sort (k_sort_hist+k_sort_scatter)', 4: 'k_spectra_small+k_spectra_big',
+    names = {0: 'k_assign (cluster-map blocks)', 1: 'ccl (k_ccl_local+k_ccl_border+k_ccl_flatten)', 2: 'k_dfs_split',
+             3: 'CSR build (k_run_tile_*+k_sort_hist+k_sort_scatter+k_run_expand)', 4: 'k_spectra_small+k_spectra_big',
              5: 'k_small_loop', 7: 'seed scan + k_clump_final'}
     dom = max((i for i in names), key=lambda i: prof.get(i, (0, 0))[0])
     ms, cnt = prof[dom]
@@ -147,10 +147,10 @@ def main():
     avg_s = (ms / max(cnt, 1)) / 1e3
     achieved = (bpp * tile_px / avg_s / 1e9) if avg_s > 0 else 0.0
     # HBM traffic per launch of that kernel from the committed PMC passes (rocprofv3 cannot run
-    # inside this process): FETCH_SIZE + WRITE_SIZE in KB, see profiles/r01_k_pmc_summary.json
+    # inside this process): FETCH_SIZE + WRITE_SIZE in KB, see profiles/r01_l_pmc_summary.json
     traffic = None
     try:
-        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_k_pmc_summary.json')))['kernels']
+        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_l_pmc_summary.json')))['kernels']
         k = pmc.get(names[dom].split(' ')[0])
         if k and args.size == 40000:
             traffic = int((k['FETCH_SIZE_KB_per_launch'] + k['WRITE_SIZE_KB_per_launch']) * 1024)
