@@ -68,6 +68,11 @@ int shp_prof_get(shp_ctx *ctx, double *ms_out, uint64_t *count_out, int n, int r
 int shp_kmeans_fit(shp_ctx *ctx, const double *xsample, int64_t nrows, int nbands, int k,
                    const double *init_centres, int max_iter, double tol_rel,
                    double *centres_out, int32_t *labels_out, int *n_iter_out);
+/* the same with the sample rows in the image's pixel type (SHP_U8 ... SHP_U32): sklearn's
+ * check_array conversion to float64 happens on the fly, the arithmetic is unchanged. */
+int shp_kmeans_fit_typed(shp_ctx *ctx, const void *xsample, int dtype, int64_t nrows, int nbands,
+                         int k, const double *init_centres, int max_iter, double tol_rel,
+                         double *centres_out, int32_t *labels_out, int *n_iter_out);
 
 /* replaces shepseg.applySpectralClusters (shepseg.py:317-361) + KMeans.predict:
  * clusters_out[nrows*ncols] int32, 1..k, 0 where any band == null_val. */

@@ -41,6 +41,8 @@ _SIGS = {
     'shp_prof_get': (_c.c_int, [_vp, _vp, _vp, _c.c_int, _c.c_int]),
     'shp_kmeans_fit': (_c.c_int, [_vp, _vp, _c.c_int64, _c.c_int, _c.c_int, _vp, _c.c_int,
                                   _c.c_double, _vp, _vp, _c.POINTER(_c.c_int)]),
+    'shp_kmeans_fit_typed': (_c.c_int, [_vp, _vp, _c.c_int, _c.c_int64, _c.c_int, _c.c_int, _vp,
+                                        _c.c_int, _c.c_double, _vp, _vp, _c.POINTER(_c.c_int)]),
     'shp_kmeans_assign': (_c.c_int, [_vp, _vp, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _vp,
                                      _c.c_int, _c.c_int, _c.c_int64, _vp]),
     'shp_clump': (_c.c_int, [_vp, _vp, _c.c_int, _c.c_int, _c.c_int, _vp,

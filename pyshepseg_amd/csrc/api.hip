@@ -154,7 +154,19 @@ API int shp_kmeans_fit(shp_ctx *ctx, const double *xsample, int64_t nrows, int n
 {
     CHK(enter(ctx));
     if (!xsample || !init_centres || !centres_out) SHP_FAIL(ctx, SHP_ERR_ARG, "NULL argument");
-    return run_kmeans_fit(ctx, xsample, nrows, nbands, k, init_centres, max_iter, tol_rel,
+    return run_kmeans_fit(ctx, xsample, FIT_DT_F64, nrows, nbands, k, init_centres, max_iter, tol_rel,
+                          centres_out, labels_out, n_iter_out);
+}
+
+// the same on rows of the image's own pixel type (no float64 copy of the sample on the host)
+API int shp_kmeans_fit_typed(shp_ctx *ctx, const void *xsample, int dtype, int64_t nrows, int nbands,
+                             int k, const double *init_centres, int max_iter, double tol_rel,
+                             double *centres_out, int32_t *labels_out, int *n_iter_out)
+{
+    CHK(enter(ctx));
+    if (!xsample || !init_centres || !centres_out) SHP_FAIL(ctx, SHP_ERR_ARG, "NULL argument");
+    if (dtype_size(dtype) == 0) SHP_FAIL(ctx, SHP_ERR_ARG, "bad pixel type %d", dtype);
+    return run_kmeans_fit(ctx, xsample, dtype, nrows, nbands, k, init_centres, max_iter, tol_rel,
                           centres_out, labels_out, n_iter_out);
 }
 
@@ -490,9 +502,19 @@ API int shp_dev_subsample(shp_ctx *ctx, const void *d_img, int dtype, int nbands
                        nbands, (uint32_t)nrows, (uint32_t)ncols, ry, rx, (uint32_t)ny, (uint32_t)nx,
                        ctx->aux.p);
     KCHK(ctx);
-    HIPCHK(ctx, hipMemcpyAsync(out_host, ctx->aux.p, total * dtype_size(dtype), hipMemcpyDeviceToHost,
-                               ctx->stream));
+    // through the context's pinned staging buffer: a pageable destination makes the runtime stage
+    // the copy itself in small synchronous pieces (1-30 ms for 12 MB, erratic)
+    const size_t bytes = total * dtype_size(dtype);
+    if (ctx->h_fit_cap < bytes) {
+        if (ctx->h_fit) hipHostFree(ctx->h_fit);
+        ctx->h_fit = nullptr; ctx->h_fit_cap = 0;
+        if (hipHostMalloc((void **)&ctx->h_fit, bytes, hipHostMallocDefault) != hipSuccess)
+            SHP_FAIL(ctx, SHP_ERR_NOMEM, "hipHostMalloc(%zu) failed", bytes);
+        ctx->h_fit_cap = bytes;
+    }
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_fit, ctx->aux.p, bytes, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(out_host, ctx->h_fit, bytes);
     return 0;
 }
 

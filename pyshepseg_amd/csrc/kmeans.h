@@ -514,7 +514,25 @@ __global__ __launch_bounds__(256) void k_fit_dist(const double *__restrict__ X, 
     dist[i] = d;
 }
 
-static int run_kmeans_fit(shp_ctx *ctx, const double *xin, int64_t nrows, int nb, int k,
+// sklearn's X -= X.mean(axis=0) on rows of pixel type T (converted to float64 as the reference's
+// check_array does): column sums in row order, X = x - mean, and the column sums of X.
+template <class T>
+static void fit_centre_rows(const T *xin, uint32_t n, int nb, double *X, std::vector<double> &mu,
+                            std::vector<double> &acc)
+{
+    for (uint32_t i = 0; i < n; i++)
+        for (int b = 0; b < nb; b++) acc[b] += (double)xin[(size_t)i * nb + b];
+    for (int b = 0; b < nb; b++) { mu[b] = acc[b] / (double)n; acc[b] = 0.0; }
+    for (uint32_t i = 0; i < n; i++)
+        for (int b = 0; b < nb; b++) {
+            const double xv = (double)xin[(size_t)i * nb + b] - mu[b];
+            X[(size_t)i * nb + b] = xv;
+            acc[b] += xv;
+        }
+}
+
+#define FIT_DT_F64 100        // xin holds float64 rows (shp_kmeans_fit); else one of the SHP_* pixel types
+static int run_kmeans_fit(shp_ctx *ctx, const void *xin_any, int xdtype, int64_t nrows, int nb, int k,
                           const double *init, int max_iter, double tol_rel, double *centres_out,
                           int32_t *labels_out, int *n_iter_out)
 {
@@ -539,15 +557,15 @@ static int run_kmeans_fit(shp_ctx *ctx, const double *xin, int64_t nrows, int nb
     }
     double *X = ctx->h_fit;
     std::vector<double> mu(nb, 0.0), acc(nb, 0.0), acc2(nb, 0.0);
-    for (uint32_t i = 0; i < n; i++)
-        for (int b = 0; b < nb; b++) acc[b] += xin[(size_t)i * nb + b];
-    for (int b = 0; b < nb; b++) { mu[b] = acc[b] / (double)n; acc[b] = 0.0; }
-    for (uint32_t i = 0; i < n; i++)
-        for (int b = 0; b < nb; b++) {
-            const double xv = xin[(size_t)i * nb + b] - mu[b];
-            X[(size_t)i * nb + b] = xv;
-            acc[b] += xv;
-        }
+    switch (xdtype) {
+    case FIT_DT_F64: fit_centre_rows((const double *)xin_any, n, nb, X, mu, acc); break;
+    case SHP_U8: fit_centre_rows((const uint8_t *)xin_any, n, nb, X, mu, acc); break;
+    case SHP_I16: fit_centre_rows((const int16_t *)xin_any, n, nb, X, mu, acc); break;
+    case SHP_U16: fit_centre_rows((const uint16_t *)xin_any, n, nb, X, mu, acc); break;
+    case SHP_I32: fit_centre_rows((const int32_t *)xin_any, n, nb, X, mu, acc); break;
+    case SHP_U32: fit_centre_rows((const uint32_t *)xin_any, n, nb, X, mu, acc); break;
+    default: SHP_FAIL(ctx, SHP_ERR_ARG, "kmeans_fit: bad sample type %d", xdtype);
+    }
     for (int b = 0; b < nb; b++) acc[b] /= (double)n;
     for (uint32_t i = 0; i < n; i++)
         for (int b = 0; b < nb; b++) { const double d = X[(size_t)i * nb + b] - acc[b]; acc2[b] += d * d; }
@@ -701,8 +719,11 @@ static int run_kmeans_fit(shp_ctx *ctx, const double *xin, int64_t nrows, int nb
     HIPCHK(ctx, hipMemcpyAsync(pin_up, dC, (size_t)kn * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipStreamSynchronize(st));
     for (int t = 0; t < kn; t++) C[t] = pin_up[t];
-    if (labels_out) HIPCHK(ctx, hipMemcpyAsync(labels_out, dlab, (size_t)n * 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(ctx, hipStreamSynchronize(st));
+    if (labels_out) {       // via the pinned sample buffer (X is no longer needed): see shp_dev_subsample
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_fit, dlab, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        memcpy(labels_out, ctx->h_fit, (size_t)n * 4);
+    }
     for (int t = 0; t < kn; t++) centres_out[t] = C[t] + mu[t % nb];
     if (n_iter_out) *n_iter_out = it;
     if (getenv("SHEPSEG_FIT_TIMING")) {

@@ -161,7 +161,9 @@ def _kmeans_plusplus(x, k, rng):
 
 
 def _fit(xSample, init, max_iter=300, tol=1e-4, wantInertia=False):
-    x = numpy.ascontiguousarray(xSample, dtype=numpy.float64)
+    xSample = numpy.asarray(xSample)
+    typed = xSample.dtype in _lib.SHP_DTYPES         # pixel types go down as they are
+    x = numpy.ascontiguousarray(xSample, dtype=None if typed else numpy.float64)
     init = numpy.ascontiguousarray(init, dtype=numpy.float64)
     (n, nb) = x.shape
     k = init.shape[0]
@@ -169,9 +171,14 @@ def _fit(xSample, init, max_iter=300, tol=1e-4, wantInertia=False):
     labels = numpy.empty(n, dtype=numpy.int32)
     nit = ctypes.c_int(0)
     c = _lib.ctx()
-    c.check(c._L.shp_kmeans_fit(c.handle, _lib.ptr(x), n, nb, k, _lib.ptr(init), int(max_iter),
-                                float(tol), _lib.ptr(centres), _lib.ptr(labels),
-                                ctypes.byref(nit)))
+    if typed:
+        c.check(c._L.shp_kmeans_fit_typed(c.handle, _lib.ptr(x), _lib.SHP_DTYPES[x.dtype], n, nb, k,
+                                          _lib.ptr(init), int(max_iter), float(tol),
+                                          _lib.ptr(centres), _lib.ptr(labels), ctypes.byref(nit)))
+    else:
+        c.check(c._L.shp_kmeans_fit(c.handle, _lib.ptr(x), n, nb, k, _lib.ptr(init), int(max_iter),
+                                    float(tol), _lib.ptr(centres), _lib.ptr(labels),
+                                    ctypes.byref(nit)))
     inertia = float(((x - centres[labels]) ** 2).sum()) if wantInertia else None
     return KMeansModel(centres, nit.value, labels, inertia)
 
