@@ -154,8 +154,8 @@ def main():
         k = pmc.get(names[dom].split(' ')[0])
         if k and args.size == 40000:
             traffic = int((k['FETCH_SIZE_KB_per_launch'] + k['WRITE_SIZE_KB_per_launch']) * 1024)
-            if dom == 2:
-                traffic *= 2          # the timed region holds the two k_dfs_split launches of a tile
+            if dom == 2:          # the timed region holds a tile's k_dfs_split launches (1 or 2)
+                traffic = int(traffic * k['launches'] / 144.0)
     except Exception:
         traffic = None
     out = {

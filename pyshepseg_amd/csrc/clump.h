@@ -577,13 +577,16 @@ __device__ __forceinline__ void dfs_split_lds(uint32_t *lab, const BigInfo &B, u
 
 // order[rank] = component index, largest first: the longest replays start first (LPT), which
 // shortens the makespan whenever there are more components than resident workgroups
+// counters[2] = how many of them need the large replay class (bitmap above bmw_small words)
 __global__ __launch_bounds__(256) void k_big_order(const BigInfo *__restrict__ big,
-                                                   const uint32_t *__restrict__ counters,
-                                                   uint32_t *__restrict__ order)
+                                                   uint32_t *counters,
+                                                   uint32_t *__restrict__ order, uint32_t ncols,
+                                                   uint32_t bmw_small)
 {
     const uint32_t nbig = counters[0];
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i >= nbig) return;
+    if (dfs_bitmap_words(big[i], ncols) > bmw_small) atomicAdd(&counters[2], 1u);
     const uint32_t si = big[i].size;
     uint32_t rank = 0;
     for (uint32_t j = 0; j < nbig; j++) {
@@ -742,8 +745,21 @@ static int run_clump(shp_ctx *ctx, const uint16_t *d_clus, uint32_t nrows, uint3
                        csize, nrows, ncols, big, bigbits); KCHK(ctx);
     ps = prof_begin(ctx, PROF_DFS);
     uint32_t *order = (uint32_t *)((char *)ctx->big.p + (size_t)maxbig * sizeof(BigInfo) + 64);
-    hipLaunchKernelGGL(k_big_order, dim3(grid_for(maxbig, 256)), dim3(256), 0, st, big, counters, order); KCHK(ctx);
-    fill_release(ctx, true);            // the replay is a latency-bound phase: outside the fill gate
+    static const uint32_t bmw_small = getenv("SHEPSEG_DFS_SMALL") ? (uint32_t)atoi(getenv("SHEPSEG_DFS_SMALL")) : DFS_BMW_SMALL;
+    hipLaunchKernelGGL(k_big_order, dim3(grid_for(maxbig, 256)), dim3(256), 0, st, big, counters, order, ncols,
+                       bmw_small); KCHK(ctx);
+    // the replay is a latency-bound phase: outside the fill gate.  The gate's synchronisation also
+    // brings the component counts back, so the launches can be sized exactly and an empty size
+    // class skipped (its 1678 workgroups would each wait for 70 KiB of LDS only to exit).
+    uint32_t grid_l = maxbig, grid_s = maxbig;
+    if (fill_gating(ctx)) {
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_pinned, counters, 12, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        const uint32_t nbig_h = ctx->h_pinned[0], nlarge_h = ctx->h_pinned[2];
+        grid_l = nlarge_h ? nbig_h : 0u;
+        grid_s = nbig_h > nlarge_h ? nbig_h : 0u;
+    }
+    fill_release(ctx, true);
     // fork: the two size classes touch disjoint components, so they can run on two streams
     static const int fork_env = getenv("SHEPSEG_DFS_FORK") ? atoi(getenv("SHEPSEG_DFS_FORK")) : -1;
     const int fork2 = fork_env >= 0 ? fork_env : ctx->dfs_fork;
@@ -753,14 +769,17 @@ static int run_clump(shp_ctx *ctx, const uint16_t *d_clus, uint32_t nrows, uint3
         HIPCHK(ctx, hipEventRecord(ctx->evfork, st));
         HIPCHK(ctx, hipStreamWaitEvent(ctx->stream2, ctx->evfork, 0));
     }
-    static const uint32_t bmw_small = getenv("SHEPSEG_DFS_SMALL") ? (uint32_t)atoi(getenv("SHEPSEG_DFS_SMALL")) : DFS_BMW_SMALL;
-    hipLaunchKernelGGL(k_dfs_split, dim3(maxbig), dim3(64), (DFS_SWN + DFS_BMW_LARGE) * 4, st, lab, big,
-                       counters, bp<uint32_t>(ctx->stack), nrows, ncols, four, bmw_small,
-                       DFS_BMW_LARGE, 1, d_singles, d_nsingles, order, csize); KCHK(ctx);
-    hipLaunchKernelGGL(k_dfs_split, dim3(maxbig), dim3(64), (DFS_SWN + bmw_small) * 4, st2, lab,
-                       big, counters, bp<uint32_t>(ctx->stack), nrows, ncols, four, 0u, bmw_small, 0,
-                       d_singles, d_nsingles, order, csize);
-    KCHK(ctx);
+    if (grid_l) {
+        hipLaunchKernelGGL(k_dfs_split, dim3(grid_l), dim3(64), (DFS_SWN + DFS_BMW_LARGE) * 4, st, lab, big,
+                           counters, bp<uint32_t>(ctx->stack), nrows, ncols, four, bmw_small,
+                           DFS_BMW_LARGE, 1, d_singles, d_nsingles, order, csize); KCHK(ctx);
+    }
+    if (grid_s) {
+        hipLaunchKernelGGL(k_dfs_split, dim3(grid_s), dim3(64), (DFS_SWN + bmw_small) * 4, st2, lab,
+                           big, counters, bp<uint32_t>(ctx->stack), nrows, ncols, four, 0u, bmw_small, 0,
+                           d_singles, d_nsingles, order, csize);
+        KCHK(ctx);
+    }
     if (fork2) {
         HIPCHK(ctx, hipEventRecord(ctx->evjoin, ctx->stream2));
         HIPCHK(ctx, hipStreamWaitEvent(st, ctx->evjoin, 0));
