@@ -260,6 +260,8 @@ def _percentile_linear_f64(a32, q):
 def autoMaxSpectralDiff(km, maxSpectralDiff, distPcntile):
     """maxSpectralDiff to use: 'auto' = percentile of the pairwise centre distances, None =
     10 x the largest, a number = itself (reference shepseg.py:400-449)."""
+    if not (maxSpectralDiff is None or (isinstance(maxSpectralDiff, str) and maxSpectralDiff == 'auto')):
+        return maxSpectralDiff          # a number: the centre distances are not needed
     centres = _centres_of(km)
     numClusters = centres.shape[0]
     numPairs = numClusters * (numClusters - 1) // 2

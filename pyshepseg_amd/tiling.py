@@ -665,7 +665,7 @@ def startSegmentationWorkers(src, jobs, d_tiles, centres, msd, imgNullVal, fourC
 def waitForTile(j, jobs, threads, forceExit, timeout):
     """Block until tile job j is segmented; raise like the reference on failure / timeout
     (tiling.py:1045-1053, :918-928)."""
-    while not j.done.wait(timeout=max(timeout, 1)):
+    while not j.done.wait(timeout=0.2):         # short slices: a failed worker is noticed at once
         if forceExit.is_set():
             break
         if not any(t.is_alive() for t in threads):

@@ -154,3 +154,29 @@ def test_tiled_device_raster_with_nulls_and_cluster_map(oracle, monkeypatch):
         assert r.maxSegId == mx
         assert np.array_equal(r.segimg, want)
         assert np.array_equal(r.hist, hist)
+
+
+def test_worker_failure_surfaces_and_does_not_hang(oracle):
+    """A failure inside the workers' first call (a model with more clusters than the assign step
+    accepts) must come back as an exception -- with the cluster map's claimed blocks, the fill gate
+    and the other workers released -- and the next run on the same contexts must work."""
+    import time
+    from pyshepseg_amd import tiling, shepseg, _lib
+    img = oracle.synthimg(2, 3, 600, 700)
+    bad = shepseg.KMeansModel(np.zeros((70000, 3)))
+    cfg = tiling.SegmentationConcurrencyConfig(concurrencyType=tiling.CONC_THREADS, numWorkers=4)
+    ras = tiling.DeviceRaster.fromArray(img)
+    try:
+        t0 = time.time()
+        with pytest.raises((tiling.PyShepSegTilingError, _lib.ShepsegHipError)):
+            tiling.doTiledShepherdSegmentation(ras, None, tileSize=256, overlapSize=64, minSegmentSize=20,
+                                               kmeansObj=bad, maxSpectralDiff=100.0, concurrencyCfg=cfg)
+        assert time.time() - t0 < 30
+        km = shepseg.fitSpectralClusters(img, 8, 5, None, True)
+        r = tiling.doTiledShepherdSegmentation(ras, None, tileSize=256, overlapSize=64, minSegmentSize=20,
+                                               kmeansObj=km, concurrencyCfg=cfg)
+    finally:
+        ras.free()
+    want, mx, hist = _oracle_tiled(oracle, img, km.cluster_centers_, 256, 64, 20,
+                                   float(r.maxSpectralDiff), None, True)
+    assert r.maxSegId == mx and np.array_equal(r.segimg, want)
