@@ -192,9 +192,11 @@ int shp_stitch_chain_dev(shp_ctx *ctx, const uint32_t *d_tile, int ys, int xs, i
                          uint32_t *d_max_seg_id, int top, int bottom, int left, int right,
                          uint32_t *d_meta, uint32_t *d_right_out, uint32_t *d_bottom_out,
                          uint32_t *d_out, int64_t out_pitch, int xout, int yout);
-/* histogram of a device label raster, hist_out_host[0..max_seg_id], entry 0 zeroed */
-int shp_histogram_dev(shp_ctx *ctx, const uint32_t *d_raster, int64_t npix, uint32_t max_seg_id,
-                      uint32_t *hist_out_host);
+/* histogram of a device label raster, hist_out_host[0..max_seg_id], entry 0 zeroed (the RAT
+ * Histogram column, HistogramAccumulator tiling.py:1915-1963).  ncols = the raster's row length
+ * (npix a multiple of it; lets a segment's pixels be combined per 2-D patch), or 0. */
+int shp_histogram_dev(shp_ctx *ctx, const uint32_t *d_raster, int64_t npix, int64_t ncols,
+                      uint32_t max_seg_id, uint32_t *hist_out_host);
 
 /* ---- per-segment statistics ("tilingstats") ----------------------------------------------------
  * replaces tilingstats.accumulateSegDict / calcStatsForCompletedSegs / SegmentStats / RatPage

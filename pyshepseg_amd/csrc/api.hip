@@ -714,25 +714,49 @@ API int shp_stitch_chain_dev(shp_ctx *ctx, const uint32_t *d_tile, int ys, int x
     return 0;
 }
 
-// histogram of a device label raster: hist_out[0..max_seg_id], hist_out[0] = 0 (tiling.py:1915-1963)
-API int shp_histogram_dev(shp_ctx *ctx, const uint32_t *d_raster, int64_t npix, uint32_t max_seg_id,
-                          uint32_t *hist_out_host)
+// histogram of a device label raster: hist_out[0..max_seg_id], hist_out[0] = 0 (tiling.py:1915-1963).
+// ncols > 0 (npix a multiple of it): the raster's row length, which lets the pixels of a segment
+// be combined per 2-D patch before they reach the global counters; 0 = unknown (1-D runs).
+API int shp_histogram_dev(shp_ctx *ctx, const uint32_t *d_raster, int64_t npix, int64_t ncols,
+                          uint32_t max_seg_id, uint32_t *hist_out_host)
 {
     CHK(enter(ctx));
-    if (!d_raster || !hist_out_host || npix < 0) SHP_FAIL(ctx, SHP_ERR_ARG, "bad argument");
+    if (!d_raster || !hist_out_host || npix < 0 || ncols < 0) SHP_FAIL(ctx, SHP_ERR_ARG, "bad argument");
+    if (ncols > 0 && (npix % ncols != 0 || ncols > 0x7fffffffll || npix / ncols > 0x7fffffffll))
+        SHP_FAIL(ctx, SHP_ERR_ARG, "npix is not a whole number of rows of %lld pixels", (long long)ncols);
     CHK(buf_ensure(ctx, ctx->segsz, ((size_t)max_seg_id + 2) * 4));
     uint32_t *h = bp<uint32_t>(ctx->segsz);
-    HIPCHK(ctx, hipMemsetAsync(h, 0, ((size_t)max_seg_id + 1) * 4, ctx->stream));
-    const int64_t CH = 1ll << 30;
-    for (int64_t o = 0; o < npix; o += CH) {
-        const uint32_t m = (uint32_t)((npix - o < CH) ? (npix - o) : CH);
-        hipLaunchKernelGGL(k_run_count, dim3(grid_for(m, 256)), dim3(256), 0, ctx->stream, d_raster + o, m,
-                           h, 0u, 1);
-        KCHK(ctx);
+    const size_t hbytes = ((size_t)max_seg_id + 1) * 4;
+    HIPCHK(ctx, hipMemsetAsync(h, 0, hbytes, ctx->stream));
+    if (ncols > 0 && npix > 0) {
+        const uint32_t nc = (uint32_t)ncols;
+        const int64_t nrows = npix / ncols, RCH = 65535ll * AGG_ROWS;      // grid.y limit
+        for (int64_t r = 0; r < nrows; r += RCH) {
+            const uint32_t nr = (uint32_t)((nrows - r < RCH) ? (nrows - r) : RCH);
+            hipLaunchKernelGGL(k_hist_patch, dim3(grid_for(nc, 64), grid_for(nr, AGG_ROWS)), dim3(256), 0,
+                               ctx->stream, d_raster + (size_t)r * nc, nr, nc, h);
+            KCHK(ctx);
+        }
+    } else {
+        const int64_t CH = 1ll << 30;
+        for (int64_t o = 0; o < npix; o += CH) {
+            const uint32_t m = (uint32_t)((npix - o < CH) ? (npix - o) : CH);
+            hipLaunchKernelGGL(k_run_count, dim3(grid_for(m, 256)), dim3(256), 0, ctx->stream, d_raster + o, m,
+                               h, 0u, 1);
+            KCHK(ctx);
+        }
     }
-    HIPCHK(ctx, hipMemcpyAsync(hist_out_host, h, ((size_t)max_seg_id + 1) * 4, hipMemcpyDeviceToHost,
-                               ctx->stream));
+    // read back through pinned staging (a pageable destination: 1-30 ms for 10 MB, erratic)
+    if (ctx->h_fit_cap < hbytes) {
+        if (ctx->h_fit) hipHostFree(ctx->h_fit);
+        ctx->h_fit = nullptr; ctx->h_fit_cap = 0;
+        if (hipHostMalloc((void **)&ctx->h_fit, hbytes + hbytes / 4, hipHostMallocDefault) != hipSuccess)
+            SHP_FAIL(ctx, SHP_ERR_NOMEM, "hipHostMalloc(%zu) failed", hbytes);
+        ctx->h_fit_cap = hbytes + hbytes / 4;
+    }
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_fit, h, hbytes, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(hist_out_host, ctx->h_fit, hbytes);
     hist_out_host[0] = 0;
     return 0;
 }

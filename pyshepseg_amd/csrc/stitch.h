@@ -337,6 +337,42 @@ __global__ __launch_bounds__(256) void k_meta_cross(uint32_t *__restrict__ mn, u
     mn[s] = 0xFFFFFFFFu; mx[s] = 0u;
 }
 
+// hist[id] += pixels of id (id 0 is not counted) over a raster of `ncols` columns: run lengths per
+// 64-px row piece are combined per 32 x 64-px patch in an LDS hash table, so a segment costs one
+// global atomic per patch it touches instead of one per run of pixels.
+__global__ __launch_bounds__(256) void k_hist_patch(const uint32_t *__restrict__ ras, uint32_t nrows,
+                                                    uint32_t ncols, uint32_t *hist)
+{
+    __shared__ AggTable tab;
+    agg_init(tab, 0u, 0u, 0u);
+    __syncthreads();
+    const unsigned lane = lane_id(), wv = threadIdx.x >> 6;
+    const uint32_t c = blockIdx.x * 64u + lane;
+    const uint32_t r0 = blockIdx.y * AGG_ROWS + wv * (AGG_ROWS / 4u);
+    const bool cin = c < ncols;
+    for (uint32_t i = 0; i < AGG_ROWS / 4u; i++) {
+        const uint32_t r = r0 + i;
+        if (r >= nrows) break;                               // uniform per wavefront
+        const uint32_t s = cin ? ras[(size_t)r * ncols + c] : 0u;
+        const uint32_t pv = __shfl_up(s, 1, 64);
+        const bool head = lane == 0 || pv != s;
+        const unsigned long long heads = __ballot(head);
+        if (head && s != 0u) {
+            const unsigned long long nxt = (lane == 63) ? 0ull : (heads & ~((2ull << lane) - 1ull));
+            const uint32_t len = (nxt ? (uint32_t)__builtin_ctzll(nxt) : 64u) - lane;
+            const int h = agg_slot(tab, s);
+            if (h >= 0) atomicAdd(&tab.v[0][h], len);
+            else atomicAdd(&hist[s], len);
+        }
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < AGG_SLOTS; i += 256u) {
+        const uint32_t s = tab.key[i];
+        if (s != 0u) atomicAdd(&hist[s], tab.v[0][i]);
+    }
+}
+
+
 // bounding-box corner of every segment + "has a pixel in the trimmed window".
 // Only corner pixels act (see k_strip_minmax): the top row and the left column of a segment are
 // both found on pixels that have neither the segment above nor to the left, and the topmost-

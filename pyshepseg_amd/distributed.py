@@ -513,7 +513,7 @@ class HipEngine(object):
     def histogram(self, maxSegId):
         hist = numpy.zeros(maxSegId + 1, dtype=numpy.uint32)
         self.c.check(self.L.shp_histogram_dev(self.c.handle, self.d_out,
-                                              (self.outHi - self.outLo) * self.nCols, maxSegId,
+                                              (self.outHi - self.outLo) * self.nCols, self.nCols, maxSegId,
                                               _lib.ptr(hist)))
         return hist
 

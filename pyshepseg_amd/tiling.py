@@ -783,7 +783,7 @@ def doTiledShepherdSegmentation(infile, outfile, tileSize=DFLT_TILESIZE,
             main.check(L.shp_dev_download(main.handle, _lib.ptr(scal), d_scal, 4))
             maxSegId = int(scal[0])
             hist = numpy.zeros(maxSegId + 1, dtype=numpy.uint32)
-            main.check(L.shp_histogram_dev(main.handle, d_out, inYsize * inXsize, maxSegId,
+            main.check(L.shp_histogram_dev(main.handle, d_out, inYsize * inXsize, inXsize, maxSegId,
                                            _lib.ptr(hist)))
             hasEmpty = bool((hist[1:] == 0).any())
             if hasEmpty:
