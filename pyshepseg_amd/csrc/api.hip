@@ -306,7 +306,8 @@ static int segment_device(shp_ctx *ctx, const void *d_img, uint32_t *d_seg, int 
                           uint32_t nrows, uint32_t ncols,
                           const double *centres, int k, int has_null, int64_t null_val, int four,
                           int min_seg_size, double msd, uint32_t *max_seg_id, int64_t *singles,
-                          int64_t *small, uint32_t *nclumps_out, bool have_clusters = false)
+                          int64_t *small, uint32_t *nclumps_out, bool have_clusters = false,
+                          const ImgGeom *geom = nullptr)
 {
     const uint32_t n = nrows * ncols;
     CHK(buf_ensure(ctx, ctx->clus, (size_t)n * 2));
@@ -329,12 +330,12 @@ static int segment_device(shp_ctx *ctx, const void *d_img, uint32_t *d_seg, int 
     uint32_t max_id = nclumps;
     // (a lone null pixel is itself a size-1 "segment" 0: then fall back to the full scan, N4)
     CHK(run_eliminate_single(ctx, d_img, dtype, nb, nrows, ncols, four, d_seg, &max_id, 1, nnull != 1u,
-                             nsingles));
+                             nsingles, geom));
     hipEventRecord(ctx->ev[4], ctx->stream);
     if (singles) *singles = (int64_t)nclumps - (int64_t)max_id;        // shepseg.py:226-227
     int64_t ne = 0;
     CHK(run_eliminate_small(ctx, d_img, dtype, nb, nrows, ncols, four, min_seg_size, msd, d_seg,
-                            &max_id, &ne, 1));
+                            &max_id, &ne, 1, geom));
     hipEventRecord(ctx->ev[5], ctx->stream);
     if (small) *small = ne;
     if (max_seg_id) *max_seg_id = max_id;
@@ -562,8 +563,22 @@ API int shp_segment_window_dev(shp_ctx *ctx, const void *d_img, int dtype, int n
     FillScope fs(ctx, 1);
     fill_acquire(ctx, 0);
     hipEventRecord(ctx->ev[0], ctx->stream);
+    // With the cluster map nothing reads the tile as a contiguous image any more: the single-pixel
+    // and spectra kernels read the window of the resident raster in place (ImgGeom).  Without it
+    // the assign step wants the compact copy.
     const void *tile_img = d_img;
-    if (!(x == 0 && y == 0 && xs == img_cols && ys == img_rows)) {
+    ImgGeom geom = geom_compact(n, (uint32_t)xs);
+    if (d_clusmap) {
+        geom.bstride = (size_t)img_rows * (size_t)img_cols;
+        geom.origin = (size_t)y * (size_t)img_cols + (size_t)x;
+        geom.pitch = (uint32_t)img_cols;
+        CHK(buf_ensure(ctx, ctx->clus, (size_t)n * 2));
+        const size_t rowbytes = (size_t)xs * 2;        // the window of the raster-wide cluster map
+        hipLaunchKernelGGL(k_window, dim3((unsigned)ys, grid_for((rowbytes + 15) / 16, 256)), dim3(256), 0,
+                           ctx->stream, (const uint8_t *)d_clusmap, 2u, (uint32_t)img_rows, (uint32_t)img_cols,
+                           (uint32_t)x, (uint32_t)y, (uint32_t)xs, (uint32_t)ys, (uint8_t *)ctx->clus.p);
+        KCHK(ctx);
+    } else if (!(x == 0 && y == 0 && xs == img_cols && ys == img_rows)) {
         const size_t total = (size_t)nbands * n;
         CHK(buf_ensure(ctx, ctx->img, total * dtype_size(dtype)));
         const size_t rowbytes = (size_t)xs * dtype_size(dtype);
@@ -574,17 +589,9 @@ API int shp_segment_window_dev(shp_ctx *ctx, const void *d_img, int dtype, int n
         KCHK(ctx);
         tile_img = ctx->img.p;
     }
-    if (d_clusmap) {            // the window of the raster-wide cluster map (shp_assign_rects_dev)
-        CHK(buf_ensure(ctx, ctx->clus, (size_t)n * 2));
-        const size_t rowbytes = (size_t)xs * 2;
-        hipLaunchKernelGGL(k_window, dim3((unsigned)ys, grid_for((rowbytes + 15) / 16, 256)), dim3(256), 0,
-                           ctx->stream, (const uint8_t *)d_clusmap, 2u, (uint32_t)img_rows, (uint32_t)img_cols,
-                           (uint32_t)x, (uint32_t)y, (uint32_t)xs, (uint32_t)ys, (uint8_t *)ctx->clus.p);
-        KCHK(ctx);
-    }
     CHK(segment_device(ctx, tile_img, d_seg_out, dtype, nbands, ys, xs, centres, k, has_null, null_val,
                        four_connected, min_seg_size, max_spectral_diff, max_seg_id_out,
-                       singles_elim_out, small_elim_out, num_clumps_out, d_clusmap != nullptr));
+                       singles_elim_out, small_elim_out, num_clumps_out, d_clusmap != nullptr, &geom));
     hipEventRecord(ctx->ev[6], ctx->stream);
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     collect_timings(ctx);

@@ -250,6 +250,33 @@ template <int DT> __device__ __forceinline__ long long ld_t(const void *__restri
     default: { constexpr int DT = SHP_U32; __VA_ARGS__; } break;             \
     }
 
+// Where a tile's pixels live: band b, tile pixel p (row-major in a tile xs pixels wide) is element
+// b * bstride + origin + (p / xs) * pitch + p % xs of the image buffer.  A compact tile image has
+// pitch == xs, bstride == pixels per band, origin == 0; a window of a resident raster is read in
+// place (pitch = raster width, origin = first pixel of the window) instead of being copied out.
+struct ImgGeom {
+    size_t bstride, origin;
+    uint32_t pitch, xs;
+    float inv_xs;
+};
+static inline ImgGeom geom_compact(size_t n, uint32_t xs)
+{
+    return ImgGeom{n, 0, xs, xs, xs ? 1.0f / (float)xs : 0.0f};
+}
+__device__ __forceinline__ size_t geom_off(const ImgGeom &g, uint32_t p)
+{
+    if (g.pitch == g.xs) return g.origin + p;
+    // row = p / xs without an integer division: the float quotient is within 0.02 of the true one
+    // (p / xs < 65536 rows, three roundings of 2^-24 each), so its floor is off by at most one
+    uint32_t r = (uint32_t)((float)p * g.inv_xs);
+    uint32_t rem = p - r * g.xs;
+    if (rem >= g.xs) {
+        if ((int32_t)rem < 0) { r -= 1u; rem += g.xs; }
+        else { r += 1u; rem -= g.xs; }
+    }
+    return g.origin + (size_t)r * g.pitch + rem;
+}
+
 // ---- workgroup-local aggregation of per-id minima / maxima ---------------------------------------
 // Atomics on one address serialise at L2, and the pixels that update one id's bounding box sit
 // close together.  Kernels that reduce per-id extremes therefore walk 2-D patches (AGG_ROWS x 64

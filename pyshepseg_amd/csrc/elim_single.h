@@ -23,10 +23,12 @@ template <int DT>
 __device__ __forceinline__ uint32_t single_target(const void *__restrict__ img, int nb,
                                                   const uint32_t *__restrict__ seg,
                                                   const uint32_t *__restrict__ segsz, uint32_t p,
-                                                  uint32_t n, uint32_t nrows, uint32_t ncols, int four)
+                                                  uint32_t n, uint32_t nrows, uint32_t ncols, int four,
+                                                  const ImgGeom g)
 {
     const uint32_t i = p / ncols, j = p - i * ncols;
     uint32_t q[9], sn[9];
+    size_t qo[9];                   // image offsets of the nine positions (see ImgGeom)
     bool ok[9];
 #pragma unroll
     for (int k = 0; k < 9; k++) {
@@ -34,6 +36,7 @@ __device__ __forceinline__ uint32_t single_target(const void *__restrict__ img, 
         const int a = (int)i + da, b = (int)j + db;
         ok[k] = k != 4 && a >= 0 && b >= 0 && a < (int)nrows && b < (int)ncols && !(four && da != 0 && db != 0);
         q[k] = ok[k] ? (uint32_t)a * ncols + (uint32_t)b : p;
+        qo[k] = g.origin + (size_t)(ok[k] ? (uint32_t)a : i) * g.pitch + (ok[k] ? (uint32_t)b : j);
         sn[k] = seg[q[k]];
     }
 #pragma unroll
@@ -42,10 +45,10 @@ __device__ __forceinline__ uint32_t single_target(const void *__restrict__ img, 
 #pragma unroll
     for (int k = 0; k < 9; k++) d[k] = 0;
     for (int b = 0; b < nb; b++) {
-        const long long vp = ld_t<DT>(img, (size_t)b * n + p);
+        const long long vp = ld_t<DT>(img, (size_t)b * g.bstride + qo[4]);
 #pragma unroll
         for (int k = 0; k < 9; k++) {
-            const long long t = vp - ld_t<DT>(img, (size_t)b * n + q[k]);
+            const long long t = vp - ld_t<DT>(img, (size_t)b * g.bstride + qo[k]);
             d[k] += t * t;
         }
     }
@@ -63,14 +66,14 @@ template <int DT>
 __global__ __launch_bounds__(256) void k_single_scan(
     const void *__restrict__ img, int nb, const uint32_t *__restrict__ seg,
     const uint32_t *__restrict__ segsz, uint32_t *__restrict__ tgt, uint32_t n, uint32_t nrows,
-    uint32_t ncols, int four, uint32_t *__restrict__ rest, uint32_t *nrest)
+    uint32_t ncols, int four, uint32_t *__restrict__ rest, uint32_t *nrest, const ImgGeom geom)
 {
     const uint32_t p = blockIdx.x * 256u + threadIdx.x;
     uint32_t out = NO_TARGET;
     bool keep = false;
     if (p < n) {
         if (segsz[seg[p]] == 1u) {
-            out = single_target<DT>(img, nb, seg, segsz, p, n, nrows, ncols, four);
+            out = single_target<DT>(img, nb, seg, segsz, p, n, nrows, ncols, four, geom);
             keep = out == NO_TARGET;
         }
         tgt[p] = out;
@@ -105,14 +108,15 @@ template <int DT>
 __global__ __launch_bounds__(256) void k_single_scan_list(
     const void *__restrict__ img, int nb, const uint32_t *__restrict__ seg,
     const uint32_t *__restrict__ segsz, uint32_t *__restrict__ tgt_l, uint32_t n, uint32_t nrows,
-    uint32_t ncols, int four, const uint32_t *__restrict__ rest, uint32_t nrest, uint32_t *nelim)
+    uint32_t ncols, int four, const uint32_t *__restrict__ rest, uint32_t nrest, uint32_t *nelim,
+    const ImgGeom geom)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i == 0) *nelim = 0u;                 // the apply kernel of this pass raises it (no memset launch)
     if (i >= nrest) return;
     const uint32_t p = rest[i];
     uint32_t out = NO_TARGET;
-    if (segsz[seg[p]] == 1u) out = single_target<DT>(img, nb, seg, segsz, p, n, nrows, ncols, four);
+    if (segsz[seg[p]] == 1u) out = single_target<DT>(img, nb, seg, segsz, p, n, nrows, ncols, four, geom);
     tgt_l[i] = out;
 }
 
@@ -212,9 +216,11 @@ static int run_seg_size(shp_ctx *ctx, const uint32_t *d_seg, uint32_t n, uint32_
 // they are the only size-1 segments (the caller checked that the null count is not 1).
 static int run_eliminate_single(shp_ctx *ctx, const void *d_img, int dtype, int nb, uint32_t nrows,
                                 uint32_t ncols, int four, uint32_t *d_seg, uint32_t *max_id,
-                                int sizes_ready = 0, int singles_ready = 0, uint32_t nsingles = 0)
+                                int sizes_ready = 0, int singles_ready = 0, uint32_t nsingles = 0,
+                                const ImgGeom *geom_in = nullptr)
 {
     const uint32_t n = nrows * ncols;
+    const ImgGeom geom = geom_in ? *geom_in : geom_compact(n, ncols);
     CHK(buf_ensure(ctx, ctx->segsz, ((size_t)*max_id + 2) * 4));
     CHK(buf_ensure(ctx, ctx->origsz, ((size_t)*max_id + 2) * 4));
     CHK(buf_ensure(ctx, ctx->aux, (size_t)n * 4));
@@ -236,7 +242,7 @@ static int run_eliminate_single(shp_ctx *ctx, const void *d_img, int dtype, int 
     } else {
         HIPCHK(ctx, hipMemsetAsync(nelim, 0, 8, st));
         DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_single_scan<DT>, dim3(g), dim3(256), 0, st, d_img, nb, d_seg,
-                                                 segsz, tgt, n, nrows, ncols, four, rest, nrest));
+                                                 segsz, tgt, n, nrows, ncols, four, rest, nrest, geom));
         KCHK(ctx);
         hipLaunchKernelGGL(k_single_apply, dim3(g), dim3(256), 0, st, d_seg, segsz, tgt, n, nelim); KCHK(ctx);
         HIPCHK(ctx, hipMemcpyAsync(ctx->h_pinned, nelim, 8, hipMemcpyDeviceToHost, st));
@@ -248,7 +254,7 @@ static int run_eliminate_single(shp_ctx *ctx, const void *d_img, int dtype, int 
     while (merged != 0 && nr != 0) {
         const unsigned gl = grid_for(nr, 256);
         DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_single_scan_list<DT>, dim3(gl), dim3(256), 0, st, d_img, nb,
-                                                 d_seg, segsz, tgt, n, nrows, ncols, four, rest, nr, nelim));
+                                                 d_seg, segsz, tgt, n, nrows, ncols, four, rest, nr, nelim, geom));
         KCHK(ctx);
         hipLaunchKernelGGL(k_single_apply_list, dim3(gl), dim3(256), 0, st, d_seg, segsz, tgt, rest, nr,
                            nelim); KCHK(ctx);

@@ -63,7 +63,7 @@ template <int DT, int BG>
 __global__ __launch_bounds__(256) void k_spectra_small(
     const void *__restrict__ img, int nb, uint32_t n, const uint32_t *__restrict__ pix,
     const uint32_t *__restrict__ off, const uint32_t *__restrict__ segsz, float *__restrict__ ssum,
-    uint32_t S)
+    uint32_t S, const ImgGeom g)
 {
     constexpr bool WIDE = DT == SHP_I32 || DT == SHP_U32;
     const uint32_t s = blockIdx.x * 256u + threadIdx.x + 1u;
@@ -73,15 +73,15 @@ __global__ __launch_bounds__(256) void k_spectra_small(
     const uint32_t o = off[s];
     for (int b0 = 0; b0 < nb; b0 += BG) {
         const int bg = nb - b0 < BG ? nb - b0 : BG;
-        const size_t base = (size_t)b0 * n;
+        const size_t base = (size_t)b0 * g.bstride;
         float acc[BG];
 #pragma unroll
         for (int j = 0; j < BG; j++) acc[j] = 0.0f;
         for (uint32_t i = 0; i < m; i++) {
-            const uint32_t idx = pix[o + i];
+            const size_t idx = geom_off(g, pix[o + i]);
             long long v[BG];
 #pragma unroll
-            for (int j = 0; j < BG; j++) v[j] = ld_t<DT>(img, base + (size_t)(j < bg ? j : 0) * n + idx);
+            for (int j = 0; j < BG; j++) v[j] = ld_t<DT>(img, base + (size_t)(j < bg ? j : 0) * g.bstride + idx);
 #pragma unroll
             for (int j = 0; j < BG; j++) acc[j] = WIDE ? f32_acc(acc[j], v[j]) : acc[j] + (float)(int)v[j];
         }
@@ -121,7 +121,7 @@ template <int DT, int BG>
 __global__ __launch_bounds__(256) void k_spectra_big(
     const void *__restrict__ img, int nb, uint32_t n, const uint32_t *__restrict__ pix,
     const uint32_t *__restrict__ off, const uint32_t *__restrict__ segsz, float *__restrict__ ssum,
-    const uint32_t *__restrict__ list)
+    const uint32_t *__restrict__ list, const ImgGeom g)
 {
     constexpr bool WIDE = DT == SHP_I32 || DT == SHP_U32;
     typedef typename std::conditional<WIDE, long long, int>::type IT;
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void k_spectra_big(
             const int bg = nb - b0 < BG ? nb - b0 : BG;
             size_t boff[BG];                         // band offsets; surplus slots re-read band 0
 #pragma unroll
-            for (int j = 0; j < BG; j++) boff[j] = (size_t)(b0 + (j < bg ? j : 0)) * n;
+            for (int j = 0; j < BG; j++) boff[j] = (size_t)(b0 + (j < bg ? j : 0)) * g.bstride;
             // ---- exact phase: private integer partial sums, bound checked per 512 pixels ----
             IT psum[BG], pabs[BG];
 #pragma unroll
@@ -149,13 +149,13 @@ __global__ __launch_bounds__(256) void k_spectra_big(
                 IT ts[BG], ta[BG];
 #pragma unroll
                 for (int j = 0; j < BG; j++) { ts[j] = psum[j]; ta[j] = pabs[j]; }
-                uint32_t idx[8];
+                size_t idx[8];
                 bool ok[8];
 #pragma unroll
                 for (int u = 0; u < 8; u++) {
                     const uint32_t i = i0 + (uint32_t)u * 64u + lane;
                     ok[u] = i < gend;
-                    idx[u] = pix[bo + (ok[u] ? i : i0)];         // unconditional loads: they all overlap
+                    idx[u] = geom_off(g, pix[bo + (ok[u] ? i : i0)]);   // unconditional loads: they all overlap
                 }
 #pragma unroll
                 for (int u = 0; u < 8; u++) {
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(256) void k_spectra_big(
                 IT cur[BG];
                 {
                     const bool valid = i0 + lane < bm;
-                    const uint32_t ix = pix[bo + (valid ? i0 + lane : i0)];
+                    const size_t ix = geom_off(g, pix[bo + (valid ? i0 + lane : i0)]);
 #pragma unroll
                     for (int j = 0; j < BG; j++) cur[j] = (IT)ld_t<DT>(img, boff[j] + ix);
                 }
@@ -199,7 +199,7 @@ __global__ __launch_bounds__(256) void k_spectra_big(
                     const uint32_t nx = c0 + 64u;
                     if (nx < bm) {                   // next step's gathers overlap this step's chain
                         const bool valid = nx + lane < bm;
-                        const uint32_t ix = pix[bo + (valid ? nx + lane : nx)];
+                        const size_t ix = geom_off(g, pix[bo + (valid ? nx + lane : nx)]);
 #pragma unroll
                         for (int j = 0; j < BG; j++) cur[j] = (IT)ld_t<DT>(img, boff[j] + ix);
                     }
@@ -621,9 +621,10 @@ static const int g_small_max = getenv("SHEPSEG_SMALL_MAX") ? atoi(getenv("SHEPSE
 static int run_eliminate_small(shp_ctx *ctx, const void *d_img, int dtype, int nb, uint32_t nrows,
                                uint32_t ncols, int four, int min_seg_size, double max_spectral_diff,
                                uint32_t *d_seg, uint32_t *max_id, int64_t *num_elim,
-                               int sizes_in_origsz = 0)
+                               int sizes_in_origsz = 0, const ImgGeom *geom_in = nullptr)
 {
     const uint32_t n = nrows * ncols;
+    const ImgGeom geom = geom_in ? *geom_in : geom_compact(n, ncols);
     const uint32_t S = *max_id;
     const size_t ns = (size_t)S + 2;
     const uint32_t min_seg = (uint32_t)(min_seg_size < 1 ? 1 : min_seg_size);
@@ -680,9 +681,9 @@ static int run_eliminate_small(shp_ctx *ctx, const void *d_img, int dtype, int n
 #define SPECTRA_LAUNCH(BGN)                                                                           \
     DISPATCH_DTYPE(dtype,                                                                             \
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_spectra_small<DT, BGN>), dim3(gs), dim3(256), 0, st, d_img, \
-                           nb, n, pix, off, segsz, ssum, S);                                          \
+                           nb, n, pix, off, segsz, ssum, S, geom);                                    \
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_spectra_big<DT, BGN>), dim3(SPECTRA_GRID), dim3(256), 0, st, \
-                           d_img, nb, n, pix, off, segsz, ssum, biglist))
+                           d_img, nb, n, pix, off, segsz, ssum, biglist, geom))
     switch (nb >= SPECTRA_BG ? SPECTRA_BG : nb) {
     case 1: SPECTRA_LAUNCH(1); break;
     case 2: SPECTRA_LAUNCH(2); break;
