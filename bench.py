@@ -147,10 +147,10 @@ def main():
     avg_s = (ms / max(cnt, 1)) / 1e3
     achieved = (bpp * tile_px / avg_s / 1e9) if avg_s > 0 else 0.0
     # HBM traffic per launch of that kernel from the committed PMC passes (rocprofv3 cannot run
-    # inside this process): FETCH_SIZE + WRITE_SIZE in KB, see profiles/r01_m_pmc_summary.json
+    # inside this process): FETCH_SIZE + WRITE_SIZE in KB, see profiles/r01_n_pmc_summary.json
     traffic = None
     try:
-        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_m_pmc_summary.json')))['kernels']
+        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_n_pmc_summary.json')))['kernels']
         k = pmc.get(names[dom].split(' ')[0])
         if k and args.size == 40000:
             traffic = int((k['FETCH_SIZE_KB_per_launch'] + k['WRITE_SIZE_KB_per_launch']) * 1024)
