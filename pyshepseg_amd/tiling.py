@@ -748,6 +748,10 @@ def doTiledShepherdSegmentation(infile, outfile, tileSize=DFLT_TILESIZE,
                 numWorkers, timings, bands=bands, maxConcurrentReads=concurrencyCfg.maxConcurrentReads,
                 verbose=verbose, stitchPrep=(tileInfo, overlapSize, arena, bool(simpleTileRecode)))
 
+            if os.environ.get('SHEPSEG_CHAIN_TIMING'):
+                # diagnostic: let every tile finish first, so that 'stitchtiles' times the bare chain
+                for t in threads:
+                    t.join()
             # ---- stitchTiles (tiling.py:950-1064): sequential, concurrent with the workers ----
             with timings.interval('stitchtiles'):
                 for j in jobs:
