@@ -180,3 +180,38 @@ def test_worker_failure_surfaces_and_does_not_hang(oracle):
     want, mx, hist = _oracle_tiled(oracle, img, km.cluster_centers_, 256, 64, 20,
                                    float(r.maxSpectralDiff), None, True)
     assert r.maxSegId == mx and np.array_equal(r.segimg, want)
+
+
+def test_knobs_off_paths_match(tmp_path):
+    """The documented fall-back paths -- no fill gate, no cluster map (per-tile assign on a copied
+    window), pixel sort instead of run sort -- give the same labels.  The knobs are read once per
+    process, so the run with them off happens in a child process."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    from pyshepseg_amd import tiling
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from pyshepseg_amd import tiling\n"
+        "ras = tiling.DeviceRaster.synth(7, 4, 900, 1100)\n"
+        "cfg = tiling.SegmentationConcurrencyConfig(concurrencyType=tiling.CONC_THREADS, numWorkers=3)\n"
+        "r = tiling.doTiledShepherdSegmentation(ras, None, tileSize=384, overlapSize=96, minSegmentSize=40,\n"
+        "        numClusters=20, fixedKMeansInit=True, concurrencyCfg=cfg)\n"
+        "np.savez(sys.argv[1], seg=r.segimg, hist=r.hist, centres=r.kmeans.cluster_centers_)\n" % ROOT)
+    env = dict(os.environ, SHEPSEG_FILL_MAX='0', SHEPSEG_CLUSTER_MAP='0', SHEPSEG_CSR_RUNS='0')
+    out = str(tmp_path / 'off.npz')
+    p = subprocess.run([sys.executable, '-c', code, out], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    off = np.load(out)
+    ras = tiling.DeviceRaster.synth(7, 4, 900, 1100)
+    try:
+        cfg = tiling.SegmentationConcurrencyConfig(concurrencyType=tiling.CONC_THREADS, numWorkers=3)
+        r = tiling.doTiledShepherdSegmentation(ras, None, tileSize=384, overlapSize=96, minSegmentSize=40,
+                                               numClusters=20, fixedKMeansInit=True, concurrencyCfg=cfg)
+    finally:
+        ras.free()
+    assert np.array_equal(off['centres'], r.kmeans.cluster_centers_)
+    assert np.array_equal(off['seg'], r.segimg)
+    assert np.array_equal(off['hist'], r.hist)
