@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256) void k_fit_assign(const double *__restrict__ X
                 if (j == 0) { bestd[r] = d[r]; best[r] = 0; }
                 else {
                     best[r] = d[r] < bestd[r] ? j : best[r];
-                    bestd[r] = __builtin_fmin(d[r], bestd[r]);
+                    bestd[r] = assign_min(d[r], bestd[r]);
                 }
             }
         }
