@@ -51,6 +51,11 @@ int shp_ctx_create_priority(int device, shp_ctx **out);  /* same, highest stream
  * (numpy allocates per call); the tiled drivers call it once per worker thread
  * (SegThreadsMgr.worker, tiling.py:1560-1600) with the job's largest tile. */
 int shp_ctx_reserve(shp_ctx *ctx, int dtype, int nbands, int64_t npix);
+/* what that reservation would still allocate on this context (bytes), and the device's free and
+ * total memory: the tiled driver starts only as many workers as fit (SegThreadsMgr's numWorkers,
+ * tiling.py:1531-1600, has no such limit because its tiles live in host memory) */
+int shp_ctx_reserve_query(shp_ctx *ctx, int dtype, int nbands, int64_t npix, int64_t *extra_bytes,
+                          int64_t *free_bytes, int64_t *total_bytes);
 void shp_ctx_destroy(shp_ctx *ctx);
 const char *shp_last_error(const shp_ctx *ctx);  /* valid until the next call on ctx */
 /* device-time (HIP events on the ctx stream) of the stages of the last shp_segment_tile /

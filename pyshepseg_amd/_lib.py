@@ -99,6 +99,8 @@ _SIGS = {
     'shp_segstats_dev': (_c.c_int, [_vp, _vp, _vp, _c.c_int, _c.c_int64, _c.c_uint32, _c.c_int,
                                     _c.c_int64, _vp, _c.c_int, _c.c_int64, _vp, _vp]),
     'shp_ctx_reserve': (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int64]),
+    'shp_ctx_reserve_query': (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int64, _c.POINTER(_c.c_int64),
+                                         _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int64)]),
     'shp_subset_recode': (_c.c_int, [_vp, _vp, _c.c_int64, _c.c_int64, _c.c_int64, _c.c_int64,
                                      _c.c_int64, _c.c_int64, _vp, _c.c_int, _c.c_uint32, _vp, _vp,
                                      _vp, _c.c_int64, _vp]),

@@ -1,6 +1,7 @@
 // api.hip -- the extern "C" boundary of libshepseg_hip.so (see include/shepseg_hip.h).
 // gfx950 only.  No CPU fallback: without a usable device every call fails.
 #include "common.h"
+#include <utility>
 #include "scan.h"
 #include "sort.h"
 #include "kmeans.h"
@@ -936,32 +937,66 @@ API int shp_spatialstats(shp_ctx *ctx, const uint32_t *seg, const void *band, in
 // a regrow synchronises and reallocates in the middle of a run): the tiled drivers call this once
 // per worker with the largest tile of the job, so that a pooled context does not keep growing
 // until it has met that tile itself.
+// the buffers one tile of npix pixels makes a worker context hold, and their sizes
+typedef std::vector<std::pair<DevBuf shp_ctx::*, size_t>> ReservePlan;
+static ReservePlan reserve_plan(int dtype, int nbands, size_t n)
+{
+    const size_t ns = n / 4 + 2;
+    const uint32_t maxbig = (uint32_t)(n / (MAX_CLUMP_SIZE + 2u) + 1u);
+    const size_t nblk = (n + SORT_TILE - 1) / SORT_TILE, nh = (size_t)256 * (nblk ? nblk : 1);
+    ReservePlan pl;
+    pl.push_back({&shp_ctx::img, (size_t)nbands * n * dtype_size(dtype)});
+    pl.push_back({&shp_ctx::clus, n * 2});
+    DevBuf shp_ctx::*perpix[] = {&shp_ctx::lab, &shp_ctx::aux, &shp_ctx::aux2, &shp_ctx::stack,
+                                 &shp_ctx::sort_k0, &shp_ctx::sort_k1, &shp_ctx::sort_v1, &shp_ctx::pix};
+    for (auto m : perpix) pl.push_back({m, n * 4});
+    pl.push_back({&shp_ctx::segsz, (n + 2) * 4});
+    pl.push_back({&shp_ctx::singles, (n + 2) * 4});
+    pl.push_back({&shp_ctx::bigbits, (n / 32 + 2) * 4});
+    pl.push_back({&shp_ctx::big, (size_t)maxbig * (sizeof(BigInfo) + 4) + 128});
+    pl.push_back({&shp_ctx::sort_hist, 2 * nh * 4});
+    pl.push_back({&shp_ctx::scan_tmp, scan_tmp_bytes(n > nh ? n : nh)});
+    DevBuf shp_ctx::*perseg[] = {&shp_ctx::origsz, &shp_ctx::chnext, &shp_ctx::chtail, &shp_ctx::mergeto,
+                                 &shp_ctx::tcount, &shp_ctx::tfill, &shp_ctx::tsorted, &shp_ctx::srclist,
+                                 &shp_ctx::tgtlist};
+    for (auto m : perseg) pl.push_back({m, ns * 4});
+    pl.push_back({&shp_ctx::off, ns * 4 + 16});
+    pl.push_back({&shp_ctx::toff, ns * 4 + 16});
+    pl.push_back({&shp_ctx::tlist, (ns + 32) * 4});
+    pl.push_back({&shp_ctx::ssum, ns * (size_t)nbands * 4});
+    pl.push_back({&shp_ctx::small, 8192});
+    return pl;
+}
+
 API int shp_ctx_reserve(shp_ctx *ctx, int dtype, int nbands, int64_t npix)
 {
     CHK(enter(ctx));
     if (dtype_size(dtype) == 0 || nbands < 1 || npix < 0 || npix >= 0x7fffffffll)
         SHP_FAIL(ctx, SHP_ERR_ARG, "bad argument");
-    const size_t n = (size_t)npix, ns = n / 4 + 2;
-    const uint32_t maxbig = (uint32_t)(n / (MAX_CLUMP_SIZE + 2u) + 1u);
-    const size_t nblk = (n + SORT_TILE - 1) / SORT_TILE, nh = (size_t)256 * (nblk ? nblk : 1);
-    CHK(buf_ensure(ctx, ctx->img, (size_t)nbands * n * dtype_size(dtype)));
-    CHK(buf_ensure(ctx, ctx->clus, n * 2));
-    DevBuf *perpix[] = {&ctx->lab, &ctx->aux, &ctx->aux2, &ctx->stack, &ctx->sort_k0, &ctx->sort_k1,
-                        &ctx->sort_v1, &ctx->pix};
-    for (DevBuf *b : perpix) CHK(buf_ensure(ctx, *b, n * 4));
-    CHK(buf_ensure(ctx, ctx->segsz, (n + 2) * 4));
-    CHK(buf_ensure(ctx, ctx->singles, (n + 2) * 4));
-    CHK(buf_ensure(ctx, ctx->bigbits, (n / 32 + 2) * 4));
-    CHK(buf_ensure(ctx, ctx->big, (size_t)maxbig * (sizeof(BigInfo) + 4) + 128));
-    CHK(buf_ensure(ctx, ctx->sort_hist, 2 * nh * 4));
-    CHK(buf_ensure(ctx, ctx->scan_tmp, scan_tmp_bytes(n > nh ? n : nh)));
-    DevBuf *perseg[] = {&ctx->origsz, &ctx->chnext, &ctx->chtail, &ctx->mergeto, &ctx->tcount,
-                        &ctx->tfill, &ctx->tsorted, &ctx->srclist, &ctx->tgtlist};
-    for (DevBuf *b : perseg) CHK(buf_ensure(ctx, *b, ns * 4));
-    CHK(buf_ensure(ctx, ctx->off, ns * 4 + 16));
-    CHK(buf_ensure(ctx, ctx->toff, ns * 4 + 16));
-    CHK(buf_ensure(ctx, ctx->tlist, (ns + 32) * 4));
-    CHK(buf_ensure(ctx, ctx->ssum, ns * (size_t)nbands * 4));
-    CHK(buf_ensure(ctx, ctx->small, 8192));
+    for (const auto &e : reserve_plan(dtype, nbands, (size_t)npix)) CHK(buf_ensure(ctx, ctx->*(e.first), e.second));
+    return 0;
+}
+
+// How much more device memory shp_ctx_reserve(dtype, nbands, npix) would allocate on this context
+// (what it already holds counts), and the device's free / total memory: the tiled driver sizes its
+// worker count with these instead of running out of memory on very large tiles.
+API int shp_ctx_reserve_query(shp_ctx *ctx, int dtype, int nbands, int64_t npix, int64_t *extra_bytes,
+                              int64_t *free_bytes, int64_t *total_bytes)
+{
+    CHK(enter(ctx));
+    if (dtype_size(dtype) == 0 || nbands < 1 || npix < 0 || npix >= 0x7fffffffll)
+        SHP_FAIL(ctx, SHP_ERR_ARG, "bad argument");
+    size_t extra = 0;
+    for (const auto &e : reserve_plan(dtype, nbands, (size_t)npix)) {
+        const size_t bytes = e.second ? e.second : 16;
+        if ((ctx->*(e.first)).cap < bytes) extra += bytes + bytes / 8 + 256;       // as buf_ensure grows
+    }
+    if (extra_bytes) *extra_bytes = (int64_t)extra;
+    if (free_bytes || total_bytes) {
+        size_t fr = 0, tot = 0;
+        HIPCHK(ctx, hipMemGetInfo(&fr, &tot));
+        if (free_bytes) *free_bytes = (int64_t)fr;
+        if (total_bytes) *total_bytes = (int64_t)tot;
+    }
     return 0;
 }

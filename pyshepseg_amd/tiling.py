@@ -544,6 +544,52 @@ class _ClusterMap(object):
             self.dptr = None
 
 
+def _workersThatFit(numWorkers, dtcode, nBands, maxTilePx, verbose=False):
+    """How many of `numWorkers` worker contexts can hold the workspace of the job's largest tile in
+    the device memory that is free now (the pooled contexts' present workspaces count: they are
+    reused in pool order).  At least 1: a single worker that does not fit fails loudly later."""
+    pool = list(reversed(_lib.pool_contexts()))          # pooled_ctx pops from the end
+    extra = ctypes.c_int64(0)
+    needs = []
+    fresh = None
+    for i in range(numWorkers):
+        if i < len(pool):
+            c = pool[i]
+            c.check(c._L.shp_ctx_reserve_query(c.handle, dtcode, nBands, maxTilePx, ctypes.byref(extra),
+                                               None, None))
+            needs.append(extra.value)
+        else:
+            if fresh is None:                            # what a context without a workspace needs
+                c = _lib.Context()
+                try:
+                    c.check(c._L.shp_ctx_reserve_query(c.handle, dtcode, nBands, maxTilePx,
+                                                       ctypes.byref(extra), None, None))
+                    fresh = extra.value
+                finally:
+                    c.close()
+            needs.append(fresh)
+    if not any(needs):
+        return numWorkers                                # every workspace is already large enough
+    free = ctypes.c_int64(0)
+    c = _lib.ctx()
+    c.check(c._L.shp_ctx_reserve_query(c.handle, dtcode, nBands, 0, None, ctypes.byref(free), None))
+    budget = int(free.value * 0.92)
+    fit = 0
+    for need in needs:
+        if need > budget:
+            break
+        budget -= need
+        fit += 1
+    fit = max(fit, 1)
+    if fit < numWorkers:
+        msg = ("pyshepseg_amd: %d of %d worker streams fit the free device memory for tiles of %.0f Mpx"
+               % (fit, numWorkers, maxTilePx / 1e6))
+        if verbose:
+            print(msg)
+        sys.stderr.write(msg + "\n")
+    return fit
+
+
 def startSegmentationWorkers(src, jobs, d_tiles, centres, msd, imgNullVal, fourConnected,
         minSegmentSize, numWorkers, timings, bands=None, yOrigin=0, maxConcurrentReads=20,
         verbose=False, stitchPrep=None):
@@ -655,8 +701,13 @@ def startSegmentationWorkers(src, jobs, d_tiles, centres, msd, imgNullVal, fourC
                 forceExit.set()
             j.done.set()
 
+    nThreads = max(1, numWorkers)
+    if onDevice and maxTilePx > 0:
+        nThreads = _workersThatFit(nThreads, dtcode, nBandsAll, maxTilePx, verbose)
+        if clusMap is not None:
+            clusMap.workersLeft = nThreads
     with timings.interval('startworkers'):
-        threads = [threading.Thread(target=worker, daemon=True) for _ in range(max(1, numWorkers))]
+        threads = [threading.Thread(target=worker, daemon=True) for _ in range(nThreads)]
         for t in threads:
             t.start()
     return threads, forceExit

@@ -250,3 +250,13 @@ def test_tiled_device_raster_other_pixel_types(dtype, nb, null, four, oracle):
     assert r.maxSegId == mx
     assert np.array_equal(r.segimg, want)
     assert np.array_equal(r.hist, hist)
+
+
+def test_worker_count_follows_free_memory(capfd):
+    """The tiled driver starts only as many worker contexts as fit the free device memory for the
+    job's largest tile (a 2-Gpx tile needs ~150 GB per context: at most one of 20 fits 288 GB)."""
+    from pyshepseg_amd import tiling, _lib
+    assert tiling._workersThatFit(6, _lib.SHP_DTYPES[np.dtype(np.uint16)], 6, 256 * 256) == 6
+    n = tiling._workersThatFit(20, _lib.SHP_DTYPES[np.dtype(np.uint16)], 6, 2000000000)
+    assert n == 1
+    assert 'worker streams fit' in capfd.readouterr().err
