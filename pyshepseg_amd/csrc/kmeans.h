@@ -332,7 +332,8 @@ __global__ __launch_bounds__(256) void k_fit_partial(const double *__restrict__ 
 {
     if (ctl->stop) return;
     __shared__ int32_t sl[FIT_CHUNK];
-    __shared__ double sx[FIT_LDS_DOUBLES];
+    extern __shared__ __attribute__((aligned(16))) double sx[];     // chunk * nb doubles (launch parameter):
+                                                                    // 12 KiB at 6 bands, so ten workgroups fit a CU
     __shared__ uint16_t order[SORTED ? FIT_CHUNK : 1];
     __shared__ uint16_t cntw[SORTED ? 4 * FIT_SORT_MAXK : 1];
     __shared__ uint16_t start[SORTED ? FIT_SORT_MAXK + 1 : 1];
@@ -642,10 +643,10 @@ static int run_kmeans_fit(shp_ctx *ctx, const void *xin_any, int xdtype, int64_t
             int32_t *dlab = (it & 1) ? dlabA : dlabB, *dlab_old = (it & 1) ? dlabB : dlabA;
             launch_fit_assign(ctx, g, dX, n, nb, dm2c, dcn, k, dlab, dlab_old, dctl); KCHK(ctx);
             if (sorted)
-                hipLaunchKernelGGL(k_fit_partial<true>, dim3(nchunks), dim3(256), 0, st, dX, n, nb, dlab, k,
+                hipLaunchKernelGGL(k_fit_partial<true>, dim3(nchunks), dim3(256), (size_t)chunk * nb * 8, st, dX, n, nb, dlab, k,
                                    dpart, dpc, chunk, dctl);
             else
-                hipLaunchKernelGGL(k_fit_partial<false>, dim3(nchunks), dim3(256), 0, st, dX, n, nb, dlab, k,
+                hipLaunchKernelGGL(k_fit_partial<false>, dim3(nchunks), dim3(256), (size_t)chunk * nb * 8, st, dX, n, nb, dlab, k,
                                    dpart, dpc, chunk, dctl);
             KCHK(ctx);
             hipLaunchKernelGGL(k_fit_reduce1, dim3(grid_for(kn, 256), ngroups), dim3(256), 0, st, dpart, dpc,
