@@ -487,7 +487,15 @@ __global__ __launch_bounds__(256) void k_fit_update(const double *__restrict__ p
     __syncthreads();
     if (threadIdx.x == 0) {
         double shift = 0.0;
-        for (int j = 0; j < k; j++) shift += w[j];
+        int j = 0;                                   // in index order; eight loads in flight
+        for (; j + 8 <= k; j += 8) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = w[j + u];
+#pragma unroll
+            for (int u = 0; u < 8; u++) shift += v[u];
+        }
+        for (; j < k; j++) shift += w[j];
         const uint32_t nd = ctl->ndiff;
         ctl->shift = shift;
         ctl->iters = it;
