@@ -148,24 +148,27 @@ struct EmptyFn {      // f(i) = 1 if id i (>= 1) is unused; f(0) = 0
 };
 
 // sizes of the surviving ids under their new numbers (the reference recomputes makeSegSize)
+// (boff: the block offsets of the scan that made `sub`, added here instead of by a launch)
 __global__ __launch_bounds__(256) void k_compact_sizes(const uint32_t *__restrict__ segsz,
                                                        const uint32_t *__restrict__ sub, uint32_t ns,
-                                                       uint32_t *__restrict__ out)
+                                                       uint32_t *__restrict__ out,
+                                                       const uint32_t *__restrict__ boff)
 {
     const uint32_t k = blockIdx.x * 256u + threadIdx.x;
     if (k >= ns) return;
     const uint32_t v = segsz[k];
     if (k == 0u) out[0] = v;
-    else if (v != 0u) out[k - sub[k]] = v;
+    else if (v != 0u) out[k - sub[k] - (boff ? boff[k / SCAN_ITEMS] : 0u)] = v;
 }
 
 __global__ __launch_bounds__(256) void k_relabel(uint32_t *__restrict__ seg,
-                                                 const uint32_t *__restrict__ sub, uint32_t n)
+                                                 const uint32_t *__restrict__ sub, uint32_t n,
+                                                 const uint32_t *__restrict__ boff)
 {
     const uint32_t p = blockIdx.x * 256u + threadIdx.x;
     if (p >= n) return;
     const uint32_t s = seg[p];
-    seg[p] = s - sub[s];
+    seg[p] = s - sub[s] - (boff ? boff[s / SCAN_ITEMS] : 0u);
 }
 
 // Compacts ids in d_seg given segsz[0..max_id].  *new_max_host = max_id - (#unused ids >= 1)
@@ -179,15 +182,16 @@ static int run_relabel(shp_ctx *ctx, uint32_t *d_seg, uint32_t n, const uint32_t
     uint32_t *sub = bp<uint32_t>(ctx->toff);
     uint32_t *tot = sub + ns;
     EmptyFn f{d_segsz};
-    CHK(scan_exclusive(ctx, f, ns, sub, tot, bp<uint32_t>(ctx->scan_tmp)));
+    const uint32_t *boff = nullptr;
+    CHK(scan_exclusive(ctx, f, ns, sub, tot, bp<uint32_t>(ctx->scan_tmp), &boff));
     if (n) {
         hipLaunchKernelGGL(k_relabel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, d_seg,
-                           sub, n);
+                           sub, n, boff);
         KCHK(ctx);
     }
     if (d_sizes_out) {
         hipLaunchKernelGGL(k_compact_sizes, dim3(grid_for(ns, 256)), dim3(256), 0, ctx->stream,
-                           d_segsz, sub, ns, d_sizes_out);
+                           d_segsz, sub, ns, d_sizes_out, boff);
         KCHK(ctx);
     }
     HIPCHK(ctx, hipMemcpyAsync(ctx->h_pinned, tot, 4, hipMemcpyDeviceToHost, ctx->stream));
