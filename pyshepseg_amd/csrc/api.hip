@@ -59,6 +59,13 @@ static int ctx_create(int device, int high_priority, shp_ctx **out)
         delete ctx;
         return SHP_ERR_HIP;
     }
+    if (hipMalloc((void **)&ctx->scan_ctr, 256) != hipSuccess || hipMemset(ctx->scan_ctr, 0, 256) != hipSuccess ||
+        hipDeviceSynchronize() != hipSuccess) {       // (the context's stream does not wait for the null stream)
+        hipHostFree(ctx->h_pinned);
+        hipStreamDestroy(ctx->stream);
+        delete ctx;
+        return SHP_ERR_NOMEM;
+    }
     for (int i = 0; i < 16; i++) hipEventCreate(&ctx->ev[i]);
     hipEventCreateWithFlags(&ctx->evfork, hipEventDisableTiming);
     hipEventCreateWithFlags(&ctx->evjoin, hipEventDisableTiming);
@@ -86,6 +93,7 @@ API void shp_ctx_destroy(shp_ctx *ctx)
             if (ctx->prof_ev[i][j]) hipEventDestroy(ctx->prof_ev[i][j]);
     if (ctx->h_pinned) hipHostFree(ctx->h_pinned);
     if (ctx->h_fit) hipHostFree(ctx->h_fit);
+    if (ctx->scan_ctr) hipFree(ctx->scan_ctr);
     if (ctx->stream2) { hipStreamSynchronize(ctx->stream2); hipStreamDestroy(ctx->stream2); }
     if (ctx->evfork) hipEventDestroy(ctx->evfork);
     if (ctx->evjoin) hipEventDestroy(ctx->evjoin);

@@ -52,6 +52,7 @@ struct shp_ctx {
     int prof_id[PROF_POOL] = {};
     int prof_used = 0;
     int dfs_fork = 1;   // run the two DFS size classes on two streams (single-tile latency)
+    uint32_t *scan_ctr = nullptr;   // device word, zero between scans: arrival counter of k_scan_local
     int gated = 0;      // this call takes part in the fill gate (tiled driver's worker calls)
     bool fill_held = false;
 };

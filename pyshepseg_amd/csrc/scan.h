@@ -9,18 +9,17 @@
 #define SCAN_ITEMS (SCAN_SUB * SCAN_STEPS)   // items per workgroup: two levels cover 67 M items, so the
                                              // scans of a tile need 2 + 1 launches instead of 3 + 2
 
-// block-local exclusive scan of SCAN_ITEMS items in SCAN_STEPS coalesced sub-tiles with a running
-// carry; bsum[block] = the block's total; total_out (optional, single-block grids) = the total
+// block-local exclusive scan of SCAN_ITEMS items (those of block `blk`) in SCAN_STEPS coalesced
+// sub-tiles with a running carry; returns the block's total (in every thread)
 template <class F>
-__global__ __launch_bounds__(256) void k_scan_local(F f, uint32_t n, uint32_t *__restrict__ out,
-                                                    uint32_t *__restrict__ bsum, uint32_t *total_out)
+__device__ __forceinline__ uint32_t scan_block(F f, uint32_t n, uint32_t *__restrict__ out, uint32_t blk)
 {
     __shared__ uint32_t wsum[4];
     const unsigned lane = lane_id(), w = threadIdx.x >> 6;
     uint32_t carry = 0;
     for (uint32_t st = 0; st < SCAN_STEPS; st++) {
-        const uint32_t base = blockIdx.x * SCAN_ITEMS + st * SCAN_SUB + threadIdx.x * 4u;
-        if (st * SCAN_SUB + blockIdx.x * SCAN_ITEMS >= n) break;          // uniform: nothing left
+        const uint32_t base = blk * SCAN_ITEMS + st * SCAN_SUB + threadIdx.x * 4u;
+        if (st * SCAN_SUB + blk * SCAN_ITEMS >= n) break;                 // uniform: nothing left
         uint32_t v[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) v[i] = (base + i < n) ? f(base + i) : 0u;
@@ -44,9 +43,49 @@ __global__ __launch_bounds__(256) void k_scan_local(F f, uint32_t n, uint32_t *_
         }
         carry += wsum[0] + wsum[1] + wsum[2] + wsum[3];
     }
+    return carry;
+}
+
+struct AgentArrFn {     // block totals written by other workgroups of the same launch
+    const uint32_t *a;
+    __device__ __forceinline__ uint32_t operator()(uint32_t i) const { return L2LOAD(&a[i]); }
+};
+
+// One launch for up to SCAN_ITEMS workgroups (67 M items): every workgroup scans its own items and
+// publishes its total (agent-scope store, drained before it takes a ticket from `ctr`); the workgroup
+// that takes the last ticket -- every total is in memory by then, and nobody waits for anybody --
+// scans the totals into boff[], writes the grand total and leaves `ctr` at zero for the next scan.
+// bsum[block] = the block's total; total_out (optional) = the sum of all.
+template <class F>
+__global__ __launch_bounds__(256) void k_scan_local(F f, uint32_t n, uint32_t *__restrict__ out,
+                                                    uint32_t *bsum, uint32_t *total_out,
+                                                    uint32_t *boff, uint32_t *ctr)
+{
+    __shared__ uint32_t s_last;
+    const uint32_t carry = scan_block(f, n, out, blockIdx.x);
+    const uint32_t nb = gridDim.x;
+    if (nb == 1u) {
+        if (threadIdx.x == 0) { bsum[0] = carry; if (total_out) *total_out = carry; }
+        return;
+    }
     if (threadIdx.x == 0) {
-        bsum[blockIdx.x] = carry;
-        if (total_out && gridDim.x == 1) *total_out = carry;
+        uint32_t last = 0;
+        if (boff) {
+            __hip_atomic_store(&bsum[blockIdx.x], carry, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            last = (atomicAdd(ctr, 1u) == nb - 1u) ? 1u : 0u;
+        } else {
+            bsum[blockIdx.x] = carry;           // the totals are scanned by a second launch
+        }
+        s_last = last;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    AgentArrFn g{bsum};
+    const uint32_t tot = scan_block(g, nb, boff, 0u);
+    if (threadIdx.x == 0) {
+        if (total_out) *total_out = tot;
+        __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -92,12 +131,17 @@ static int scan_exclusive(shp_ctx *ctx, F f, uint32_t n, uint32_t *out, uint32_t
     const uint32_t nb = (n + SCAN_ITEMS - 1) / SCAN_ITEMS;
     uint32_t *bsum = tmp;
     uint32_t *boff = tmp + nb + 1;
+    static const int one_env = getenv("SHEPSEG_SCAN_ONE") ? atoi(getenv("SHEPSEG_SCAN_ONE")) : 1;
+    const bool one_launch = one_env && nb > 1 && nb <= SCAN_ITEMS;    // the last workgroup scans the totals
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_local<F>), dim3(nb), dim3(256), 0, ctx->stream, f, n,
-                       out, bsum, nb == 1 ? total_dev : (uint32_t *)nullptr);
+                       out, bsum, (nb == 1 || one_launch) ? total_dev : (uint32_t *)nullptr,
+                       one_launch ? boff : (uint32_t *)nullptr, ctx->scan_ctr);
     KCHK(ctx);
     if (nb == 1) return 0;                   // the kernel wrote the total itself
-    ArrFn g{bsum};
-    CHK(scan_exclusive(ctx, g, nb, boff, total_dev, tmp + 2 * (size_t)nb + 2));
+    if (!one_launch) {
+        ArrFn g{bsum};
+        CHK(scan_exclusive(ctx, g, nb, boff, total_dev, tmp + 2 * (size_t)nb + 2));
+    }
     if (lazy_boff) { *lazy_boff = boff; return 0; }
     hipLaunchKernelGGL(k_scan_add, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, out, n, boff);
     KCHK(ctx);
