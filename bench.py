@@ -85,11 +85,43 @@ def cpu_baseline(ras, args, centres, msd):
                       % (w, w, len(tiles), args.tile, args.overlap, dt)}
 
 
+def spawn_ranks(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes
+    (this process has not touched the GPU and never does), relay rank 0's JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+           '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1', '--master-port', str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    p = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in p.stdout.splitlines():
+        if ln.startswith('{') and '"metric"' in ln:
+            line = ln
+        else:
+            sys.stderr.write(ln + '\n')
+    if p.returncode != 0 or line is None:
+        sys.stderr.write('bench.py: the %d-rank run failed (exit code %d)\n' % (args.gpus, p.returncode))
+        sys.exit(p.returncode or 1)
+    if json.loads(line).get('n_gpus') != args.gpus:
+        sys.stderr.write('bench.py: the ranks report n_gpus != %d\n' % args.gpus)
+        sys.exit(1)
+    print(line)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        return spawn_ranks(args)
     rank = int(os.environ.get('RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus and not (args.gpus == 1 and world == 1):
+        sys.stderr.write('bench.py: --gpus %d but WORLD_SIZE=%d\n' % (args.gpus, world))
+        sys.exit(2)
     os.environ.setdefault('SHEPSEG_DEVICE', str(local_rank))
     dist = None
     force_dist = os.environ.get('SHEPSEG_FORCE_DIST', '0') == '1' and 'RANK' in os.environ

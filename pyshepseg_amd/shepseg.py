@@ -226,17 +226,15 @@ def diagonalClusterCentres(xSample, numClusters, _minmax=None):
     """Initial centres evenly spaced along the diagonal of the data's bounding box, cast to
     the sample's integer dtype (reference shepseg.py:364-397).  _minmax: per-band (min, max)
     of xSample when the caller already has them."""
-    (numPoints, numBands) = xSample.shape
     if _minmax is not None:
         (bandMin, bandMax) = _minmax
     else:
         bandMin = xSample.min(axis=0)
         bandMax = xSample.max(axis=0)
-    centres = numpy.empty((numClusters, numBands), dtype=xSample.dtype)
+    # centre i = min + (i + 1) * (max - min) / (k + 1) per band, truncated to the sample's dtype
     step = (bandMax - bandMin) / (numClusters + 1)
-    for i in range(numClusters):
-        centres[i] = bandMin + (i + 1) * step
-    return centres
+    ramp = numpy.arange(1, numClusters + 1, dtype=numpy.float64)
+    return (bandMin + numpy.multiply.outer(ramp, step)).astype(xSample.dtype)
 
 
 def _percentile_linear_f64(a32, q):

@@ -276,41 +276,31 @@ class TileInfo(object):
         return self.tiles[(col, row)]
 
 
+def _axisTiles(n, tileSize, step):
+    """(start, size) of the tiles along one axis of n pixels: a tile starts every `step` pixels;
+    one that could not be followed by another whole tile (start + 2 * tileSize > n) runs to the
+    image edge and is the last one."""
+    if n <= 0:
+        return []
+    nfull = 0 if n < 2 * tileSize else (n - 2 * tileSize) // step + 1
+    return [(i * step, tileSize) for i in range(nfull)] + [(nfull * step, n - nfull * step)]
+
+
 def getTilesForFile(ds, tileSize, overlapSize):
-    """TileInfo for a raster (anything with RasterXSize / RasterYSize).  Tile origins every
-    tileSize-overlapSize; a tile grows to the image edge when another whole tile would not fit
-    (reference tiling.py:376-443)."""
+    """TileInfo for a raster (anything with RasterXSize / RasterYSize): the reference's grid
+    (tiling.py:376-443) in closed form, axis by axis."""
     tileSize = int(tileSize)
-    overlapSize = int(overlapSize)
+    step = tileSize - int(overlapSize)
+    if step <= 0:
+        raise PyShepSegTilingError("overlapSize must be smaller than tileSize")
+    xs = _axisTiles(ds.RasterXSize, tileSize, step)
+    ys = _axisTiles(ds.RasterYSize, tileSize, step)
     tileInfo = TileInfo()
-    yDone = False
-    ypos = 0
-    xtile = 0
-    ytile = 0
-    while not yDone:
-        xDone = False
-        xpos = 0
-        xtile = 0
-        ysize = tileSize
-        if (ypos + ysize * 2) > ds.RasterYSize:
-            ysize = ds.RasterYSize - ypos
-            yDone = True
-            if ysize == 0:
-                break
-        while not xDone:
-            xsize = tileSize
-            if (xpos + xsize * 2) > ds.RasterXSize:
-                xsize = ds.RasterXSize - xpos
-                xDone = True
-                if xsize == 0:
-                    break
-            tileInfo.addTile(xpos, ypos, xsize, ysize, xtile, ytile)
-            xpos += (tileSize - overlapSize)
-            xtile += 1
-        ypos += (tileSize - overlapSize)
-        ytile += 1
-    tileInfo.ncols = xtile
-    tileInfo.nrows = ytile
+    for (row, (ypos, ysize)) in enumerate(ys):
+        for (col, (xpos, xsize)) in enumerate(xs):
+            tileInfo.addTile(xpos, ypos, xsize, ysize, col, row)
+    tileInfo.nrows = len(ys)
+    tileInfo.ncols = len(xs) if ys else 0
     return tileInfo
 
 
@@ -328,10 +318,19 @@ def _subsample_indices(n, skip, tileSize=TILESIZE):
 
 
 _sampleBuf = {}
+_sampleLock = threading.Lock()      # held from the read-back to the end of the fit that consumes it
 
 
 def readSubsampledImage(src, bandNumbers, subsampleProp):
     """Sub-sampled copy of the selected bands: (nBands, nRowsSub, nColsSub)."""
+    with _sampleLock:
+        out = _readSubsampledImage(src, bandNumbers, subsampleProp)
+        return out.copy() if isinstance(src, DeviceRaster) else out
+
+
+def _readSubsampledImage(src, bandNumbers, subsampleProp):
+    """The same without the copy: for a DeviceRaster the result is a buffer kept between calls
+    (the caller holds _sampleLock until it has consumed it)."""
     skip = int(round(1. / subsampleProp))
     (nb, nlines, npix) = src.shape
     ry = _subsample_indices(nlines, skip)
@@ -381,9 +380,10 @@ def fitSpectralClustersWholeFile(inDs, bandNumbers, numClusters=60, subsamplePcn
             imgNullVal = inDs.bandNull(bandNumbers)
         else:
             imgNullVal = inDs.nullVal
-    img = readSubsampledImage(inDs, bandNumbers, subsampleProp)
-    kmeansObj = shepseg.fitSpectralClusters(img, numClusters=numClusters, subsamplePcnt=100,
-                                            imgNullVal=imgNullVal, fixedKMeansInit=fixedKMeansInit)
+    with _sampleLock:
+        img = _readSubsampledImage(inDs, bandNumbers, subsampleProp)
+        kmeansObj = shepseg.fitSpectralClusters(img, numClusters=numClusters, subsamplePcnt=100,
+                                                imgNullVal=imgNullVal, fixedKMeansInit=fixedKMeansInit)
     return (kmeansObj, subsamplePcnt, imgNullVal)
 
 
@@ -406,14 +406,15 @@ class _MetaArena(object):
         self.extra = []
         self.lock = threading.Lock()
 
-    def alloc(self, nseg):
+    def alloc(self, nseg, c=None):
+        """c: the calling thread's own context (contexts are not shared between threads)."""
         need = (16 * int(nseg) + 255) & ~255
         with self.lock:
             if self.used + need <= self.nbytes:
                 p = self.base.value + self.used
                 self.used += need
                 return p
-        d = _devAlloc(self.c, need)
+        d = _devAlloc(c if c is not None else self.c, need)
         with self.lock:
             self.extra.append((d, need))
         return d.value
@@ -422,6 +423,13 @@ class _MetaArena(object):
         _devRelease(self.c, self.base, self.nbytes)
         for (d, n) in self.extra:
             _devRelease(self.c, d, n)
+        self.extra = []
+
+    def free(self):
+        """After a failed run: hipFree instead of returning the blocks to the cache."""
+        for (d, _n) in [(self.base, self.nbytes)] + self.extra:
+            if d is not None and d.value:
+                self.c._L.shp_dev_free(self.c.handle, d)
         self.extra = []
 
 
@@ -689,7 +697,7 @@ def startSegmentationWorkers(src, jobs, d_tiles, centres, msd, imgNullVal, fourC
                     (tileInfo, overlapSize, arena, simple) = stitchPrep
                     (top, bottom, left, right, _x, _y) = trimmedWindow(
                         tileInfo, j.col, j.row, j.xpos, j.ypos, j.xsize, j.ysize, overlapSize)
-                    j.meta = arena.alloc(mx.value + 1)
+                    j.meta = arena.alloc(mx.value + 1, c)
                     c.check(L.shp_stitch_prepare_dev(
                         c.handle, dseg, j.ysize, j.xsize, overlapSize,
                         int(j.row > 0 and not simple), int(j.col > 0 and not simple), mx.value,
@@ -716,13 +724,21 @@ def startSegmentationWorkers(src, jobs, d_tiles, centres, msd, imgNullVal, fourC
 def waitForTile(j, jobs, threads, forceExit, timeout):
     """Block until tile job j is segmented; raise like the reference on failure / timeout
     (tiling.py:1045-1053, :918-928)."""
+    t0 = time.time()
+    timedOut = False
     while not j.done.wait(timeout=0.2):         # short slices: a failed worker is noticed at once
         if forceExit.is_set():
             break
         if not any(t.is_alive() for t in threads):
             break
+        if timeout is not None and time.time() - t0 > timeout:
+            timedOut = True
+            break
     if j.error is not None or not j.done.is_set():
         forceExit.set()
+        if timedOut and j.error is None:
+            raise PyShepSegTilingError("Timeout waiting for tile ({}, {}) after {} seconds".format(
+                j.col, j.row, timeout))
         err = j.error
         for jj in jobs:
             err = err or jj.error
@@ -790,6 +806,8 @@ def doTiledShepherdSegmentation(infile, outfile, tileSize=DFLT_TILESIZE,
         d_strips = _devAlloc(main, nbStrips)
         arena = _MetaArena(main, 16 * (total // 8 + 1024))
         forceExit = None
+        threads = []
+        ok = False
         try:
             numWorkers = 1
             if concurrencyCfg.concurrencyType != CONC_NONE:
@@ -860,15 +878,31 @@ def doTiledShepherdSegmentation(infile, outfile, tileSize=DFLT_TILESIZE,
                 else:
                     _writeGdal(outfile, segimg, hist, infile, outputDriver, creationOptions,
                                writeHistogram)
+            ok = True
         finally:
+            # no buffer goes back to the cache (or to hipFree) while a worker may still write to
+            # it: workers only test forceExit between tiles, so wait for them and for the chain
             if forceExit is not None:
                 forceExit.set()
+            stuck = False
+            for t in threads:
+                t.join(timeout=None if ok else 120.0)
+                stuck = stuck or t.is_alive()
             L.shp_sync(main.handle)
-            _devRelease(main, d_tiles, nbTiles)
-            _devRelease(main, d_out, nbOut)
-            _devRelease(main, d_scal, 256)
-            _devRelease(main, d_strips, nbStrips)
-            arena.release()
+            if stuck:
+                sys.stderr.write("pyshepseg_amd: a worker did not stop after a failure; its device "
+                                 "buffers are leaked rather than reused\n")
+            elif ok:
+                _devRelease(main, d_tiles, nbTiles)
+                _devRelease(main, d_out, nbOut)
+                _devRelease(main, d_scal, 256)
+                _devRelease(main, d_strips, nbStrips)
+                arena.release()
+            else:           # failed run: free, do not recycle
+                for (p_, n_) in ((d_tiles, nbTiles), (d_out, nbOut), (d_scal, 256), (d_strips, nbStrips)):
+                    if p_ is not None and p_.value:
+                        L.shp_dev_free(main.handle, p_)
+                arena.free()
 
     result.maxSegId = maxSegId
     result.numTileRows = tileInfo.nrows
