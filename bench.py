@@ -1,17 +1,24 @@
 #!/usr/bin/env python
 """Headline benchmark: Mpixels/s segmented on synthetic 6-band 40000x40000 tiled imagery.
 
-    python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...)
+    python bench.py --gpus N --steps K --warmup W [--workload c3|c4|c5]
+    (N > 1 without a launcher: bench.py starts the N ranks itself; under
+     `python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...` it is one rank)
 
-A step = one complete tiled Shepherd segmentation of the image (global k-means subsample +
-Lloyd fit, every tile through assign -> clump -> elimination, cross-tile stitch, histogram)
-with the image already resident in HBM (synthimg v1 generated on the device) and the
-stitched labels left in HBM.  Workload = BASELINE.json configs[2] (C3): tile 4096 / overlap
-1024, k = 60, minSegmentSize = 50, fixed k-means init.  value = image pixels / step time.
+Workloads (BASELINE.json configs):
+  c3 (default, the config the metric is quoted on): a step = one complete tiled Shepherd
+      segmentation of the 40000^2 x 6 image (global k-means subsample + Lloyd fit, every tile
+      through assign -> clump -> elimination, cross-tile stitch, histogram) with the image already
+      resident in HBM (synthimg v1 generated on the device) and the stitched labels left in HBM;
+      tile 4096 / overlap 1024, k = 60, minSegmentSize = 50, fixed k-means init.
+  c4: the same with the 10-band image synthimg(13, 10, ...).
+  c5: a step = per-segment statistics (mean, stddev, median, pixcount) of one uint16 band over a
+      1.6 Gpx label raster of 50 M segments (4 x 8-pixel blocks), rasters resident in HBM, the
+      result columns copied to the host.
+value = image pixels / step time.
 
-torch is used only for process-group plumbing (barrier, max over ranks); the product path is
-pyshepseg_amd -> ctypes -> libshepseg_hip.so.
+torch is used only for process-group plumbing when N > 1 (barrier, max over ranks); the product
+path is pyshepseg_amd -> ctypes -> libshepseg_hip.so.
 """
 import argparse
 import ctypes
@@ -35,15 +42,20 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=2)
     ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--workload', choices=('c3', 'c4', 'c5'), default='c3')
     ap.add_argument('--size', type=int, default=40000, help='image rows = cols')
-    ap.add_argument('--bands', type=int, default=6)
+    ap.add_argument('--bands', type=int, default=None, help='default: 6 (c3), 10 (c4), 1 (c5)')
     ap.add_argument('--tile', type=int, default=4096)
     ap.add_argument('--overlap', type=int, default=1024)
     ap.add_argument('--workers', type=int, default=int(os.environ.get('SHEPSEG_WORKERS', '20')))
     ap.add_argument('--simple-recode', type=int, default=0, help='diagnostic: simpleTileRecode')
-    ap.add_argument('--cpu-sample', type=int, default=9216,
+    ap.add_argument('--cpu-sample', type=int, default=14336,
                     help='window edge of the cpu_baseline sample (0 = skip)')
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.bands is None:
+        args.bands = {'c3': 6, 'c4': 10, 'c5': 1}[args.workload]
+    args.seed = 13 if args.workload == 'c4' else 11
+    return args
 
 
 def prof_totals(contexts):
@@ -59,30 +71,57 @@ def prof_totals(contexts):
     return tot
 
 
+def host_window(ras, w):
+    """Top-left w x w window of every band of a DeviceRaster as a host array."""
+    from pyshepseg_amd import _lib
+    idx = np.arange(w, dtype=np.uint32)
+    img = np.empty((ras.shape[0], w, w), dtype=ras.dtype)
+    c = _lib.ctx()
+    c.check(c._L.shp_dev_subsample(c.handle, ctypes.c_void_p(ras.ptr), _lib.SHP_DTYPES[ras.dtype],
+                                   ras.shape[0], ras.shape[1], ras.shape[2], _lib.ptr(idx), w,
+                                   _lib.ptr(idx), w, _lib.ptr(img)))
+    return img
+
+
 def cpu_baseline(ras, args, centres, msd):
     """The C oracle (a port of the reference, oracle/shepseg_oracle.c) timed on this box's host
-    cores, single thread, on a bounded window of the same image with the same tiling."""
+    cores on a bounded window of the same image with the same tiling: the tiles of the window one
+    per thread over all the cores this process may use (ctypes releases the GIL; the reference
+    itself farms tiles to workers the same way, tiling.py:1560-1600), then the stitch; one tile
+    alone gives the single-thread rate."""
+    from concurrent.futures import ThreadPoolExecutor
     from oracle import oracle
-    from pyshepseg_amd import _lib
     oracle.build()
     w = min(args.cpu_sample, args.size)
-    idx = np.arange(w, dtype=np.uint32)
-    img = np.empty((args.bands, w, w), dtype=np.uint16)
-    c = _lib.ctx()
-    c.check(c._L.shp_dev_subsample(c.handle, ctypes.c_void_p(ras.ptr), 2, args.bands, ras.shape[1],
-                                   ras.shape[2], _lib.ptr(idx), w, _lib.ptr(idx), w, _lib.ptr(img)))
-    t0 = time.time()
+    img = host_window(ras, w)
     tiles, ntc, ntr = oracle.get_tiles(w, w, args.tile, args.overlap)
-    local = {}
-    for (tc, tr), (x, y, xs, ys) in tiles.items():
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    nthreads = max(1, min(cores, len(tiles)))
+
+    def one(key):
+        (x, y, xs, ys) = tiles[key]
         sub = np.ascontiguousarray(img[:, y:y + ys, x:x + xs])
-        local[(tc, tr)] = oracle.segment_tile(sub, centres, 50, msd, None, True)['segimg']
+        return key, oracle.segment_tile(sub, centres, 50, msd, None, True)['segimg']
+
+    t0 = time.time()
+    one((0, 0))
+    t_one = time.time() - t0
+    (_x, _y, xs0, ys0) = tiles[(0, 0)]
+    t0 = time.time()
+    order = sorted(tiles, key=lambda k: -(tiles[k][2] * tiles[k][3]))
+    with ThreadPoolExecutor(nthreads) as ex:
+        local = dict(ex.map(one, order))
     oracle.stitch_tiles(local, tiles, ntc, ntr, w, w, args.overlap)
     dt = time.time() - t0
-    return {"value": round(w * w / dt / 1e6, 3), "unit": "Mpixels/s", "cores": 1, "kind": "port",
-            "sample": "top-left %dx%d window of the same synthetic image, %d tiles (tile %d / "
-                      "overlap %d) + stitch, %.1f s of single-thread C oracle"
-                      % (w, w, len(tiles), args.tile, args.overlap, dt)}
+    return {"value": round(w * w / dt / 1e6, 3), "unit": "Mpixels/s", "cores": nthreads, "kind": "port",
+            "single_thread_value": round(xs0 * ys0 / t_one / 1e6 / 1.64, 3),
+            "sample": "top-left %dx%d window of the same synthetic image, %d tiles (tile %d / overlap %d) "
+                      "one per thread on %d threads + stitch: %.1f s of C oracle; single_thread_value = one "
+                      "%dx%d tile alone (%.1f s) per output pixel (tiled runs process 1.64 x the image)"
+                      % (w, w, len(tiles), args.tile, args.overlap, nthreads, dt, xs0, ys0, t_one)}
 
 
 def spawn_ranks(args):
@@ -112,31 +151,23 @@ def spawn_ranks(args):
     print(line)
 
 
-def main():
-    args = parse()
-    if args.gpus > 1 and 'RANK' not in os.environ:
-        return spawn_ranks(args)
-    rank = int(os.environ.get('RANK', '0'))
-    world = int(os.environ.get('WORLD_SIZE', '1'))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
-    if world != args.gpus and not (args.gpus == 1 and world == 1):
-        sys.stderr.write('bench.py: --gpus %d but WORLD_SIZE=%d\n' % (args.gpus, world))
-        sys.exit(2)
-    os.environ.setdefault('SHEPSEG_DEVICE', str(local_rank))
-    dist = None
-    force_dist = os.environ.get('SHEPSEG_FORCE_DIST', '0') == '1' and 'RANK' in os.environ
-    if world > 1 or force_dist:
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend='nccl')
+def pmc_traffic(kernel_name, scale=1.0):
+    """HBM bytes per launch of a kernel from the committed PMC passes (rocprofv3 cannot run inside
+    this process): FETCH_SIZE + WRITE_SIZE, see profiles/README.md."""
+    for fn in ('r02_pmc_summary.json', 'r01_n_pmc_summary.json'):
+        try:
+            pmc = json.load(open(os.path.join(ROOT, 'profiles', fn)))['kernels']
+            k = pmc.get(kernel_name)
+            if k:
+                return int((k['FETCH_SIZE_KB_per_launch'] + k['WRITE_SIZE_KB_per_launch']) * 1024 * scale), fn
+        except Exception:
+            pass
+    return None, None
 
+
+def bench_segmentation(args):
     from pyshepseg_amd import tiling, _lib
-    if world > 1 or force_dist:
-        from pyshepseg_amd import distributed
-        return distributed.bench_main(args, rank, world, local_rank, dist)
-
-    ras = tiling.DeviceRaster.synth(11, args.bands, args.size, args.size)
+    ras = tiling.DeviceRaster.synth(args.seed, args.bands, args.size, args.size)
     cfg = tiling.SegmentationConcurrencyConfig(concurrencyType=tiling.CONC_THREADS,
                                                numWorkers=args.workers)
 
@@ -166,7 +197,7 @@ def main():
     npix = args.size * args.size
     value = npix / dt / 1e6
     # dominant kernel by accumulated device time
-    names = {0: 'k_assign (cluster-map blocks)', 1: 'ccl (k_ccl_local+k_ccl_border+k_ccl_flatten)', 2: 'k_dfs_split',
+    names = {0: 'k_assign (cluster-map blocks)', 1: 'ccl (k_ccl_local+k_ccl_border+k_ccl_flatten)', 2: 'k_dfs_pool',
              3: 'CSR build (k_run_tile_*+k_sort_hist+k_sort_scatter+k_run_expand)', 4: 'k_spectra_small+k_spectra_big',
              5: 'k_small_loop', 7: 'seed scan + k_clump_final'}
     dom = max((i for i in names), key=lambda i: prof.get(i, (0, 0))[0])
@@ -178,32 +209,23 @@ def main():
     bpp = {0: 2 * args.bands + 2, 1: 6, 2: 6, 7: 6}.get(dom, 2 * args.bands + 4)
     avg_s = (ms / max(cnt, 1)) / 1e3
     achieved = (bpp * tile_px / avg_s / 1e9) if avg_s > 0 else 0.0
-    # HBM traffic per launch of that kernel from the committed PMC passes (rocprofv3 cannot run
-    # inside this process): FETCH_SIZE + WRITE_SIZE in KB, see profiles/r01_n_pmc_summary.json
-    traffic = None
-    try:
-        pmc = json.load(open(os.path.join(ROOT, 'profiles', 'r01_n_pmc_summary.json')))['kernels']
-        k = pmc.get(names[dom].split(' ')[0])
-        if k and args.size == 40000:
-            traffic = int((k['FETCH_SIZE_KB_per_launch'] + k['WRITE_SIZE_KB_per_launch']) * 1024)
-            if dom == 2:          # the timed region holds a tile's k_dfs_split launches (1 or 2)
-                traffic = int(traffic * k['launches'] / 144.0)
-    except Exception:
-        traffic = None
+    traffic, traffic_src = (pmc_traffic(names[dom].split(' ')[0]) if args.size == 40000 else (None, None))
+    wl = args.workload.upper()
     out = {
-        "metric": "Mpixels/sec segmented, 6-band 40k x 40k tiled",
+        "metric": "Mpixels/sec segmented, %d-band 40k x 40k tiled" % args.bands,
         "value": round(value, 3), "unit": "Mpixels/s", "n_gpus": 1, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 2), "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "u16", "data": "synthetic",
-        "config": {"workload": "C3: tiled %dx%d, %d-band uint16 synthimg v1, tileSize=%d, "
+        "config": {"workload": "%s: tiled %dx%d, %d-band uint16 synthimg v1 (seed %d), tileSize=%d, "
                                "overlap=%d, k=60, minSegmentSize=50, fixedKMeansInit, image + "
-                               "labels resident in HBM" % (args.size, args.size, args.bands,
+                               "labels resident in HBM" % (wl, args.size, args.size, args.bands, args.seed,
                                                            args.tile, args.overlap),
                    "tiles": len(ti.tiles), "worker_streams": args.workers,
                    "max_seg_id": int(r.maxSegId)},
         "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 3),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                     "traffic_source": traffic_src,
                      "avg_launch_ms": round(ms / max(cnt, 1), 3), "launches": int(cnt),
                      "bytes_per_launch": int(bpp * tile_px),
                      "whole_path_frac_of_hbm_roofline":
@@ -219,6 +241,106 @@ def main():
                                            float(r.maxSpectralDiff))
     print(json.dumps(out))
     ras.free()
+
+
+def bench_stats(args):
+    """C5: tilingstats on a resident label raster + band."""
+    from pyshepseg_amd import tiling, tilingstats, _lib
+    N, BH, BW = args.size, 4, 8
+    c = _lib.ctx()
+    ras = tiling.DeviceRaster.synth(args.seed, 1, N, N)
+    d_seg = ctypes.c_void_p()
+    c.check(c._L.shp_dev_alloc(c.handle, N * N * 4, ctypes.byref(d_seg)))
+    S = ctypes.c_uint32(0)
+    c.check(c._L.shp_dev_block_labels(c.handle, N, N, BH, BW, d_seg, ctypes.byref(S)))
+    S = S.value
+    sel = [('mean', 'mean'), ('sd', 'stddev'), ('med', 'median'), ('n', 'pixcount')]
+    fast, ni, nf = tilingstats.makeFastStatsSelection(list(range(len(sel))), sel)
+    ic = np.zeros((ni, S + 1), dtype=np.int64)
+    fc = np.zeros((nf, S + 1), dtype=np.float32)
+
+    def step():
+        c.check(c._L.shp_segstats_dev(c.handle, d_seg, ctypes.c_void_p(ras.ptr), 2, N * N, S, 0, 0,
+                                      _lib.ptr(fast), len(sel), -9999, _lib.ptr(ic), _lib.ptr(fc)))
+
+    for _ in range(args.warmup):
+        step()
+    prof_totals([c])
+    c.check(c._L.shp_sync(c.handle))
+    t0 = time.time()
+    for _ in range(args.steps):
+        step()
+    c.check(c._L.shp_sync(c.handle))
+    dt = (time.time() - t0) / max(args.steps, 1)
+    ms, cnt = prof_totals([c]).get(8, (0.0, 0))
+    assert int(ic[fast[3, 3]].sum()) == N * N
+    npix = N * N
+    alg = 6 * npix + 4 * len(sel) * (S + 1)            # SURVEY 8(d): 6 B/px + 4 * nCols B/segment
+    avg_s = (ms / max(cnt, 1)) / 1e3
+    achieved = alg / avg_s / 1e9 if avg_s > 0 else 0.0
+    out = {
+        "metric": "Mpixels/sec, tilingstats per-segment mean/stddev/median/pixcount",
+        "value": round(npix / dt / 1e6, 3), "unit": "Mpixels/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 2), "higher_is_better": True,
+        "scaling": "strong", "vs_baseline": None, "dtype": "u16", "data": "synthetic",
+        "config": {"workload": "C5: %dx%d label raster of %d x %d-pixel blocks (%d segments) + one uint16 "
+                               "synthimg v1 band resident in HBM; 4 result columns (%.2f GB) copied to "
+                               "pageable host arrays inside the step" % (
+                                   N, N, BH, BW, S, (ni * 8 + nf * 4) * (S + 1) / 1e9),
+                   "segments": S, "segments_per_s": round(S / dt, 0)},
+        "roofline": {"bound": "hbm", "kernel": "segstats device pipeline (k_stats_keys + 6 radix passes "
+                                               "+ k_run_count + k_seg_stats)",
+                     "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
+                     "avg_launch_ms": round(ms / max(cnt, 1), 3), "launches": int(cnt),
+                     "bytes_per_launch": int(alg)},
+    }
+    if args.cpu_sample > 0:
+        from oracle import oracle
+        oracle.build()
+        w = min(4096, N)
+        band = host_window(ras, w)[0]
+        lab = (((np.arange(w, dtype=np.uint32) // BH)[:, None] * np.uint32((w + BW - 1) // BW)) +
+               (np.arange(w, dtype=np.uint32) // BW)[None, :] + np.uint32(1))
+        t0 = time.time()
+        oracle.segstats(np.ascontiguousarray(lab), band, sel)
+        t = time.time() - t0
+        out["cpu_baseline"] = {"value": round(w * w / t / 1e6, 3), "unit": "Mpixels/s", "cores": 1,
+                               "kind": "port",
+                               "sample": "top-left %dx%d window (%d segments), %.1f s of single-thread C "
+                                         "oracle (orc_segstats)" % (w, w, int(lab.max()), t)}
+    print(json.dumps(out))
+    c.check(c._L.shp_dev_free(c.handle, d_seg))
+    ras.free()
+
+
+def main():
+    args = parse()
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        return spawn_ranks(args)
+    rank = int(os.environ.get('RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus and not (args.gpus == 1 and world == 1):
+        sys.stderr.write('bench.py: --gpus %d but WORLD_SIZE=%d\n' % (args.gpus, world))
+        sys.exit(2)
+    os.environ.setdefault('SHEPSEG_DEVICE', str(local_rank))
+    dist = None
+    force_dist = os.environ.get('SHEPSEG_FORCE_DIST', '0') == '1' and 'RANK' in os.environ
+    if world > 1 or force_dist:
+        if args.workload == 'c5':
+            sys.stderr.write('bench.py: --workload c5 runs on one GPU (the sharded statistics are '
+                             'covered by tests/test_distributed_cpu.py)\n')
+            sys.exit(2)
+        import torch
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend='nccl')
+        from pyshepseg_amd import distributed
+        return distributed.bench_main(args, rank, world, local_rank, dist)
+    if args.workload == 'c5':
+        return bench_stats(args)
+    return bench_segmentation(args)
 
 
 if __name__ == '__main__':

@@ -135,6 +135,11 @@ int shp_sync(shp_ctx *ctx);
 /* synthimg v1 window written straight into device memory (band-planar uint16) */
 int shp_dev_synthimg(shp_ctx *ctx, uint64_t seed, int nbands, int64_t y0, int64_t x0, int nrows,
                      int ncols, void *d_out);
+/* synthetic label raster of block_rows x block_cols-pixel blocks numbered row-major from 1 (the
+ * benchmark input of the statistics path, BASELINE config 5: "~50M segments"); *max_id_out = the
+ * number of blocks.  Benchmark plumbing like shp_dev_synthimg: it replaces nothing in the reference. */
+int shp_dev_block_labels(shp_ctx *ctx, int nrows, int ncols, int block_rows, int block_cols,
+                         uint32_t *d_out, uint32_t *max_id_out);
 /* out_host[b][i][j] = img[b][row_idx[i]][col_idx[j]] of a device raster (k-means subsample) */
 int shp_dev_subsample(shp_ctx *ctx, const void *d_img, int dtype, int nbands, int nrows, int ncols,
                       const uint32_t *row_idx, int ny, const uint32_t *col_idx, int nx,

@@ -69,6 +69,8 @@ _SIGS = {
     'shp_sync': (_c.c_int, [_vp]),
     'shp_dev_synthimg': (_c.c_int, [_vp, _c.c_uint64, _c.c_int, _c.c_int64, _c.c_int64, _c.c_int,
                                     _c.c_int, _vp]),
+    'shp_dev_block_labels': (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _vp,
+                                        _c.POINTER(_c.c_uint32)]),
     'shp_dev_subsample': (_c.c_int, [_vp, _vp, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _vp,
                                      _c.c_int, _vp, _c.c_int, _vp]),
     'shp_segment_window_dev': (_c.c_int, [_vp, _vp, _c.c_int, _c.c_int, _c.c_int, _c.c_int,

@@ -74,7 +74,7 @@ static int ctx_create(int device, int high_priority, shp_ctx **out)
                  &ctx->pix, &ctx->segsz, &ctx->origsz, &ctx->off, &ctx->ssum, &ctx->chnext,
                  &ctx->chtail, &ctx->mergeto, &ctx->tcount, &ctx->toff, &ctx->tfill, &ctx->tlist,
                  &ctx->tsorted, &ctx->small, &ctx->cen, &ctx->fit_x, &ctx->fit_lab, &ctx->fit_part,
-                 &ctx->big, &ctx->srclist, &ctx->tgtlist, &ctx->bigbits, &ctx->singles};
+                 &ctx->big, &ctx->srclist, &ctx->tgtlist, &ctx->bigbits, &ctx->singles, &ctx->dbg};
     *out = ctx;
     return SHP_OK;
 }
@@ -367,7 +367,6 @@ API int shp_segment_tile(shp_ctx *ctx, const void *img, int dtype, int nbands, i
     if (small_elim_out) *small_elim_out = 0;
     if (num_clumps_out) *num_clumps_out = 0;
     if (n == 0) return 0;
-    ctx->dfs_fork = 1;
     hipEventRecord(ctx->ev[0], ctx->stream);
     CHK(upload_img(ctx, img, dtype, nbands, n));
     CHK(buf_ensure(ctx, ctx->seg, (size_t)n * 4));
@@ -475,6 +474,34 @@ API int shp_dev_synthimg(shp_ctx *ctx, uint64_t seed, int nbands, int64_t y0, in
     return 0;
 }
 
+// synthetic label raster for the statistics benchmark (BASELINE config 5): bh x bw-pixel blocks
+// numbered row-major from 1; returns the largest id
+__global__ __launch_bounds__(256) void k_block_labels(uint32_t nrows, uint32_t ncols, uint32_t bh, uint32_t bw,
+                                                      uint32_t ncb, uint32_t *__restrict__ out)
+{
+    const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= (size_t)nrows * ncols) return;
+    const uint32_t r = (uint32_t)(i / ncols), c = (uint32_t)(i - (size_t)r * ncols);
+    out[i] = (r / bh) * ncb + c / bw + 1u;
+}
+
+API int shp_dev_block_labels(shp_ctx *ctx, int nrows, int ncols, int block_rows, int block_cols,
+                             uint32_t *d_out, uint32_t *max_id_out)
+{
+    CHK(enter(ctx));
+    if (!d_out || nrows < 0 || ncols < 0 || block_rows < 1 || block_cols < 1) SHP_FAIL(ctx, SHP_ERR_ARG, "bad argument");
+    const uint64_t ncb = ((uint64_t)ncols + block_cols - 1) / block_cols, nrb = ((uint64_t)nrows + block_rows - 1) / block_rows;
+    if (ncb * nrb >= 0xffffffffull) SHP_FAIL(ctx, SHP_ERR_ARG, "too many blocks");
+    if (max_id_out) *max_id_out = (uint32_t)(ncb * nrb);
+    const size_t total = (size_t)nrows * ncols;
+    if (total == 0) return 0;
+    hipLaunchKernelGGL(k_block_labels, dim3(grid_for(total, 256)), dim3(256), 0, ctx->stream, (uint32_t)nrows,
+                       (uint32_t)ncols, (uint32_t)block_rows, (uint32_t)block_cols, (uint32_t)ncb, d_out);
+    KCHK(ctx);
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
 // gather rows y0,y0+ystep.. / cols likewise of every band of a device raster into a host array
 __global__ __launch_bounds__(256) void k_subsample(const void *__restrict__ img, int dtype, int nb,
                                                    uint32_t rows, uint32_t cols,
@@ -568,7 +595,6 @@ API int shp_segment_window_dev(shp_ctx *ctx, const void *d_img, int dtype, int n
     if (small_elim_out) *small_elim_out = 0;
     if (num_clumps_out) *num_clumps_out = 0;
     if (n == 0) return 0;
-    ctx->dfs_fork = 0;      // many tiles in flight: one stream per worker is enough
     FillScope fs(ctx, 1);
     fill_acquire(ctx, 0);
     hipEventRecord(ctx->ev[0], ctx->stream);
@@ -651,7 +677,6 @@ API int shp_segment_tile_to_dev(shp_ctx *ctx, const void *img, int dtype, int nb
     if (small_elim_out) *small_elim_out = 0;
     if (num_clumps_out) *num_clumps_out = 0;
     if (n == 0) return 0;
-    ctx->dfs_fork = 0;
     FillScope fs(ctx, 1);
     hipEventRecord(ctx->ev[0], ctx->stream);
     CHK(upload_img(ctx, img, dtype, nbands, n));          // (PCIe: outside the gate)

@@ -230,12 +230,13 @@ __global__ __launch_bounds__(256) void k_run_count(const uint32_t *__restrict__ 
 
 __global__ __launch_bounds__(256) void k_big_list(const uint32_t *__restrict__ lab,
                                                   uint32_t *csize, uint32_t n, uint32_t ncols,
-                                                  BigInfo *big, uint32_t *counters, uint32_t *bigbits)
+                                                  BigInfo *big, uint32_t *counters, uint32_t *bigbits,
+                                                  uint32_t bigmin)
 {
     const uint32_t p = blockIdx.x * 256u + threadIdx.x;
     if (p >= n || lab[p] != p) return;
     const uint32_t s = csize[p];
-    if (s < MAX_CLUMP_SIZE + 2u) return;
+    if (s < bigmin) return;
     const uint32_t bi = atomicAdd(&counters[0], 1u);
     const uint32_t off = atomicAdd(&counters[1], s);
     BigInfo b;
@@ -318,7 +319,7 @@ __global__ __launch_bounds__(256) void k_big_bbox(const uint32_t *__restrict__ l
 //     order (cx outer, cy inner): one ballot decides which are unvisited members, they are
 //     labelled together and pushed in lane order, the last one becoming the next pop;
 //   * all 64 lanes scan the bounding box for the next seed in raster order.
-#define DFS_SWN 1536u        // stack window entries in LDS (6 KiB)
+#define DFS_SWN 512u         // stack window entries in LDS per walker (2 KiB)
 __device__ __forceinline__ unsigned long long dfs_bitmap_words(const BigInfo &B, uint32_t ncols);
 
 __device__ __forceinline__ void dfs_split_global(uint32_t *lab, const BigInfo &B, uint32_t *sw,
@@ -423,13 +424,11 @@ __device__ __forceinline__ void dfs_split_global(uint32_t *lab, const BigInfo &B
     }
 }
 
-// LDS variant of the replay for components whose bounding box fits the LDS bitmap (all of
+// LDS variant of the replay for components whose bounding box fits the walker pool (all of
 // them on the benchmark imagery): membership/unvisited state is one bit per bounding-box pixel
-// in LDS (64 KiB), so a pop costs one LDS round trip instead of a dependent HBM/L2 access, and the walk
+// in LDS, so a pop costs one LDS round trip instead of a dependent HBM/L2 access, and the walk
 // no longer suffers when other streams pollute L2.  Labels are still written to `lab` with
 // fire-and-forget stores.  Components that do not fit take dfs_split_global.
-#define DFS_BMW_SMALL 10240u // class A bitmap words (327680 padded bounding-box pixels, 40 KiB)
-#define DFS_BMW_LARGE 16384u // class B bitmap words (524288 bounding-box pixels, 64 KiB)
 
 // The bitmap carries a one-bit border of zeros on every side, so the walk needs no bounds checks.
 __device__ __forceinline__ unsigned long long dfs_bitmap_words(const BigInfo &B, uint32_t ncols)
@@ -454,16 +453,25 @@ __device__ __forceinline__ void dfs_split_lds(uint32_t *lab, const BigInfo &B, u
     // padded coordinates: member (y, x) of the box sits at row y + 1, bit column x + 1;
     // its pixel index is gbase + (y + 1) * ncols + (x + 1)   (mod 2^32)
     const uint32_t gbase = (minr - 1u) * ncols + minc - 1u;
-    // ---- build the member bitmap from the flattened CCL labels ----
-    for (uint32_t pr = 0; pr < H + 2u; pr++) {
-        const bool rin = pr >= 1u && pr <= H;
+    // ---- build the member bitmap from the flattened CCL labels: eight rows per step, so that
+    //      eight independent 256-byte loads are in flight (a dependent load per row made the build
+    //      as long as a short walk) ----
+    for (uint32_t pr0 = 0; pr0 < H + 2u; pr0 += 8u) {
         for (uint32_t c0 = 0; c0 < wpr * 32u; c0 += 64u) {
             const uint32_t bc = c0 + lane;
-            const bool mem = rin && bc >= 1u && bc <= W && lab[gbase + pr * ncols + bc] == root;
-            const unsigned long long m = __ballot(mem);
-            if (lane == 0) {
-                bm[pr * wpr + (c0 >> 5)] = (uint32_t)m;
-                if ((c0 >> 5) + 1u < wpr) bm[pr * wpr + (c0 >> 5) + 1u] = (uint32_t)(m >> 32);
+            const bool cin = bc >= 1u && bc <= W;
+            uint32_t v[8];
+#pragma unroll
+            for (uint32_t u = 0; u < 8u; u++) {
+                const uint32_t pr = pr0 + u;
+                v[u] = (cin && pr >= 1u && pr <= H) ? lab[gbase + pr * ncols + bc] : NULL_LAB;
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 8u; u++) {
+                const uint32_t pr = pr0 + u;
+                const unsigned long long m = __ballot(v[u] == root);
+                if (pr < H + 2u && lane < 2u && (c0 >> 5) + lane < wpr)
+                    bm[pr * wpr + (c0 >> 5) + lane] = lane ? (uint32_t)(m >> 32) : (uint32_t)m;
             }
         }
     }
@@ -577,7 +585,7 @@ __device__ __forceinline__ void dfs_split_lds(uint32_t *lab, const BigInfo &B, u
 
 // order[rank] = component index, largest first: the longest replays start first (LPT), which
 // shortens the makespan whenever there are more components than resident workgroups
-// counters[2] = how many of them need the large replay class (bitmap above bmw_small words)
+// counters[2] = how many of them do not fit the walker pool (bitmap above bmw_small words)
 __global__ __launch_bounds__(256) void k_big_order(const BigInfo *__restrict__ big,
                                                    uint32_t *counters,
                                                    uint32_t *__restrict__ order, uint32_t ncols,
@@ -596,34 +604,102 @@ __global__ __launch_bounds__(256) void k_big_order(const BigInfo *__restrict__ b
     order[rank] = i;
 }
 
-// Two launches per tile share this kernel: class A (bitmap <= 40 KiB: nearly all components,
-// 46 KiB of LDS per workgroup so three fit a CU and other kernels still find LDS) and class B
-// (<= 64 KiB bitmap, or no bitmap at all -> global path).  The two launches run one after the
-// other in the tile's stream, so the tile waits for the longest walk of EACH class: the
-// boundary sits where class B is nearly empty (24 KiB: 16.8 + 12.6 ms per tile, 40 KiB: 7.6 +
-// 16.0 ms).  Keeping the footprint below half a CU's LDS matters: with 80 KiB per workgroup
-// the replays of 16 concurrent tiles filled every CU's LDS and starved every other kernel that
-// needs a few KiB of it; forking the classes onto two streams oversubscribes the hardware queues.
-__global__ __launch_bounds__(64) void k_dfs_split(uint32_t *lab, const BigInfo *__restrict__ big,
-                                                  const uint32_t *__restrict__ counters,
-                                                  uint32_t *stackbuf, uint32_t nrows,
-                                                  uint32_t ncols, int four, uint32_t bmw_lo,
-                                                  uint32_t bmw_hi, int take_global,
-                                                  uint32_t *singles, uint32_t *nsingles,
-                                                  const uint32_t *__restrict__ order, uint32_t *csize)
+// One launch per tile.  A workgroup holds DFS_WAVES independent walkers (one wavefront each) that
+// share a pool of LDS granules: a walker takes a component, claims the contiguous granules its
+// bounding-box bitmap needs (a bit mask in LDS, claimed with one atomic OR), walks, gives them back,
+// takes the next component.  The bitmaps are sized by the component (median 6 KiB, 99 % below 28 KiB
+// on the benchmark imagery) instead of by a launch-wide worst case (40 / 64 KiB in round 1), so a
+// CU carries eight walkers in 84 KiB where it carried three in 138 KiB, and the rest of the LDS
+// stays free for the other streams' kernels; the LDS footprint above 80 KiB keeps a second walker
+// workgroup off the same CU.
+// Components are taken largest first.  The first pass is static and interleaved (walker w of
+// workgroup b takes rank w * gridDim.x + b), which hands every workgroup one component of each
+// size class instead of the eight largest to workgroup 0; whatever is left is pulled from a
+// counter.  A walker that finds no room waits for its neighbours' releases (they never wait for
+// anything, so the wait is finite); after DFS_ALLOC_SPINS polls, or for a bitmap larger than the
+// whole pool, it walks in global memory instead.
+#define DFS_WAVES 8u
+#define DFS_GRAN_WORDS 512u          // granule = 2 KiB
+#define DFS_POOL_GRANS_DEFAULT 34u   // 68 KiB pool (+ 16 KiB of stack windows + the mask = 84 KiB)
+#define DFS_ALLOC_SPINS 200000u
+
+// start granule of `need` contiguous free granules, or -1; wave-uniform, lane 0 talks to the mask
+__device__ __forceinline__ int dfs_pool_alloc(unsigned long long *mask, uint32_t need, uint32_t ngrans)
+{
+    int res = -1;
+    if (lane_id() == 0) {
+        const unsigned long long all = ngrans >= 64u ? ~0ull : ((1ull << ngrans) - 1ull);
+        const unsigned long long ones = need >= 64u ? ~0ull : ((1ull << need) - 1ull);
+        for (uint32_t spin = 0; spin < DFS_ALLOC_SPINS; spin++) {
+            const unsigned long long m = __hip_atomic_load(mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const unsigned long long fr = ~m & all;
+            unsigned long long f = fr;          // bit j of f: granules j .. j + need - 1 are free
+            for (uint32_t have = 1; have < need;) {
+                const uint32_t sh = need - have < have ? need - have : have;
+                f &= f >> sh;
+                have += sh;
+            }
+            if (f) {
+                const int j = __builtin_ctzll(f);
+                const unsigned long long claim = ones << j;
+                const unsigned long long old = __hip_atomic_fetch_or(mask, claim, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (!(old & claim)) { res = j; break; }
+                __hip_atomic_fetch_and(mask, ~(claim & ~old), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            __builtin_amdgcn_s_sleep(16);
+        }
+    }
+    return __builtin_amdgcn_readfirstlane(res);
+}
+
+__global__ __launch_bounds__(DFS_WAVES * 64) void k_dfs_pool(        // blockDim.x / 64 walkers (<= DFS_WAVES)
+
+    uint32_t *lab, const BigInfo *__restrict__ big, uint32_t *counters, uint32_t *stackbuf, uint32_t nrows,
+    uint32_t ncols, int four, uint32_t pool_grans, uint32_t *singles, uint32_t *nsingles,
+    const uint32_t *__restrict__ order, uint32_t *csize, unsigned long long *dbg)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t dfs_lds[];
-    uint32_t *sw = dfs_lds;                  // DFS_SWN entries
-    uint32_t *bm = dfs_lds + DFS_SWN;        // bmw_hi words
-    if (blockIdx.x >= counters[0]) return;
-    const uint32_t bi = order[blockIdx.x];
-    __builtin_amdgcn_s_setprio(3);          // a lone latency-bound wave: win issue arbitration
-    const BigInfo B = big[bi];
-    const unsigned long long words = dfs_bitmap_words(B, ncols);
-    if (words > bmw_lo && words <= bmw_hi)
-        dfs_split_lds(lab, B, bm, sw, stackbuf, ncols, four, singles, nsingles, csize);
-    else if (take_global && words > bmw_hi)
-        dfs_split_global(lab, B, sw, stackbuf, nrows, ncols, four, singles, nsingles, csize);
+    unsigned long long *mask = (unsigned long long *)dfs_lds;             // 4 words (2 used)
+    const unsigned w = threadIdx.x >> 6, lane = lane_id();
+    const uint32_t nwalk = blockDim.x >> 6;
+    uint32_t *sw = dfs_lds + 4u + w * DFS_SWN;
+    uint32_t *pool = dfs_lds + 4u + nwalk * DFS_SWN;
+    if (threadIdx.x == 0) *mask = 0ull;
+    __syncthreads();                        // the only workgroup-wide rendezvous: walkers are independent
+    const uint32_t nbig = counters[0];
+    __builtin_amdgcn_s_setprio(3);          // lone latency-bound waves: win issue arbitration
+    uint32_t idx = w * gridDim.x + blockIdx.x;
+    for (;;) {
+        if (idx >= nbig) break;
+        const BigInfo B = big[order[idx]];
+        const unsigned long long words = dfs_bitmap_words(B, ncols);
+        int g0 = -1;
+        uint32_t need = 0;
+        const unsigned long long t0 = dbg ? wall_clock64() : 0ull;
+        if (words <= (unsigned long long)pool_grans * DFS_GRAN_WORDS) {
+            need = ((uint32_t)words + DFS_GRAN_WORDS - 1u) / DFS_GRAN_WORDS;
+            g0 = dfs_pool_alloc(mask, need, pool_grans);
+        }
+        const unsigned long long t1 = dbg ? wall_clock64() : 0ull;
+        if (g0 >= 0) {
+            dfs_split_lds(lab, B, pool + (uint32_t)g0 * DFS_GRAN_WORDS, sw, stackbuf, ncols, four, singles, nsingles, csize);
+            __builtin_amdgcn_wave_barrier();
+            if (lane == 0) {
+                const unsigned long long ones = need >= 64u ? ~0ull : ((1ull << need) - 1ull);
+                __hip_atomic_fetch_and(mask, ~(ones << g0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        } else {
+            dfs_split_global(lab, B, sw, stackbuf, nrows, ncols, four, singles, nsingles, csize);
+        }
+        if (dbg && lane == 0) {          // SHEPSEG_DFS_STATS: size, bitmap words, wait / walk ticks (100 MHz), start
+            unsigned long long *d = dbg + (size_t)idx * 6u;
+            d[0] = B.size; d[1] = words; d[2] = t1 - t0; d[3] = wall_clock64() - t1; d[4] = t0;
+            d[5] = ((unsigned long long)blockIdx.x << 8) | w | (g0 < 0 ? 1ull << 40 : 0ull);
+        }
+        uint32_t nx = 0;
+        if (lane == 0) nx = atomicAdd(&counters[3], 1u);
+        idx = nwalk * gridDim.x + (uint32_t)__builtin_amdgcn_readfirstlane((int)nx);
+    }
 }
 
 struct SeedFn {
@@ -740,51 +816,62 @@ static int run_clump(shp_ctx *ctx, const uint16_t *d_clus, uint32_t nrows, uint3
     uint32_t *bigbits = bp<uint32_t>(ctx->bigbits), *rank = bp<uint32_t>(ctx->aux2);
     hipLaunchKernelGGL(k_ccl_flatten, dim3(g), dim3(256), 0, st, lab, n, csize, bigbits); KCHK(ctx);
     prof_end(ctx, ps);
-    hipLaunchKernelGGL(k_big_list, dim3(g), dim3(256), 0, st, lab, csize, n, ncols, big, counters, bigbits); KCHK(ctx);
+    // (SHEPSEG_DBG_SKIP_DFS: diagnostic only -- no component is cut, wrong labels, times the rest)
+    static const uint32_t bigmin = getenv("SHEPSEG_DBG_SKIP_DFS") ? 0x7fffffffu : MAX_CLUMP_SIZE + 2u;
+    hipLaunchKernelGGL(k_big_list, dim3(g), dim3(256), 0, st, lab, csize, n, ncols, big, counters, bigbits, bigmin); KCHK(ctx);
     hipLaunchKernelGGL(k_big_bbox, dim3(grid_for(ncols, 64), grid_for(nrows, AGG_ROWS)), dim3(256), 0, st, lab,
                        csize, nrows, ncols, big, bigbits); KCHK(ctx);
     ps = prof_begin(ctx, PROF_DFS);
     uint32_t *order = (uint32_t *)((char *)ctx->big.p + (size_t)maxbig * sizeof(BigInfo) + 64);
-    static const uint32_t bmw_small = getenv("SHEPSEG_DFS_SMALL") ? (uint32_t)atoi(getenv("SHEPSEG_DFS_SMALL")) : DFS_BMW_SMALL;
     hipLaunchKernelGGL(k_big_order, dim3(grid_for(maxbig, 256)), dim3(256), 0, st, big, counters, order, ncols,
-                       bmw_small); KCHK(ctx);
-    // the replay is a latency-bound phase: outside the fill gate.  The gate's synchronisation also
-    // brings the component counts back, so the launches can be sized exactly and an empty size
-    // class skipped (its 1678 workgroups would each wait for 70 KiB of LDS only to exit).
-    uint32_t grid_l = maxbig, grid_s = maxbig;
-    if (fill_gating(ctx)) {
-        HIPCHK(ctx, hipMemcpyAsync(ctx->h_pinned, counters, 12, hipMemcpyDeviceToHost, st));
-        HIPCHK(ctx, hipStreamSynchronize(st));
-        const uint32_t nbig_h = ctx->h_pinned[0], nlarge_h = ctx->h_pinned[2];
-        grid_l = nlarge_h ? nbig_h : 0u;
-        grid_s = nbig_h > nlarge_h ? nbig_h : 0u;
+                       DFS_POOL_GRANS_DEFAULT * DFS_GRAN_WORDS); KCHK(ctx);
+    // the replay is a latency-bound phase: outside the fill gate.  The component count comes back
+    // first, so that the launch is sized exactly (a workgroup per DFS_WAVES components; every one of
+    // them reserves the whole walker pool in LDS, so none is launched for nothing).
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_pinned, counters, 12, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    const uint32_t nbig_h = ctx->h_pinned[0];
+    fill_release(ctx, false);
+    unsigned long long *dbg = nullptr;
+    if (getenv("SHEPSEG_DFS_STATS") && nbig_h) {
+        CHK(buf_ensure(ctx, ctx->dbg, (size_t)nbig_h * 48u));
+        dbg = bp<unsigned long long>(ctx->dbg);
     }
-    fill_release(ctx, true);
-    // fork: the two size classes touch disjoint components, so they can run on two streams
-    static const int fork_env = getenv("SHEPSEG_DFS_FORK") ? atoi(getenv("SHEPSEG_DFS_FORK")) : -1;
-    const int fork2 = fork_env >= 0 ? fork_env : ctx->dfs_fork;
-    if (fork2) CHK(ensure_stream2(ctx));
-    hipStream_t st2 = fork2 ? ctx->stream2 : st;
-    if (fork2) {
-        HIPCHK(ctx, hipEventRecord(ctx->evfork, st));
-        HIPCHK(ctx, hipStreamWaitEvent(ctx->stream2, ctx->evfork, 0));
-    }
-    if (grid_l) {
-        hipLaunchKernelGGL(k_dfs_split, dim3(grid_l), dim3(64), (DFS_SWN + DFS_BMW_LARGE) * 4, st, lab, big,
-                           counters, bp<uint32_t>(ctx->stack), nrows, ncols, four, bmw_small,
-                           DFS_BMW_LARGE, 1, d_singles, d_nsingles, order, csize); KCHK(ctx);
-    }
-    if (grid_s) {
-        hipLaunchKernelGGL(k_dfs_split, dim3(grid_s), dim3(64), (DFS_SWN + bmw_small) * 4, st2, lab,
-                           big, counters, bp<uint32_t>(ctx->stack), nrows, ncols, four, 0u, bmw_small, 0,
-                           d_singles, d_nsingles, order, csize);
-        KCHK(ctx);
-    }
-    if (fork2) {
-        HIPCHK(ctx, hipEventRecord(ctx->evjoin, ctx->stream2));
-        HIPCHK(ctx, hipStreamWaitEvent(st, ctx->evjoin, 0));
+    if (nbig_h) {
+        static const uint32_t pool_grans = getenv("SHEPSEG_DFS_POOL") ? (uint32_t)atoi(getenv("SHEPSEG_DFS_POOL")) : DFS_POOL_GRANS_DEFAULT;
+        static const uint32_t per_wg = getenv("SHEPSEG_DFS_PER_WG") ? (uint32_t)atoi(getenv("SHEPSEG_DFS_PER_WG")) : DFS_WAVES;
+        const uint32_t pg = pool_grans < 1u ? 1u : pool_grans > 64u ? 64u : pool_grans;
+        const uint32_t pw = per_wg < 1u ? 1u : per_wg > DFS_WAVES ? DFS_WAVES : per_wg;
+        const size_t lds = (4u + pw * DFS_SWN + (size_t)pg * DFS_GRAN_WORDS) * 4u;
+        static bool attr_set = false;       // (benign race: the attribute is idempotent)
+        if (!attr_set) {
+            HIPCHK(ctx, hipFuncSetAttribute((const void *)k_dfs_pool, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(k_dfs_pool, dim3((nbig_h + pw - 1u) / pw), dim3(pw * 64u), lds, st, lab, big,
+                           counters, bp<uint32_t>(ctx->stack), nrows, ncols, four, pg, d_singles, d_nsingles,
+                           order, csize, dbg); KCHK(ctx);
     }
     prof_end(ctx, ps);
+    if (dbg) {
+        std::vector<unsigned long long> h((size_t)nbig_h * 6u);
+        HIPCHK(ctx, hipMemcpyAsync(h.data(), dbg, h.size() * 8u, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        unsigned long long tmin = ~0ull, tend = 0, swait = 0, swalk = 0, spx = 0;
+        for (uint32_t i = 0; i < nbig_h; i++) {
+            tmin = h[i * 6 + 4] < tmin ? h[i * 6 + 4] : tmin;
+            const unsigned long long e = h[i * 6 + 4] + h[i * 6 + 2] + h[i * 6 + 3];
+            tend = e > tend ? e : tend;
+            swait += h[i * 6 + 2]; swalk += h[i * 6 + 3]; spx += h[i * 6];
+        }
+        fprintf(stderr, "dfs: %u components, %llu px, span %.2f ms, sum wait %.2f ms, sum walk %.2f ms (%.1f ns/px)\n",
+                nbig_h, spx, (tend - tmin) / 1e5, swait / 1e5, swalk / 1e5, swalk * 10.0 / (double)(spx ? spx : 1));
+        for (uint32_t i = 0; i < nbig_h && i < 12u; i++)
+            fprintf(stderr, "  rank %u: %llu px, %llu words, start %.2f wait %.2f walk %.2f ms (%.1f ns/px) wg %llu wave %llu%s\n", i,
+                    h[i * 6], h[i * 6 + 1], (h[i * 6 + 4] - tmin) / 1e5, h[i * 6 + 2] / 1e5, h[i * 6 + 3] / 1e5,
+                    h[i * 6 + 3] * 10.0 / (double)h[i * 6], (h[i * 6 + 5] >> 8) & 0xffffffffull, h[i * 6 + 5] & 255ull,
+                    (h[i * 6 + 5] >> 40) ? " GLOBAL" : "");
+    }
     if (fill_gating(ctx)) {
         HIPCHK(ctx, hipStreamSynchronize(st));
         fill_acquire(ctx, 1);

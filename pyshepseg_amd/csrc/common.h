@@ -39,7 +39,7 @@ struct shp_ctx {
     // named workspace buffers (grow-only)
     DevBuf img, clus, lab, seg, aux, aux2, stack, scan_tmp, sort_k0, sort_k1, sort_v1, sort_hist,
         pix, segsz, origsz, off, ssum, chnext, chtail, mergeto, tcount, toff, tfill, tlist, tsorted,
-        small, cen, fit_x, fit_lab, fit_part, big, srclist, tgtlist, bigbits, singles;
+        small, cen, fit_x, fit_lab, fit_part, big, srclist, tgtlist, bigbits, singles, dbg;
     uint32_t *h_pinned = nullptr;   // SHP_PINNED_BYTES of pinned host staging (small transfers)
     double *h_fit = nullptr;        // pinned, grow-only: the centred k-means sample
     size_t h_fit_cap = 0;
@@ -51,7 +51,6 @@ struct shp_ctx {
     hipEvent_t prof_ev[PROF_POOL][2] = {};
     int prof_id[PROF_POOL] = {};
     int prof_used = 0;
-    int dfs_fork = 1;   // run the two DFS size classes on two streams (single-tile latency)
     uint32_t *scan_ctr = nullptr;   // device word, zero between scans: arrival counter of k_scan_local
     int gated = 0;      // this call takes part in the fill gate (tiled driver's worker calls)
     bool fill_held = false;
@@ -112,7 +111,7 @@ struct FillScope {          // an API call never leaves with the gate held (erro
 
 // kernels whose launch durations bench.py reports against the roofline
 enum { PROF_ASSIGN = 0, PROF_CCL = 1, PROF_DFS = 2, PROF_SORT = 3, PROF_SPECTRA = 4,
-       PROF_SMALL_LOOP = 5, PROF_SINGLE = 6, PROF_LABEL = 7 };
+       PROF_SMALL_LOOP = 5, PROF_SINGLE = 6, PROF_LABEL = 7, PROF_SEGSTATS = 8 };
 
 static inline int prof_begin(shp_ctx *ctx, int id)
 {

@@ -419,6 +419,99 @@ __device__ __forceinline__ bool find_merge_wave(uint32_t s, uint32_t target, con
     return merges;                           // wave-uniform: does s merge in this pass?
 }
 
+// The same for small sources, several per wavefront: a source of `target` pixels has target * nq
+// (pixel, neighbour) pairs, 8 for the two-pixel segments that make up most of the work -- one
+// wavefront per source left 56 of 64 lanes idle there.  Here the sources found in a 64-id slice
+// (bit mask m, ids b0 + bit + 1) are dealt to groups of G >= target * nq lanes; every lane walks
+// the chunk chain to its own pixel (short: these segments are mostly still one chunk), evaluates
+// its pair and the group reduces the same (distSqr, k, position) key over G lanes.
+// Returns how many of the sources merge in this pass.
+template <unsigned G>
+__device__ __forceinline__ uint32_t find_merge_packed(unsigned long long m, uint32_t b0, uint32_t target,
+                                                      const SmallArgs &a)
+{
+    const unsigned lane = lane_id(), grp = lane / G, gl = lane % G;
+    const uint32_t nq = a.four ? 4u : 8u;
+    const float nf = (float)target;
+    const uint32_t npairs = target * nq;
+    uint32_t merges = 0;
+    while (m) {
+        uint32_t s = 0;                              // this group's source (0 = none in this round)
+#pragma unroll
+        for (unsigned j = 0; j < 64u / G; j++) {
+            if (m) {
+                const uint32_t sid = b0 + (uint32_t)__builtin_ctzll(m) + 1u;
+                m &= m - 1ull;
+                if (grp == j) s = sid;
+            }
+        }
+        unsigned long long best = ~0ull;
+        uint32_t bestnb = 0;
+        if (s != 0u && gl < npairs) {
+            const uint32_t kk = gl / nq, pos = gl - kk * nq;
+            uint32_t c = s, k = kk, cm = a.origsz[c];
+            while (k >= cm) {                        // chunk chain = the reference's list order
+                k -= cm;
+                c = a.chnext[c];
+                if (c == 0u) break;
+                cm = a.origsz[c];
+            }
+            if (c != 0u) {
+                const uint32_t p = a.pix[a.off[c] + k];
+                const uint32_t r = p / a.ncols, cc = p - r * a.ncols;
+                int di, dj;                          // neighbour `pos` in (ii outer, jj inner) order
+                if (a.four) {
+                    di = (pos == 0u) ? -1 : (pos == 3u) ? 1 : 0;
+                    dj = (pos == 1u) ? -1 : (pos == 2u) ? 1 : 0;
+                } else {
+                    const uint32_t e = pos < 4u ? pos : pos + 1u;      // skip the centre
+                    di = (int)(e / 3u) - 1;
+                    dj = (int)(e % 3u) - 1;
+                }
+                const int ii = (int)r + di, jj = (int)cc + dj;
+                if (ii >= 0 && jj >= 0 && ii < (int)a.nrows && jj < (int)a.ncols) {
+                    const uint32_t nbid = a.seg[(uint32_t)ii * a.ncols + (uint32_t)jj];
+                    if (nbid != s && nbid != 0u) {
+                        const uint32_t szn = a.segsz[nbid];
+                        if (szn > target) {
+                            const float sf = (float)szn;
+                            float d = 0.0f;
+                            for (int b = 0; b < a.nb; b++) {
+                                const float x = a.ssum[(size_t)s * a.nb + b] / nf;
+                                const float e2 = a.ssum[(size_t)nbid * a.nb + b] / sf;
+                                const float t = x - e2;
+                                const float t2 = t * t;
+                                d = d + t2;
+                            }
+                            best = ((unsigned long long)__float_as_uint(d) << 32) |
+                                   (unsigned long long)(kk * 8u + pos);
+                            bestnb = nbid;
+                        }
+                    }
+                }
+            }
+        }
+        unsigned long long gmin = best;
+#pragma unroll
+        for (unsigned d = G / 2u; d >= 1u; d >>= 1) {
+            const unsigned long long o = __shfl_xor(gmin, (int)d, 64);
+            gmin = o < gmin ? o : gmin;
+        }
+        bool merged = false;
+        if (s != 0u) {
+            if (gmin == ~0ull) {
+                if (gl == 0u) a.mergeto[s] = 0u;
+            } else if (best == gmin) {               // unique: (k, position) differs between lanes
+                const float bd = __uint_as_float((uint32_t)(gmin >> 32));
+                merged = !((double)bd > a.thr2);
+                a.mergeto[s] = merged ? bestnb : 0u;
+            }
+        }
+        merges += (uint32_t)__popcll(__ballot(merged));
+    }
+    return merges;
+}
+
 __global__ __launch_bounds__(256) void k_small_loop(SmallArgs a)
 {
     __shared__ uint32_t wpix[4][64];
@@ -503,7 +596,11 @@ __global__ __launch_bounds__(256) void k_small_loop(SmallArgs a)
                     if (lane == 0) gbase = atomicAdd(&cnt->nsrc, (uint32_t)__popcll(m));
                     gbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)gbase);
                     if (sz[u] == target) a.srclist[gbase + (uint32_t)__popcll(m & lanemask_lt())] = b0 + lane + 1u;
-                    while (m) {
+                    const uint32_t npairs = target * (a.four ? 4u : 8u);
+                    if (npairs <= 8u) wmerges += find_merge_packed<8>(m, b0, target, a);
+                    else if (npairs <= 16u) wmerges += find_merge_packed<16>(m, b0, target, a);
+                    else if (npairs <= 32u) wmerges += find_merge_packed<32>(m, b0, target, a);
+                    else while (m) {
                         const uint32_t src = b0 + (uint32_t)__builtin_ctzll(m) + 1u;
                         m &= m - 1ull;
                         wmerges += find_merge_wave(src, target, a, wpix[w]) ? 1u : 0u;
@@ -718,6 +815,8 @@ static int run_eliminate_small(shp_ctx *ctx, const void *d_img, int dtype, int n
         g_small_cv.wait(lk, [] { return g_small_running < g_small_max; });
         g_small_running++;
     }
+    static const int dbg_skip_loop = getenv("SHEPSEG_DBG_SKIP_SMALL") ? atoi(getenv("SHEPSEG_DBG_SKIP_SMALL")) : 0;
+    if (dbg_skip_loop) args.min_seg = 1;      // diagnostic only: the loop ends at once (wrong labels)
     static const unsigned small_blocks = getenv("SHEPSEG_SMALL_BLOCKS") ? (unsigned)atoi(getenv("SHEPSEG_SMALL_BLOCKS")) : SMALL_BLOCKS;
     ps = prof_begin(ctx, PROF_SMALL_LOOP);           // events hug the kernel: no copies, no host waits
     hipLaunchKernelGGL(k_small_loop, dim3(small_blocks), dim3(256), 0, st, args);

@@ -146,6 +146,7 @@ static int run_segstats(shp_ctx *ctx, const uint32_t *d_seg, const void *d_band,
     uint32_t *pin = ctx->h_pinned + 16;
     memcpy(pin, sel_host, (size_t)nstats * 20);
     HIPCHK(ctx, hipMemcpyAsync(d_sel, pin, (size_t)nstats * 20, hipMemcpyHostToDevice, st));
+    const int ps = prof_begin(ctx, PROF_SEGSTATS);      // device time of the kernels (keys .. statistics)
     if (n) {
         hipLaunchKernelGGL(k_stats_keys, dim3(grid_for(n, 256)), dim3(256), 0, st, d_seg, d_band, dtype, n,
                            S, has_null, (long long)null_val, bias, kseg, kval); KCHK(ctx);
@@ -167,6 +168,7 @@ static int run_segstats(shp_ctx *ctx, const uint32_t *d_seg, const void *d_band,
     CHK(scan_exclusive(ctx, cf, (uint32_t)ns, off, nullptr, bp<uint32_t>(ctx->scan_tmp)));
     hipLaunchKernelGGL(k_seg_stats, dim3(grid_for(ns, 256)), dim3(256), 0, st, v2, off, cnt, S, bias, d_sel,
                        nstats, (long long)missing, d_int, d_flt); KCHK(ctx);
+    prof_end(ctx, ps);
     if (nint) HIPCHK(ctx, hipMemcpyAsync(intcols_out, d_int, (size_t)nint * ns * 8, hipMemcpyDeviceToHost, st));
     if (nflt) HIPCHK(ctx, hipMemcpyAsync(fltcols_out, d_flt, (size_t)nflt * ns * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipStreamSynchronize(st));

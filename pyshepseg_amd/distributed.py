@@ -599,7 +599,7 @@ def bench_main(args, rank, world, local_rank, dist):
     nb = args.bands
 
     def makeSlice(yLo, yHi):
-        return tiling.DeviceRaster.synth(11, nb, yHi - yLo, args.size, y0=yLo, x0=0)
+        return tiling.DeviceRaster.synth(getattr(args, 'seed', 11), nb, yHi - yLo, args.size, y0=yLo, x0=0)
     engine = HipEngine(makeSlice, numWorkers=args.workers)
 
     def step():
@@ -620,14 +620,15 @@ def bench_main(args, rank, world, local_rank, dist):
         npix = args.size * args.size
         value = npix / dt / 1e6
         out = {
-            "metric": "Mpixels/sec segmented, 6-band 40k x 40k tiled",
+            "metric": "Mpixels/sec segmented, %d-band 40k x 40k tiled" % nb,
             "value": round(value, 3), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 2), "higher_is_better": True,
             "scaling": "strong", "vs_baseline": None, "dtype": "u16", "data": "synthetic",
-            "config": {"workload": "C3: tiled %dx%d, %d-band uint16 synthimg v1, tileSize=%d, "
+            "config": {"workload": "%s: tiled %dx%d, %d-band uint16 synthimg v1, tileSize=%d, "
                                    "overlap=%d, k=60, minSegmentSize=50, fixedKMeansInit, tile rows "
                                    "sharded over %d GPUs, image + labels resident in HBM"
-                                   % (args.size, args.size, nb, args.tile, args.overlap, world),
+                                   % (getattr(args, 'workload', 'c3').upper(), args.size, args.size, nb,
+                                      args.tile, args.overlap, world),
                        "tiles": r.numTileRows * r.numTileCols, "worker_streams": args.workers,
                        "max_seg_id": int(r.maxSegId),
                        "parallelism": "tile rows sharded; stitch chain over send/recv (RCCL)"},
