@@ -96,24 +96,61 @@ ORC_API void orc_synthimg(uint64_t seed, int nbands, int64_t y0, int64_t x0,
 
 /* ------------------------------------------------------------------ */
 /* k-means assign: shepseg.py:317-361 applySpectralClusters +           */
-/* sklearn KMeans.predict (3rd party, sklearn/cluster/_kmeans.py         */
-/* _labels_inertia -> _k_means_lloyd.pyx _update_chunk_dense):           */
-/*   d_j = |c_j|^2 - 2 x.c_j  in float64, argmin, first minimum wins.    */
-/* Evaluation order is pinned here as a band-ordered fma chain so that   */
-/* the GPU kernel can reproduce it bit for bit; N13 shows any float64     */
-/* evaluation reproduces sklearn's labels on integer imagery.            */
+/* sklearn KMeans.predict (3rd party, sklearn 0.24.2                     */
+/* sklearn/cluster/_kmeans.py _labels_inertia -> _k_means_lloyd.pyx      */
+/* _update_chunk_dense):                                                 */
+/*   pairwise = |c_j|^2 (row_norms = numpy einsum 'ij,ij->i'), then      */
+/*   BLAS dgemm(alpha = -2, X, C^T, beta = 1) onto it, argmin, first     */
+/*   minimum wins.                                                       */
+/* Evaluation order, pinned against the oracle stack (numpy 1.26.4,      */
+/* scipy-bundled OpenBLAS) by oracle/refgen/fit_probe.py:                */
+/*   * |c|^2: einsum's baseline-SSE2 loop -- two lanes (even / odd       */
+/*     elements), product and sum rounded separately, whole blocks of 8  */
+/*     elements taken vector 3,2,1,0, the rest in order, lanes added at  */
+/*     the end;                                                          */
+/*   * nBands >= 2: the dot product is accumulated from zero by fused    */
+/*     multiply-adds in band order, then d = |c|^2 + (-2 dot) (the       */
+/*     scaling by -2 is exact, so operand -2c gives the same bits);      */
+/*   * nBands == 1 (a rank-1 update): d = fma(x, -2c, |c|^2).            */
+/* On integer imagery with well separated centres any float64 order     */
+/* gives the same labels; on exact ties (few grey levels,   */
+/* duplicated centres) only this one does.                               */
 /* ------------------------------------------------------------------ */
+static double orc_sqnorm(const double *c, int nb)
+{
+    double a0 = 0.0, a1 = 0.0;
+    int i = 0, count = nb;
+    for (; count >= 8; count -= 8, i += 8) {
+        double t0, t1, p;
+        p = c[i + 6] * c[i + 6]; t0 = p + a0; p = c[i + 7] * c[i + 7]; t1 = p + a1;
+        p = c[i + 4] * c[i + 4]; t0 = p + t0; p = c[i + 5] * c[i + 5]; t1 = p + t1;
+        p = c[i + 2] * c[i + 2]; t0 = p + t0; p = c[i + 3] * c[i + 3]; t1 = p + t1;
+        p = c[i + 0] * c[i + 0]; a0 = p + t0; p = c[i + 1] * c[i + 1]; a1 = p + t1;
+    }
+    for (; count > 0; count -= 2, i += 2) {
+        double p = c[i] * c[i];
+        double q = (count > 1) ? c[i + 1] * c[i + 1] : 0.0;
+        a0 = p + a0;
+        a1 = q + a1;
+    }
+    return a0 + a1;
+}
+
+/* distance term of one sample against one centre (m2c = -2c, cn = |c|^2) */
+static inline double orc_dist(const double *x, const double *m2c, int nb, double cn)
+{
+    if (nb == 1) return fma(x[0], m2c[0], cn);
+    double dot = 0.0;
+    for (int b = 0; b < nb; b++) dot = fma(x[b], m2c[b], dot);
+    return cn + dot;
+}
+
 ORC_API void orc_kmeans_prepare(const double *centres, int k, int nbands,
                                 double *m2c /* k*nbands: -2*c */, double *cnorm /* k */)
 {
     for (int j = 0; j < k; j++) {
-        double s = 0.0;
-        for (int b = 0; b < nbands; b++) {
-            double c = centres[j * nbands + b];
-            s = fma(c, c, s);
-            m2c[j * nbands + b] = -2.0 * c;
-        }
-        cnorm[j] = s;
+        for (int b = 0; b < nbands; b++) m2c[j * nbands + b] = -2.0 * centres[j * nbands + b];
+        cnorm[j] = orc_sqnorm(centres + (size_t)j * nbands, nbands);
     }
 }
 
@@ -137,8 +174,7 @@ ORC_API int orc_kmeans_assign(const void *img, int dtype, int nbands, int nrows,
         int best = 0;
         double bestd = 0.0;
         for (int j = 0; j < k; j++) {
-            double d = cnorm[j];
-            for (int b = 0; b < nbands; b++) d = fma(x[b], m2c[j * nbands + b], d);
+            double d = orc_dist(x, m2c + (size_t)j * nbands, nbands, cnorm[j]);
             if (j == 0 || d < bestd) { bestd = d; best = j; }
         }
         clusters_out[p] = isnull ? 0 : best + 1;             /* shepseg.py:356 */
@@ -467,22 +503,19 @@ ORC_API int orc_segment_tile(const void *img, int dtype, int nbands, int nrows, 
 /* ------------------------------------------------------------------ */
 static void lloyd_assign(const double *X, size_t n, int nb, const double *C, int k, int32_t *lab)
 {
+    /* the E-step of fit is the same chunked dgemm as predict (_k_means_lloyd.pyx), on the centred data */
     double *cn = (double *)malloc(sizeof(double) * k);
-    for (int j = 0; j < k; j++) {
-        double s = 0.0;
-        for (int b = 0; b < nb; b++) s = fma(C[j * nb + b], C[j * nb + b], s);
-        cn[j] = s;
-    }
+    double *m2c = (double *)malloc(sizeof(double) * k * nb);
+    orc_kmeans_prepare(C, k, nb, m2c, cn);
     for (size_t i = 0; i < n; i++) {
         int best = 0; double bd = 0.0;
         for (int j = 0; j < k; j++) {
-            double d = cn[j];
-            for (int b = 0; b < nb; b++) d = fma(X[i * nb + b], -2.0 * C[j * nb + b], d);
+            double d = orc_dist(X + i * nb, m2c + (size_t)j * nb, nb, cn[j]);
             if (j == 0 || d < bd) { bd = d; best = j; }
         }
         lab[i] = best;
     }
-    free(cn);
+    free(cn); free(m2c);
 }
 
 ORC_API int orc_kmeans_fit(const double *xin, int64_t nrows, int nbands, int k,

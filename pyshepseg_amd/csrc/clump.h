@@ -424,6 +424,36 @@ __device__ __forceinline__ void dfs_split_global(uint32_t *lab, const BigInfo &B
     }
 }
 
+// The stack window of a walker (DFS_SWN entries in LDS): the oldest half is spilled to / refilled
+// from the component's slice of a global scratch array.  Out of line: they run once per few
+// hundred steps and must not weigh on the registers and wait counters of the walk.
+// (stack pointers travel by value, packed sp_l | sp_g << 32: a reference parameter of an
+// out-of-line function would pin them to scratch memory in the walk)
+#define UNI(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))      // wave-uniform by construction
+__device__ __noinline__ unsigned long long dfs_spill(uint32_t *sw, uint32_t *gstack, uint32_t sp_l, uint32_t sp_g)
+{
+    const unsigned lane = lane_id();
+    for (uint32_t i = lane; i < DFS_SWN / 2u; i += 64u) gstack[sp_g + i] = sw[i];
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t i0 = 0; i0 + DFS_SWN / 2u < sp_l; i0 += 64u) {
+        const uint32_t i = i0 + lane;
+        uint32_t v = 0;
+        if (i + DFS_SWN / 2u < sp_l) v = sw[i + DFS_SWN / 2u];
+        __builtin_amdgcn_wave_barrier();
+        if (i + DFS_SWN / 2u < sp_l) sw[i] = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+    return (unsigned long long)(sp_l - DFS_SWN / 2u) | ((unsigned long long)(sp_g + DFS_SWN / 2u) << 32);
+}
+__device__ __noinline__ unsigned long long dfs_refill(uint32_t *sw, const uint32_t *gstack, uint32_t sp_g)
+{
+    const unsigned lane = lane_id();
+    const uint32_t k = sp_g < DFS_SWN / 2u ? sp_g : DFS_SWN / 2u;
+    for (uint32_t i = lane; i < k; i += 64u) sw[i] = gstack[sp_g - k + i];
+    __builtin_amdgcn_wave_barrier();
+    return (unsigned long long)k | ((unsigned long long)(sp_g - k) << 32);
+}
+
 // LDS variant of the replay for components whose bounding box fits the walker pool (all of
 // them on the benchmark imagery): membership/unvisited state is one bit per bounding-box pixel
 // in LDS, so a pop costs one LDS round trip instead of a dependent HBM/L2 access, and the walk
@@ -476,17 +506,28 @@ __device__ __forceinline__ void dfs_split_lds(uint32_t *lab, const BigInfo &B, u
         }
     }
     __builtin_amdgcn_wave_barrier();
+    // Positions are kept in three forms at once, each a uniform value plus a per-lane neighbour delta:
+    //   q  = bit index in the padded bitmap (row pitch P = 32 * wpr bits)   -> LDS word and bit
+    //   g  = pixel index in the tile                                        -> label store
+    //   pk = (row << 16 | column), padded coordinates                       -> stack entry
+    // Lanes 0..nq-1 own the neighbours in the reference's push order (cx outer, cy inner); the other
+    // lanes carry zero deltas, i.e. they probe the current position itself, whose bit is already
+    // cleared: they never find anything and need no masking.
     int dy = 0, dx = 0;
-    const unsigned nq = four ? 4u : 8u;
     if (four) {
         dy = (lane == 1) ? -1 : (lane == 2) ? 1 : 0;
         dx = (lane == 0) ? -1 : (lane == 3) ? 1 : 0;
-    } else {
-        const unsigned l8 = lane & 7u;         // (dy,dx) in push order: dx outer, dy inner
+    } else if (lane < 8u) {
+        const unsigned l8 = lane;              // (dy,dx) in push order: dx outer, dy inner
         dx = (l8 < 3u) ? -1 : (l8 < 5u) ? 0 : 1;
         dy = (l8 == 0u || l8 == 3u || l8 == 5u) ? -1 : (l8 == 1u || l8 == 6u) ? 0 : 1;
     }
-    const bool qlane = lane < nq;
+    if (lane >= (four ? 4u : 8u)) { dy = 0; dx = 0; }
+    const uint32_t P = wpr << 5;
+    const uint32_t dq = (uint32_t)(dy * (int)P + dx);
+    const uint32_t dg = (uint32_t)(dy * (int)ncols + dx);
+    const uint32_t dpk = (uint32_t)(dy * 65536 + dx);
+    const uint32_t ltm = (uint32_t)lt;           // (only lanes 0..7 ever push)
     uint32_t wcur = 0;                           // first word that can still hold a set bit
     for (;;) {
         // ---- next seed = first set bit in raster order ----
@@ -512,74 +553,62 @@ __device__ __forceinline__ void dfs_split_lds(uint32_t *lab, const BigInfo &B, u
             bm[sword] = sbits & (sbits - 1u);   // clear the seed's (lowest) bit
         }
         __builtin_amdgcn_wave_barrier();
-        uint32_t sp_l = 0, sp_g = 0;
-        bool have = true;
+        uint32_t sp_l = 0, sp_g = 0;             // stack entries in the LDS window / spilled
         uint32_t cnt = 0;
-        // Neighbour probe of the current position: every lane fetches the bitmap word of its own
-        // neighbour.  No bounds checks (the border bits are zero); 24-bit multiplies are full rate.
-        // The probe of the NEXT position is issued as soon as that position is known, before the
-        // stack bookkeeping of the current step, so the LDS round trip overlaps it.
-        uint32_t ny, nx, wi, bit, word;
-#define DFS_PROBE(PY, PX)                                                  \
-        do {                                                               \
-            ny = (PY) + (uint32_t)dy; nx = (PX) + (uint32_t)dx;            \
-            wi = __umul24(ny, wpr) + (nx >> 5);      /* idle lanes: a valid neighbour word too */ \
-            bit = qlane ? 1u << (nx & 31u) : 0u;     /* ... but no bit to test */                   \
-            word = bm[wi];                                                 \
-        } while (0)
-        DFS_PROBE(sy, sx);
-        while (have && cnt < MAX_CLUMP_SIZE) {
-            const bool avail = (word & bit) != 0u;
-            const unsigned long long m = __ballot(avail);
-            const uint32_t npush = (uint32_t)__popcll(m);
-            if (npush == 0) {
-                if (sp_l == 0 && sp_g > 0) {
-                    const uint32_t k = sp_g < DFS_SWN / 2u ? sp_g : DFS_SWN / 2u;
-                    for (uint32_t i = lane; i < k; i += 64u) sw[i] = gstack[sp_g - k + i];
-                    sp_g -= k;
-                    sp_l = k;
-                    __builtin_amdgcn_wave_barrier();
+        // current position (uniform)
+        uint32_t cq = UNI(sy * P + sx), cg = UNI(seed), cpk = UNI((sy << 16) | sx);
+        uint32_t q = cq + dq;
+        uint32_t word = bm[q >> 5];              // probe of the current position's neighbours
+        for (;;) {
+            const bool avail = ((word >> (q & 31u)) & 1u) != 0u;
+            const uint32_t m = (uint32_t)__ballot(avail);
+            if (m == 0u) {
+                // dead end: pop.  (refill the window from the spill area first when it ran dry)
+                if (sp_l == 0u) {
+                    if (sp_g == 0u) break;                       // stack empty: the piece is complete
+                    const unsigned long long r = dfs_refill(sw, gstack, sp_g);
+                    sp_l = UNI((uint32_t)r); sp_g = UNI((uint32_t)(r >> 32));
                 }
-                if (sp_l > 0) {
-                    const uint32_t e = sw[--sp_l];
-                    DFS_PROBE(e >> 16, e & 0xffffu);
-                } else {
-                    have = false;
-                }
-            } else {
-                // this step's neighbours: label them, clear their bits (before the next probe reads)
-                const uint32_t packed = (ny << 16) | nx;
-                const uint32_t gidx = gbase + __umul24(ny, ncols) + nx;
-                if (avail) atomicAnd(&bm[wi], ~bit);
-                const unsigned last = 63u - (unsigned)__clzll(m);
-                const uint32_t e = (uint32_t)__builtin_amdgcn_readlane((int)packed, (int)last);
-                DFS_PROBE(e >> 16, e & 0xffffu);             // the last one pushed is popped next
-                if (avail) lab[gidx] = FL;
-                if (sp_l + 8u > DFS_SWN) {
-                    for (uint32_t i = lane; i < DFS_SWN / 2u; i += 64u) gstack[sp_g + i] = sw[i];
-                    __builtin_amdgcn_wave_barrier();
-                    for (uint32_t i0 = 0; i0 + DFS_SWN / 2u < sp_l; i0 += 64u) {
-                        const uint32_t i = i0 + lane;
-                        uint32_t v = 0;
-                        if (i + DFS_SWN / 2u < sp_l) v = sw[i + DFS_SWN / 2u];
-                        __builtin_amdgcn_wave_barrier();
-                        if (i + DFS_SWN / 2u < sp_l) sw[i] = v;
-                    }
-                    sp_g += DFS_SWN / 2u;
-                    sp_l -= DFS_SWN / 2u;
-                    __builtin_amdgcn_wave_barrier();
-                }
-                if (avail && lane != last) sw[sp_l + (uint32_t)__popcll(m & lt)] = packed;
-                sp_l += npush - 1u;
-                cnt += npush;
-                __builtin_amdgcn_wave_barrier();
+                sp_l -= 1u;
+                const uint32_t e = UNI(sw[sp_l]);
+                cpk = e;
+                cq = __umul24(e >> 16, P) + (e & 0xffffu);
+                cg = gbase + __umul24(e >> 16, ncols) + (e & 0xffffu);
+                q = cq + dq;
+                word = bm[q >> 5];
+                continue;
+            }
+            // this step's neighbours: clear their bits first (the next probe must see them gone; a
+            // set bit is cleared by xor, two lanes may share a word), then move to the last one
+            // pushed -- it is the next pop -- and probe from there while the labels and the stack
+            // entries of this step are still being written
+            const uint32_t g = cg + dg, pk = cpk + dpk;
+            if (avail) atomicXor(&bm[q >> 5], 1u << (q & 31u));
+            const int last = 31 - __builtin_clz(m);
+            const uint32_t np = (uint32_t)__builtin_popcount(m);
+            cq = (uint32_t)__builtin_amdgcn_readlane((int)q, last);
+            cg = (uint32_t)__builtin_amdgcn_readlane((int)g, last);
+            cpk = (uint32_t)__builtin_amdgcn_readlane((int)pk, last);
+            q = cq + dq;
+            word = bm[q >> 5];
+            if (avail) {
+                lab[g] = FL;
+                // (the last one is written too, one slot above the new top: never read)
+                sw[sp_l + (uint32_t)__builtin_popcount(m & ltm)] = pk;
+            }
+            sp_l += np - 1u;
+            cnt += np;
+            if (cnt >= MAX_CLUMP_SIZE) break;
+            if (sp_l + 9u > DFS_SWN) {
+                const unsigned long long r = dfs_spill(sw, gstack, sp_l, sp_g);
+                sp_l = UNI((uint32_t)r); sp_g = UNI((uint32_t)(r >> 32));
             }
         }
-#undef DFS_PROBE
         if (lane == 0) {
             csize[seed] = cnt + 1u;
             if (cnt == 0 && singles) singles[atomicAdd(nsingles, 1u)] = seed;
         }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
@@ -624,13 +653,14 @@ __global__ __launch_bounds__(256) void k_big_order(const BigInfo *__restrict__ b
 #define DFS_ALLOC_SPINS 200000u
 
 // start granule of `need` contiguous free granules, or -1; wave-uniform, lane 0 talks to the mask
-__device__ __forceinline__ int dfs_pool_alloc(unsigned long long *mask, uint32_t need, uint32_t ngrans)
+__device__ __forceinline__ int dfs_pool_alloc(unsigned long long *mask, uint32_t need, uint32_t ngrans,
+                                              uint32_t max_spins)
 {
     int res = -1;
     if (lane_id() == 0) {
         const unsigned long long all = ngrans >= 64u ? ~0ull : ((1ull << ngrans) - 1ull);
         const unsigned long long ones = need >= 64u ? ~0ull : ((1ull << need) - 1ull);
-        for (uint32_t spin = 0; spin < DFS_ALLOC_SPINS; spin++) {
+        for (uint32_t spin = 0; spin < max_spins; spin++) {
             const unsigned long long m = __hip_atomic_load(mask, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             const unsigned long long fr = ~m & all;
             unsigned long long f = fr;          // bit j of f: granules j .. j + need - 1 are free
@@ -664,13 +694,29 @@ __global__ __launch_bounds__(DFS_WAVES * 64) void k_dfs_pool(        // blockDim
     const uint32_t nwalk = blockDim.x >> 6;
     uint32_t *sw = dfs_lds + 4u + w * DFS_SWN;
     uint32_t *pool = dfs_lds + 4u + nwalk * DFS_SWN;
-    if (threadIdx.x == 0) *mask = 0ull;
+    uint32_t *turn = dfs_lds + 2u;          // first-pass allocations go in walker order (largest first)
+    if (threadIdx.x == 0) { *mask = 0ull; *turn = 0u; }
     __syncthreads();                        // the only workgroup-wide rendezvous: walkers are independent
     const uint32_t nbig = counters[0];
     __builtin_amdgcn_s_setprio(3);          // lone latency-bound waves: win issue arbitration
     uint32_t idx = w * gridDim.x + blockIdx.x;
+    bool first = true;
     for (;;) {
-        if (idx >= nbig) break;
+        if (first) {
+            // walker w holds the workgroup's w-th largest component: it claims its bitmap before the
+            // smaller ones behind it (a free-for-all let them crowd the largest one out for
+            // milliseconds); one attempt each, whoever finds no room then retries at leisure
+            if (lane == 0) {
+                uint32_t spin = 0;
+                while (__hip_atomic_load(turn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) != w && ++spin < DFS_ALLOC_SPINS)
+                    __builtin_amdgcn_s_sleep(2);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (idx >= nbig) {
+            if (first && lane == 0) __hip_atomic_fetch_add(turn, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            break;
+        }
         const BigInfo B = big[order[idx]];
         const unsigned long long words = dfs_bitmap_words(B, ncols);
         int g0 = -1;
@@ -678,8 +724,15 @@ __global__ __launch_bounds__(DFS_WAVES * 64) void k_dfs_pool(        // blockDim
         const unsigned long long t0 = dbg ? wall_clock64() : 0ull;
         if (words <= (unsigned long long)pool_grans * DFS_GRAN_WORDS) {
             need = ((uint32_t)words + DFS_GRAN_WORDS - 1u) / DFS_GRAN_WORDS;
-            g0 = dfs_pool_alloc(mask, need, pool_grans);
+            g0 = dfs_pool_alloc(mask, need, pool_grans, first ? 1u : DFS_ALLOC_SPINS);
+            if (first) {
+                if (lane == 0) __hip_atomic_fetch_add(turn, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (g0 < 0) g0 = dfs_pool_alloc(mask, need, pool_grans, DFS_ALLOC_SPINS);
+            }
+        } else if (first && lane == 0) {
+            __hip_atomic_fetch_add(turn, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         }
+        first = false;
         const unsigned long long t1 = dbg ? wall_clock64() : 0ull;
         if (g0 >= 0) {
             dfs_split_lds(lab, B, pool + (uint32_t)g0 * DFS_GRAN_WORDS, sw, stackbuf, ncols, four, singles, nsingles, csize);

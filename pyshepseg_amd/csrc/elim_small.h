@@ -302,6 +302,7 @@ struct SmallCtl {
     uint32_t xcd_n[16];             // workgroups of this launch per XCD (counted at kernel start)
     uint32_t xcd_cnt[16];           // per-XCD arrival counters of the two-level grid barrier
     unsigned long long tphase[4];   // SHEPSEG_SMALL_TIMING: wall_clock64 ticks spent in control+find / link / apply
+    uint32_t plog[64][4];           // per pass: target, sources, find ticks, merge-phase ticks
 };
 
 struct SmallArgs {
@@ -330,6 +331,32 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
     return v;
 }
 
+// A source that merges links itself into its target's list at once (the find phase does not read
+// these lists): the list is kept in ascending source id by a lock-free sorted insert (head in
+// tfill[t], links in tlist[s]; inserts only, so a failed CAS simply retries), the first source to
+// arrive registers the target.
+__device__ __forceinline__ void link_source(const SmallArgs &a, SmallCnt *cnt, uint32_t s, uint32_t t)
+{
+    for (uint32_t tries = 0;; tries++) {
+        uint32_t prev = 0, cur = L2LOAD(&a.tfill[t]);
+        while (cur != 0 && cur < s) { prev = cur; cur = L2LOAD(&a.tlist[cur]); }
+        __hip_atomic_store(&a.tlist[s], cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // the link must have reached the coherent level before s becomes reachable: both are
+        // agent-scope atomics, so draining this lane's stores is enough (a release fence
+        // would also write back the XCD's whole L2, once per source)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        uint32_t *slot = prev ? &a.tlist[prev] : &a.tfill[t];
+        if (atomicCAS(slot, cur, s) == cur) {
+            if (prev == 0 && cur == 0) a.tgtlist[atomicAdd(&cnt->ntgt, 1u)] = t;   // list was empty
+            break;
+        }
+        if (tries > SMALL_SPIN_LIMIT) {
+            __hip_atomic_store(&a.ctl->fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+    }
+}
+
 // findMergeSegment (shepseg.py:1003-1063) for one source by one wavefront.  The source's pixel
 // list (chunk chain = the reference's list order) is gathered 64 entries at a time into this
 // wave's LDS slice; lanes then own (pixel k, neighbour position) pairs.  The reference keeps
@@ -337,7 +364,7 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
 // of (distSqr, k, position): one 64-bit wave reduction (distSqr >= +0, so its float32 bit
 // pattern orders like the value).
 __device__ __forceinline__ bool find_merge_wave(uint32_t s, uint32_t target, const SmallArgs &a,
-                                                uint32_t *wpix)
+                                                uint32_t *wpix, SmallCnt *cnt)
 {
     const unsigned lane = lane_id();
     const float nf = (float)target;
@@ -367,43 +394,57 @@ __device__ __forceinline__ bool find_merge_wave(uint32_t s, uint32_t target, con
             ci += take;
         }
         __builtin_amdgcn_wave_barrier();
+        // the (pixel, neighbour) pairs of these <= 64 list entries, four 64-pair steps at a time and
+        // stage by stage (neighbour id, its size, its sums), so that a round trip to memory is paid
+        // per stage and not per step: the pass loop is a chain of such round trips
         const uint32_t npairs = got * nq;
-        for (uint32_t q0 = 0; q0 < npairs; q0 += 64u) {
-            const uint32_t q = q0 + lane;
-            if (q < npairs) {
-                const uint32_t kk = q / nq, pos = q - kk * nq;
-                const uint32_t p = wpix[kk];
-                const uint32_t r = p / a.ncols, cc = p - r * a.ncols;
-                int di, dj;                  // neighbour `pos` in (ii outer, jj inner) order
-                if (a.four) {
-                    di = (pos == 0u) ? -1 : (pos == 3u) ? 1 : 0;
-                    dj = (pos == 1u) ? -1 : (pos == 2u) ? 1 : 0;
-                } else {
-                    const uint32_t e = pos < 4u ? pos : pos + 1u;      // skip the centre
-                    di = (int)(e / 3u) - 1;
-                    dj = (int)(e % 3u) - 1;
-                }
-                const int ii = (int)r + di, jj = (int)cc + dj;
-                if (ii >= 0 && jj >= 0 && ii < (int)a.nrows && jj < (int)a.ncols) {
-                    const uint32_t nbid = a.seg[(uint32_t)ii * a.ncols + (uint32_t)jj];
-                    if (nbid != s && nbid != 0u) {
-                        const uint32_t szn = a.segsz[nbid];
-                        if (szn > target) {
-                            const float sf = (float)szn;
-                            float d = 0.0f;
-                            for (int b = 0; b < a.nb; b++) {
-                                const float x = a.ssum[(size_t)s * a.nb + b] / nf;
-                                const float e2 = a.ssum[(size_t)nbid * a.nb + b] / sf;
-                                const float t = x - e2;
-                                const float t2 = t * t;
-                                d = d + t2;
-                            }
-                            const unsigned long long key =
-                                ((unsigned long long)__float_as_uint(d) << 32) |
-                                (unsigned long long)((kbase + kk) * 8u + pos);
-                            if (key < best) { best = key; bestnb = nbid; }
-                        }
+        for (uint32_t q0 = 0; q0 < npairs; q0 += 256u) {
+            uint32_t nbid[4], szn[4];
+#pragma unroll
+            for (uint32_t u = 0; u < 4u; u++) {
+                const uint32_t q = q0 + u * 64u + lane;
+                nbid[u] = 0u;
+                if (q < npairs) {
+                    const uint32_t kk = q / nq, pos = q - kk * nq;
+                    const uint32_t p = wpix[kk];
+                    const uint32_t r = p / a.ncols, cc = p - r * a.ncols;
+                    int di, dj;                  // neighbour `pos` in (ii outer, jj inner) order
+                    if (a.four) {
+                        di = (pos == 0u) ? -1 : (pos == 3u) ? 1 : 0;
+                        dj = (pos == 1u) ? -1 : (pos == 2u) ? 1 : 0;
+                    } else {
+                        const uint32_t e = pos < 4u ? pos : pos + 1u;      // skip the centre
+                        di = (int)(e / 3u) - 1;
+                        dj = (int)(e % 3u) - 1;
                     }
+                    const int ii = (int)r + di, jj = (int)cc + dj;
+                    if (ii >= 0 && jj >= 0 && ii < (int)a.nrows && jj < (int)a.ncols)
+                        nbid[u] = a.seg[(uint32_t)ii * a.ncols + (uint32_t)jj];
+                }
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 4u; u++) {
+                if (nbid[u] == s) nbid[u] = 0u;
+                szn[u] = nbid[u] ? a.segsz[nbid[u]] : 0u;
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 4u; u++) {
+                if (szn[u] > target) {
+                    const uint32_t q = q0 + u * 64u + lane;
+                    const uint32_t kk = q / nq, pos = q - kk * nq;
+                    const float sf = (float)szn[u];
+                    float d = 0.0f;
+                    for (int b = 0; b < a.nb; b++) {
+                        const float x = a.ssum[(size_t)s * a.nb + b] / nf;
+                        const float e2 = a.ssum[(size_t)nbid[u] * a.nb + b] / sf;
+                        const float t = x - e2;
+                        const float t2 = t * t;
+                        d = d + t2;
+                    }
+                    const unsigned long long key =
+                        ((unsigned long long)__float_as_uint(d) << 32) |
+                        (unsigned long long)((kbase + kk) * 8u + pos);
+                    if (key < best) { best = key; bestnb = nbid[u]; }
                 }
             }
         }
@@ -414,8 +455,10 @@ __device__ __forceinline__ bool find_merge_wave(uint32_t s, uint32_t target, con
     if (wmin == ~0ull) { if (lane == 0) a.mergeto[s] = 0; return false; }
     const float bd = __uint_as_float((uint32_t)(wmin >> 32));
     const bool merges = !((double)bd > a.thr2);
-    if (best == wmin)                        // unique: (k, position) differs between lanes
+    if (best == wmin) {                      // unique: (k, position) differs between lanes
         a.mergeto[s] = merges ? bestnb : 0u;
+        if (merges) link_source(a, cnt, s, bestnb);
+    }
     return merges;                           // wave-uniform: does s merge in this pass?
 }
 
@@ -428,7 +471,7 @@ __device__ __forceinline__ bool find_merge_wave(uint32_t s, uint32_t target, con
 // Returns how many of the sources merge in this pass.
 template <unsigned G>
 __device__ __forceinline__ uint32_t find_merge_packed(unsigned long long m, uint32_t b0, uint32_t target,
-                                                      const SmallArgs &a)
+                                                      const SmallArgs &a, SmallCnt *cnt)
 {
     const unsigned lane = lane_id(), grp = lane / G, gl = lane % G;
     const uint32_t nq = a.four ? 4u : 8u;
@@ -505,6 +548,7 @@ __device__ __forceinline__ uint32_t find_merge_packed(unsigned long long m, uint
                 const float bd = __uint_as_float((uint32_t)(gmin >> 32));
                 merged = !((double)bd > a.thr2);
                 a.mergeto[s] = merged ? bestnb : 0u;
+                if (merged) link_source(a, cnt, s, bestnb);
             }
         }
         merges += (uint32_t)__popcll(__ballot(merged));
@@ -597,67 +641,63 @@ __global__ __launch_bounds__(256) void k_small_loop(SmallArgs a)
                     gbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)gbase);
                     if (sz[u] == target) a.srclist[gbase + (uint32_t)__popcll(m & lanemask_lt())] = b0 + lane + 1u;
                     const uint32_t npairs = target * (a.four ? 4u : 8u);
-                    if (npairs <= 8u) wmerges += find_merge_packed<8>(m, b0, target, a);
-                    else if (npairs <= 16u) wmerges += find_merge_packed<16>(m, b0, target, a);
-                    else if (npairs <= 32u) wmerges += find_merge_packed<32>(m, b0, target, a);
+                    if (npairs <= 8u) wmerges += find_merge_packed<8>(m, b0, target, a, cnt);
+                    else if (npairs <= 16u) wmerges += find_merge_packed<16>(m, b0, target, a, cnt);
+                    else if (npairs <= 32u) wmerges += find_merge_packed<32>(m, b0, target, a, cnt);
                     else while (m) {
                         const uint32_t src = b0 + (uint32_t)__builtin_ctzll(m) + 1u;
                         m &= m - 1ull;
-                        wmerges += find_merge_wave(src, target, a, wpix[w]) ? 1u : 0u;
+                        wmerges += find_merge_wave(src, target, a, wpix[w], cnt) ? 1u : 0u;
                     }
                 }
             }
             if (wmerges && lane == 0) atomicAdd(&cnt->nmerge, wmerges);
         }
         if (!(a.bar2 ? small_grid_barrier2(ctl, bar) : small_grid_barrier(ctl, G, a.poll))) return;
-        if (gtid == 0) { const unsigned long long t = wall_clock64(); ctl->tphase[0] += t - tmark; tmark = t; }
         const uint32_t nsrc = cnt->nsrc;
+        if (gtid == 0) {
+            const unsigned long long t = wall_clock64();
+            const uint32_t pi = (uint32_t)ctl->tphase[3] & 63u;
+            ctl->plog[pi][0] = target; ctl->plog[pi][1] = nsrc; ctl->plog[pi][2] = (uint32_t)(t - tmark); ctl->plog[pi][3] = 0;
+            ctl->tphase[0] += t - tmark; tmark = t;
+        }
         if (cnt->nmerge == 0u) {
             // nobody merges (every candidate was further than maxSpectralDiff, or had no larger
             // neighbour): nothing to link, relabel or absorb, the size histogram is unchanged
             if (gtid == 0) ctl->tphase[3] += 1;
             continue;
         }
-        // ---- merge step 1: every source links itself into its target's list, kept in ascending
-        //      source id by a lock-free sorted insert (head in tfill[t], links in tlist[s]; inserts
-        //      only, so a failed CAS simply retries), the first one to arrive registers the
-        //      target; then the sources' pixels are relabelled (wave per source; doMerge
-        //      :1107-1109).  One phase instead of count / allocate / fill / rank. ----
-        for (uint32_t i = gtid; i < nsrc; i += gthreads) {
-            const uint32_t s = a.srclist[i];
-            const uint32_t t = a.mergeto[s];
-            if (t == 0) continue;
-            for (uint32_t tries = 0;; tries++) {
-                uint32_t prev = 0, cur = L2LOAD(&a.tfill[t]);
-                while (cur != 0 && cur < s) { prev = cur; cur = L2LOAD(&a.tlist[cur]); }
-                __hip_atomic_store(&a.tlist[s], cur, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                // the link must have reached the coherent level before s becomes reachable: both are
-                // agent-scope atomics, so draining this lane's stores is enough (a release fence
-                // would also write back the XCD's whole L2, once per source)
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                uint32_t *slot = prev ? &a.tlist[prev] : &a.tfill[t];
-                if (atomicCAS(slot, cur, s) == cur) {
-                    if (prev == 0 && cur == 0) a.tgtlist[atomicAdd(&cnt->ntgt, 1u)] = t;   // list was empty
-                    break;
+        // ---- merge phase.  The sources linked themselves to their targets during the find phase, so
+        //      one more barrier is all a pass needs: the sources' pixels are relabelled (doMerge
+        //      :1107-1109; a source's chunk chain ends at chtail[s] -- what the targets append behind
+        //      it meanwhile is not followed) while each target absorbs its sources in ascending id
+        //      (doMerge :1112-1123).  The two touch disjoint state. ----
+        if (target <= 16u) {                   // a thread per source: at most 16 pixels each
+            for (uint32_t i = gtid; i < nsrc; i += gthreads) {
+                const uint32_t s = a.srclist[i];
+                const uint32_t t = a.mergeto[s];
+                if (t == 0) continue;
+                const uint32_t last = a.chtail[s];
+                for (uint32_t c = s;; c = a.chnext[c]) {
+                    const uint32_t o = a.off[c], m = a.origsz[c];
+                    for (uint32_t j = 0; j < m; j++) a.seg[a.pix[o + j]] = t;
+                    if (c == last) break;
                 }
-                if (tries > SMALL_SPIN_LIMIT) {
-                    __hip_atomic_store(&ctl->fail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    break;
+            }
+        } else {
+            for (uint32_t i = gwave; i < nsrc; i += gwaves) {
+                const uint32_t s = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.srclist[i]);
+                const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.mergeto[s]);
+                if (t == 0) continue;
+                const uint32_t last = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.chtail[s]);
+                for (uint32_t c = s;; c = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.chnext[c])) {
+                    const uint32_t o = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.off[c]);
+                    const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.origsz[c]);
+                    for (uint32_t j = lane; j < m; j += 64u) a.seg[a.pix[o + j]] = t;
+                    if (c == last) break;
                 }
             }
         }
-        for (uint32_t i = gwave; i < nsrc; i += gwaves) {
-            const uint32_t s = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.srclist[i]);
-            const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.mergeto[s]);
-            if (t == 0) continue;
-            for (uint32_t c = s; c != 0; c = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.chnext[c])) {
-                const uint32_t o = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.off[c]);
-                const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.origsz[c]);
-                for (uint32_t j = lane; j < m; j += 64u) a.seg[a.pix[o + j]] = t;
-            }
-        }
-        if (!(a.bar2 ? small_grid_barrier2(ctl, bar) : small_grid_barrier(ctl, G, a.poll))) return;
-        if (gtid == 0) { const unsigned long long t = wall_clock64(); ctl->tphase[1] += t - tmark; tmark = t; }
         const uint32_t ntgt = cnt->ntgt;
         // ---- merge step 2: each target absorbs its sources in ascending id (doMerge :1112-1123)
         //      size-histogram updates go through LDS, numElim through a wave reduction ----
@@ -678,8 +718,8 @@ __global__ __launch_bounds__(256) void k_small_loop(SmallArgs a)
                 a.segsz[s] = 0;
                 a.chnext[tail] = s;
                 tail = a.chtail[s];
-                a.mergeto[s] = 0;
-                n++;
+                n++;                                 // (mergeto[s] stays: the relabel beside us reads it,
+                                                     //  and every pass rewrites it for its own sources)
                 s = nxt;
             }
             a.segsz[t] = sz;
@@ -700,7 +740,11 @@ __global__ __launch_bounds__(256) void k_small_loop(SmallArgs a)
         if (threadIdx.x < a.min_seg && lhist[threadIdx.x] != 0u)
             atomicAdd(&a.hist[threadIdx.x], lhist[threadIdx.x]);          // wrapping add of the delta
         if (!(a.bar2 ? small_grid_barrier2(ctl, bar) : small_grid_barrier(ctl, G, a.poll))) return;
-        if (gtid == 0) { const unsigned long long t = wall_clock64(); ctl->tphase[2] += t - tmark; tmark = t; ctl->tphase[3] += 1; }
+        if (gtid == 0) {
+            const unsigned long long t = wall_clock64();
+            ctl->plog[(uint32_t)ctl->tphase[3] & 63u][3] = (uint32_t)(t - tmark);
+            ctl->tphase[1] += t - tmark; tmark = t; ctl->tphase[3] += 1;
+        }
     }
 }
 
@@ -835,9 +879,12 @@ static int run_eliminate_small(shp_ctx *ctx, const void *d_img, int dtype, int n
         SHP_FAIL(ctx, SHP_ERR_STATE, "small-segment loop: grid barrier timed out (fail=%u done=%u)",
                  pin->fail, pin->done);
     if (getenv("SHEPSEG_SMALL_TIMING"))
-        fprintf(stderr, "small loop: passes %llu  find %.2f ms  link+relabel %.2f ms  apply %.2f ms (S=%u)\n",
-                pin->tphase[3], pin->tphase[0] / 1e5, pin->tphase[1] / 1e5, pin->tphase[2] / 1e5, S);
+        fprintf(stderr, "small loop: passes %llu  find+link %.2f ms  relabel+apply %.2f ms (S=%u)\n",
+                pin->tphase[3], pin->tphase[0] / 1e5, pin->tphase[1] / 1e5, S);
     if (getenv("SHEPSEG_SMALL_TIMING")) {
+        for (unsigned i = 0; i < 64u && i < pin->tphase[3]; i++)
+            fprintf(stderr, "  pass %u: target %u, %u sources, find %.1f us, merge %.1f us\n", i, pin->plog[i][0],
+                    pin->plog[i][1], pin->plog[i][2] / 100.0, pin->plog[i][3] / 100.0);
         fprintf(stderr, "  workgroups per XCD:");
         for (int i = 0; i < 16; i++) fprintf(stderr, " %u", pin->xcd_n[i]);
         fprintf(stderr, "\n");

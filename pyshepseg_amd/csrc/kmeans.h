@@ -2,9 +2,12 @@
 //
 // assign replaces shepseg.applySpectralClusters (shepseg.py:317-361) + sklearn
 // KMeans.predict:  label = argmin_j ( |c_j|^2 - 2 x.c_j ), float64, first minimum wins,
-// evaluated as a band-ordered fma chain (identical to oracle/shepseg_oracle.c so the result
-// is bit-exact by construction; SURVEY N13: any float64 evaluation reproduces sklearn on
-// integer imagery, float32 does not).
+// evaluated in the order of sklearn 0.24.2's chunked dgemm onto the pre-filled squared norms
+// (oracle/shepseg_oracle.c orc_dist / orc_sqnorm, pinned by oracle/refgen/fit_probe.py): the
+// dot product accumulated from zero by fma in band order with the operand -2c, added to |c|^2
+// (one band: fma(x, -2c, |c|^2)); |c|^2 in numpy einsum's two-lane order.  SURVEY N13: any
+// float64 evaluation reproduces sklearn on integer imagery with separated centres, float32 does
+// not; on exact ties only this order does.
 //
 // Roofline: 2*nB*k flop/px in FP64 (720 at 6x60).  gfx950 FP64 vector and matrix peaks are
 // equal (78.6 TFLOP/s), so the contraction runs on v_fma_f64 with the centroid operand in
@@ -15,6 +18,29 @@
 #include <chrono>
 
 #define ASSIGN_PPT 4   // pixels per thread (amortises the scalar centroid loads)
+
+// |c|^2 as numpy 1.26 evaluates row_norms(C, squared=True) = einsum('ij,ij->i') on x86-64 (baseline
+// SSE2, no fma): two lanes over the even / odd elements, products and sums rounded separately,
+// whole blocks of 8 elements taken vector 3, 2, 1, 0, the rest in order; lanes added at the end.
+__host__ __device__ inline double kmeans_sqnorm(const double *c, int nb)
+{
+    double a0 = 0.0, a1 = 0.0;
+    int i = 0, count = nb;
+    for (; count >= 8; count -= 8, i += 8) {
+        double t0, t1, p;
+        p = c[i + 6] * c[i + 6]; t0 = p + a0; p = c[i + 7] * c[i + 7]; t1 = p + a1;
+        p = c[i + 4] * c[i + 4]; t0 = p + t0; p = c[i + 5] * c[i + 5]; t1 = p + t1;
+        p = c[i + 2] * c[i + 2]; t0 = p + t0; p = c[i + 3] * c[i + 3]; t1 = p + t1;
+        p = c[i + 0] * c[i + 0]; a0 = p + t0; p = c[i + 1] * c[i + 1]; a1 = p + t1;
+    }
+    for (; count > 0; count -= 2, i += 2) {
+        const double p = c[i] * c[i];
+        const double q = (count > 1) ? c[i + 1] * c[i + 1] : 0.0;
+        a0 = p + a0;
+        a1 = q + a1;
+    }
+    return a0 + a1;
+}
 
 // RECT: the pixels are a rectangle of a band-planar raster (x0, y0, w, h; `pitch` pixels per raster
 // row; `npix` = pixels per band of the whole raster) and the clusters go to the same position of a
@@ -80,8 +106,9 @@ __global__ __launch_bounds__(256) void k_assign(
         for (int j = 0; j < k; j++) {
             double d[ASSIGN_PPT];
             const double cn = cnorm[j];
+            const bool seeded = nb == 1;             // one band: fma(x, -2c, |c|^2); else dot from zero
 #pragma unroll
-            for (int q = 0; q < ASSIGN_PPT; q++) d[q] = cn;
+            for (int q = 0; q < ASSIGN_PPT; q++) d[q] = seeded ? cn : 0.0;
             if (NB > 0) {
 #pragma unroll
                 for (int b = 0; b < NB; b++) {
@@ -98,6 +125,10 @@ __global__ __launch_bounds__(256) void k_assign(
                         d[q] = __builtin_fma(xv, c, d[q]);
                     }
                 }
+            }
+            if (!seeded) {
+#pragma unroll
+                for (int q = 0; q < ASSIGN_PPT; q++) d[q] = cn + d[q];
             }
             // first minimum wins: the index moves only on a strict improvement, the value is a min
 #pragma unroll
@@ -128,13 +159,8 @@ static inline void kmeans_prepare_host(const double *centres, int k, int nb, dou
                                        double *cnorm)
 {
     for (int j = 0; j < k; j++) {
-        double s = 0.0;
-        for (int b = 0; b < nb; b++) {
-            const double c = centres[j * nb + b];
-            s = __builtin_fma(c, c, s);
-            m2c[j * nb + b] = -2.0 * c;
-        }
-        cnorm[j] = s;
+        for (int b = 0; b < nb; b++) m2c[j * nb + b] = -2.0 * centres[j * nb + b];
+        cnorm[j] = kmeans_sqnorm(centres + (size_t)j * nb, nb);
     }
 }
 
@@ -249,12 +275,16 @@ __global__ __launch_bounds__(256) void k_fit_assign(const double *__restrict__ X
             const double cn = cnorm[j];
             double d[FIT_RPT];
 #pragma unroll
-            for (int r = 0; r < FIT_RPT; r++) d[r] = cn;
+            for (int r = 0; r < FIT_RPT; r++) d[r] = (NB == 1) ? cn : 0.0;       // (see k_assign)
 #pragma unroll
             for (int b = 0; b < NB; b++) {
                 const double c = m2c[j * NB + b];
 #pragma unroll
                 for (int r = 0; r < FIT_RPT; r++) d[r] = __builtin_fma(x[r][b], c, d[r]);
+            }
+            if (NB != 1) {
+#pragma unroll
+                for (int r = 0; r < FIT_RPT; r++) d[r] = cn + d[r];
             }
 #pragma unroll
             for (int r = 0; r < FIT_RPT; r++) {
@@ -280,8 +310,9 @@ __global__ __launch_bounds__(256) void k_fit_assign(const double *__restrict__ X
             int best = 0;
             double bestd = 0.0;
             for (int j = 0; j < k; j++) {
-                double d = cnorm[j];
+                double d = nb == 1 ? cnorm[j] : 0.0;
                 for (int b = 0; b < nb; b++) d = __builtin_fma(X[(size_t)i * nb + b], m2c[j * nb + b], d);
+                if (nb != 1) d = cnorm[j] + d;
                 if (j == 0 || d < bestd) { bestd = d; best = j; }
             }
             lab[i] = best;
@@ -505,13 +536,8 @@ __global__ __launch_bounds__(256) void k_fit_update(const double *__restrict__ p
     }
     for (int t = threadIdx.x; t < kn; t += 256) C[t] = S[t];
     for (int j = threadIdx.x; j < k; j += 256) {
-        double sn = 0.0;
-        for (int b = 0; b < nb; b++) {
-            const double c = S[j * nb + b];
-            sn = __builtin_fma(c, c, sn);
-            m2c[j * nb + b] = -2.0 * c;
-        }
-        cnorm[j] = sn;
+        for (int b = 0; b < nb; b++) m2c[j * nb + b] = -2.0 * S[j * nb + b];
+        cnorm[j] = kmeans_sqnorm(&S[j * nb], nb);
     }
 }
 

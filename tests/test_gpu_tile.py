@@ -119,8 +119,10 @@ def test_c1_known_counts(shepseg, oracle):
     assert abs(float(r.maxSpectralDiff) - 809.8255004882812) < 1e-9
 
 
-def test_kmeans_fit_device(golden, shepseg, oracle):
-    g = golden('kmeans_fit_synth512')
+@pytest.mark.parametrize('name', ['kmeans_fit_synth512', 'kmeans_fit_c1', 'kmeans_fit_10band',
+                                  'kmeans_fit_nulls'])
+def test_kmeans_fit_device(name, golden, shepseg, oracle):
+    g = golden(name)
     km = shepseg._fit(g['sample'], g['init'])
     assert km.n_iter_ == int(g['n_iter'])
     pairs = set(zip(km.labels_.tolist(), g['labels'].tolist()))
@@ -131,6 +133,15 @@ def test_kmeans_fit_device(golden, shepseg, oracle):
     # run-to-run determinism of the device reduction
     km2 = shepseg._fit(g['sample'], g['init'])
     assert np.array_equal(km.cluster_centers_, km2.cluster_centers_)
+
+
+def test_predict_exact_ties_device(golden, shepseg):
+    """exact ties between two centres: the device E-step follows the reference's evaluation order"""
+    g = golden('kmeans_predict_ties')
+    for tag in 'abcd':
+        km = shepseg.KMeansModel(g[tag + '_centres'])
+        got = shepseg.applySpectralClusters(km, g[tag + '_img'], None)
+        assert np.array_equal(got, g[tag + '_clusters']), tag
 
 
 def test_edge_shapes(shepseg, oracle):

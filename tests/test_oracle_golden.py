@@ -61,8 +61,14 @@ def test_clump_split_fixture_really_splits(golden):
     assert (sizes > 10000).sum() >= 1
 
 
-def test_oracle_kmeans_fit(golden, oracle):
-    g = golden('kmeans_fit_synth512')
+FIT_FIXTURES = ['kmeans_fit_synth512', 'kmeans_fit_c1', 'kmeans_fit_10band', 'kmeans_fit_nulls']
+
+
+@pytest.mark.parametrize('name', FIT_FIXTURES)
+def test_oracle_kmeans_fit(name, golden, oracle):
+    """sklearn 0.24.2 KMeans(init=diagonal, n_init=1).fit on reference-generated samples: same
+    iteration count, same partition (cluster indices may be permuted), centres 1e-8"""
+    g = golden(name)
     centres, labels, nit = oracle.kmeans_fit(g['sample'].astype(np.float64),
                                              g['init'].astype(np.float64))
     assert nit == int(g['n_iter'])
@@ -71,6 +77,16 @@ def test_oracle_kmeans_fit(golden, oracle):
     a = centres[np.lexsort(centres.T[::-1])]
     b = g['centres'][np.lexsort(g['centres'].T[::-1])]
     assert np.allclose(a, b, rtol=0, atol=1e-8)
+
+
+def test_oracle_predict_exact_ties(golden, oracle):
+    """KMeans.predict where many pixels are exactly equidistant from two centres (few grey
+    levels, one duplicated centre): the label is decided by the evaluation order of the
+    reference's E-step, which the oracle restates (orc_dist / orc_sqnorm)."""
+    g = golden('kmeans_predict_ties')
+    for tag in 'abcd':
+        got = oracle.kmeans_assign(g[tag + '_img'], g[tag + '_centres'])
+        assert np.array_equal(got, g[tag + '_clusters']), tag
 
 
 def test_synthimg_checksums(oracle):
