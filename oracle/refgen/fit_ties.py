@@ -159,7 +159,7 @@ def main():
             ties = exact_tie_samples(xs, l2, prev[0])
             reloc = relocation_tie(xs, prev[1], exact_centres(xs, l2, k))
         kind = 'EXACT TIES (%d tied samples, e.g. sample %d between clusters %d/%d)' % (
-            len(ties), ties[0][0], ties[0][1], ties[0][2]) if ties else 'NO EXACT TIE FOUND'
+            len(ties), ties[0][0], ties[0][1], ties[0][2]) if ties else 'no E-step tie'
         if reloc:
             kind += ' + EXACT TIE AMONG THE FARTHEST SAMPLES OF THE EMPTY-CLUSTER RELOCATION'
         if not ties and not reloc:
