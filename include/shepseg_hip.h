@@ -208,6 +208,18 @@ int shp_stitch_chain_dev(shp_ctx *ctx, const uint32_t *d_tile, int ys, int xs, i
 int shp_histogram_dev(shp_ctx *ctx, const uint32_t *d_raster, int64_t npix, int64_t ncols,
                       uint32_t max_seg_id, uint32_t *hist_out_host);
 
+/* ---- the tables of the elimination stage, exported ------------------------------------------------
+ * shepseg.makeSegmentLocations (shepseg.py:880-915; RowColArray :816-870) as a CSR: segment s's pixels
+ * are pix_out[offsets_out[s] .. offsets_out[s + 1]) (linear indices row * ncols + col, raster
+ * order), s = 0 .. max_seg_id; offsets_out has max_seg_id + 2 entries, pix_out nrows * ncols.
+ * (Entry 0 lists the null pixels; the reference's dict has no key 0.) */
+int shp_segment_locations(shp_ctx *ctx, const uint32_t *seg, int nrows, int ncols, uint32_t max_seg_id,
+                          uint32_t *offsets_out, uint32_t *pix_out);
+/* shepseg.buildSegmentSpectra (shepseg.py:780-813): float32 per-band sums of every segment's pixels
+ * accumulated in raster order, spect_sum_out[(max_seg_id + 1) * nbands], row 0 = the null pixels */
+int shp_build_segment_spectra(shp_ctx *ctx, const uint32_t *seg, const void *img, int dtype, int nbands,
+                              int nrows, int ncols, uint32_t max_seg_id, float *spect_sum_out);
+
 /* ---- per-segment statistics ("tilingstats") ----------------------------------------------------
  * replaces tilingstats.accumulateSegDict / calcStatsForCompletedSegs / SegmentStats / RatPage
  * (tilingstats.py:466-617, :866-1008, :1949-2045) for one image band against a label raster.

@@ -112,6 +112,26 @@ def eliminate_small_segments(seg, img, max_seg_id, min_seg_size, max_spectral_di
                                                   int(four_connected), ctypes.c_uint32(min_seg_id)))
 
 
+def build_segment_spectra(seg, img, max_seg_id):
+    """shepseg.buildSegmentSpectra: float32 (max_seg_id + 1, nBands)"""
+    img, dt = _img(img)
+    nb, nr, nc = img.shape
+    seg = np.ascontiguousarray(seg, dtype=np.uint32)
+    out = np.zeros((int(max_seg_id) + 1, nb), dtype=np.float32)
+    lib().orc_build_segment_spectra(_p(seg), _p(img), dt, nb, nr, nc, ctypes.c_uint32(int(max_seg_id)), _p(out))
+    return out
+
+
+def segment_locations(seg, max_seg_id):
+    """shepseg.makeSegmentLocations as (offsets (max_seg_id + 2,), rowcols (N, 2))"""
+    seg = np.ascontiguousarray(seg, dtype=np.uint32)
+    nr, nc = seg.shape
+    off = np.zeros(int(max_seg_id) + 2, dtype=np.uint32)
+    rc = np.zeros((int((seg != 0).sum()), 2), dtype=np.uint32)
+    lib().orc_segment_locations(_p(seg), nr, nc, ctypes.c_uint32(int(max_seg_id)), _p(off), _p(rc))
+    return off, rc
+
+
 def segment_tile(img, centres, min_seg_size, max_spectral_diff, null_val=None, four_connected=True):
     img, dt = _img(img)
     nb, nr, nc = img.shape

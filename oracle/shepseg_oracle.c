@@ -344,6 +344,36 @@ static float *build_segment_spectra(const uint32_t *seg, const void *img, int dt
     return ss;
 }
 
+/* buildSegmentSpectra as a test entry point: spect_sum_out has (max_seg_id + 1) * nbands floats */
+ORC_API void orc_build_segment_spectra(const uint32_t *seg, const void *img, int dtype, int nbands,
+                                       int nrows, int ncols, uint32_t max_seg_id, float *spect_sum_out)
+{
+    float *ss = build_segment_spectra(seg, img, dtype, nbands, (size_t)nrows * ncols, max_seg_id);
+    memcpy(spect_sum_out, ss, sizeof(float) * ((size_t)max_seg_id + 1) * nbands);
+    free(ss);
+}
+
+/* makeSegmentLocations (shepseg.py:880-915) as a CSR: off_out[s] .. off_out[s + 1] are segment s's
+ * entries of rc_out ((row, col) pairs, raster order), s = 0 .. max_seg_id; the null segment has
+ * none (the reference's dict holds ids >= MINSEGID only, and skips null pixels) */
+ORC_API void orc_segment_locations(const uint32_t *seg, int nrows, int ncols, uint32_t max_seg_id,
+                                   uint32_t *off_out /* max_seg_id + 2 */, uint32_t *rc_out)
+{
+    size_t npix = (size_t)nrows * ncols;
+    uint32_t *fill = (uint32_t *)calloc((size_t)max_seg_id + 2, sizeof(uint32_t));
+    memset(off_out, 0, sizeof(uint32_t) * ((size_t)max_seg_id + 2));
+    for (size_t p = 0; p < npix; p++) if (seg[p] != 0) off_out[seg[p] + 1]++;
+    for (uint32_t s = 1; s <= max_seg_id + 1; s++) off_out[s] += off_out[s - 1];
+    for (int r = 0; r < nrows; r++)
+        for (int c = 0; c < ncols; c++) {
+            uint32_t s = seg[(size_t)r * ncols + c];
+            if (s == 0) continue;
+            uint32_t at = off_out[s] + fill[s]++;
+            rc_out[2 * (size_t)at] = (uint32_t)r; rc_out[2 * (size_t)at + 1] = (uint32_t)c;
+        }
+    free(fill);
+}
+
 typedef struct { uint32_t n; uint32_t *rc; } seg_loc_t;   /* RowColArray shepseg.py:816-870 */
 
 /* findMergeSegment: shepseg.py:1003-1063 (N6: float32 means / float32 sequential

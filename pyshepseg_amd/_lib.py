@@ -53,6 +53,9 @@ _SIGS = {
     'shp_eliminate_small': (_c.c_int, [_vp, _vp, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
                                        _c.c_int, _c.c_double, _vp, _c.POINTER(_c.c_uint32),
                                        _c.POINTER(_c.c_int64)]),
+    'shp_segment_locations': (_c.c_int, [_vp, _vp, _c.c_int, _c.c_int, _c.c_uint32, _vp, _vp]),
+    'shp_build_segment_spectra': (_c.c_int, [_vp, _vp, _vp, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
+                                             _c.c_uint32, _vp]),
     'shp_segment_tile': (_c.c_int, [_vp, _vp, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _vp,
                                     _c.c_int, _c.c_int, _c.c_int64, _c.c_int, _c.c_int,
                                     _c.c_double, _vp, _c.POINTER(_c.c_uint32),

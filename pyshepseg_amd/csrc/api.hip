@@ -310,6 +310,48 @@ API int shp_eliminate_small(shp_ctx *ctx, const void *img, int dtype, int nbands
     return 0;
 }
 
+API int shp_segment_locations(shp_ctx *ctx, const uint32_t *seg, int nrows, int ncols, uint32_t max_seg_id,
+                              uint32_t *offsets_out, uint32_t *pix_out)
+{
+    CHK(enter(ctx));
+    if (!seg || !offsets_out || !pix_out || nrows < 0 || ncols < 0 ||
+        (uint64_t)nrows * (uint64_t)ncols >= 0x7fffffffull)
+        SHP_FAIL(ctx, SHP_ERR_ARG, "bad argument");
+    const uint32_t n = (uint32_t)nrows * (uint32_t)ncols;
+    memset(offsets_out, 0, ((size_t)max_seg_id + 2) * 4);
+    if (n == 0) return 0;
+    CHK(check_seg_ids(ctx, seg, n, max_seg_id));
+    CHK(buf_ensure(ctx, ctx->seg, (size_t)n * 4));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->seg.p, seg, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    uint32_t *pix = nullptr;
+    CHK(run_segment_tables(ctx, bp<uint32_t>(ctx->seg), n, (uint32_t)ncols, max_seg_id, nullptr, 0, 0, &pix));
+    HIPCHK(ctx, hipMemcpyAsync(offsets_out, ctx->off.p, ((size_t)max_seg_id + 2) * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(pix_out, pix, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
+API int shp_build_segment_spectra(shp_ctx *ctx, const uint32_t *seg, const void *img, int dtype, int nbands,
+                                  int nrows, int ncols, uint32_t max_seg_id, float *spect_sum_out)
+{
+    CHK(enter(ctx));
+    CHK(check_img_args(ctx, img, dtype, nbands, nrows, ncols));
+    if (!seg || !spect_sum_out) SHP_FAIL(ctx, SHP_ERR_ARG, "NULL argument");
+    const uint32_t n = (uint32_t)nrows * (uint32_t)ncols;
+    const size_t nout = ((size_t)max_seg_id + 1) * nbands;
+    memset(spect_sum_out, 0, nout * 4);
+    if (n == 0) return 0;
+    CHK(check_seg_ids(ctx, seg, n, max_seg_id));
+    CHK(upload_img(ctx, img, dtype, nbands, n));
+    CHK(buf_ensure(ctx, ctx->seg, (size_t)n * 4));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->seg.p, seg, (size_t)n * 4, hipMemcpyHostToDevice, ctx->stream));
+    uint32_t *pix = nullptr;
+    CHK(run_segment_tables(ctx, bp<uint32_t>(ctx->seg), n, (uint32_t)ncols, max_seg_id, ctx->img.p, dtype, nbands, &pix));
+    HIPCHK(ctx, hipMemcpyAsync(spect_sum_out, ctx->ssum.p, nout * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
 // Device-resident fused pipeline on ctx->img -> ctx->seg.  Records stage events 1..5.
 static int segment_device(shp_ctx *ctx, const void *d_img, uint32_t *d_seg, int dtype, int nb,
                           uint32_t nrows, uint32_t ncols,

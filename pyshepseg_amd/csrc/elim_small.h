@@ -63,10 +63,10 @@ template <int DT, int BG>
 __global__ __launch_bounds__(256) void k_spectra_small(
     const void *__restrict__ img, int nb, uint32_t n, const uint32_t *__restrict__ pix,
     const uint32_t *__restrict__ off, const uint32_t *__restrict__ segsz, float *__restrict__ ssum,
-    uint32_t S, const ImgGeom g)
+    uint32_t S, const ImgGeom g, uint32_t first)
 {
     constexpr bool WIDE = DT == SHP_I32 || DT == SHP_U32;
-    const uint32_t s = blockIdx.x * 256u + threadIdx.x + 1u;
+    const uint32_t s = blockIdx.x * 256u + threadIdx.x + first;     // first = 1, or 0 to include the null segment
     if (s > S) return;
     const uint32_t m = segsz[s];
     if (m == 0u || m > 64u) return;
@@ -93,7 +93,7 @@ __global__ __launch_bounds__(256) void k_spectra_small(
 
 // list[0] = number of segments with > 64 pixels (zeroed by k_small_init), ids from list[16]
 __global__ __launch_bounds__(256) void k_big_seg_list(const uint32_t *__restrict__ segsz, uint32_t S,
-                                                      uint32_t *list)
+                                                      uint32_t *list, uint32_t first)
 {
     __shared__ uint32_t s_buf[4096];
     __shared__ uint32_t s_cnt, s_base;
@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void k_big_seg_list(const uint32_t *__restrict
     __syncthreads();
     const unsigned lane = lane_id();
     for (uint32_t it = 0; it < 16u; it++) {
-        const uint32_t s = blockIdx.x * 4096u + it * 256u + threadIdx.x + 1u;
+        const uint32_t s = blockIdx.x * 4096u + it * 256u + threadIdx.x + first;
         const bool big = s <= S && segsz[s] > 64u;
         const unsigned long long mb = __ballot(big);
         if (mb != 0ull) {
@@ -228,6 +228,37 @@ __global__ __launch_bounds__(256) void k_spectra_big(
             if (lane < (unsigned)bg) ssum[(size_t)bs * nb + b0 + lane] = acc;
         }
     }
+}
+
+// float32 sums of segments first .. S (buildSegmentSpectra): the ids above 64 pixels are compacted into
+// biglist (its counter word biglist[0] must be zero), then the two kernels above
+static int launch_spectra(shp_ctx *ctx, const void *d_img, int dtype, int nb, uint32_t n, const uint32_t *pix,
+                          const uint32_t *off, const uint32_t *segsz, float *ssum, uint32_t S,
+                          const ImgGeom &geom, uint32_t *biglist, uint32_t first)
+{
+    hipStream_t st = ctx->stream;
+    const unsigned gs = grid_for((size_t)S + 1, 256);
+    hipLaunchKernelGGL(k_big_seg_list, dim3(grid_for((size_t)S + 1, 4096)), dim3(256), 0, st, segsz, S, biglist, first);
+    KCHK(ctx);
+#define SPECTRA_LAUNCH(BGN)                                                                           \
+    DISPATCH_DTYPE(dtype,                                                                             \
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_spectra_small<DT, BGN>), dim3(gs), dim3(256), 0, st, d_img, \
+                           nb, n, pix, off, segsz, ssum, S, geom, first);                             \
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_spectra_big<DT, BGN>), dim3(SPECTRA_GRID), dim3(256), 0, st, \
+                           d_img, nb, n, pix, off, segsz, ssum, biglist, geom))
+    switch (nb >= SPECTRA_BG ? SPECTRA_BG : nb) {
+    case 1: SPECTRA_LAUNCH(1); break;
+    case 2: SPECTRA_LAUNCH(2); break;
+    case 3: SPECTRA_LAUNCH(3); break;
+    case 4: SPECTRA_LAUNCH(4); break;
+    case 5: SPECTRA_LAUNCH(5); break;
+    case 6: SPECTRA_LAUNCH(6); break;
+    case 7: SPECTRA_LAUNCH(7); break;
+    default: SPECTRA_LAUNCH(8); break;
+    }
+#undef SPECTRA_LAUNCH
+    KCHK(ctx);
+    return 0;
 }
 
 // per-segment state of the pass loop; sizes come from `src` (segsz itself, or origsz when the
@@ -816,27 +847,7 @@ static int run_eliminate_small(shp_ctx *ctx, const void *d_img, int dtype, int n
                        mergeto, tcount, tfill, hist, S, min_seg, tlist, (uint32_t *)ctl,
                        (uint32_t)(sizeof(SmallCtl) / 4), off, off_boff); KCHK(ctx);
     ps = prof_begin(ctx, PROF_SPECTRA);
-    uint32_t *biglist = tlist;          // free until the pass loop starts
-    hipLaunchKernelGGL(k_big_seg_list, dim3(grid_for((size_t)S, 4096)), dim3(256), 0, st, segsz, S, biglist);
-    KCHK(ctx);
-#define SPECTRA_LAUNCH(BGN)                                                                           \
-    DISPATCH_DTYPE(dtype,                                                                             \
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_spectra_small<DT, BGN>), dim3(gs), dim3(256), 0, st, d_img, \
-                           nb, n, pix, off, segsz, ssum, S, geom);                                    \
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_spectra_big<DT, BGN>), dim3(SPECTRA_GRID), dim3(256), 0, st, \
-                           d_img, nb, n, pix, off, segsz, ssum, biglist, geom))
-    switch (nb >= SPECTRA_BG ? SPECTRA_BG : nb) {
-    case 1: SPECTRA_LAUNCH(1); break;
-    case 2: SPECTRA_LAUNCH(2); break;
-    case 3: SPECTRA_LAUNCH(3); break;
-    case 4: SPECTRA_LAUNCH(4); break;
-    case 5: SPECTRA_LAUNCH(5); break;
-    case 6: SPECTRA_LAUNCH(6); break;
-    case 7: SPECTRA_LAUNCH(7); break;
-    default: SPECTRA_LAUNCH(8); break;
-    }
-#undef SPECTRA_LAUNCH
-    KCHK(ctx);
+    CHK(launch_spectra(ctx, d_img, dtype, nb, n, pix, off, segsz, ssum, S, geom, tlist /* free until the pass loop */, 1u));
     prof_end(ctx, ps);
 
     const double thr2 = max_spectral_diff * max_spectral_diff;       // float64 square (N8)
@@ -893,5 +904,35 @@ static int run_eliminate_small(shp_ctx *ctx, const void *d_img, int dtype, int n
     uint32_t new_max = 0;
     CHK(run_relabel(ctx, d_seg, n, segsz, S, &new_max));
     *max_id = new_max;
+    return 0;
+}
+
+// makeSegmentLocations / buildSegmentSpectra on the device structures of the elimination stage: the
+// CSR of pixels by segment (csr.h) with its offsets, and the ordered float32 sums.  d_seg: n labels
+// 0..S on the device; on return ctx->off holds S + 2 offsets (exclusive scan of the sizes), *pix_out
+// the n pixel indices, ctx->ssum (when d_img) the (S + 1) * nb sums, row 0 = the null segment's.
+static int run_segment_tables(shp_ctx *ctx, const uint32_t *d_seg, uint32_t n, uint32_t ncols, uint32_t S,
+                              const void *d_img, int dtype, int nb, uint32_t **pix_out)
+{
+    const size_t ns = (size_t)S + 2;
+    CHK(buf_ensure(ctx, ctx->segsz, (ns + 1) * 4));
+    CHK(buf_ensure(ctx, ctx->off, (ns + 1) * 4 + 16));
+    CHK(buf_ensure(ctx, ctx->tlist, (ns + 32) * 4));
+    CHK(buf_ensure(ctx, ctx->scan_tmp, scan_tmp_bytes(ns > n ? ns : n)));
+    uint32_t *segsz = bp<uint32_t>(ctx->segsz), *off = bp<uint32_t>(ctx->off);
+    CHK(run_seg_size(ctx, d_seg, n, S + 1u, segsz));                 // (one entry past S: zero)
+    uint32_t *pix = nullptr;
+    CHK(build_segment_csr(ctx, d_seg, n, S, &pix));
+    ArrFn szf{segsz};
+    CHK(scan_exclusive(ctx, szf, S + 2u, off, nullptr, bp<uint32_t>(ctx->scan_tmp)));
+    if (d_img) {
+        CHK(buf_ensure(ctx, ctx->ssum, ns * nb * 4));
+        uint32_t *biglist = bp<uint32_t>(ctx->tlist);
+        HIPCHK(ctx, hipMemsetAsync(biglist, 0, 64, ctx->stream));
+        HIPCHK(ctx, hipMemsetAsync(ctx->ssum.p, 0, ns * nb * 4, ctx->stream));      // ids without pixels: 0
+        CHK(launch_spectra(ctx, d_img, dtype, nb, n, pix, off, segsz, bp<float>(ctx->ssum), S,
+                           geom_compact(n, ncols), biglist, 0u));
+    }
+    *pix_out = pix;
     return 0;
 }

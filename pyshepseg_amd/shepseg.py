@@ -354,29 +354,33 @@ class RowColArray(object):
 
 
 def makeSegmentLocations(seg, segSize):
-    """dict: segment id -> RowColArray of its pixels in raster order
-    (reference shepseg.py:880-915).  Host-side helper (stable argsort), not on the hot path."""
-    seg = numpy.asarray(seg)
+    """dict: segment id -> RowColArray of its pixels in raster order (reference shepseg.py:880-915),
+    read back from the device CSR the elimination stage builds (shp_segment_locations)."""
+    seg = numpy.ascontiguousarray(seg, dtype=SegIdType)
     (nRows, nCols) = seg.shape
-    flat = seg.reshape(-1)
-    order = numpy.argsort(flat, kind='stable')
-    counts = numpy.bincount(flat, minlength=len(segSize))
-    offs = numpy.concatenate(([0], numpy.cumsum(counts)))
-    rows = (order // nCols).astype(numpy.uint32)
-    cols = (order % nCols).astype(numpy.uint32)
-    rc = numpy.stack((rows, cols), axis=1)
+    maxSegId = len(segSize) - 1
+    offs = numpy.zeros(maxSegId + 2, dtype=numpy.uint32)
+    pix = numpy.empty(seg.size, dtype=numpy.uint32)
+    c = _lib.ctx()
+    c.check(c._L.shp_segment_locations(c.handle, _lib.ptr(seg), nRows, nCols, maxSegId,
+                                       _lib.ptr(offs), _lib.ptr(pix)))
+    rc = numpy.empty((seg.size, 2), dtype=numpy.uint32)
+    numpy.floor_divide(pix, numpy.uint32(max(nCols, 1)), out=rc[:, 0])
+    numpy.remainder(pix, numpy.uint32(max(nCols, 1)), out=rc[:, 1])
     d = {}
-    for segid in range(MINSEGID, len(segSize)):
+    for segid in range(MINSEGID, maxSegId + 1):
         d[SegIdType(segid)] = RowColArray(rc[offs[segid]:offs[segid + 1]])
     return d
 
 
 def buildSegmentSpectra(seg, img, maxSegId):
-    """float32 per-segment per-band sums accumulated in raster order
-    (reference shepseg.py:780-813).  Host-side helper, not on the hot path."""
-    (nBands, nRows, nCols) = img.shape
-    spectSum = numpy.zeros((maxSegId + 1, nBands), dtype=numpy.float32)
-    flat = numpy.asarray(seg).reshape(-1)
-    for k in range(nBands):
-        numpy.add.at(spectSum[:, k], flat, img[k].reshape(-1))
+    """float32 per-segment per-band sums accumulated in raster order (reference shepseg.py:780-813),
+    computed by the device kernels of the elimination stage (shp_build_segment_spectra)."""
+    img_c, dt = _lib.as_image(img)
+    (nBands, nRows, nCols) = img_c.shape
+    seg = numpy.ascontiguousarray(seg, dtype=SegIdType)
+    spectSum = numpy.zeros((int(maxSegId) + 1, nBands), dtype=numpy.float32)
+    c = _lib.ctx()
+    c.check(c._L.shp_build_segment_spectra(c.handle, _lib.ptr(seg), _lib.ptr(img_c), dt, nBands, nRows,
+                                           nCols, int(maxSegId), _lib.ptr(spectSum)))
     return spectSum

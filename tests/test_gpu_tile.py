@@ -144,6 +144,27 @@ def test_predict_exact_ties_device(golden, shepseg):
         assert np.array_equal(got, g[tag + '_clusters']), tag
 
 
+def test_segment_spectra_and_locations_device(golden, shepseg):
+    """the public buildSegmentSpectra / makeSegmentLocations run on the device tables of the
+    elimination stage (ordered float32 sums, CSR of pixels by segment): bit for bit the reference's"""
+    g = golden('spectra_segloc')
+    for tag in 'abc':
+        seg, img = g[tag + '_seg'], g[tag + '_img']
+        S = int(seg.max())
+        ss = shepseg.buildSegmentSpectra(seg, img, S)
+        assert ss.dtype == np.float32 and ss.shape == g[tag + '_spect_sum'].shape
+        assert np.array_equal(ss.view(np.uint32), g[tag + '_spect_sum'].view(np.uint32)), tag
+        segSize = shepseg.makeSegSize(seg)
+        loc = shepseg.makeSegmentLocations(seg, segSize)
+        off, rc = g[tag + '_segloc_off'], g[tag + '_segloc_rc']
+        assert sorted(int(k) for k in loc) == list(range(1, S + 1))
+        for s in range(1, S + 1):
+            (rows, cols) = loc[shepseg.SegIdType(s)].getSegmentIndices()
+            want = rc[off[s]:off[s + 1]]
+            assert np.array_equal(rows, want[:, 0]) and np.array_equal(cols, want[:, 1]), (tag, s)
+            assert (seg[rows, cols] == s).all()
+
+
 def test_edge_shapes(shepseg, oracle):
     km = shepseg.KMeansModel(np.array([[10., 10.], [200., 200.]]))
     # all-null image

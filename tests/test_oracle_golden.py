@@ -89,6 +89,19 @@ def test_oracle_predict_exact_ties(golden, oracle):
         assert np.array_equal(got, g[tag + '_clusters']), tag
 
 
+def test_oracle_spectra_and_locations(golden, oracle):
+    """buildSegmentSpectra / makeSegmentLocations (shepseg.py:780-915) against the reference's own
+    arrays, incl. float32 sums beyond 2^24 (order-dependent) and the null segment's row"""
+    g = golden('spectra_segloc')
+    for tag in 'abc':
+        seg, img = g[tag + '_seg'], g[tag + '_img']
+        S = int(seg.max())
+        ss = oracle.build_segment_spectra(seg, img, S)
+        assert np.array_equal(ss.view(np.uint32), g[tag + '_spect_sum'].view(np.uint32)), tag
+        off, rc = oracle.segment_locations(seg, S)
+        assert np.array_equal(off, g[tag + '_segloc_off']) and np.array_equal(rc, g[tag + '_segloc_rc']), tag
+
+
 def test_synthimg_checksums(oracle):
     a = oracle.synthimg(1, 3, 64, 64)
     assert (int(a.min()), int(a.max()), int(a.sum(dtype=np.int64))) == (2196, 4157, 38984854)
