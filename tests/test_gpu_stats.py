@@ -57,6 +57,58 @@ def test_stats_vs_oracle_large(oracle):
     assert r.columns['n'].sum() == ((seg != 0) & (band != 0)).sum()
 
 
+def test_stats_streamed_in_pages(oracle, monkeypatch):
+    """row blocks smaller than the segments (so most of them straddle a block boundary), RAT pages
+    of 100 rows, ids without pixels: same columns as the oracle, pages written once each, in the
+    reference's layout (startSegId = multiple of the page size, the last page shorter)"""
+    from pyshepseg_amd import tilingstats
+    monkeypatch.setattr(tilingstats, 'RAT_PAGE_SIZE', 100)
+    rng = np.random.RandomState(5)
+    seg = (np.arange(300)[:, None] // 7 * 60 + np.arange(400)[None, :] // 9 + 1).astype(np.uint32)
+    seg[100:220, 50:300] = 77                      # a big segment across many blocks
+    seg[seg == 300] = 301                          # id 300 has no pixels (the stitch can leave such ids)
+    seg[seg == 1234] = 0
+    seg[:3] = 0
+    band = oracle.synthimg(23, 1, 300, 400)[0]
+    band[rng.rand(300, 400) < 0.05] = 7
+    sel = [('mn', 'min'), ('mx', 'max'), ('mean', 'mean'), ('sd', 'stddev'), ('med', 'median'),
+           ('mode', 'mode'), ('p10', 'percentile', 10), ('n', 'pixcount')]
+    S = int(seg.max())
+    ic, fc = oracle.segstats(seg, band, sel, null_val=7)
+    whole = tilingstats.calcPerSegmentStatsTiled(band, 1, seg, sel, imgNullVal=7)
+    for chunk in (400 * 5, 400 * 64, 400 * 300):
+        r = tilingstats.calcPerSegmentStatsTiled(band, 1, seg, sel, imgNullVal=7, chunkPixels=chunk)
+        for i, name in enumerate(['mn', 'mx', 'med', 'mode', 'p10', 'n']):
+            assert np.array_equal(r.columns[name], ic[i]), (chunk, name)
+            assert np.array_equal(r.columns[name], whole.columns[name])
+        assert np.array_equal(r.columns['mean'].view(np.uint32), fc[0].view(np.uint32))
+        assert np.array_equal(r.columns['sd'].view(np.uint32), fc[1].view(np.uint32))
+        starts = sorted(p[0] for p in r.pagesWritten)
+        assert starts == list(range(0, S + 1, 100)) and len(set(starts)) == len(starts)
+        assert dict(r.pagesWritten)[starts[-1]] == S + 1 - starts[-1]
+        # the id without pixels: missing value everywhere, 0 pixels
+        assert r.columns['n'][300] == 0 and r.columns['mn'][300] == -9999 and r.columns['mean'][300] == -9999
+    assert set(r.timings.makeSummaryDict()) >= {'reading', 'accumulation', 'statscompletion', 'writing'}
+
+
+def test_rat_page_semantics():
+    """RatPage / getRatPageId as the reference defines them (tilingstats.py:1950-2045)"""
+    from pyshepseg_amd import tilingstats as ts
+    assert ts.getRatPageId(0) == 0 and ts.getRatPageId(99999) == 0 and ts.getRatPageId(100000) == 100000
+    p0 = ts.RatPage(2, 1, 0, 5)
+    assert p0.complete.tolist() == [True, False, False, False, False]
+    assert p0.intcols.dtype == np.int64 and p0.floatcols.dtype == np.float32
+    assert (p0.intcols[:, 0] == 0).all() and (p0.floatcols[:, 0] == 0).all() and not p0.pageComplete()
+    p0.setRatVal(3, ts.STAT_DTYPE_INT, 1, 42)
+    p0.setRatVal(3, ts.STAT_DTYPE_FLOAT, 0, 2.5)
+    assert p0.getRatVal(3, ts.STAT_DTYPE_INT, 1) == 42 and p0.getRatVal(3, ts.STAT_DTYPE_FLOAT, 0) == 2.5
+    for s_ in (1, 2, 3, 4):
+        p0.setSegmentComplete(s_)
+    assert p0.getSegmentComplete(2) and p0.pageComplete()
+    p1 = ts.RatPage(1, 1, 100000, 3)
+    assert not p1.complete.any() and p1.getIndexInPage(100002) == 2
+
+
 def test_stats_errors():
     from pyshepseg_amd import tilingstats
     with pytest.raises(tilingstats.PyShepSegStatsError):
