@@ -43,6 +43,11 @@ def parse():
     ap.add_argument('--steps', type=int, default=2)
     ap.add_argument('--warmup', type=int, default=1)
     ap.add_argument('--workload', choices=('c3', 'c4', 'c5'), default='c3')
+    ap.add_argument('--source', choices=('hbm', 'npy'), default='hbm',
+                    help="c3/c4: 'npy' = the image is a .npy file read through the I/O pipeline and the "
+                         "labels are written to a .npy file (PCIe-inclusive; never the headline value)")
+    ap.add_argument('--scratch', default=os.environ.get('SHEPSEG_SCRATCH', '/tmp'),
+                    help='directory of the --source npy files')
     ap.add_argument('--size', type=int, default=40000, help='image rows = cols')
     ap.add_argument('--bands', type=int, default=None, help='default: 6 (c3), 10 (c4), 1 (c5)')
     ap.add_argument('--tile', type=int, default=4096)
@@ -165,18 +170,49 @@ def pmc_traffic(kernel_name, scale=1.0):
     return None, None
 
 
+def write_npy_image(ras, path):
+    """The synthetic image as a band-planar .npy file (row blocks downloaded from the device)."""
+    from pyshepseg_amd import _lib
+    (nb, nr, nc) = ras.shape
+    mm = np.lib.format.open_memmap(path, mode='w+', dtype=ras.dtype, shape=ras.shape)
+    c = _lib.ctx()
+    rows = max(1, (256 << 20) // (nc * ras.dtype.itemsize))
+    buf = np.empty((rows, nc), dtype=ras.dtype)
+    for b in range(nb):
+        for y0 in range(0, nr, rows):
+            y1 = min(nr, y0 + rows)
+            v = buf[:y1 - y0]
+            c.check(c._L.shp_dev_download(c.handle, _lib.ptr(v), ctypes.c_void_p(
+                ras.ptr + ((b * nr + y0) * nc) * ras.dtype.itemsize), v.nbytes))
+            mm[b, y0:y1] = v
+    mm.flush()
+    del mm
+
+
 def bench_segmentation(args):
     from pyshepseg_amd import tiling, _lib
     ras = tiling.DeviceRaster.synth(args.seed, args.bands, args.size, args.size)
     cfg = tiling.SegmentationConcurrencyConfig(concurrencyType=tiling.CONC_THREADS,
                                                numWorkers=args.workers)
+    (src, dst) = (ras, tiling._KEEP_ON_DEVICE)
+    if args.source == 'npy':
+        # one HW queue each for the uploader and the writer: two worker streams fewer
+        cfg.numWorkers = max(1, args.workers - 2)
+        src = os.path.join(args.scratch, 'shepseg_bench_%d_%db_seed%d.npy' % (args.size, args.bands, args.seed))
+        dst = os.path.join(args.scratch, 'shepseg_bench_%d_out.npy' % args.size)
+        if not os.path.exists(src):
+            t0 = time.time()
+            write_npy_image(ras, src)
+            sys.stderr.write('bench.py: wrote %s (%.1f GB) in %.1f s\n' % (src, ras.nbytes / 1e9, time.time() - t0))
+        ras.free()                        # the pipeline brings the file into HBM itself
 
     def step():
         r = tiling.doTiledShepherdSegmentation(
-            ras, tiling._KEEP_ON_DEVICE, tileSize=args.tile, overlapSize=args.overlap,
+            src, dst, tileSize=args.tile, overlapSize=args.overlap,
             minSegmentSize=50, numClusters=60, fixedKMeansInit=True, concurrencyCfg=cfg,
             simpleTileRecode=bool(args.simple_recode))
-        tiling.freeDeviceOutput(r)
+        if args.source == 'hbm':
+            tiling.freeDeviceOutput(r)
         return r
 
     for _ in range(args.warmup):
@@ -202,14 +238,17 @@ def bench_segmentation(args):
              5: 'k_small_loop', 7: 'seed scan + k_clump_final'}
     dom = max((i for i in names), key=lambda i: prof.get(i, (0, 0))[0])
     ms, cnt = prof[dom]
-    ti = tiling.getTilesForFile(ras, args.tile, args.overlap)
+    class _Geom(object):
+        RasterXSize = RasterYSize = args.size
+    ti = tiling.getTilesForFile(_Geom, args.tile, args.overlap)
     tile_px = sum(t[2] * t[3] for t in ti.tiles.values()) / max(len(ti.tiles), 1)
     # algorithmic bytes per launch: clump kernels read a 2-byte cluster id and write a 4-byte label
     # per tile pixel; assign reads nB*2 B and writes 2 B; the rest move (2*nB + 4) B per pixel.
     bpp = {0: 2 * args.bands + 2, 1: 6, 2: 6, 7: 6}.get(dom, 2 * args.bands + 4)
     avg_s = (ms / max(cnt, 1)) / 1e3
     achieved = (bpp * tile_px / avg_s / 1e9) if avg_s > 0 else 0.0
-    traffic, traffic_src = (pmc_traffic(names[dom].split(' ')[0]) if args.size == 40000 else (None, None))
+    traffic, traffic_src = (pmc_traffic(names[dom].split(' ')[0]) if args.size == 40000 and args.bands == 6
+                            else (None, None))
     wl = args.workload.upper()
     out = {
         "metric": "Mpixels/sec segmented, %d-band 40k x 40k tiled" % args.bands,
@@ -218,9 +257,15 @@ def bench_segmentation(args):
         "scaling": "strong", "vs_baseline": None, "dtype": "u16", "data": "synthetic",
         "config": {"workload": "%s: tiled %dx%d, %d-band uint16 synthimg v1 (seed %d), tileSize=%d, "
                                "overlap=%d, k=60, minSegmentSize=50, fixedKMeansInit, image + "
-                               "labels resident in HBM" % (wl, args.size, args.size, args.bands, args.seed,
-                                                           args.tile, args.overlap),
-                   "tiles": len(ti.tiles), "worker_streams": args.workers,
+                               "%s" % (wl, args.size, args.size, args.bands, args.seed,
+                                       args.tile, args.overlap,
+                                       "labels resident in HBM" if args.source == 'hbm' else
+                                       "read from a .npy file through the I/O pipeline (page-locked "
+                                       "staging, one upload per pixel overlapped with compute), labels "
+                                       "streamed to a .npy file: %.1f GB in + %.1f GB out over PCIe per step"
+                                       % (args.bands * npix * 2 / 1e9, npix * 4 / 1e9)),
+                   "source": args.source,
+                   "tiles": len(ti.tiles), "worker_streams": cfg.numWorkers,
                    "max_seg_id": int(r.maxSegId)},
         "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 3),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -236,11 +281,12 @@ def bench_segmentation(args):
     out["config"]["step_s"] = step_s
     out["config"]["host_timers_s"] = {k: round(v['total'], 3)
                                        for k, v in r.timings.makeSummaryDict().items()}
-    if args.cpu_sample > 0:
+    if args.cpu_sample > 0 and args.source == 'hbm':
         out["cpu_baseline"] = cpu_baseline(ras, args, r.kmeans.cluster_centers_,
                                            float(r.maxSpectralDiff))
     print(json.dumps(out))
-    ras.free()
+    if args.source == 'hbm':
+        ras.free()
 
 
 def bench_stats(args):

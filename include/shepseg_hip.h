@@ -131,6 +131,11 @@ int shp_dev_upload(shp_ctx *ctx, void *dst_dev, const void *src_host, size_t byt
 int shp_dev_download(shp_ctx *ctx, void *dst_host, const void *src_dev, size_t bytes);
 int shp_dev_memset(shp_ctx *ctx, void *dst_dev, int value, size_t bytes);
 int shp_dev_copy(shp_ctx *ctx, void *dst_dev, const void *src_dev, size_t bytes);   /* D2D */
+/* page-locked host buffers for the raster I/O pipeline (reads staged for H2D, finished output rows
+ * staged from D2H): what the reference's per-tile GDAL ReadAsArray / WriteArray buffers become
+ * (tiling.py:1436-1443, :1032-1034) */
+int shp_host_alloc(shp_ctx *ctx, size_t bytes, void **hptr);
+int shp_host_free(shp_ctx *ctx, void *hptr);
 int shp_sync(shp_ctx *ctx);
 /* synthimg v1 window written straight into device memory (band-planar uint16) */
 int shp_dev_synthimg(shp_ctx *ctx, uint64_t seed, int nbands, int64_t y0, int64_t x0, int nrows,

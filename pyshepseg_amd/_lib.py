@@ -68,6 +68,8 @@ _SIGS = {
     'shp_dev_upload': (_c.c_int, [_vp, _vp, _vp, _c.c_size_t]),
     'shp_dev_download': (_c.c_int, [_vp, _vp, _vp, _c.c_size_t]),
     'shp_dev_memset': (_c.c_int, [_vp, _vp, _c.c_int, _c.c_size_t]),
+    'shp_host_alloc': (_c.c_int, [_vp, _c.c_size_t, _c.POINTER(_vp)]),
+    'shp_host_free': (_c.c_int, [_vp, _vp]),
     'shp_dev_copy': (_c.c_int, [_vp, _vp, _vp, _c.c_size_t]),
     'shp_sync': (_c.c_int, [_vp]),
     'shp_dev_synthimg': (_c.c_int, [_vp, _c.c_uint64, _c.c_int, _c.c_int64, _c.c_int64, _c.c_int,

@@ -486,6 +486,26 @@ API int shp_dev_download(shp_ctx *ctx, void *dst_host, const void *src_dev, size
     return 0;
 }
 
+// pinned (page-locked) host memory for the raster I/O pipeline: transfers from / to it run at full
+// PCIe rate and asynchronously, pageable memory is staged by the runtime in small synchronous pieces
+API int shp_host_alloc(shp_ctx *ctx, size_t bytes, void **hptr)
+{
+    CHK(enter(ctx));
+    if (!hptr) SHP_FAIL(ctx, SHP_ERR_ARG, "NULL argument");
+    *hptr = nullptr;
+    hipError_t e = hipHostMalloc(hptr, bytes ? bytes : 16, hipHostMallocDefault);
+    if (e != hipSuccess) SHP_FAIL(ctx, SHP_ERR_NOMEM, "hipHostMalloc(%zu): %s", bytes, hipGetErrorString(e));
+    return 0;
+}
+
+API int shp_host_free(shp_ctx *ctx, void *hptr)
+{
+    CHK(enter(ctx));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (hptr) HIPCHK(ctx, hipHostFree(hptr));
+    return 0;
+}
+
 API int shp_dev_copy(shp_ctx *ctx, void *dst_dev, const void *src_dev, size_t bytes)
 {
     CHK(enter(ctx));

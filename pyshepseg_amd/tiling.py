@@ -112,15 +112,19 @@ class Timers(object):
 # ------------------------------------------------------------------------------------------
 class DeviceRaster(object):
     """A band-planar raster resident in HBM (device 0 of the calling thread's context)."""
-    def __init__(self, nBands, nRows, nCols, dtype=numpy.uint16, nullVal=None):
+    def __init__(self, nBands, nRows, nCols, dtype=numpy.uint16, nullVal=None, cached=False):
         self.dtype = numpy.dtype(dtype)
         self.shape = (int(nBands), int(nRows), int(nCols))
         self.nullVal = nullVal
         self.RasterXSize, self.RasterYSize = self.shape[2], self.shape[1]
         self.nbytes = int(nBands) * int(nRows) * int(nCols) * self.dtype.itemsize
         c = _lib.ctx()
-        p = ctypes.c_void_p()
-        c.check(c._L.shp_dev_alloc(c.handle, self.nbytes, ctypes.byref(p)))
+        self.cached = cached                # block taken from / returned to the scratch-raster cache
+        if cached:
+            p = _devAlloc(c, self.nbytes)
+        else:
+            p = ctypes.c_void_p()
+            c.check(c._L.shp_dev_alloc(c.handle, self.nbytes, ctypes.byref(p)))
         self.ptr = p.value
         self.device = c.device
 
@@ -151,7 +155,10 @@ class DeviceRaster(object):
     def free(self):
         if self.ptr:
             c = _lib.ctx()
-            c.check(c._L.shp_dev_free(c.handle, ctypes.c_void_p(self.ptr)))
+            if self.cached:
+                _devRelease(c, ctypes.c_void_p(self.ptr), self.nbytes)
+            else:
+                c.check(c._L.shp_dev_free(c.handle, ctypes.c_void_p(self.ptr)))
             self.ptr = None
 
 
@@ -169,6 +176,11 @@ class _ArraySource(object):
     def read(self, bands, xpos, ypos, xsize, ysize):
         return numpy.ascontiguousarray(self.arr[bands, ypos:ypos + ysize, xpos:xpos + xsize])
 
+    def readRowsInto(self, bands, y0, y1, out):
+        """rows [y0, y1) of the given bands into out (nBands, y1 - y0, nCols), band by band"""
+        for (i, b) in enumerate(bands):
+            numpy.copyto(out[i], self.arr[b, y0:y1, :], casting='unsafe')
+
 
 class _GdalSource(object):
     def __init__(self, path):
@@ -180,6 +192,8 @@ class _GdalSource(object):
         self.shape = (self.ds.RasterCount, self.RasterYSize, self.RasterXSize)
         self.nullVal = None
         self.local = threading.local()
+        from osgeo import gdal_array
+        self.dtype = numpy.dtype(gdal_array.GDALTypeCodeToNumericTypeCode(self.ds.GetRasterBand(1).DataType))
 
     def bandNull(self, bandNumbers):
         arr = numpy.array([self.ds.GetRasterBand(i).GetNoDataValue() for i in bandNumbers])
@@ -194,6 +208,14 @@ class _GdalSource(object):
             ds = self.local.ds = gdal.Open(self.path)      # per-thread dataset (tiling.py:1565)
         return numpy.array([ds.GetRasterBand(int(b) + 1).ReadAsArray(xpos, ypos, xsize, ysize)
                             for b in bands])
+
+    def readRowsInto(self, bands, y0, y1, out):
+        from osgeo import gdal
+        ds = getattr(self.local, 'ds', None)
+        if ds is None:
+            ds = self.local.ds = gdal.Open(self.path)
+        for (i, b) in enumerate(bands):
+            out[i] = ds.GetRasterBand(int(b) + 1).ReadAsArray(0, y0, self.RasterXSize, y1 - y0)
 
 
 def _open_source(infile):
@@ -351,6 +373,9 @@ def _readSubsampledImage(src, bandNumbers, subsampleProp):
         if bands == list(range(nb)):
             return out              # (consumed by fitSpectralClusters before the next call)
         return numpy.ascontiguousarray(out[bands])
+    if isinstance(src, _ArraySource):
+        # the kept rows only (a memmap then touches 1/skip of the file, not all of it)
+        return numpy.ascontiguousarray(numpy.stack([src.arr[b][ry][:, rx] for b in bands]))
     rows = []
     for ypos in range(0, nlines, TILESIZE):
         ysize = min(TILESIZE, nlines - ypos)
@@ -385,6 +410,282 @@ def fitSpectralClustersWholeFile(inDs, bandNumbers, numClusters=60, subsamplePcn
         kmeansObj = shepseg.fitSpectralClusters(img, numClusters=numClusters, subsamplePcnt=100,
                                                 imgNullVal=imgNullVal, fixedKMeansInit=fixedKMeansInit)
     return (kmeansObj, subsamplePcnt, imgNullVal)
+
+
+# ------------------------------------------------------------------------------------------
+# raster I/O pipeline (BASELINE config 3: "async read / compute overlap on HIP streams")
+# ------------------------------------------------------------------------------------------
+class _PinnedBuffer(object):
+    """Page-locked host memory with a numpy view (transfers from pageable memory are staged by the
+    runtime in small synchronous pieces: 1-30 ms for a few MB, erratic)."""
+    def __init__(self, c, nbytes):
+        self.c = c
+        self.nbytes = max(int(nbytes), 16)
+        p = ctypes.c_void_p()
+        c.check(c._L.shp_host_alloc(c.handle, self.nbytes, ctypes.byref(p)))
+        self.ptr = p.value
+        self.u8 = numpy.ctypeslib.as_array((ctypes.c_uint8 * self.nbytes).from_address(self.ptr))
+
+    def view(self, dtype, shape):
+        n = int(numpy.prod(shape)) * numpy.dtype(dtype).itemsize
+        return self.u8[:n].view(dtype).reshape(shape)
+
+    def free(self):
+        if self.ptr:
+            self.u8 = None
+            self.c.check(self.c._L.shp_host_free(self.c.handle, ctypes.c_void_p(self.ptr)))
+            self.ptr = None
+
+
+_pinnedPool = {}
+_pinnedLock = threading.Lock()
+
+
+def _pinnedGet(c, nbytes):
+    """Page-locking host memory is slow (~1 s per few GB): the staging buffers are kept between runs."""
+    nbytes = max(int(nbytes), 16)
+    with _pinnedLock:
+        lst = _pinnedPool.get(nbytes)
+        if lst:
+            return lst.pop()
+    return _PinnedBuffer(c, nbytes)
+
+
+def _pinnedPut(buf):
+    with _pinnedLock:
+        _pinnedPool.setdefault(buf.nbytes, []).append(buf)
+
+
+def clearPinnedPool():
+    with _pinnedLock:
+        for lst in _pinnedPool.values():
+            for b in lst:
+                b.c = _lib.ctx()
+                b.free()
+        _pinnedPool.clear()
+
+
+STREAM_BLOCK_ROWS = int(os.environ.get('SHEPSEG_STREAM_ROWS', '256'))
+
+
+class _RasterStreamer(object):
+    """Brings a host raster (array, memmap, GDAL) into a band-planar device raster block of rows by
+    block of rows, once per pixel: a reader thread fills page-locked buffers (the file read), an
+    uploader thread sends them to HBM on its own stream, and tiles start as soon as their last
+    row is resident (waitRows).  What the reference does per tile under a read semaphore
+    (tiling.py:1436-1443, :1575-1583) -- but its overlapping tiles read every pixel 1.6 times,
+    and a 288-GB device holds the whole raster."""
+    def __init__(self, src, bands, ras, timings, nReaders=None):
+        self.src, self.bands, self.ras, self.timings = src, list(bands), ras, timings
+        (self.nb, self.nrows, self.ncols) = ras.shape
+        self.blockRows = max(1, min(STREAM_BLOCK_ROWS, self.nrows))
+        self.nblocks = (self.nrows + self.blockRows - 1) // self.blockRows
+        if nReaders is None:
+            nReaders = int(os.environ.get('SHEPSEG_STREAM_READERS', '6'))
+        nReaders = max(1, min(nReaders, self.nblocks))
+        self.cond = threading.Condition()
+        self.rowsReady = 0
+        self.blockDone = numpy.zeros(self.nblocks, dtype=bool)
+        self.nextBlock = 0
+        self.readersLeft = nReaders
+        self.error = None
+        self.stop = threading.Event()
+        self.cUp = _lib.Context()
+        self.t0 = time.time()
+        blockBytes = self.nb * self.blockRows * self.ncols * ras.dtype.itemsize
+        self.free = queue.Queue()
+        self.full = queue.Queue()
+        self.bufs = [_pinnedGet(self.cUp, blockBytes) for _ in range(nReaders + 2)]
+        for b in self.bufs:
+            self.free.put(b)
+        # several readers: one thread copies ~15 GB/s out of the page cache, PCIe takes 50
+        self.threads = [threading.Thread(target=self._guard, args=(self._reader,), daemon=True)
+                        for _ in range(nReaders)]
+        self.threads.append(threading.Thread(target=self._guard, args=(self._uploader,), daemon=True))
+        for t in self.threads:
+            t.start()
+
+    def _guard(self, fn):
+        try:
+            fn()
+        except Exception as e:
+            with self.cond:
+                self.error = e
+                self.cond.notify_all()
+            self.stop.set()
+            self.full.put(None)
+
+    def _reader(self):
+        while not self.stop.is_set():
+            with self.cond:
+                k = self.nextBlock
+                self.nextBlock += 1
+            if k >= self.nblocks:
+                break
+            (y0, y1) = (k * self.blockRows, min(self.nrows, (k + 1) * self.blockRows))
+            buf = None
+            while buf is None and not self.stop.is_set():
+                try:
+                    buf = self.free.get(timeout=0.2)
+                except queue.Empty:
+                    pass
+            if self.stop.is_set():
+                return
+            with self.timings.interval('reading'):
+                v = buf.view(self.ras.dtype, (self.nb, y1 - y0, self.ncols))
+                self.src.readRowsInto(self.bands, y0, y1, v)
+            self.full.put((buf, k, y0, y1))
+        with self.cond:
+            self.readersLeft -= 1
+            last = self.readersLeft == 0
+        if last:
+            self.full.put(None)
+
+    def _uploader(self):
+        c = self.cUp
+        isz = self.ras.dtype.itemsize
+        while True:
+            item = self.full.get()
+            if item is None or self.stop.is_set():
+                return
+            (buf, k, y0, y1) = item
+            nbytes = (y1 - y0) * self.ncols * isz
+            for b in range(self.nb):
+                dst = self.ras.ptr + (b * self.nrows + y0) * self.ncols * isz
+                c.check(c._L.shp_dev_upload(c.handle, ctypes.c_void_p(dst),
+                                            ctypes.c_void_p(buf.ptr + b * nbytes), nbytes))
+            self.free.put(buf)
+            if os.environ.get('SHEPSEG_IO_TIMING') and y1 == self.nrows:
+                sys.stderr.write('  [io] last block uploaded (t0 + %.3f s since the stream started)\n'
+                                 % (time.time() - self.t0))
+            with self.cond:
+                self.blockDone[k] = True
+                while self.rowsReady < self.nrows and self.blockDone[self.rowsReady // self.blockRows]:
+                    self.rowsReady = min(self.nrows, (self.rowsReady // self.blockRows + 1) * self.blockRows)
+                self.cond.notify_all()
+
+    def waitRows(self, y1, forceExit=None):
+        with self.cond:
+            while self.rowsReady < y1:
+                if self.error is not None:
+                    raise PyShepSegTilingError("reading the raster failed: %s" % (self.error,))
+                if forceExit is not None and forceExit.is_set():
+                    raise PyShepSegTilingError("raster stream: another worker failed")
+                self.cond.wait(timeout=0.5)
+
+    def close(self):
+        self.stop.set()
+        self.full.put(None)
+        for t in self.threads:
+            t.join(timeout=60.0)
+        self.cUp.check(self.cUp._L.shp_sync(self.cUp.handle))
+        for b in self.bufs:
+            _pinnedPut(b)
+        self.bufs = []
+        self.cUp.close()
+
+
+class _NpyRowWriter(object):
+    """A (nRows, nCols) uint32 .npy file written rows at a time with pwrite: storing into a fresh
+    memory map costs a page fault per 4 KiB (1 GB/s and worse from several threads), a write into
+    the page cache is one kernel copy."""
+    def __init__(self, path, nrows, ncols):
+        (self.nrows, self.ncols) = (nrows, ncols)
+        with open(path, 'wb') as f:
+            numpy.lib.format.write_array_header_1_0(
+                f, {'descr': numpy.lib.format.dtype_to_descr(numpy.dtype(numpy.uint32)),
+                    'fortran_order': False, 'shape': (nrows, ncols)})
+            self.offset = f.tell()
+        self.fd = os.open(path, os.O_WRONLY)
+        os.ftruncate(self.fd, self.offset + nrows * ncols * 4)
+
+    def writeRows(self, y0, y1, v):
+        mv = memoryview(numpy.ascontiguousarray(v)).cast('B')
+        pos = self.offset + y0 * self.ncols * 4
+        done = 0
+        while done < len(mv):
+            done += os.pwrite(self.fd, mv[done:], pos + done)
+
+    def close(self):
+        if self.fd is not None:
+            os.close(self.fd)
+            self.fd = None
+
+
+class _OutputWriter(object):
+    """Finished rows of the stitched raster leave the device while later tiles are still being
+    segmented: rows [yLo, yHi) are downloaded through page-locked staging on the writer's own
+    stream and handed to the sink (an ndarray / .npy memmap slice assignment, or GDAL WriteArray) --
+    instead of one blocking download of the whole raster at the end (tiling.py:1032-1034 writes
+    each trimmed tile as it is stitched)."""
+    CHUNK_BYTES = 64 << 20
+
+    def __init__(self, d_out, nrows, ncols, sink, timings, nCopiers=None):
+        (self.d_out, self.nrows, self.ncols, self.sink, self.timings) = (d_out, nrows, ncols, sink, timings)
+        self.c = _lib.Context()
+        self.rowsPer = max(1, min(nrows, self.CHUNK_BYTES // max(ncols * 4, 1)))
+        if nCopiers is None:
+            nCopiers = int(os.environ.get('SHEPSEG_STREAM_WRITERS', '3'))
+        self.free = queue.Queue()
+        self.bufs = [_pinnedGet(self.c, self.rowsPer * ncols * 4) for _ in range(nCopiers + 1)]
+        for b in self.bufs:
+            self.free.put(b)
+        self.q = queue.Queue()
+        self.cq = queue.Queue()
+        self.error = None
+        # one thread downloads (PCIe), several hand the rows to the sink: a fresh file's pages are
+        # first touched there, a few GB/s per thread
+        self.copiers = [threading.Thread(target=self._copy, daemon=True) for _ in range(max(1, nCopiers))]
+        self.thread = threading.Thread(target=self._run, daemon=True)
+        for t in self.copiers + [self.thread]:
+            t.start()
+
+    def _copy(self):
+        while True:
+            item = self.cq.get()
+            if item is None:
+                return
+            (buf, y0, y1) = item
+            try:
+                with self.timings.interval('writing'):
+                    self.sink(y0, y1, buf.view(numpy.uint32, (y1 - y0, self.ncols)))
+            except Exception as e:
+                self.error = e
+            self.free.put(buf)
+
+    def _run(self):
+        try:
+            while True:
+                item = self.q.get()
+                if item is None:
+                    return
+                (yLo, yHi) = item
+                for y0 in range(yLo, yHi, self.rowsPer):
+                    y1 = min(yHi, y0 + self.rowsPer)
+                    buf = self.free.get()
+                    self.c.check(self.c._L.shp_dev_download(
+                        self.c.handle, ctypes.c_void_p(buf.ptr),
+                        ctypes.c_void_p(self.d_out.value + 4 * y0 * self.ncols), (y1 - y0) * self.ncols * 4))
+                    self.cq.put((buf, y0, y1))
+        except Exception as e:
+            self.error = e
+
+    def rowsFinal(self, yLo, yHi):
+        if yHi > yLo:
+            self.q.put((yLo, yHi))
+
+    def finish(self):
+        self.q.put(None)
+        self.thread.join()
+        for _ in self.copiers:
+            self.cq.put(None)
+        for t in self.copiers:
+            t.join()
+        for b in self.bufs:
+            _pinnedPut(b)
+        self.c.close()
+        if self.error is not None:
+            raise self.error
 
 
 # ------------------------------------------------------------------------------------------
@@ -600,7 +901,7 @@ def _workersThatFit(numWorkers, dtcode, nBands, maxTilePx, verbose=False):
 
 def startSegmentationWorkers(src, jobs, d_tiles, centres, msd, imgNullVal, fourConnected,
         minSegmentSize, numWorkers, timings, bands=None, yOrigin=0, maxConcurrentReads=20,
-        verbose=False, stitchPrep=None):
+        verbose=False, stitchPrep=None, rowGate=None):
     """Start `numWorkers` threads, each with a pooled HIP context (one stream), that segment
     the jobs' windows of `src` (tile window rows are relative to yOrigin when src holds only a
     slice of the raster) into the device label block d_tiles.  Mirrors SegThreadsMgr.worker
@@ -621,8 +922,8 @@ def startSegmentationWorkers(src, jobs, d_tiles, centres, msd, imgNullVal, fourC
     # avoids a tail where a few workers finish the big ones alone (the stitch consumes in
     # row-major order regardless and its sequential part is thin)
     order = sorted(range(len(jobs)), key=lambda i: (-(jobs[i].xsize * jobs[i].ysize), i))
-    if os.environ.get('SHEPSEG_TILE_ORDER', 'lpt') != 'lpt':
-        order = list(range(len(jobs)))
+    if os.environ.get('SHEPSEG_TILE_ORDER', 'lpt') != 'lpt' or rowGate is not None:
+        order = list(range(len(jobs)))           # (a raster still streaming in: tiles in arrival order)
     inQue = queue.Queue()
     for i in order:
         inQue.put(jobs[i])
@@ -664,6 +965,12 @@ def startSegmentationWorkers(src, jobs, d_tiles, centres, msd, imgNullVal, fourC
                 ncl = ctypes.c_uint32(0)
                 dseg = ctypes.c_void_p(d_tiles.value + 4 * j.offset)
                 if onDevice:
+                    if rowGate is not None:
+                        need = j.ypos - yOrigin + j.ysize
+                        if clusMap is not None:         # the cluster map is assigned in whole blocks
+                            B = clusMap.BLOCK
+                            need = min(srcYsize, ((need + B - 1) // B) * B)
+                        rowGate.waitRows(need, forceExit)
                     with timings.interval('segmentation'):
                         dclus = None
                         if clusMap is not None:
@@ -767,6 +1074,12 @@ def doTiledShepherdSegmentation(infile, outfile, tileSize=DFLT_TILESIZE,
     if (overlapSize % 2) != 0:
         raise PyShepSegTilingError("Overlap size must be an even number")     # tiling.py:746
     timings = Timers()
+    ioT0 = time.time()
+
+    def ioMark(what):
+        if os.environ.get('SHEPSEG_IO_TIMING'):
+            sys.stderr.write('  [io] %-34s %.3f s\n' % (what, time.time() - ioT0))
+
     with timings.interval('walltime'):
         src = _open_source(infile)
         nBandsAll = src.shape[0]
@@ -774,6 +1087,20 @@ def doTiledShepherdSegmentation(infile, outfile, tileSize=DFLT_TILESIZE,
             bandNumbers = list(range(1, nBandsAll + 1))
         bands = [b - 1 for b in bandNumbers]
         (inYsize, inXsize) = (src.RasterYSize, src.RasterXSize)
+        # a host raster is streamed into HBM once, row block by row block, while the model is fitted
+        # and the first tiles run (see _RasterStreamer); the per-tile read + upload path remains for
+        # pixel types that need a conversion and for rasters that do not fit the device
+        (streamer, devRas) = (None, None)
+        workSrc = src
+        if (not isinstance(src, DeviceRaster) and os.environ.get('SHEPSEG_STREAM_INPUT', '1') != '0' and
+                numpy.dtype(src.dtype) in _lib.SHP_DTYPES and inYsize * inXsize > 0 and
+                _rasterFitsDevice(len(bands), inYsize, inXsize, numpy.dtype(src.dtype).itemsize)):
+            devRas = DeviceRaster(len(bands), inYsize, inXsize, src.dtype,
+                                  imgNullVal if imgNullVal is not None else getattr(src, 'nullVal', None),
+                                  cached=True)
+            streamer = _RasterStreamer(src, bands, devRas, timings)
+            workSrc = devRas
+            ioMark('stream started')
 
         with timings.interval('spectralclusters'):
             if kmeansObj is None:
@@ -782,6 +1109,7 @@ def doTiledShepherdSegmentation(infile, outfile, tileSize=DFLT_TILESIZE,
             elif imgNullVal is None:
                 imgNullVal = (src.bandNull(bandNumbers) if isinstance(src, _GdalSource)
                               else src.nullVal)
+        ioMark('model fitted')
         centres = numpy.ascontiguousarray(kmeansObj.cluster_centers_, dtype=numpy.float64)
         msd = shepseg.autoMaxSpectralDiff(kmeansObj, maxSpectralDiff, spectDistPcntile)
         if verbose:
@@ -808,14 +1136,40 @@ def doTiledShepherdSegmentation(infile, outfile, tileSize=DFLT_TILESIZE,
         forceExit = None
         threads = []
         ok = False
+        writer = None
         try:
             numWorkers = 1
             if concurrencyCfg.concurrencyType != CONC_NONE:
                 numWorkers = max(1, int(concurrencyCfg.numWorkers))
             threads, forceExit = startSegmentationWorkers(
-                src, jobs, d_tiles, centres, msd, imgNullVal, fourConnected, minSegmentSize,
-                numWorkers, timings, bands=bands, maxConcurrentReads=concurrencyCfg.maxConcurrentReads,
-                verbose=verbose, stitchPrep=(tileInfo, overlapSize, arena, bool(simpleTileRecode)))
+                workSrc, jobs, d_tiles, centres, msd, imgNullVal, fourConnected, minSegmentSize,
+                numWorkers, timings, bands=(None if streamer is not None else bands),
+                maxConcurrentReads=concurrencyCfg.maxConcurrentReads,
+                verbose=verbose, stitchPrep=(tileInfo, overlapSize, arena, bool(simpleTileRecode)),
+                rowGate=streamer)
+            # finished rows of the stitched raster stream out while the rest is still in the making
+            writer = None
+            segimg = None
+            gdalOut = None
+            if outfile is not _KEEP_ON_DEVICE and inYsize * inXsize > 0:
+                if outfile is None:
+                    segimg = numpy.empty((inYsize, inXsize), dtype=shepseg.SegIdType)
+                    dest = segimg
+                elif isinstance(outfile, str) and outfile.endswith('.npy'):
+                    dest = _NpyRowWriter(outfile, inYsize, inXsize)
+                else:
+                    gdalOut = _createGdalOutput(outfile, inYsize, inXsize, infile, outputDriver, creationOptions)
+                    dest = None
+                if isinstance(dest, _NpyRowWriter):
+                    sink = dest.writeRows
+                elif dest is not None:
+                    def sink(y0, y1, v, dest=dest):
+                        dest[y0:y1] = v
+                else:
+                    def sink(y0, y1, v, band=gdalOut[1]):
+                        band.WriteArray(v, 0, y0)
+                writer = _OutputWriter(d_out, inYsize, inXsize, sink, timings)
+            rowsWritten = 0
 
             if os.environ.get('SHEPSEG_CHAIN_TIMING'):
                 # diagnostic: let every tile finish first, so that 'stitchtiles' times the bare chain
@@ -848,9 +1202,20 @@ def doTiledShepherdSegmentation(infile, outfile, tileSize=DFLT_TILESIZE,
                         overlapSize, topB, topPitch, leftB, leftPitch, j.maxLocal,
                         int(bool(simpleTileRecode)), d_scal, top, bottom, left, right,
                         ctypes.c_void_p(j.meta), rightOut, bottomOut, d_out, inXsize, xout, yout))
+                    if writer is not None and j.col == tileInfo.ncols - 1:
+                        # the tile row is stitched: its output rows are final once the device is done
+                        main.check(L.shp_sync(main.handle))
+                        writer.rowsFinal(rowsWritten, yout + (bottom - top))
+                        rowsWritten = yout + (bottom - top)
                 main.check(L.shp_sync(main.handle))
+            ioMark('last tile stitched')
             for t in threads:
                 t.join()
+            if writer is not None:
+                writer.rowsFinal(rowsWritten, inYsize)
+                writer.finish()
+                writer = None
+            ioMark('output written')
 
             scal = numpy.zeros(1, dtype=numpy.uint32)
             main.check(L.shp_dev_download(main.handle, _lib.ptr(scal), d_scal, 4))
@@ -866,24 +1231,30 @@ def doTiledShepherdSegmentation(infile, outfile, tileSize=DFLT_TILESIZE,
             if outfile is _KEEP_ON_DEVICE:
                 result.outDev = (d_out.value, inYsize, inXsize, nbOut)
                 d_out = None                        # ownership moves to the caller
-            else:
-                segimg = numpy.empty((inYsize, inXsize), dtype=shepseg.SegIdType)
-                main.check(L.shp_dev_download(main.handle, _lib.ptr(segimg), d_out, segimg.nbytes))
-                if outfile is None:
-                    result.segimg = segimg
-                elif isinstance(outfile, str) and outfile.endswith('.npy'):
-                    numpy.save(outfile, segimg)
-                    if writeHistogram:
-                        numpy.save(outfile[:-4] + '_hist.npy', hist)
+            elif outfile is None:
+                result.segimg = segimg if segimg is not None else numpy.zeros((inYsize, inXsize), shepseg.SegIdType)
+            elif isinstance(outfile, str) and outfile.endswith('.npy'):
+                if inYsize * inXsize == 0:
+                    numpy.save(outfile, numpy.zeros((inYsize, inXsize), shepseg.SegIdType))
                 else:
-                    _writeGdal(outfile, segimg, hist, infile, outputDriver, creationOptions,
-                               writeHistogram)
+                    dest.close()
+                if writeHistogram:
+                    numpy.save(outfile[:-4] + '_hist.npy', hist)
+            elif gdalOut is not None:
+                _finishGdalOutput(gdalOut, hist, writeHistogram)
             ok = True
         finally:
             # no buffer goes back to the cache (or to hipFree) while a worker may still write to
             # it: workers only test forceExit between tiles, so wait for them and for the chain
             if forceExit is not None:
                 forceExit.set()
+            if streamer is not None:
+                streamer.close()
+            if writer is not None:              # (failure path: the queue is abandoned)
+                try:
+                    writer.finish()
+                except Exception:
+                    pass
             stuck = False
             for t in threads:
                 t.join(timeout=None if ok else 120.0)
@@ -903,6 +1274,8 @@ def doTiledShepherdSegmentation(infile, outfile, tileSize=DFLT_TILESIZE,
                     if p_ is not None and p_.value:
                         L.shp_dev_free(main.handle, p_)
                 arena.free()
+            if devRas is not None and not stuck:
+                devRas.free()
 
     result.maxSegId = maxSegId
     result.numTileRows = tileInfo.nrows
@@ -945,7 +1318,20 @@ def _warnEmptySegments(hist, overlapSize):
     print('\n'.join(msg), file=sys.stderr)
 
 
-def _writeGdal(outfile, segimg, hist, infile, outputDriver, creationOptions, writeHistogram):
+def _rasterFitsDevice(nBands, nRows, nCols, itemsize):
+    """Is there room in HBM for the raster beside what a tiled run needs (cluster map, tile labels,
+    strips, stitched output: ~20 B per pixel) and a few worker workspaces?"""
+    c = _lib.ctx()
+    free = ctypes.c_int64(0)
+    c.check(c._L.shp_ctx_reserve_query(c.handle, 2, 1, 0, None, ctypes.byref(free), None))
+    npx = nRows * nCols
+    cached = _devCacheBytes[0]
+    return (free.value + cached) * 0.9 > npx * (nBands * itemsize + 20) + (8 << 30)
+
+
+def _createGdalOutput(outfile, ys, xs, infile, outputDriver, creationOptions):
+    """The output dataset (thematic uint32, georeferenced like the input; tiling.py:961-975);
+    returns (dataset, band)."""
     try:
         from osgeo import gdal
     except ImportError:
@@ -954,7 +1340,6 @@ def _writeGdal(outfile, segimg, hist, infile, outputDriver, creationOptions, wri
     drvr = gdal.GetDriverByName(outputDriver)
     if drvr is None:
         raise PyShepSegTilingError("This GDAL does not support driver '{}'".format(outputDriver))
-    (ys, xs) = segimg.shape
     ds = drvr.Create(outfile, xs, ys, 1, gdal.GDT_UInt32, creationOptions)
     if isinstance(infile, str):
         inDs = gdal.Open(infile)
@@ -963,7 +1348,13 @@ def _writeGdal(outfile, segimg, hist, infile, outputDriver, creationOptions, wri
     band = ds.GetRasterBand(1)
     band.SetMetadataItem('LAYER_TYPE', 'thematic')
     band.SetNoDataValue(shepseg.SEGNULLVAL)
-    band.WriteArray(segimg)
+    return (ds, band)
+
+
+def _finishGdalOutput(gdalOut, hist, writeHistogram):
+    """RAT 'Histogram' column (tiling.py:1343-1358) and flush."""
+    from osgeo import gdal
+    (ds, band) = gdalOut
     if writeHistogram:
         rat = band.GetDefaultRAT()
         rat.SetRowCount(len(hist))

@@ -82,6 +82,59 @@ def test_tiled_npy_roundtrip(tmp_path, oracle):
     assert np.array_equal(np.load(tmp_path / 'out_hist.npy'), hist)
 
 
+def test_streamed_input_and_output_match_the_per_tile_path(tmp_path, oracle, monkeypatch):
+    """a .npy raster streamed into HBM block by block (several blocks per tile row) with a band
+    selection, finished rows streamed out to a .npy memmap: same labels as the DeviceRaster path
+    and as the per-tile read + upload path (SHEPSEG_STREAM_INPUT=0)"""
+    from pyshepseg_amd import tiling, shepseg
+    monkeypatch.setattr(tiling, 'STREAM_BLOCK_ROWS', 37)
+    img = oracle.synthimg(9, 5, 700, 640)
+    np.save(tmp_path / 'in.npy', img)
+    sel = [1, 3, 4]                                     # 1-based band numbers, as the reference takes them
+    sub = np.ascontiguousarray(img[[0, 2, 3]])
+    km = shepseg.fitSpectralClusters(sub, 12, 5, None, True)
+    cfg = tiling.SegmentationConcurrencyConfig(concurrencyType=tiling.CONC_THREADS, numWorkers=4)
+    kw = dict(tileSize=256, overlapSize=64, minSegmentSize=25, kmeansObj=km, concurrencyCfg=cfg)
+    r = tiling.doTiledShepherdSegmentation(str(tmp_path / 'in.npy'), str(tmp_path / 'out.npy'),
+                                           bandNumbers=sel, **kw)
+    out = np.load(tmp_path / 'out.npy')
+    want, mx, hist = _oracle_tiled(oracle, sub, km.cluster_centers_, 256, 64, 25,
+                                   float(r.maxSpectralDiff), None, True)
+    assert r.maxSegId == mx and np.array_equal(out, want) and np.array_equal(r.hist, hist)
+    assert {'reading', 'writing', 'segmentation', 'stitchtiles'} <= set(r.timings.makeSummaryDict())
+    monkeypatch.setenv('SHEPSEG_STREAM_INPUT', '0')
+    r2 = tiling.doTiledShepherdSegmentation(img, None, bandNumbers=sel, **kw)
+    assert np.array_equal(r2.segimg, want) and r2.maxSegId == mx
+
+
+def test_failing_reader_surfaces(oracle):
+    """an exception in the raster reader thread reaches the caller and nothing hangs"""
+    import time
+    from pyshepseg_amd import tiling, shepseg
+
+    class Bad(tiling._ArraySource):
+        def readRowsInto(self, bands, y0, y1, out):
+            if y0 > 0:
+                raise IOError("disk on fire")
+            tiling._ArraySource.readRowsInto(self, bands, y0, y1, out)
+
+    img = oracle.synthimg(2, 3, 2000, 300)
+    km = shepseg.fitSpectralClusters(img, 8, 5, None, True)
+    real = tiling._open_source
+    tiling._open_source = lambda x: Bad(x) if isinstance(x, np.ndarray) else real(x)
+    try:
+        t0 = time.time()
+        with pytest.raises(tiling.PyShepSegTilingError):
+            tiling.doTiledShepherdSegmentation(img, None, tileSize=256, overlapSize=64, minSegmentSize=20,
+                                               kmeansObj=km)
+        assert time.time() - t0 < 60
+    finally:
+        tiling._open_source = real
+    r = tiling.doTiledShepherdSegmentation(img, None, tileSize=256, overlapSize=64, minSegmentSize=20,
+                                           kmeansObj=km)
+    assert r.maxSegId > 0
+
+
 @pytest.mark.parametrize('dtype,null', [(np.uint16, None), (np.int16, -7), (np.uint8, 0), (np.int32, 123456)])
 def test_assign_rects_cluster_map_vs_oracle(dtype, null, oracle):
     """shp_assign_rects_dev: rectangles of a device raster into the raster-wide cluster map ==
