@@ -207,6 +207,12 @@ int shp_stitch_chain_dev(shp_ctx *ctx, const uint32_t *d_tile, int ys, int xs, i
                          uint32_t *d_max_seg_id, int top, int bottom, int left, int right,
                          uint32_t *d_meta, uint32_t *d_right_out, uint32_t *d_bottom_out,
                          uint32_t *d_out, int64_t out_pitch, int xout, int yout);
+/* one stitched, trimmed tile (w x h at xout, yout of the device raster) sub-sampled into one overview
+ * layer exactly as SegmentationConcurrencyMgr.writeOverviews does tile by tile (tiling.py:1360-1383):
+ * every level-th pixel from offset level / 2 of the tile, written at (xout / level, yout / level),
+ * clipped to the ov_w x ov_h layer.  Asynchronous, ordered behind the tile's output write. */
+int shp_overview_window_dev(shp_ctx *ctx, const uint32_t *d_raster, int64_t pitch, int xout, int yout,
+                            int w, int h, int level, uint32_t *d_ov, int ov_w, int ov_h);
 /* histogram of a device label raster, hist_out_host[0..max_seg_id], entry 0 zeroed (the RAT
  * Histogram column, HistogramAccumulator tiling.py:1915-1963).  ncols = the raster's row length
  * (npix a multiple of it; lets a segment's pixels be combined per 2-D patch), or 0. */

@@ -100,6 +100,8 @@ _SIGS = {
                                         _vp, _c.c_int64, _c.c_uint32, _c.c_int, _vp, _c.c_int,
                                         _c.c_int, _c.c_int, _c.c_int, _vp, _vp, _vp, _vp, _c.c_int64,
                                         _c.c_int, _c.c_int]),
+    'shp_overview_window_dev': (_c.c_int, [_vp, _vp, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
+                                           _c.c_int, _vp, _c.c_int, _c.c_int]),
     'shp_histogram_dev': (_c.c_int, [_vp, _vp, _c.c_int64, _c.c_int64, _c.c_uint32, _vp]),
     'shp_segstats': (_c.c_int, [_vp, _vp, _vp, _c.c_int, _c.c_int64, _c.c_uint32, _c.c_int,
                                 _c.c_int64, _vp, _c.c_int, _c.c_int64, _vp, _vp]),

@@ -817,6 +817,27 @@ API int shp_stitch_chain_dev(shp_ctx *ctx, const uint32_t *d_tile, int ys, int x
     return 0;
 }
 
+// one trimmed tile's contribution to one overview layer; runs behind the tile's output write on the
+// context's side stream (shp_stitch_chain_dev), so the chain itself is not held up
+API int shp_overview_window_dev(shp_ctx *ctx, const uint32_t *d_raster, int64_t pitch, int xout, int yout,
+                                int w, int h, int level, uint32_t *d_ov, int ov_w, int ov_h)
+{
+    CHK(enter(ctx));
+    if (!d_raster || !d_ov || pitch < 0 || xout < 0 || yout < 0 || w < 0 || h < 0 || level < 1 || ov_w < 0 || ov_h < 0)
+        SHP_FAIL(ctx, SHP_ERR_ARG, "bad argument");
+    const uint32_t o = (uint32_t)level / 2u;
+    const uint64_t nsr = (uint32_t)h > o ? ((uint32_t)h - o + level - 1u) / level : 0u;
+    const uint64_t nsc = (uint32_t)w > o ? ((uint32_t)w - o + level - 1u) / level : 0u;
+    if (nsr * nsc == 0) return 0;
+    if (nsr * nsc >= 0x7fffffffull) SHP_FAIL(ctx, SHP_ERR_ARG, "window too large");
+    CHK(ensure_stream2(ctx));
+    hipLaunchKernelGGL(k_overview_window, dim3(grid_for((size_t)(nsr * nsc), 256)), dim3(256), 0, ctx->stream2, d_raster,
+                       (size_t)pitch, (uint32_t)xout, (uint32_t)yout, (uint32_t)w, (uint32_t)h, (uint32_t)level, d_ov,
+                       (uint32_t)ov_w, (uint32_t)ov_h);
+    KCHK(ctx);
+    return 0;
+}
+
 // histogram of a device label raster: hist_out[0..max_seg_id], hist_out[0] = 0 (tiling.py:1915-1963).
 // ncols > 0 (npix a multiple of it): the raster's row length, which lets the pixels of a segment
 // be combined per 2-D patch before they reach the global counters; 0 = unknown (1-D runs).

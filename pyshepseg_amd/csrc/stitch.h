@@ -607,3 +607,22 @@ static int run_stitch_finish(shp_ctx *ctx, const uint32_t *d_tile, uint32_t ys, 
     (void)ys;
     return 0;
 }
+
+// ---- overview layers (tiling.py:1360-1383 writeOverviews) ------------------------------------------
+// The reference sub-samples every stitched, trimmed tile by taking every lvl-th pixel from offset
+// lvl / 2 of THE TILE and writes the block at (xout / lvl, yout / lvl) of the overview band, clipped
+// to the band: ov[yout / lvl + r][xout / lvl + c] = raster[yout + lvl / 2 + r * lvl][xout + lvl / 2 + c * lvl].
+__global__ __launch_bounds__(256) void k_overview_window(const uint32_t *__restrict__ ras, size_t pitch,
+                                                         uint32_t xout, uint32_t yout, uint32_t w, uint32_t h,
+                                                         uint32_t lvl, uint32_t *__restrict__ ov, uint32_t ovw,
+                                                         uint32_t ovh)
+{
+    const uint32_t o = lvl / 2u;
+    const uint32_t nsr = h > o ? (h - o + lvl - 1u) / lvl : 0u, nsc = w > o ? (w - o + lvl - 1u) / lvl : 0u;
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= nsr * nsc) return;
+    const uint32_t r = i / nsc, c = i - r * nsc;
+    const uint32_t dr = yout / lvl + r, dc = xout / lvl + c;
+    if (dr >= ovh || dc >= ovw) return;
+    ov[(size_t)dr * ovw + dc] = ras[(size_t)(yout + o + r * lvl) * pitch + xout + o + c * lvl];
+}

@@ -58,6 +58,8 @@ class TiledSegmentationResult(object):
         self.outDs = None
         self.segimg = None
         self.hist = None
+        self.overviews = None           # {level: array}: the output file's pyramid layers (tiling.py:1360-1404)
+        self.bandStatistics = None      # [(item, value)]: the STATISTICS_* metadata (utils.py:47-95)
 
 
 class SegmentationConcurrencyConfig(object):
@@ -1170,6 +1172,13 @@ def doTiledShepherdSegmentation(infile, outfile, tileSize=DFLT_TILESIZE,
                         band.WriteArray(v, 0, y0)
                 writer = _OutputWriter(d_out, inYsize, inXsize, sink, timings)
             rowsWritten = 0
+            ovLevels = overviewLevels(inXsize, inYsize) if outfile is not _KEEP_ON_DEVICE else []
+            ovDev = []
+            for lvl in ovLevels:
+                (oh, ow) = ((inYsize + lvl - 1) // lvl, (inXsize + lvl - 1) // lvl)
+                d = _devAlloc(main, oh * ow * 4)
+                main.check(L.shp_dev_memset(main.handle, d, 0, oh * ow * 4))
+                ovDev.append((lvl, d, oh, ow))
 
             if os.environ.get('SHEPSEG_CHAIN_TIMING'):
                 # diagnostic: let every tile finish first, so that 'stitchtiles' times the bare chain
@@ -1202,6 +1211,9 @@ def doTiledShepherdSegmentation(infile, outfile, tileSize=DFLT_TILESIZE,
                         overlapSize, topB, topPitch, leftB, leftPitch, j.maxLocal,
                         int(bool(simpleTileRecode)), d_scal, top, bottom, left, right,
                         ctypes.c_void_p(j.meta), rightOut, bottomOut, d_out, inXsize, xout, yout))
+                    for (lvl, d, oh, ow) in ovDev:
+                        main.check(L.shp_overview_window_dev(main.handle, d_out, inXsize, xout, yout,
+                                                             right - left, bottom - top, lvl, d, ow, oh))
                     if writer is not None and j.col == tileInfo.ncols - 1:
                         # the tile row is stitched: its output rows are final once the device is done
                         main.check(L.shp_sync(main.handle))
@@ -1228,6 +1240,12 @@ def doTiledShepherdSegmentation(infile, outfile, tileSize=DFLT_TILESIZE,
                 _warnEmptySegments(hist, overlapSize)
 
             result = TiledSegmentationResult()
+            result.bandStatistics = estimateStatsFromHisto(hist) if hist.sum() > 0 else []
+            result.overviews = {}
+            for (lvl, d, oh, ow) in ovDev:
+                a = numpy.empty((oh, ow), dtype=shepseg.SegIdType)
+                main.check(L.shp_dev_download(main.handle, _lib.ptr(a), d, a.nbytes))
+                result.overviews[lvl] = a
             if outfile is _KEEP_ON_DEVICE:
                 result.outDev = (d_out.value, inYsize, inXsize, nbOut)
                 d_out = None                        # ownership moves to the caller
@@ -1240,8 +1258,10 @@ def doTiledShepherdSegmentation(infile, outfile, tileSize=DFLT_TILESIZE,
                     dest.close()
                 if writeHistogram:
                     numpy.save(outfile[:-4] + '_hist.npy', hist)
+                for (lvl, a) in result.overviews.items():
+                    numpy.save(outfile[:-4] + '_ov%d.npy' % lvl, a)
             elif gdalOut is not None:
-                _finishGdalOutput(gdalOut, hist, writeHistogram)
+                _finishGdalOutput(gdalOut, hist, writeHistogram, result.overviews, result.bandStatistics)
             ok = True
         finally:
             # no buffer goes back to the cache (or to hipFree) while a worker may still write to
@@ -1276,6 +1296,9 @@ def doTiledShepherdSegmentation(infile, outfile, tileSize=DFLT_TILESIZE,
                 arena.free()
             if devRas is not None and not stuck:
                 devRas.free()
+            if not stuck:
+                for (_lvl, d, oh, ow) in (ovDev if 'ovDev' in locals() else []):
+                    _devRelease(main, d, oh * ow * 4)
 
     result.maxSegId = maxSegId
     result.numTileRows = tileInfo.nrows
@@ -1287,6 +1310,42 @@ def doTiledShepherdSegmentation(infile, outfile, tileSize=DFLT_TILESIZE,
     result.hist = hist
     result.timings = timings
     return result
+
+
+def overviewLevels(inXsize, inYsize):
+    """The overview (pyramid) levels of an output raster: 4, 8, 16 ... the last one being the first
+    whose layer is smaller than 1024 pixels on the raster's larger side; none below 4096 pixels
+    (the rule of the reference's setupOverviews, tiling.py:1385-1404)."""
+    outSize = max(int(inXsize), int(inYsize))
+    levels = []
+    lvl = 4
+    if outSize // lvl >= 1024:
+        levels.append(lvl)
+        while outSize // lvl >= 1024:
+            lvl *= 2
+            levels.append(lvl)
+    return levels
+
+
+def estimateStatsFromHisto(hist):
+    """The band statistics the reference derives from the segment histogram and stores as GDAL
+    metadata (utils.estimateStatsFromHisto, utils.py:47-95): list of (item name, string value) in
+    the reference's order, values formatted as it formats them (ints for the thematic band)."""
+    hist = numpy.asarray(hist)
+    mask = hist > 0
+    nVals = hist.sum()
+    minVal = mask.argmax()
+    maxVal = hist.shape[0] - numpy.flip(mask).argmax() - 1
+    values = numpy.arange(hist.shape[0])
+    meanVal = (values * hist).sum() / nVals
+    stdDevVal = numpy.sqrt((hist * numpy.power(values - meanVal, 2)).sum() / nVals)
+    modeVal = numpy.argmax(hist)
+    medianVal = (hist.cumsum() >= hist.sum() / 2).nonzero()[0][0]
+    return [("STATISTICS_MINIMUM", repr(int(minVal))), ("STATISTICS_MAXIMUM", repr(int(maxVal))),
+            ("STATISTICS_MEAN", repr(float(meanVal))), ("STATISTICS_STDDEV", repr(float(stdDevVal))),
+            ("STATISTICS_MODE", repr(int(modeVal))), ("STATISTICS_MEDIAN", repr(int(medianVal))),
+            ("STATISTICS_SKIPFACTORX", "1"), ("STATISTICS_SKIPFACTORY", "1"),
+            ("STATISTICS_HISTOBINFUNCTION", "direct")]
 
 
 _KEEP_ON_DEVICE = object()      # outfile sentinel used by bench.py: labels stay in HBM
@@ -1351,10 +1410,18 @@ def _createGdalOutput(outfile, ys, xs, infile, outputDriver, creationOptions):
     return (ds, band)
 
 
-def _finishGdalOutput(gdalOut, hist, writeHistogram):
-    """RAT 'Histogram' column (tiling.py:1343-1358) and flush."""
+def _finishGdalOutput(gdalOut, hist, writeHistogram, overviews, bandStatistics):
+    """Overview layers (tiling.py:1360-1404), RAT 'Histogram' column (tiling.py:1343-1358), band
+    statistics metadata (utils.py:47-95) and flush."""
     from osgeo import gdal
     (ds, band) = gdalOut
+    if overviews:
+        levels = sorted(overviews)
+        ds.BuildOverviews("NEAREST", levels)
+        for (j, lvl) in enumerate(levels):
+            band.GetOverview(j).WriteArray(overviews[lvl], 0, 0)
+    for (k, v) in bandStatistics:
+        band.SetMetadataItem(k, v)
     if writeHistogram:
         rat = band.GetDefaultRAT()
         rat.SetRowCount(len(hist))

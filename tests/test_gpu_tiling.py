@@ -82,6 +82,27 @@ def test_tiled_npy_roundtrip(tmp_path, oracle):
     assert np.array_equal(np.load(tmp_path / 'out_hist.npy'), hist)
 
 
+@pytest.mark.parametrize('name', ['stitch_3x4_8conn', 'stitch_3x3_null', 'stitch_2x2'])
+def test_overviews_vs_reference(name, golden, monkeypatch, tmp_path):
+    """the output pyramid layers, written tile by tile like the reference's writeOverviews (levels
+    2, 4, 8: the fixtures are below the size where the reference starts building them)"""
+    from pyshepseg_amd import tiling, shepseg
+    g = golden(name)
+    gov = golden('overviews_stats')
+    monkeypatch.setattr(tiling, 'overviewLevels', lambda xs, ys: [2, 4, 8])
+    km = shepseg.KMeansModel(g['centres'])
+    null = int(g['null_val']) if int(g['has_null']) else None
+    r = tiling.doTiledShepherdSegmentation(
+        g['img'], str(tmp_path / 'o.npy'), tileSize=int(g['tile_size']), overlapSize=int(g['overlap']),
+        minSegmentSize=int(g['min_seg']), maxSpectralDiff=float(g['msd']), imgNullVal=null,
+        fourConnected=bool(g['four']), kmeansObj=km)
+    assert np.array_equal(np.load(tmp_path / 'o.npy'), g['mosaic'])
+    for lvl in (2, 4, 8):
+        assert np.array_equal(r.overviews[lvl], gov['%s_ov%d' % (name, lvl)]), lvl
+        assert np.array_equal(np.load(tmp_path / ('o_ov%d.npy' % lvl)), r.overviews[lvl])
+    assert ['%s=%s' % kv for kv in r.bandStatistics] == gov[name + '_stats'].tolist()
+
+
 def test_streamed_input_and_output_match_the_per_tile_path(tmp_path, oracle, monkeypatch):
     """a .npy raster streamed into HBM block by block (several blocks per tile row) with a band
     selection, finished rows streamed out to a .npy memmap: same labels as the DeviceRaster path

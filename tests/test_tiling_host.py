@@ -65,6 +65,21 @@ def test_diagonal_centres_cast_like_reference():
             assert got.dtype == x.dtype and np.array_equal(got, want)
 
 
+def test_overview_levels_and_band_statistics(golden):
+    """setupOverviews' level rule and estimateStatsFromHisto's metadata strings against the
+    reference's own output (oracle/refgen/gen_golden_overviews.py)"""
+    from pyshepseg_amd import tiling
+    g = golden('overviews_stats')
+    for key in [k for k in g if k.startswith('levels_')]:
+        size = int(key.split('_')[1])
+        assert tiling.overviewLevels(size, size // 2) == g[key].tolist(), key
+        assert tiling.overviewLevels(size // 2, size) == g[key].tolist(), key
+    for case in ('stitch_3x4_8conn', 'stitch_3x3_null', 'stitch_2x2'):
+        hist = golden(case)['hist']
+        got = ['%s=%s' % kv for kv in tiling.estimateStatsFromHisto(hist)]
+        assert got == g[case + '_stats'].tolist(), case
+
+
 def test_subsample_indices_restart_per_block():
     from pyshepseg_amd import tiling
     idx = tiling._subsample_indices(2500, 40)
