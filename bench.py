@@ -17,8 +17,8 @@ Workloads (BASELINE.json configs):
       result columns copied to the host.
 value = image pixels / step time.
 
-torch is used only for process-group plumbing when N > 1 (barrier, max over ranks); the product
-path is pyshepseg_amd -> ctypes -> libshepseg_hip.so.
+No torch anywhere: with N > 1 the ranks talk over RCCL bound directly behind the C-ABI
+(pyshepseg_amd/comm.py); the product path is pyshepseg_amd -> ctypes -> libshepseg_hip.so.
 """
 import argparse
 import ctypes
@@ -31,7 +31,7 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-# must be in the environment before the HIP runtime starts (torch initialises it first when N > 1)
+# must be in the environment before the HIP runtime starts
 os.environ.setdefault('GPU_MAX_HW_QUEUES', '24')
 
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
@@ -131,25 +131,30 @@ def cpu_baseline(ras, args, centres, msd):
 
 def spawn_ranks(args):
     """`python bench.py --gpus N` without a launcher: start the N ranks as fresh child processes
-    (this process has not touched the GPU and never does), relay rank 0's JSON line."""
+    (this process has not touched the GPU and never does) with the environment a launcher would
+    set, relay rank 0's JSON line."""
     import socket
     import subprocess
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
-           '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1', '--master-port', str(port),
-           os.path.abspath(__file__)] + sys.argv[1:]
-    p = subprocess.run(cmd, stdout=subprocess.PIPE, text=True)
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+                   LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else None, text=True))
+    out0 = procs[0].communicate()[0]
+    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
     line = None
-    for ln in p.stdout.splitlines():
+    for ln in (out0 or '').splitlines():
         if ln.startswith('{') and '"metric"' in ln:
             line = ln
         else:
             sys.stderr.write(ln + '\n')
-    if p.returncode != 0 or line is None:
-        sys.stderr.write('bench.py: the %d-rank run failed (exit code %d)\n' % (args.gpus, p.returncode))
-        sys.exit(p.returncode or 1)
+    if any(rcs) or line is None:
+        sys.stderr.write('bench.py: the %d-rank run failed (exit codes %s)\n' % (args.gpus, rcs))
+        sys.exit(next((rc for rc in rcs if rc), 1))
     if json.loads(line).get('n_gpus') != args.gpus:
         sys.stderr.write('bench.py: the ranks report n_gpus != %d\n' % args.gpus)
         sys.exit(1)
@@ -371,19 +376,14 @@ def main():
         sys.stderr.write('bench.py: --gpus %d but WORLD_SIZE=%d\n' % (args.gpus, world))
         sys.exit(2)
     os.environ.setdefault('SHEPSEG_DEVICE', str(local_rank))
-    dist = None
     force_dist = os.environ.get('SHEPSEG_FORCE_DIST', '0') == '1' and 'RANK' in os.environ
     if world > 1 or force_dist:
         if args.workload == 'c5':
             sys.stderr.write('bench.py: --workload c5 runs on one GPU (the sharded statistics are '
                              'covered by tests/test_distributed_cpu.py)\n')
             sys.exit(2)
-        import torch
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend='nccl')
         from pyshepseg_amd import distributed
-        return distributed.bench_main(args, rank, world, local_rank, dist)
+        return distributed.bench_main(args, rank, world, local_rank)
     if args.workload == 'c5':
         return bench_stats(args)
     return bench_segmentation(args)

@@ -300,6 +300,25 @@ int shp_spatialstats_dev(shp_ctx *ctx, const uint32_t *d_seg, const void *d_band
                          int func, const double *params, int64_t missing, int nint, int nflt,
                          int64_t *intcols_out, float *floatcols_out);
 
+/* ---- multi-GPU exchange -----------------------------------------------------------------
+ * One process per GPU.  The reference ships whole pickled tile results to one process over a
+ * multiprocessing.managers TCP channel (NetworkDataChannel, tiling.py:1799-1912; SegmentationResultCache
+ * :1966-2001); here the tiles are sharded and only the stitch's boundary data crosses GPUs, over RCCL:
+ * shp_comm_send / shp_comm_recv move a recoded overlap strip (device memory, xGMI point to point),
+ * shp_comm_bcast the k-means centres, shp_comm_allgather the sample parts, shp_comm_allreduce
+ * (op 0: int64 sum, op 1: float64 max) the segment histogram and the timing.  A communicator is
+ * bound to a context (its device and stream); every call returns when the operation is complete.
+ * shp_comm_unique_id: 128 bytes made by rank 0 and handed to the other ranks out of band. */
+typedef struct shp_comm shp_comm;
+int  shp_comm_unique_id(void *id_out_128);
+int  shp_comm_create(shp_ctx *ctx, int rank, int world, const void *unique_id_128, shp_comm **out);
+void shp_comm_destroy(shp_comm *comm);
+int  shp_comm_send(shp_comm *comm, const void *d_buf, size_t bytes, int dst);
+int  shp_comm_recv(shp_comm *comm, void *d_buf, size_t bytes, int src);
+int  shp_comm_bcast(shp_comm *comm, void *d_buf, size_t bytes, int root);
+int  shp_comm_allgather(shp_comm *comm, const void *d_send, void *d_recv, size_t bytes_per_rank);
+int  shp_comm_allreduce(shp_comm *comm, void *d_buf, size_t count, int op);
+
 #ifdef __cplusplus
 }
 #endif

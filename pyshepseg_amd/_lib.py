@@ -122,6 +122,14 @@ _SIGS = {
     'shp_spatialstats_dev': (_c.c_int, [_vp, _vp, _vp, _c.c_int, _c.c_int64, _c.c_int64, _c.c_uint32,
                                         _c.c_int64, _c.c_int, _vp, _c.c_int64, _c.c_int, _c.c_int,
                                         _vp, _vp]),
+    'shp_comm_unique_id': (_c.c_int, [_vp]),
+    'shp_comm_create': (_c.c_int, [_vp, _c.c_int, _c.c_int, _vp, _c.POINTER(_vp)]),
+    'shp_comm_destroy': (None, [_vp]),
+    'shp_comm_send': (_c.c_int, [_vp, _vp, _c.c_size_t, _c.c_int]),
+    'shp_comm_recv': (_c.c_int, [_vp, _vp, _c.c_size_t, _c.c_int]),
+    'shp_comm_bcast': (_c.c_int, [_vp, _vp, _c.c_size_t, _c.c_int]),
+    'shp_comm_allgather': (_c.c_int, [_vp, _vp, _vp, _c.c_size_t]),
+    'shp_comm_allreduce': (_c.c_int, [_vp, _vp, _c.c_size_t, _c.c_int]),
     'shp_gather_flagged_dev': (_c.c_int, [_vp, _vp, _vp, _c.c_int, _c.c_int64, _c.c_uint32, _vp,
                                           _c.c_int64, _vp, _vp, _vp]),
 }

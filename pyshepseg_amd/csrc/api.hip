@@ -14,6 +14,7 @@ static int read_u32(shp_ctx *ctx, const uint32_t *d, uint32_t *h);
 #include "segstats.h"
 #include "subset.h"
 #include "spatial.h"
+#include "comm.h"
 
 #define API extern "C" __attribute__((visibility("default")))
 
@@ -1115,4 +1116,86 @@ API int shp_ctx_reserve_query(shp_ctx *ctx, int dtype, int nbands, int64_t npix,
         if (total_bytes) *total_bytes = (int64_t)tot;
     }
     return 0;
+}
+
+// ---- RCCL communicator (multi-GPU stitch exchange) ----------------------------------------------
+API int shp_comm_unique_id(void *id_out_128)
+{
+    if (!id_out_128) return SHP_ERR_ARG;
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId size");
+    return ncclGetUniqueId((ncclUniqueId *)id_out_128) == ncclSuccess ? SHP_OK : SHP_ERR_HIP;
+}
+
+API int shp_comm_create(shp_ctx *ctx, int rank, int world, const void *unique_id_128, shp_comm **out)
+{
+    CHK(enter(ctx));
+    if (!out || !unique_id_128 || world < 1 || rank < 0 || rank >= world) SHP_FAIL(ctx, SHP_ERR_ARG, "bad argument");
+    *out = nullptr;
+    shp_comm *cm = new shp_comm();
+    cm->ctx = ctx; cm->rank = rank; cm->world = world;
+    ncclUniqueId id;
+    memcpy(&id, unique_id_128, sizeof(id));
+    ncclResult_t r = ncclCommInitRank(&cm->nc, world, id, rank);        // (the context's device is current)
+    if (r != ncclSuccess) {
+        delete cm;
+        SHP_FAIL(ctx, SHP_ERR_HIP, "ncclCommInitRank(rank %d of %d): %s", rank, world, ncclGetErrorString(r));
+    }
+    *out = cm;
+    return 0;
+}
+
+API void shp_comm_destroy(shp_comm *cm)
+{
+    if (!cm) return;
+    if (cm->ctx) { hipSetDevice(cm->ctx->device); hipStreamSynchronize(cm->ctx->stream); }
+    if (cm->nc) ncclCommDestroy(cm->nc);
+    delete cm;
+}
+
+API int shp_comm_send(shp_comm *cm, const void *d_buf, size_t bytes, int dst)
+{
+    if (!cm) return SHP_ERR_ARG;
+    CHK(enter(cm->ctx));
+    if ((!d_buf && bytes) || dst < 0 || dst >= cm->world) SHP_FAIL(cm->ctx, SHP_ERR_ARG, "bad argument");
+    NCCLCHK(cm->ctx, ncclSend(d_buf, bytes, ncclUint8, dst, cm->nc, cm->ctx->stream));
+    return comm_finish(cm);
+}
+
+API int shp_comm_recv(shp_comm *cm, void *d_buf, size_t bytes, int src)
+{
+    if (!cm) return SHP_ERR_ARG;
+    CHK(enter(cm->ctx));
+    if ((!d_buf && bytes) || src < 0 || src >= cm->world) SHP_FAIL(cm->ctx, SHP_ERR_ARG, "bad argument");
+    NCCLCHK(cm->ctx, ncclRecv(d_buf, bytes, ncclUint8, src, cm->nc, cm->ctx->stream));
+    return comm_finish(cm);
+}
+
+API int shp_comm_bcast(shp_comm *cm, void *d_buf, size_t bytes, int root)
+{
+    if (!cm) return SHP_ERR_ARG;
+    CHK(enter(cm->ctx));
+    if ((!d_buf && bytes) || root < 0 || root >= cm->world) SHP_FAIL(cm->ctx, SHP_ERR_ARG, "bad argument");
+    NCCLCHK(cm->ctx, ncclBroadcast(d_buf, d_buf, bytes, ncclUint8, root, cm->nc, cm->ctx->stream));
+    return comm_finish(cm);
+}
+
+// every rank contributes bytes_per_rank bytes; d_recv holds world * bytes_per_rank
+API int shp_comm_allgather(shp_comm *cm, const void *d_send, void *d_recv, size_t bytes_per_rank)
+{
+    if (!cm) return SHP_ERR_ARG;
+    CHK(enter(cm->ctx));
+    if (!d_send || !d_recv) SHP_FAIL(cm->ctx, SHP_ERR_ARG, "NULL argument");
+    NCCLCHK(cm->ctx, ncclAllGather(d_send, d_recv, bytes_per_rank, ncclUint8, cm->nc, cm->ctx->stream));
+    return comm_finish(cm);
+}
+
+// in place; op 0 = sum of int64, 1 = max of float64
+API int shp_comm_allreduce(shp_comm *cm, void *d_buf, size_t count, int op)
+{
+    if (!cm) return SHP_ERR_ARG;
+    CHK(enter(cm->ctx));
+    if ((!d_buf && count) || (op != 0 && op != 1)) SHP_FAIL(cm->ctx, SHP_ERR_ARG, "bad argument");
+    NCCLCHK(cm->ctx, ncclAllReduce(d_buf, d_buf, count, op == 0 ? ncclInt64 : ncclFloat64,
+                                   op == 0 ? ncclSum : ncclMax, cm->nc, cm->ctx->stream));
+    return comm_finish(cm);
 }

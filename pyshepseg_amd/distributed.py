@@ -1,5 +1,5 @@
-"""Multi-GPU tiled Shepherd segmentation: one process per GPU (torch.distributed, RCCL over
-xGMI on the GPU box, gloo in the CPU tests).
+"""Multi-GPU tiled Shepherd segmentation: one process per GPU, RCCL over xGMI bound directly
+behind the C-ABI (pyshepseg_amd/comm.py: RcclComm; SocketComm in the CPU tests).
 
 What shards and what does not
 -----------------------------
@@ -136,57 +136,11 @@ def boundaryPlan(tileInfo, shards, p, overlapSize):
     return plan
 
 
-class Comm(object):
-    """Thin torch.distributed wrapper (nccl = RCCL on the GPU box, gloo in CPU tests)."""
-    def __init__(self, dist=None, device=None):
-        self.dist = dist
-        self.rank = dist.get_rank() if dist is not None else 0
-        self.world = dist.get_world_size() if dist is not None else 1
-        self.device = device            # torch device for collectives' tensors
-
-    def _t(self, arr):
-        import torch
-        t = torch.from_numpy(numpy.ascontiguousarray(arr))
-        return t.to(self.device) if self.device is not None else t
-
-    def allgather_obj(self, obj):
-        if self.world == 1:
-            return [obj]
-        out = [None] * self.world
-        self.dist.all_gather_object(out, obj)
-        return out
-
-    def bcast_obj(self, obj, src=0):
-        if self.world == 1:
-            return obj
-        lst = [obj]
-        self.dist.broadcast_object_list(lst, src=src)
-        return lst[0]
-
-    def allreduce_sum_i64(self, arr):
-        if self.world == 1:
-            return arr
-        t = self._t(arr.astype(numpy.int64))
-        self.dist.all_reduce(t)
-        return t.cpu().numpy()
-
-    def max_f64(self, v):
-        if self.world == 1:
-            return v
-        import torch
-        t = self._t(numpy.array([v], dtype=numpy.float64))
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
-        return float(t.cpu().numpy()[0])
-
-    def barrier(self):
-        if self.world > 1:
-            self.dist.barrier()
-
-    def send(self, tensor, dst):
-        self.dist.send(tensor, dst)
-
-    def recv(self, tensor, src):
-        self.dist.recv(tensor, src)
+def Comm(_unused=None, device=None):
+    """World-size-1 communicator (kept for callers that ran the sharded driver in one process);
+    multi-rank communicators come from pyshepseg_amd.comm."""
+    from . import comm as _comm
+    return _comm.LocalComm()
 
 
 # ------------------------------------------------------------------------------------------
@@ -370,7 +324,8 @@ def calcPerSegmentStatsDistributed(engine, comm, hist, imgbandnum, statsSelectio
 class HipEngine(object):
     """Holds rows [yLo, yHi) of the raster in HBM (a DeviceRaster created by `makeSlice`),
     segments this rank's tiles with pooled worker contexts and stitches them on the device.
-    Boundary strips travel as torch CUDA tensors over torch.distributed (nccl = RCCL)."""
+    Boundary strips go from this rank's strip block straight into ncclSend (RcclComm), or through
+    host memory when the communicator is not on the device (SocketComm: ranks sharing a GPU)."""
 
     def __init__(self, makeSlice, numWorkers=16, keepOutput=False):
         self.makeSlice = makeSlice          # f(yLo, yHi) -> DeviceRaster of those rows
@@ -464,51 +419,34 @@ class HipEngine(object):
                 ctypes.c_void_p(self.d_strips.value + 4 * j.bottomOff), self.d_out, self.nCols, xout,
                 yout - self.outLo))
 
-    @staticmethod
-    def _onGpu(comm):
-        return comm.device is not None and str(comm.device).startswith('cuda')
-
     def sendBoundary(self, comm, dst, maxSegId, items):
         """items: (kind, job, h, w) from boundaryPlan; strips are dense h x w blocks."""
-        import torch
         self.c.check(self.L.shp_sync(self.c.handle))
-        gpu = self._onGpu(comm)
-        hdr = torch.tensor([maxSegId], dtype=torch.int64, device=comm.device)
-        comm.send(hdr, dst)
+        comm.send_obj(int(maxSegId), dst)
         for (kind, a, h, w) in items:
             n = h * w
-            buf = torch.empty(n, dtype=torch.int32, device=comm.device)
             (ptr, _pitch) = self.bottomStripOf(a) if kind == 'b' else self.rightStripOf(a)
-            if gpu:      # device-to-device into the RCCL send buffer
-                self.c.check(self.L.shp_dev_copy(self.c.handle, ctypes.c_void_p(buf.data_ptr()),
-                                                 ctypes.c_void_p(ptr), n * 4))
-            else:        # gloo (tests): stage through host memory
-                self.c.check(self.L.shp_dev_download(self.c.handle, ctypes.c_void_p(buf.data_ptr()),
-                                                     ctypes.c_void_p(ptr), n * 4))
-            comm.send(buf, dst)
+            if comm.onDevice:        # device memory straight into RCCL
+                comm.send_dev(ptr, n * 4, dst)
+            else:                    # ranks without a device transport: stage through host memory
+                buf = numpy.empty(n, dtype=numpy.uint32)
+                self.c.check(self.L.shp_dev_download(self.c.handle, _lib.ptr(buf), ctypes.c_void_p(ptr), n * 4))
+                comm.send_bytes(buf, dst)
 
     def recvBoundary(self, comm, src, plan):
-        import torch
-        gpu = self._onGpu(comm)
-        hdr = torch.zeros(1, dtype=torch.int64, device=comm.device)
-        comm.recv(hdr, src)
+        maxSegId = int(comm.recv_obj(src))
         strips = {}
         for (kind, col, row, h, w) in plan:
             n = h * w
-            buf = torch.empty(n, dtype=torch.int32, device=comm.device)
-            comm.recv(buf, src)
-            if gpu:
-                self.recvBufs.append(buf)                # keep alive until finish()
-                strips[(kind, col, row)] = (buf.data_ptr(), w)
+            d = tiling._devAlloc(self.c, n * 4)
+            self.recvDev.append((d, n * 4))
+            if comm.onDevice:
+                comm.recv_dev(d.value, n * 4, src)
             else:
-                d = tiling._devAlloc(self.c, n * 4)
-                self.c.check(self.L.shp_dev_upload(self.c.handle, d, ctypes.c_void_p(buf.data_ptr()),
-                                                   n * 4))
-                self.recvDev.append((d, n * 4))
-                strips[(kind, col, row)] = (d.value, w)
-        if gpu:
-            torch.cuda.synchronize()
-        return int(hdr.cpu()[0]), strips
+                buf = numpy.frombuffer(comm.recv_bytes(src), dtype=numpy.uint32)
+                self.c.check(self.L.shp_dev_upload(self.c.handle, d, _lib.ptr(numpy.ascontiguousarray(buf)), n * 4))
+            strips[(kind, col, row)] = (d.value, w)
+        return maxSegId, strips
 
     def histogram(self, maxSegId):
         hist = numpy.zeros(maxSegId + 1, dtype=numpy.uint32)
@@ -590,17 +528,17 @@ class HipEngine(object):
 # ------------------------------------------------------------------------------------------
 # bench.py entry for --gpus N > 1
 # ------------------------------------------------------------------------------------------
-def bench_main(args, rank, world, local_rank, dist):
-    """One rank of the multi-GPU benchmark: this rank's rows of the synthetic C3 image are
-    generated in its own HBM (synthimg is position-deterministic); a step = runDistributed."""
-    import torch
-    dev = torch.device('cuda', local_rank)
-    comm = Comm(dist, device=dev)
+def bench_main(args, rank, world, local_rank):
+    """One rank of the multi-GPU benchmark: this rank's rows of the synthetic image are generated
+    in its own HBM (synthimg is position-deterministic); a step = runDistributed."""
+    from . import comm as _comm
+    comm = _comm.fromEnvironment()
     nb = args.bands
 
     def makeSlice(yLo, yHi):
         return tiling.DeviceRaster.synth(getattr(args, 'seed', 11), nb, yHi - yLo, args.size, y0=yLo, x0=0)
     engine = HipEngine(makeSlice, numWorkers=args.workers)
+    sync = _lib.ctx()
 
     def step():
         return runDistributed(engine, comm, args.size, args.size, args.tile, args.overlap,
@@ -608,12 +546,12 @@ def bench_main(args, rank, world, local_rank, dist):
 
     for _ in range(args.warmup):
         r = step()
+    sync.check(sync._L.shp_sync(sync.handle))
     comm.barrier()
-    torch.cuda.synchronize()
     t0 = time.time()
     for _ in range(args.steps):
         r = step()
-    torch.cuda.synchronize()
+    sync.check(sync._L.shp_sync(sync.handle))
     comm.barrier()
     dt = comm.max_f64((time.time() - t0) / max(args.steps, 1))
     if rank == 0:
@@ -631,12 +569,13 @@ def bench_main(args, rank, world, local_rank, dist):
                                       args.tile, args.overlap, world),
                        "tiles": r.numTileRows * r.numTileCols, "worker_streams": args.workers,
                        "max_seg_id": int(r.maxSegId),
-                       "parallelism": "tile rows sharded; stitch chain over send/recv (RCCL)"},
+                       "parallelism": "tiles sharded by area; stitch chain over ncclSend/ncclRecv (%s)"
+                                      % type(comm).__name__},
             "roofline": {"bound": "hbm", "kernel": "whole path", "achieved": round(
                 value * 1e6 * (2 * nb + 4) / 1e9, 3), "peak": 8000.0 * world, "unit": "GB/s",
                 "frac": round(value * 1e6 * (2 * nb + 4) / 1e9 / (8000.0 * world), 6),
                 "traffic": None},
         }
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     comm.barrier()
-    dist.destroy_process_group()
+    comm.close()

@@ -71,24 +71,18 @@ class OracleEngine(object):
         self.maxSeg = max(self.maxSeg, int(trimmed.max()))
 
     def sendBoundary(self, comm, dst, maxSegId, items):
-        import torch
-        comm.send(torch.tensor([maxSegId], dtype=torch.int64), dst)
+        comm.send_obj(int(maxSegId), dst)
         for (kind, a, h, w) in items:
             s = self.bottomStripOf(a) if kind == 'b' else self.rightStripOf(a)
             assert s.shape == (h, w)
-            s = np.ascontiguousarray(s).view(np.int32).reshape(-1)
-            comm.send(torch.from_numpy(s.copy()), dst)
+            comm.send_bytes(np.ascontiguousarray(s, dtype=np.uint32), dst)
 
     def recvBoundary(self, comm, src, plan):
-        import torch
-        hdr = torch.zeros(1, dtype=torch.int64)
-        comm.recv(hdr, src)
+        maxSegId = int(comm.recv_obj(src))
         strips = {}
         for (kind, col, row, h, w) in plan:
-            buf = torch.empty(h * w, dtype=torch.int32)
-            comm.recv(buf, src)
-            strips[(kind, col, row)] = buf.numpy().view(np.uint32).reshape(h, w)
-        return int(hdr[0]), strips
+            strips[(kind, col, row)] = np.frombuffer(comm.recv_bytes(src), dtype=np.uint32).reshape(h, w).copy()
+        return maxSegId, strips
 
     def histogram(self, maxSegId):
         return np.bincount(self.out.ravel(), minlength=maxSegId + 1)[:maxSegId + 1]

@@ -1,4 +1,4 @@
-"""Rank program of tests/test_distributed_cpu.py (gloo, no GPU): runs the multi-GPU driver with
+"""Rank program of tests/test_distributed_cpu.py (socket transport, no GPU): runs the multi-GPU driver with
 the oracle engine and writes this rank's output rows to disk."""
 import os
 import sys
@@ -13,13 +13,12 @@ sys.path.insert(0, HERE)
 def main():
     outdir = sys.argv[1]
     tile, ov, simple = int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
-    import torch.distributed as dist
-    dist.init_process_group(backend='gloo')
     from oracle import oracle
     from pyshepseg_amd import distributed
+    from pyshepseg_amd import comm as shpcomm
     from dist_oracle_engine import OracleEngine
     img = np.load(os.path.join(outdir, 'img.npy'))
-    comm = distributed.Comm(dist)
+    comm = shpcomm.SocketComm()
     eng = OracleEngine(img, oracle)
     r = distributed.runDistributed(eng, comm, img.shape[1], img.shape[2], tile, ov,
                                    minSegmentSize=12, numClusters=8, fixedKMeansInit=True,
@@ -32,8 +31,7 @@ def main():
     np.savez(os.path.join(outdir, 'rank%d.npz' % comm.rank), out=eng.out, outLo=r.outRows[0],
              outHi=r.outRows[1], maxSegId=r.maxSegId, hist=r.hist,
              centres=r.kmeans.cluster_centers_, msd=r.maxSpectralDiff, rows=np.array(r.rowRange))
-    dist.barrier()
-    dist.destroy_process_group()
+    comm.close()
 
 
 if __name__ == '__main__':

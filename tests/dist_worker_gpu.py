@@ -1,5 +1,6 @@
 """Rank program of tests/test_gpu_distributed.py: the multi-GPU driver with the HIP engine.
-With backend gloo every rank uses GPU 0 (one-GPU test box); with nccl one GPU per rank."""
+Transport 'socket': every rank uses GPU 0 (one-GPU test box), strips staged through host memory;
+'rccl': one GPU per rank, strips device to device."""
 import os
 import sys
 
@@ -10,19 +11,14 @@ sys.path.insert(0, os.path.dirname(HERE))
 
 
 def main():
-    outdir, backend = sys.argv[1], sys.argv[2]
-    import torch.distributed as dist
-    dist.init_process_group(backend=backend)
-    if backend == 'gloo':
+    outdir, transport = sys.argv[1], sys.argv[2]
+    if transport == 'socket':
         os.environ['SHEPSEG_DEVICE'] = '0'
-        device = None
     else:
-        import torch
-        lr = int(os.environ.get('LOCAL_RANK', '0'))
-        torch.cuda.set_device(lr)
-        device = torch.device('cuda', lr)
+        os.environ['SHEPSEG_DEVICE'] = os.environ.get('LOCAL_RANK', '0')
     from pyshepseg_amd import distributed, tiling
-    comm = distributed.Comm(dist, device=device)
+    from pyshepseg_amd import comm as shpcomm
+    comm = shpcomm.SocketComm() if transport == 'socket' else shpcomm.RcclComm()
     nb, nr, nc = 6, 1500, 1300
 
     def makeSlice(yLo, yHi):
@@ -39,8 +35,7 @@ def main():
     np.savez(os.path.join(outdir, 'rank%d.npz' % comm.rank), out=out, outLo=r.outRows[0],
              outHi=r.outRows[1], maxSegId=r.maxSegId, hist=r.hist,
              centres=r.kmeans.cluster_centers_, msd=r.maxSpectralDiff)
-    dist.barrier()
-    dist.destroy_process_group()
+    comm.close()
 
 
 if __name__ == '__main__':

@@ -1,4 +1,4 @@
-"""CPU (gloo, world_size 2 and 3): the multi-GPU driver's sharding, k-means gather/broadcast,
+"""CPU (socket transport, world_size 2 and 3): the multi-GPU driver's sharding, k-means gather/broadcast,
 stitch chain with boundary exchange and histogram all-reduce, run with the oracle engine, must
 reproduce the single-process tiled result exactly."""
 import os
@@ -15,6 +15,26 @@ from conftest import ROOT
 class _Ds(object):
     def __init__(self, ys, xs):
         self.RasterYSize, self.RasterXSize = ys, xs
+
+
+def test_socket_comm_collectives(tmp_path):
+    """the socket transport's point-to-point and collectives at world size 3"""
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from pyshepseg_amd import comm as C\n"
+        "c = C.SocketComm()\n"
+        "r, w = c.rank, c.world\n"
+        "assert c.allgather_obj({'r': r}) == [{'r': i} for i in range(w)]\n"
+        "assert c.bcast_obj('x' * 100000 if r == 1 else None, src=1) == 'x' * 100000\n"
+        "assert c.allreduce_sum_i64(np.arange(5) * (r + 1)).tolist() == (np.arange(5) * sum(range(1, w + 1))).tolist()\n"
+        "assert c.max_f64(1.5 * r) == 1.5 * (w - 1)\n"
+        "a = np.arange(300000, dtype=np.uint32) + r\n"
+        "c.send_bytes(a, (r + 1) %% w)\n"
+        "b = np.frombuffer(c.recv_bytes((r - 1) %% w), dtype=np.uint32)\n"
+        "assert np.array_equal(b, np.arange(300000, dtype=np.uint32) + (r - 1) %% w)\n"
+        "c.barrier(); c.close()\n" % ROOT)
+    _run_ranks(3, ['-c', code], tmp_path, timeout=120)
 
 
 def test_shard_tile_rows():
@@ -80,12 +100,18 @@ def test_shard_plan_random_grids():
                     assert ('r', col - 1, row) in got
 
 
-def _free_port():
-    s = socket.socket()
-    s.bind(('127.0.0.1', 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+def _run_ranks(world, argv, tmp_path, timeout=600):
+    """start `world` rank processes with the environment a launcher sets; all must exit 0"""
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT='0', OMP_NUM_THREADS='1',
+                   SHEPSEG_COMM_DIR=str(tmp_path / 'comm'))
+        procs.append(subprocess.Popen([sys.executable] + argv, env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=timeout) for p in procs]
+    for (p, (_o, e)) in zip(procs, outs):
+        assert p.returncode == 0, e[-3000:]
 
 
 @pytest.mark.parametrize('world,simple,NR', [(2, 0, 330), (3, 0, 330), (2, 1, 330), (3, 0, 150)])
@@ -95,13 +121,8 @@ def test_two_rank_chain_matches_single_process(world, simple, NR, tmp_path, orac
     img[:, :4, :] = 65535                      # a null border row band (nulls are not given here)
     np.save(tmp_path / 'img.npy', img)
     tile, ov = 96, 32
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1', OMP_NUM_THREADS='1')
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
-           '--nproc-per-node', str(world), '--master-addr', '127.0.0.1',
-           '--master-port', str(_free_port()), os.path.join(ROOT, 'tests', 'dist_worker.py'),
-           str(tmp_path), str(tile), str(ov), str(simple)]
-    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
-    assert p.returncode == 0, p.stderr[-3000:]
+    _run_ranks(world, [os.path.join(ROOT, 'tests', 'dist_worker.py'), str(tmp_path), str(tile), str(ov),
+                       str(simple)], tmp_path)
     parts = [np.load(tmp_path / ('rank%d.npz' % r)) for r in range(world)]
     # single-process reference: oracle tiles + oracle stitch with the same centres
     centres, msd = parts[0]['centres'], float(parts[0]['msd'])

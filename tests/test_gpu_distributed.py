@@ -1,7 +1,7 @@
-"""GPU: the multi-GPU driver with the HIP engine.  The test box has one GPU, so two ranks
-share it and exchange the boundary strips over gloo (host-staged); the strips, the maxSegId
-chain and the histogram all-reduce are the same code as with nccl.  Result must equal the
-single-process tiled run."""
+"""GPU: the multi-GPU driver with the HIP engine.  The test box has one GPU, so two ranks share it
+and exchange the boundary strips over the socket transport (host-staged); at world size 1 the
+RCCL communicator itself runs (ncclCommInitRank, its collectives and a self send/recv are
+exercised separately).  Result must equal the single-process tiled run."""
 import os
 import socket
 import subprocess
@@ -15,23 +15,47 @@ from conftest import ROOT
 pytestmark = pytest.mark.gpu
 
 
-def _free_port():
-    s = socket.socket()
-    s.bind(('127.0.0.1', 0))
-    p = s.getsockname()[1]
-    s.close()
-    return p
+def _run_ranks(world, argv, tmp_path, timeout=900, extra=None):
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world),
+                   MASTER_ADDR='127.0.0.1', MASTER_PORT='0', SHEPSEG_COMM_DIR=str(tmp_path / 'comm'))
+        env.update(extra or {})
+        procs.append(subprocess.Popen([sys.executable] + argv, env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = [p.communicate(timeout=timeout) for p in procs]
+    for (p, (_o, e)) in zip(procs, outs):
+        assert p.returncode == 0, e[-3000:]
+
+
+def test_rccl_comm_world_one(tmp_path):
+    """the RCCL binding itself: communicator creation from a unique id, every collective the
+    driver uses, in a fresh process (one rank: more ranks need more GPUs)"""
+    code = (
+        "import sys, ctypes, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "from pyshepseg_amd import comm as C, _lib\n"
+        "c = C.RcclComm()\n"
+        "assert (c.rank, c.world) == (0, 1)\n"
+        "st = c._staging(4096)\n"
+        "a = np.arange(16, dtype=np.int64)\n"
+        "c.c.check(c.L.shp_dev_upload(c.c.handle, st, _lib.ptr(a), a.nbytes))\n"
+        "c.c.check(c.L.shp_comm_allreduce(c.h, st, 16, 0))\n"
+        "c.c.check(c.L.shp_comm_bcast(c.h, st, 128, 0))\n"
+        "out = ctypes.c_void_p(st.value + 2048)\n"
+        "c.c.check(c.L.shp_comm_allgather(c.h, st, out, 128))\n"
+        "b = np.zeros(16, dtype=np.int64)\n"
+        "c.c.check(c.L.shp_dev_download(c.c.handle, _lib.ptr(b), out, 128))\n"
+        "assert np.array_equal(a, b)\n"
+        "c.close()\n" % ROOT)
+    _run_ranks(1, ['-c', code], tmp_path, timeout=300)
 
 
 @pytest.mark.parametrize('world', [1, 2])
 def test_hip_engine_chain_matches_single_process(world, tmp_path):
     from pyshepseg_amd import tiling
-    env = dict(os.environ, MASTER_ADDR='127.0.0.1')
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(world),
-           '--master-addr', '127.0.0.1', '--master-port', str(_free_port()),
-           os.path.join(ROOT, 'tests', 'dist_worker_gpu.py'), str(tmp_path), 'gloo']
-    p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
-    assert p.returncode == 0, p.stderr[-3000:]
+    _run_ranks(world, [os.path.join(ROOT, 'tests', 'dist_worker_gpu.py'), str(tmp_path),
+                       'socket' if world > 1 else 'rccl'], tmp_path)
     parts = [np.load(tmp_path / ('rank%d.npz' % r)) for r in range(world)]
     from pyshepseg_amd import tilingstats
     from oracle import oracle
