@@ -189,7 +189,9 @@ int shp_stitch_tile_dev(shp_ctx *ctx, uint32_t *d_tile, int ys, int xs, int over
  *  shp_stitch_prepare_dev -- purely local to the tile, run by the worker that segmented it:
  *     fills d_meta = 4 x (max_local+1) uint32: flags (1 = crosses the top strip's midline,
  *     2 = crosses the left strip's, 4 = has a pixel in the trimmed window), bounding-box top row,
- *     bounding-box left column, and room for the LUT.  Synchronous.
+ *     bounding-box left column, and room for the LUT.  cross_px_out (may be NULL) receives the
+ *     number of pixels of the top / left strip that belong to midline-crossing segments: handed
+ *     to the chain call, it bounds the (segment, neighbour id) pair table there.  Synchronous.
  *  shp_stitch_chain_dev -- the sequential step (asynchronous on the ctx stream): modes over the
  *     overlap strips of the tile above / to the left (d_top_b / d_left_b as in
  *     shp_stitch_tile_dev, but they now point at the DENSE recoded strips written by earlier
@@ -200,13 +202,14 @@ int shp_stitch_tile_dev(shp_ctx *ctx, uint32_t *d_tile, int ys, int xs, int over
  *     stream, off the chain (shp_sync waits for both streams). */
 int shp_stitch_prepare_dev(shp_ctx *ctx, const uint32_t *d_tile, int ys, int xs, int overlap,
                            int has_top, int has_left, uint32_t max_local, int top, int bottom,
-                           int left, int right, uint32_t *d_meta);
+                           int left, int right, uint32_t *d_meta, uint32_t *cross_px_out);
 int shp_stitch_chain_dev(shp_ctx *ctx, const uint32_t *d_tile, int ys, int xs, int overlap,
                          const uint32_t *d_top_b, int64_t top_pitch, const uint32_t *d_left_b,
                          int64_t left_pitch, uint32_t max_local, int simple_recode,
                          uint32_t *d_max_seg_id, int top, int bottom, int left, int right,
                          uint32_t *d_meta, uint32_t *d_right_out, uint32_t *d_bottom_out,
-                         uint32_t *d_out, int64_t out_pitch, int xout, int yout);
+                         uint32_t *d_out, int64_t out_pitch, int xout, int yout,
+                         uint32_t top_cross_px, uint32_t left_cross_px /* 0xFFFFFFFF = unknown */);
 /* one stitched, trimmed tile (w x h at xout, yout of the device raster) sub-sampled into one overview
  * layer exactly as SegmentationConcurrencyMgr.writeOverviews does tile by tile (tiling.py:1360-1383):
  * every level-th pixel from offset level / 2 of the tile, written at (xout / level, yout / level),

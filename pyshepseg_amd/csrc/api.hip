@@ -780,7 +780,7 @@ API int shp_sync(shp_ctx *ctx)
 
 API int shp_stitch_prepare_dev(shp_ctx *ctx, const uint32_t *d_tile, int ys, int xs, int overlap,
                                int has_top, int has_left, uint32_t max_local, int top, int bottom,
-                               int left, int right, uint32_t *d_meta)
+                               int left, int right, uint32_t *d_meta, uint32_t *cross_px_out)
 {
     CHK(enter(ctx));
     if (!d_tile || !d_meta || ys < 0 || xs < 0 || overlap < 0) SHP_FAIL(ctx, SHP_ERR_ARG, "bad argument");
@@ -788,10 +788,18 @@ API int shp_stitch_prepare_dev(shp_ctx *ctx, const uint32_t *d_tile, int ys, int
         SHP_FAIL(ctx, SHP_ERR_ARG, "bad trimmed window");
     FillScope fs(ctx, 1);
     fill_acquire(ctx, 3);
+    uint32_t *d_cross = nullptr;
+    if (cross_px_out) {
+        CHK(buf_ensure(ctx, ctx->small, 4096));
+        d_cross = bp<uint32_t>(ctx->small) + 64;
+        HIPCHK(ctx, hipMemsetAsync(d_cross, 0, 8, ctx->stream));
+    }
     CHK(run_stitch_prepare(ctx, d_tile, (uint32_t)ys, (uint32_t)xs, (uint32_t)overlap, has_top, has_left,
                            max_local, (uint32_t)top, (uint32_t)bottom, (uint32_t)left, (uint32_t)right,
-                           d_meta));
+                           d_meta, d_cross));
+    if (cross_px_out) HIPCHK(ctx, hipMemcpyAsync(ctx->h_pinned, d_cross, 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (cross_px_out) { cross_px_out[0] = ctx->h_pinned[0]; cross_px_out[1] = ctx->h_pinned[1]; }
     return 0;
 }
 
@@ -800,7 +808,8 @@ API int shp_stitch_chain_dev(shp_ctx *ctx, const uint32_t *d_tile, int ys, int x
                              int64_t left_pitch, uint32_t max_local, int simple_recode,
                              uint32_t *d_max_seg_id, int top, int bottom, int left, int right,
                              uint32_t *d_meta, uint32_t *d_right_out, uint32_t *d_bottom_out,
-                             uint32_t *d_out, int64_t out_pitch, int xout, int yout)
+                             uint32_t *d_out, int64_t out_pitch, int xout, int yout,
+                             uint32_t top_cross_px, uint32_t left_cross_px)
 {
     CHK(enter(ctx));
     if (!d_tile || !d_max_seg_id || !d_meta || ys < 0 || xs < 0 || overlap < 0)
@@ -810,7 +819,7 @@ API int shp_stitch_chain_dev(shp_ctx *ctx, const uint32_t *d_tile, int ys, int x
     CHK(run_stitch_chain(ctx, d_tile, (uint32_t)ys, (uint32_t)xs, (uint32_t)overlap, d_top_b,
                          (size_t)top_pitch, d_left_b, (size_t)left_pitch, max_local, simple_recode,
                          d_max_seg_id, (uint32_t)top, (uint32_t)bottom, (uint32_t)left, (uint32_t)right,
-                         d_meta, d_right_out, d_bottom_out));
+                         d_meta, d_right_out, d_bottom_out, top_cross_px, left_cross_px));
     if (d_out)
         CHK(run_stitch_finish(ctx, d_tile, (uint32_t)ys, (uint32_t)xs, max_local, (uint32_t)top,
                               (uint32_t)bottom, (uint32_t)left, (uint32_t)right, d_meta, d_out,

@@ -427,10 +427,36 @@ __global__ __launch_bounds__(256) void k_meta_pixels(const uint32_t *__restrict_
     }
 }
 
+// pixels of a strip whose segment crosses the strip's midline: an upper bound of the distinct
+// (segment, neighbour id) pairs the chain step will hash, so that it can size (and clear) a table of
+// that order instead of one sized by the whole strip
+__global__ __launch_bounds__(256) void k_cross_count(const uint32_t *__restrict__ tile, uint32_t xs,
+                                                     uint32_t srows, uint32_t scols,
+                                                     const uint32_t *__restrict__ flags, uint32_t bit,
+                                                     uint32_t *count)
+{
+    __shared__ uint32_t s_cnt;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    uint32_t mine = 0;
+    for (uint32_t i = blockIdx.x * 1024u + threadIdx.x, e = 0; e < 4u; e++, i += 256u) {
+        if (i < srows * scols) {
+            const uint32_t r = i / scols, c = i - r * scols;
+            const uint32_t s = tile[r * xs + c];
+            mine += (s != 0u && (flags[s] & bit)) ? 1u : 0u;
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d, 64);
+    if (lane_id() == 0 && mine) atomicAdd(&s_cnt, mine);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_cnt) atomicAdd(count, s_cnt);
+}
+
 static int run_stitch_prepare(shp_ctx *ctx, const uint32_t *d_tile, uint32_t ys, uint32_t xs,
                               uint32_t overlap, int has_top, int has_left, uint32_t max_local,
                               uint32_t top, uint32_t bottom, uint32_t left, uint32_t right,
-                              uint32_t *d_meta)
+                              uint32_t *d_meta, uint32_t *d_cross /* 2 counters, zeroed by the caller; may be NULL */)
 {
     hipStream_t st = ctx->stream;
     const uint32_t n = ys * xs, nseg = max_local + 1u;
@@ -451,6 +477,11 @@ static int run_stitch_prepare(shp_ctx *ctx, const uint32_t *d_tile, uint32_t ys,
         hipLaunchKernelGGL(k_meta_cross, dim3(grid_for(nseg, 256)), dim3(256), 0, st, mn, mx,
                            (horizontal ? srows : scols) / 2u, nseg,
                            horizontal ? META_CROSS_TOP : META_CROSS_LEFT, flags); KCHK(ctx);
+        if (d_cross) {
+            hipLaunchKernelGGL(k_cross_count, dim3(grid_for((size_t)srows * scols, 1024)), dim3(256), 0, st, d_tile,
+                               xs, srows, scols, flags, horizontal ? META_CROSS_TOP : META_CROSS_LEFT,
+                               d_cross + (horizontal ? 0 : 1)); KCHK(ctx);
+        }
     }
     hipLaunchKernelGGL(k_meta_pixels, dim3(grid_for(xs, 64), grid_for(ys, AGG_ROWS)), dim3(256), 0, st, d_tile,
                        ys, xs, top, bottom, left, right, segtop, segleft, flags); KCHK(ctx);
@@ -527,7 +558,8 @@ static int run_stitch_chain(shp_ctx *ctx, const uint32_t *d_tile, uint32_t ys, u
                             const uint32_t *d_left_b, size_t left_pitch, uint32_t max_local, int simple,
                             uint32_t *d_max_seg_id, uint32_t top, uint32_t bottom, uint32_t left,
                             uint32_t right, uint32_t *d_meta, uint32_t *d_right_out,
-                            uint32_t *d_bottom_out)
+                            uint32_t *d_bottom_out, uint32_t top_cross_px = 0xFFFFFFFFu,
+                            uint32_t left_cross_px = 0xFFFFFFFFu)
 {
     hipStream_t st = ctx->stream;
     const uint32_t n = ys * xs;
@@ -542,9 +574,14 @@ static int run_stitch_chain(shp_ctx *ctx, const uint32_t *d_tile, uint32_t ys, u
     if (simple) {
         hipLaunchKernelGGL(k_lut_simple, dim3(grid_for(nseg, 256)), dim3(256), 0, st, lut, nseg, d_max_seg_id); KCHK(ctx);
     } else {
+        // the pair table holds one entry per distinct (crossing segment, neighbour id): at most the
+        // strip's pixels of crossing segments, which the prepare step counted (else the whole strip)
         uint32_t maxstrip = 0;
-        if (d_top_b) maxstrip = an_rows * xs;
-        if (d_left_b && ys * an_cols > maxstrip) maxstrip = ys * an_cols;
+        if (d_top_b) maxstrip = top_cross_px < an_rows * xs ? top_cross_px : an_rows * xs;
+        if (d_left_b) {
+            const uint32_t b = left_cross_px < ys * an_cols ? left_cross_px : ys * an_cols;
+            if (b > maxstrip) maxstrip = b;
+        }
         uint32_t hsize = 1024;
         while (hsize < 2u * maxstrip) hsize <<= 1;
         CHK(buf_ensure(ctx, ctx->aux, (size_t)nseg * 4 * 6 + 256));

@@ -417,7 +417,7 @@ class HipEngine(object):
                 int(bool(simple)), self.d_scal, t, b, l, r, ctypes.c_void_p(j.meta),
                 ctypes.c_void_p(self.d_strips.value + 4 * j.rightOff),
                 ctypes.c_void_p(self.d_strips.value + 4 * j.bottomOff), self.d_out, self.nCols, xout,
-                yout - self.outLo))
+                yout - self.outLo, j.crossPx[0], j.crossPx[1]))
 
     def sendBoundary(self, comm, dst, maxSegId, items):
         """items: (kind, job, h, w) from boundaryPlan; strips are dense h x w blocks."""

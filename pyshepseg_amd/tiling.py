@@ -695,7 +695,7 @@ class _OutputWriter(object):
 # ------------------------------------------------------------------------------------------
 class _TileJob(object):
     __slots__ = ('col', 'row', 'xpos', 'ypos', 'xsize', 'ysize', 'offset', 'maxLocal', 'done',
-                 'error', 'meta', 'rightOff', 'bottomOff')
+                 'error', 'meta', 'rightOff', 'bottomOff', 'crossPx')
 
 
 class _MetaArena(object):
@@ -785,6 +785,7 @@ def makeTileJobs(tileInfo, rows=None, tiles=None):
         j.maxLocal = 0
         j.done = threading.Event()
         j.error = None
+        j.crossPx = (0xFFFFFFFF, 0xFFFFFFFF)
         total += j.xsize * j.ysize
         jobs.append(j)
     return jobs, total
@@ -1007,10 +1008,12 @@ def startSegmentationWorkers(src, jobs, d_tiles, centres, msd, imgNullVal, fourC
                     (top, bottom, left, right, _x, _y) = trimmedWindow(
                         tileInfo, j.col, j.row, j.xpos, j.ypos, j.xsize, j.ysize, overlapSize)
                     j.meta = arena.alloc(mx.value + 1, c)
+                    cross = (ctypes.c_uint32 * 2)(0, 0)
                     c.check(L.shp_stitch_prepare_dev(
                         c.handle, dseg, j.ysize, j.xsize, overlapSize,
                         int(j.row > 0 and not simple), int(j.col > 0 and not simple), mx.value,
-                        top, bottom, left, right, ctypes.c_void_p(j.meta)))
+                        top, bottom, left, right, ctypes.c_void_p(j.meta), cross))
+                    j.crossPx = (int(cross[0]), int(cross[1]))
                 if verbose:
                     print("Tile ({}, {}): {} segments".format(j.col, j.row, mx.value))
             except Exception as e:
@@ -1210,7 +1213,8 @@ def doTiledShepherdSegmentation(infile, outfile, tileSize=DFLT_TILESIZE,
                         main.handle, ctypes.c_void_p(d_tiles.value + 4 * j.offset), j.ysize, j.xsize,
                         overlapSize, topB, topPitch, leftB, leftPitch, j.maxLocal,
                         int(bool(simpleTileRecode)), d_scal, top, bottom, left, right,
-                        ctypes.c_void_p(j.meta), rightOut, bottomOut, d_out, inXsize, xout, yout))
+                        ctypes.c_void_p(j.meta), rightOut, bottomOut, d_out, inXsize, xout, yout,
+                        j.crossPx[0], j.crossPx[1]))
                     for (lvl, d, oh, ow) in ovDev:
                         main.check(L.shp_overview_window_dev(main.handle, d_out, inXsize, xout, yout,
                                                              right - left, bottom - top, lvl, d, ow, oh))

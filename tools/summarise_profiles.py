@@ -13,6 +13,15 @@ def one(pattern):
 st = one('gpurun_out/prof_%s_stats/**/*kernel_stats.csv' % tag)
 if st:
     open(os.path.join(out, 'kernel_stats_c3_default.csv'), 'w').write(open(st).read())
+for wl in ('c4', 'c5'):
+    st2 = one('gpurun_out/prof_%s_%s/**/*kernel_stats.csv' % (tag, wl))
+    if st2:
+        open(os.path.join(out, 'kernel_stats_%s.csv' % wl), 'w').write(open(st2).read())
+    lg = 'gpurun_out/prof_%s_%s.log' % (tag, wl)
+    if os.path.exists(lg):
+        for ln in open(lg):
+            if ln.startswith('{"metric"'):
+                open(os.path.join(out, 'bench_line_%s_under_rocprof.json' % wl), 'w').write(ln)
 log = 'gpurun_out/prof_%s_stats.log' % tag
 if os.path.exists(log):
     for ln in open(log):
@@ -46,6 +55,6 @@ if agg:
                "`python bench.py --steps 1 --warmup 1 --cpu-sample 0`; raw counter values in KB per launch, "
                "averaged over all launches. gfx950: FETCH_SIZE counts 1/2 of wide coalesced reads (k_window: "
                "~107 MB raw vs 219 MB read), exact for 16-B streaming writes; uncalibrated for the scattered "
-               "4-byte accesses of k_small_loop / k_dfs_split.",
+               "4-byte accesses of k_small_loop / k_dfs_pool.",
                "kernels": dict(rows)}, open(os.path.join(out, 'pmc_summary.json'), 'w'), indent=1)
 print('summaries in', out, os.listdir(out))
