@@ -52,7 +52,7 @@ def parse():
     ap.add_argument('--bands', type=int, default=None, help='default: 6 (c3), 10 (c4), 1 (c5)')
     ap.add_argument('--tile', type=int, default=4096)
     ap.add_argument('--overlap', type=int, default=1024)
-    ap.add_argument('--workers', type=int, default=int(os.environ.get('SHEPSEG_WORKERS', '20')))
+    ap.add_argument('--workers', type=int, default=int(os.environ.get('SHEPSEG_WORKERS', '36')))
     ap.add_argument('--simple-recode', type=int, default=0, help='diagnostic: simpleTileRecode')
     ap.add_argument('--cpu-sample', type=int, default=14336,
                     help='window edge of the cpu_baseline sample (0 = skip)')
@@ -201,8 +201,6 @@ def bench_segmentation(args):
                                                numWorkers=args.workers)
     (src, dst) = (ras, tiling._KEEP_ON_DEVICE)
     if args.source == 'npy':
-        # one HW queue each for the uploader and the writer: two worker streams fewer
-        cfg.numWorkers = max(1, args.workers - 2)
         src = os.path.join(args.scratch, 'shepseg_bench_%d_%db_seed%d.npy' % (args.size, args.bands, args.seed))
         dst = os.path.join(args.scratch, 'shepseg_bench_%d_out.npy' % args.size)
         if not os.path.exists(src):
@@ -270,7 +268,7 @@ def bench_segmentation(args):
                                        "streamed to a .npy file: %.1f GB in + %.1f GB out over PCIe per step"
                                        % (args.bands * npix * 2 / 1e9, npix * 4 / 1e9)),
                    "source": args.source,
-                   "tiles": len(ti.tiles), "worker_streams": cfg.numWorkers,
+                   "tiles": len(ti.tiles), "workers": cfg.numWorkers, "fill_streams": int(os.environ.get('SHEPSEG_FILL_MAX', '4')), "walker_streams": int(os.environ.get('SHEPSEG_WALK_STREAMS', '12')),
                    "max_seg_id": int(r.maxSegId)},
         "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 3),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -46,6 +46,12 @@ int shp_version(void);
 int shp_device_count(void);                      /* number of usable HIP devices (0 = none) */
 int shp_ctx_create(int device, shp_ctx **out);   /* owns one HIP stream + device workspace */
 int shp_ctx_create_priority(int device, shp_ctx **out);  /* same, highest stream priority */
+/* A worker context of the tiled drivers: device workspace without a stream of its own.  Inside the
+ * worker calls (shp_assign_rects_dev, shp_segment_window_dev, shp_segment_tile_to_dev,
+ * shp_stitch_prepare_dev) it borrows a stream of a process-wide pool for each phase (SHEPSEG_FILL_MAX
+ * fill streams, SHEPSEG_WALK_STREAMS = 12 walker streams), so that more tiles than hardware queues
+ * can be in flight; other calls run on one idle stream all shared contexts use. */
+int shp_ctx_create_shared(int device, shp_ctx **out);
 /* Grow the context's (grow-only) workspace for tiles of up to npix pixels of this type now, instead
  * of in the middle of a run when the first such tile arrives.  The reference has no counterpart
  * (numpy allocates per call); the tiled drivers call it once per worker thread

@@ -35,6 +35,7 @@ _SIGS = {
     'shp_device_count': (_c.c_int, []),
     'shp_ctx_create': (_c.c_int, [_c.c_int, _c.POINTER(_vp)]),
     'shp_ctx_create_priority': (_c.c_int, [_c.c_int, _c.POINTER(_vp)]),
+    'shp_ctx_create_shared': (_c.c_int, [_c.c_int, _c.POINTER(_vp)]),
     'shp_ctx_destroy': (None, [_vp]),
     'shp_last_error': (_c.c_char_p, [_vp]),
     'shp_last_timings': (_c.c_int, [_vp, _vp]),
@@ -159,7 +160,7 @@ def lib():
 class Context(object):
     """One shp_ctx: a HIP stream plus device workspace.  Not shared between threads."""
 
-    def __init__(self, device=None, highPriority=False):
+    def __init__(self, device=None, highPriority=False, sharedStreams=False):
         L = lib()
         if device is None:
             device = int(os.environ.get('SHEPSEG_DEVICE', os.environ.get('LOCAL_RANK', '0')))
@@ -169,7 +170,9 @@ class Context(object):
                                   "(gfx950 / MI355X); there is no CPU fallback")
         device = device % ndev
         h = _vp()
-        rc = (L.shp_ctx_create_priority if highPriority else L.shp_ctx_create)(device, ctypes.byref(h))
+        create = (L.shp_ctx_create_shared if sharedStreams else
+                  L.shp_ctx_create_priority if highPriority else L.shp_ctx_create)
+        rc = create(device, ctypes.byref(h))
         if rc != 0:
             raise ShepsegHipError("shp_ctx_create(device=%d) failed with code %d" % (device, rc))
         self.handle = h
@@ -222,7 +225,9 @@ class pooled_ctx(object):
         with _pool_lock:
             self.c = _pool.pop() if _pool else None
         if self.c is None:
-            self.c = Context()
+            # worker contexts borrow their streams from the library's pool (common.h): the tiles in
+            # flight are then not bounded by the hardware queues
+            self.c = Context(sharedStreams=os.environ.get('SHEPSEG_SHARED_STREAMS', '1') != '0')
         return self.c
 
     def __exit__(self, *args):

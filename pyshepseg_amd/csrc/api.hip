@@ -29,16 +29,20 @@ API int shp_device_count(void)
     return n;
 }
 
-static int ctx_create(int device, int high_priority, shp_ctx **out);
+static int ctx_create(int device, int high_priority, shp_ctx **out, bool shared = false);
 
 API int shp_ctx_create(int device, shp_ctx **out) { return ctx_create(device, 0, out); }
+
+// a worker context of the tiled drivers: device workspace without a stream of its own (see the
+// stream pool in common.h); it falls back to an ordinary context on a second device of the process
+API int shp_ctx_create_shared(int device, shp_ctx **out) { return ctx_create(device, 0, out, true); }
 
 // a context whose streams are created with the highest stream priority (the tiled drivers use
 // one for the sequential stitch chain so that its small kernels are not queued behind the
 // worker streams' launches)
 API int shp_ctx_create_priority(int device, shp_ctx **out) { return ctx_create(device, 1, out); }
 
-static int ctx_create(int device, int high_priority, shp_ctx **out)
+static int ctx_create(int device, int high_priority, shp_ctx **out, bool shared)
 {
     if (!out) return SHP_ERR_ARG;
     *out = nullptr;
@@ -51,19 +55,34 @@ static int ctx_create(int device, int high_priority, shp_ctx **out)
     int prio_lo = 0, prio_hi = 0;
     hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);      // hi = numerically lowest
     ctx->stream_priority = high_priority ? prio_hi : 0;
-    if (hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, ctx->stream_priority) != hipSuccess) {
+    if (shared) {
+        std::lock_guard<std::mutex> lk(g_streams.mu);
+        if (g_streams.device < 0) {
+            if (hipStreamCreateWithPriority(&g_streams.misc, hipStreamNonBlocking, 0) != hipSuccess) {
+                delete ctx;
+                return SHP_ERR_HIP;
+            }
+            g_streams.device = device;
+        }
+        if (g_streams.device == device) {
+            ctx->shared = true;
+            ctx->stream = g_streams.misc;
+        }
+    }
+    if (!ctx->shared &&
+        hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, ctx->stream_priority) != hipSuccess) {
         delete ctx;
         return SHP_ERR_HIP;
     }
     if (hipHostMalloc((void **)&ctx->h_pinned, SHP_PINNED_BYTES, hipHostMallocDefault) != hipSuccess) {
-        hipStreamDestroy(ctx->stream);
+        if (!ctx->shared) hipStreamDestroy(ctx->stream);
         delete ctx;
         return SHP_ERR_HIP;
     }
     if (hipMalloc((void **)&ctx->scan_ctr, 256) != hipSuccess || hipMemset(ctx->scan_ctr, 0, 256) != hipSuccess ||
         hipDeviceSynchronize() != hipSuccess) {       // (the context's stream does not wait for the null stream)
         hipHostFree(ctx->h_pinned);
-        hipStreamDestroy(ctx->stream);
+        if (!ctx->shared) hipStreamDestroy(ctx->stream);
         delete ctx;
         return SHP_ERR_NOMEM;
     }
@@ -98,7 +117,7 @@ API void shp_ctx_destroy(shp_ctx *ctx)
     if (ctx->stream2) { hipStreamSynchronize(ctx->stream2); hipStreamDestroy(ctx->stream2); }
     if (ctx->evfork) hipEventDestroy(ctx->evfork);
     if (ctx->evjoin) hipEventDestroy(ctx->evjoin);
-    hipStreamDestroy(ctx->stream);
+    if (!ctx->shared) hipStreamDestroy(ctx->stream);
     delete ctx;
 }
 
@@ -743,6 +762,7 @@ API int shp_segment_tile_to_dev(shp_ctx *ctx, const void *img, int dtype, int nb
     FillScope fs(ctx, 1);
     hipEventRecord(ctx->ev[0], ctx->stream);
     CHK(upload_img(ctx, img, dtype, nbands, n));          // (PCIe: outside the gate)
+    if (ctx->shared) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));     // (the phases run on borrowed streams)
     fill_acquire(ctx, 0);
     CHK(segment_device(ctx, ctx->img.p, d_seg_out, dtype, nbands, nrows, ncols, centres, k, has_null,
                        null_val, four_connected, min_seg_size, max_spectral_diff, max_seg_id_out,

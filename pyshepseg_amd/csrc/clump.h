@@ -874,7 +874,6 @@ static int run_clump(shp_ctx *ctx, const uint16_t *d_clus, uint32_t nrows, uint3
     hipLaunchKernelGGL(k_big_list, dim3(g), dim3(256), 0, st, lab, csize, n, ncols, big, counters, bigbits, bigmin); KCHK(ctx);
     hipLaunchKernelGGL(k_big_bbox, dim3(grid_for(ncols, 64), grid_for(nrows, AGG_ROWS)), dim3(256), 0, st, lab,
                        csize, nrows, ncols, big, bigbits); KCHK(ctx);
-    ps = prof_begin(ctx, PROF_DFS);
     uint32_t *order = (uint32_t *)((char *)ctx->big.p + (size_t)maxbig * sizeof(BigInfo) + 64);
     hipLaunchKernelGGL(k_big_order, dim3(grid_for(maxbig, 256)), dim3(256), 0, st, big, counters, order, ncols,
                        DFS_POOL_GRANS_DEFAULT * DFS_GRAN_WORDS); KCHK(ctx);
@@ -885,6 +884,9 @@ static int run_clump(shp_ctx *ctx, const uint16_t *d_clus, uint32_t nrows, uint3
     HIPCHK(ctx, hipStreamSynchronize(st));
     const uint32_t nbig_h = ctx->h_pinned[0];
     fill_release(ctx, false);
+    if (nbig_h) walk_begin(ctx);
+    st = ctx->stream;
+    ps = prof_begin(ctx, PROF_DFS);              // events hug the kernel
     unsigned long long *dbg = nullptr;
     if (getenv("SHEPSEG_DFS_STATS") && nbig_h) {
         CHK(buf_ensure(ctx, ctx->dbg, (size_t)nbig_h * 48u));
@@ -925,9 +927,11 @@ static int run_clump(shp_ctx *ctx, const uint16_t *d_clus, uint32_t nrows, uint3
                     h[i * 6 + 3] * 10.0 / (double)h[i * 6], (h[i * 6 + 5] >> 8) & 0xffffffffull, h[i * 6 + 5] & 255ull,
                     (h[i * 6 + 5] >> 40) ? " GLOBAL" : "");
     }
-    if (fill_gating(ctx)) {
+    if (fill_gating(ctx) || stream_sharing(ctx)) {
         HIPCHK(ctx, hipStreamSynchronize(st));
+        walk_end(ctx);
         fill_acquire(ctx, 1);
+        st = ctx->stream;
     }
     ps = prof_begin(ctx, PROF_LABEL);
     // seed rank -> clump id

@@ -54,6 +54,9 @@ struct shp_ctx {
     uint32_t *scan_ctr = nullptr;   // device word, zero between scans: arrival counter of k_scan_local
     int gated = 0;      // this call takes part in the fill gate (tiled driver's worker calls)
     bool fill_held = false;
+    bool gate_held = false;
+    bool shared = false;    // a worker context without a stream of its own: it borrows one per phase
+    int borrowed = 0;       // 0 = none (ctx->stream is the pool's idle stream), 1 = a fill stream, 2 = a walker stream
 };
 
 // Fill gate.  A tile alternates between phases that fill the GPU (HBM-bound passes over the whole
@@ -74,39 +77,121 @@ struct FillGate {
 static FillGate g_fill;
 static const int g_fill_max = getenv("SHEPSEG_FILL_MAX") ? atoi(getenv("SHEPSEG_FILL_MAX")) : FILL_MAX_DEFAULT;
 
+// Stream pool.  A process gets about 24 hardware queues before the driver time-slices them, so the
+// number of streams is what bounds the tiles in flight -- and a tile that owns a stream keeps it
+// through its host-side waits (for the fill gate, for a pass-loop slot) as well.  A SHARED context
+// has no stream of its own: inside a worker call of the tiled driver it borrows a fill stream for
+// each GPU-filling phase (with the gate slot: there are as many as the gate admits) and a walker
+// stream for each latency-bound kernel, and gives it back once the phase has left the GPU (every
+// phase ends in a host synchronisation, so the next phase may run on any other stream).  More tiles
+// than streams can then be in flight.  Outside worker calls a shared context uses the pool's idle
+// stream, which all of them share.
+#define WALK_STREAMS_DEFAULT 12
+struct StreamPool {
+    std::mutex mu;
+    std::condition_variable cv;
+    std::vector<hipStream_t> idle[2];     // 0 = fill streams, 1 = walker streams
+    int made[2] = {0, 0};
+    int device = -1;
+    hipStream_t misc = nullptr;
+};
+static StreamPool g_streams;
+static const int g_walk_streams = getenv("SHEPSEG_WALK_STREAMS") ? atoi(getenv("SHEPSEG_WALK_STREAMS")) : WALK_STREAMS_DEFAULT;
+static inline int stream_pool_cap(int cls)
+{
+    if (cls == 1) return g_walk_streams < 1 ? 1 : g_walk_streams;
+    return g_fill_max > 0 ? g_fill_max : 8;
+}
+static inline void stream_take(shp_ctx *ctx, int cls)
+{
+    std::unique_lock<std::mutex> lk(g_streams.mu);
+    for (;;) {
+        if (!g_streams.idle[cls].empty()) {
+            ctx->stream = g_streams.idle[cls].back();
+            g_streams.idle[cls].pop_back();
+            break;
+        }
+        if (g_streams.made[cls] < stream_pool_cap(cls)) {
+            hipStream_t s = nullptr;
+            if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, 0) == hipSuccess) {
+                g_streams.made[cls]++;
+                ctx->stream = s;
+                break;
+            }
+        }
+        g_streams.cv.wait(lk);
+    }
+    ctx->borrowed = cls + 1;
+}
+// (the caller has synchronised the stream: the next borrower starts on an empty one)
+static inline void stream_give(shp_ctx *ctx)
+{
+    if (!ctx->borrowed) return;
+    {
+        std::lock_guard<std::mutex> lk(g_streams.mu);
+        g_streams.idle[ctx->borrowed - 1].push_back(ctx->stream);
+        ctx->stream = g_streams.misc;
+    }
+    ctx->borrowed = 0;
+    g_streams.cv.notify_all();
+}
+static inline bool stream_sharing(const shp_ctx *ctx) { return ctx->shared && ctx->gated; }
+
 static inline bool fill_gating(const shp_ctx *ctx) { return g_fill_max > 0 && ctx->gated; }
 static inline void fill_acquire(shp_ctx *ctx, int prio)
 {
-    if (!fill_gating(ctx) || ctx->fill_held) return;
-    std::unique_lock<std::mutex> lk(g_fill.mu);
-    g_fill.waiting[prio]++;
-    g_fill.cv.wait(lk, [&] {
-        if (g_fill.running >= g_fill_max) return false;
-        for (int p = prio + 1; p < FILL_PRIOS; p++)
-            if (g_fill.waiting[p]) return false;
-        return true;
-    });
-    g_fill.waiting[prio]--;
-    g_fill.running++;
+    if (ctx->fill_held || !(fill_gating(ctx) || stream_sharing(ctx))) return;
+    if (fill_gating(ctx)) {
+        std::unique_lock<std::mutex> lk(g_fill.mu);
+        g_fill.waiting[prio]++;
+        g_fill.cv.wait(lk, [&] {
+            if (g_fill.running >= g_fill_max) return false;
+            for (int p = prio + 1; p < FILL_PRIOS; p++)
+                if (g_fill.waiting[p]) return false;
+            return true;
+        });
+        g_fill.waiting[prio]--;
+        g_fill.running++;
+        ctx->gate_held = true;
+        if (g_fill.running < g_fill_max) g_fill.cv.notify_all();
+    }
+    if (stream_sharing(ctx)) stream_take(ctx, 0);
     ctx->fill_held = true;
-    if (g_fill.running < g_fill_max) g_fill.cv.notify_all();
 }
 // sync: wait until the phase's kernels have left the GPU before letting the next tile in
 static inline void fill_release(shp_ctx *ctx, bool sync)
 {
     if (!ctx->fill_held) return;
-    if (sync) (void)hipStreamSynchronize(ctx->stream);
-    {
-        std::lock_guard<std::mutex> lk(g_fill.mu);
-        g_fill.running--;
+    if (sync || ctx->borrowed) (void)hipStreamSynchronize(ctx->stream);
+    stream_give(ctx);
+    if (ctx->gate_held) {
+        {
+            std::lock_guard<std::mutex> lk(g_fill.mu);
+            g_fill.running--;
+        }
+        ctx->gate_held = false;
+        g_fill.cv.notify_all();
     }
     ctx->fill_held = false;
-    g_fill.cv.notify_all();
 }
-struct FillScope {          // an API call never leaves with the gate held (error paths)
+// a latency-bound kernel of a shared context runs on a borrowed walker stream
+static inline void walk_begin(shp_ctx *ctx)
+{
+    if (stream_sharing(ctx) && !ctx->borrowed) stream_take(ctx, 1);
+}
+static inline void walk_end(shp_ctx *ctx)       // (after the caller's stream synchronisation)
+{
+    if (ctx->borrowed == 2) stream_give(ctx);
+}
+struct FillScope {          // an API call never leaves with the gate or a borrowed stream held (error paths)
     shp_ctx *ctx;
     FillScope(shp_ctx *c, int gated) : ctx(c) { c->gated = gated; }
-    ~FillScope() { fill_release(ctx, false); ctx->gated = 0; }
+    ~FillScope()
+    {
+        fill_release(ctx, false);
+        if (ctx->borrowed) { (void)hipStreamSynchronize(ctx->stream); stream_give(ctx); }
+        ctx->gated = 0;
+    }
 };
 
 // kernels whose launch durations bench.py reports against the roofline

@@ -873,12 +873,15 @@ static int run_eliminate_small(shp_ctx *ctx, const void *d_img, int dtype, int n
     static const int dbg_skip_loop = getenv("SHEPSEG_DBG_SKIP_SMALL") ? atoi(getenv("SHEPSEG_DBG_SKIP_SMALL")) : 0;
     if (dbg_skip_loop) args.min_seg = 1;      // diagnostic only: the loop ends at once (wrong labels)
     static const unsigned small_blocks = getenv("SHEPSEG_SMALL_BLOCKS") ? (unsigned)atoi(getenv("SHEPSEG_SMALL_BLOCKS")) : SMALL_BLOCKS;
+    walk_begin(ctx);
+    st = ctx->stream;
     ps = prof_begin(ctx, PROF_SMALL_LOOP);           // events hug the kernel: no copies, no host waits
     hipLaunchKernelGGL(k_small_loop, dim3(small_blocks), dim3(256), 0, st, args);
     hipError_t lerr = hipGetLastError();
     prof_end(ctx, ps);
     hipError_t cerr = hipMemcpyAsync(pin, ctl, sizeof(SmallCtl), hipMemcpyDeviceToHost, st);
     hipError_t serr = hipStreamSynchronize(st);
+    walk_end(ctx);
     {
         std::lock_guard<std::mutex> lk(g_small_mu);
         g_small_running--;

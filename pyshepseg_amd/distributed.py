@@ -567,7 +567,7 @@ def bench_main(args, rank, world, local_rank):
                                    "sharded over %d GPUs, image + labels resident in HBM"
                                    % (getattr(args, 'workload', 'c3').upper(), args.size, args.size, nb,
                                       args.tile, args.overlap, world),
-                       "tiles": r.numTileRows * r.numTileCols, "worker_streams": args.workers,
+                       "tiles": r.numTileRows * r.numTileCols, "workers": args.workers,
                        "max_seg_id": int(r.maxSegId),
                        "parallelism": "tiles sharded by area; stitch chain over ncclSend/ncclRecv (%s)"
                                       % type(comm).__name__},
