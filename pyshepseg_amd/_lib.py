@@ -15,7 +15,8 @@ os.environ.setdefault('GPU_MAX_HW_QUEUES', '24')
 import numpy
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIBPATH = os.path.join(_HERE, 'libshepseg_hip.so')
+# (SHEPSEG_LIBPATH: another build of the same ABI, for A/B timing on one box)
+LIBPATH = os.environ.get('SHEPSEG_LIBPATH') or os.path.join(_HERE, 'libshepseg_hip.so')
 
 SHP_DTYPES = {numpy.dtype(numpy.uint8): 0, numpy.dtype(numpy.int16): 1,
               numpy.dtype(numpy.uint16): 2, numpy.dtype(numpy.int32): 3,

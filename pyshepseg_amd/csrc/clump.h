@@ -615,13 +615,15 @@ __device__ __forceinline__ void dfs_split_lds(uint32_t *lab, const BigInfo &B, u
 // order[rank] = component index, largest first: the longest replays start first (LPT), which
 // shortens the makespan whenever there are more components than resident workgroups
 // counters[2] = how many of them do not fit the walker pool (bitmap above bmw_small words)
+// (mirror: the component count for the host, see PIN_MIRROR)
 __global__ __launch_bounds__(256) void k_big_order(const BigInfo *__restrict__ big,
                                                    uint32_t *counters,
                                                    uint32_t *__restrict__ order, uint32_t ncols,
-                                                   uint32_t bmw_small)
+                                                   uint32_t bmw_small, uint32_t *mirror)
 {
     const uint32_t nbig = counters[0];
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i == 0u && mirror) MIRROR_STORE(mirror, nbig);
     if (i >= nbig) return;
     if (dfs_bitmap_words(big[i], ncols) > bmw_small) atomicAdd(&counters[2], 1u);
     const uint32_t si = big[i].size;
@@ -875,14 +877,14 @@ static int run_clump(shp_ctx *ctx, const uint16_t *d_clus, uint32_t nrows, uint3
     hipLaunchKernelGGL(k_big_bbox, dim3(grid_for(ncols, 64), grid_for(nrows, AGG_ROWS)), dim3(256), 0, st, lab,
                        csize, nrows, ncols, big, bigbits); KCHK(ctx);
     uint32_t *order = (uint32_t *)((char *)ctx->big.p + (size_t)maxbig * sizeof(BigInfo) + 64);
+    uint32_t *mir_nbig = ctx->h_pinned + PIN_MIRROR + MIR_NBIG;
     hipLaunchKernelGGL(k_big_order, dim3(grid_for(maxbig, 256)), dim3(256), 0, st, big, counters, order, ncols,
-                       DFS_POOL_GRANS_DEFAULT * DFS_GRAN_WORDS); KCHK(ctx);
+                       DFS_POOL_GRANS_DEFAULT * DFS_GRAN_WORDS, mir_nbig); KCHK(ctx);
     // the replay is a latency-bound phase: outside the fill gate.  The component count comes back
     // first, so that the launch is sized exactly (a workgroup per DFS_WAVES components; every one of
     // them reserves the whole walker pool in LDS, so none is launched for nothing).
-    HIPCHK(ctx, hipMemcpyAsync(ctx->h_pinned, counters, 12, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipStreamSynchronize(st));
-    const uint32_t nbig_h = ctx->h_pinned[0];
+    const uint32_t nbig_h = *(volatile uint32_t *)mir_nbig;
     fill_release(ctx, false);
     if (nbig_h) walk_begin(ctx);
     st = ctx->stream;

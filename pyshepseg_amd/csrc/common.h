@@ -18,6 +18,13 @@
 #define PROF_N 16
 #define PROF_POOL 32
 #define SHP_PINNED_BYTES (1u << 20)   // pinned host staging per context
+// The last 64 words of the staging block are MIRRORS: scalars the host needs after a phase (counts,
+// scan totals) are stored there by the kernel that produces them (system-scope stores to the mapped
+// pinned block) instead of by a copy command queued behind it -- under load every command on a
+// stream costs 40-80 us, and there were ten such copies per tile.
+#define PIN_MIRROR (SHP_PINNED_BYTES / 4u - 64u)
+enum { MIR_NBIG = 0, MIR_RELABEL = 4, MIR_RUNS = 5 };
+#define MIRROR_STORE(ptr, v) __hip_atomic_store((ptr), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM)
 
 struct DevBuf {
     void *p = nullptr;

@@ -139,11 +139,11 @@ static int build_segment_csr(shp_ctx *ctx, const uint32_t *d_seg, uint32_t n, ui
     uint32_t *rkeys = bp<uint32_t>(ctx->aux), *rvals = bp<uint32_t>(ctx->aux2);
     hipLaunchKernelGGL(k_run_tile_count, dim3(nblk), dim3(256), 0, st, d_seg, n, bcount, zero, nzero); KCHK(ctx);
     ArrFn bf{bcount};
-    CHK(scan_exclusive(ctx, bf, nblk, boff, tot, bp<uint32_t>(ctx->scan_tmp)));
-    HIPCHK(ctx, hipMemcpyAsync(ctx->h_pinned, tot, 4, hipMemcpyDeviceToHost, st));
+    uint32_t *mir = ctx->h_pinned + PIN_MIRROR + MIR_RUNS;        // the scan stores its total there
+    CHK(scan_exclusive(ctx, bf, nblk, boff, tot, bp<uint32_t>(ctx->scan_tmp), nullptr, mir));
     hipLaunchKernelGGL(k_run_tile_emit, dim3(nblk), dim3(256), 0, st, d_seg, n, boff, rkeys, rvals); KCHK(ctx);
     HIPCHK(ctx, hipStreamSynchronize(st));
-    const uint32_t m = ctx->h_pinned[0];
+    const uint32_t m = *(volatile uint32_t *)mir;
     if (m == 0 || m > n) SHP_FAIL(ctx, SHP_ERR_STATE, "run count %u out of range (n = %u)", m, n);
     uint32_t *svals = nullptr;
     CHK(sort_pairs(ctx, rkeys, rvals, m, bits_for(S), nullptr, &svals));       // -> ctx->pix

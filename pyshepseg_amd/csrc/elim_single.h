@@ -19,10 +19,11 @@
 // segment sizes, then the band values of all nine positions are fetched as independent loads
 // (an excluded position re-reads the centre pixel and is ignored), so one candidate costs three
 // memory round trips instead of 3 + 2 * nBands.  DT = pixel type (see ld_t).
-template <int DT>
+// COH: seg / segsz are being changed by earlier passes of the SAME kernel (k_single_tail): read them
+// at the L2 instead of through the read-only path.
+template <int DT, bool COH = false>
 __device__ __forceinline__ uint32_t single_target(const void *__restrict__ img, int nb,
-                                                  const uint32_t *__restrict__ seg,
-                                                  const uint32_t *__restrict__ segsz, uint32_t p,
+                                                  const uint32_t *seg, const uint32_t *segsz, uint32_t p,
                                                   uint32_t n, uint32_t nrows, uint32_t ncols, int four,
                                                   const ImgGeom g)
 {
@@ -37,10 +38,10 @@ __device__ __forceinline__ uint32_t single_target(const void *__restrict__ img, 
         ok[k] = k != 4 && a >= 0 && b >= 0 && a < (int)nrows && b < (int)ncols && !(four && da != 0 && db != 0);
         q[k] = ok[k] ? (uint32_t)a * ncols + (uint32_t)b : p;
         qo[k] = g.origin + (size_t)(ok[k] ? (uint32_t)a : i) * g.pitch + (ok[k] ? (uint32_t)b : j);
-        sn[k] = seg[q[k]];
+        sn[k] = COH ? L2LOAD(&seg[q[k]]) : seg[q[k]];
     }
 #pragma unroll
-    for (int k = 0; k < 9; k++) ok[k] = ok[k] && segsz[sn[k]] > 1u;
+    for (int k = 0; k < 9; k++) ok[k] = ok[k] && (COH ? L2LOAD(&segsz[sn[k]]) : segsz[sn[k]]) > 1u;
     long long d[9];
 #pragma unroll
     for (int k = 0; k < 9; k++) d[k] = 0;
@@ -112,7 +113,7 @@ __global__ __launch_bounds__(256) void k_single_scan_list(
     const ImgGeom geom)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i == 0) *nelim = 0u;                 // the apply kernel of this pass raises it (no memset launch)
+    if (i == 0) { nelim[0] = 0u; nelim[1] = 0u; }     // the apply kernel of this pass raises them (no memset launch)
     if (i >= nrest) return;
     const uint32_t p = rest[i];
     uint32_t out = NO_TARGET;
@@ -120,22 +121,88 @@ __global__ __launch_bounds__(256) void k_single_scan_list(
     tgt_l[i] = out;
 }
 
+// rest2 (optional): the single pixels of the list that found no target are appended there, their
+// count in nelim[1] -- the candidates of the later passes
 __global__ __launch_bounds__(256) void k_single_apply_list(uint32_t *__restrict__ seg, uint32_t *segsz,
                                                            const uint32_t *__restrict__ tgt_l,
                                                            const uint32_t *__restrict__ rest,
                                                            uint32_t nrest,
-                                                           uint32_t *nelim)
+                                                           uint32_t *nelim, uint32_t *__restrict__ rest2)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= nrest) return;
-    const uint32_t t = tgt_l[i];
-    if (t == NO_TARGET) return;
-    const uint32_t p = rest[i];
-    const uint32_t old = seg[p];
-    seg[p] = t;
-    segsz[old] = 0;
-    atomicAdd(&segsz[t], 1u);
-    *nelim = 1u;
+    const uint32_t t = i < nrest ? tgt_l[i] : NO_TARGET;
+    const uint32_t p = i < nrest ? rest[i] : 0u;
+    if (t != NO_TARGET) {
+        const uint32_t old = seg[p];
+        seg[p] = t;
+        segsz[old] = 0;
+        atomicAdd(&segsz[t], 1u);
+        *nelim = 1u;
+    }
+    if (rest2) {         // (one global atomic per workgroup: atomics on one counter serialise at the L2)
+        __shared__ uint32_t s_buf[256];
+        __shared__ uint32_t s_cnt, s_base;
+        if (threadIdx.x == 0) s_cnt = 0u;
+        __syncthreads();
+        const bool keep = i < nrest && t == NO_TARGET;
+        const unsigned long long m = __ballot(keep);
+        if (m != 0ull) {
+            uint32_t base = 0;
+            if (lane_id() == 0) base = atomicAdd(&s_cnt, (uint32_t)__popcll(m));
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            if (keep) s_buf[base + (uint32_t)__popcll(m & lanemask_lt())] = p;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) s_base = s_cnt ? atomicAdd(&nelim[1], s_cnt) : 0u;
+        __syncthreads();
+        if (threadIdx.x < s_cnt) rest2[s_base + threadIdx.x] = s_buf[threadIdx.x];
+    }
+}
+
+// Every later pass of the single-pixel stage in ONE workgroup: the candidates left after the first
+// pass are few (a single pixel stays without a target only while all its neighbours are single
+// pixels too), so the scan / apply / "did anything merge" round trip of a pass -- three commands and
+// a host synchronisation each -- becomes two workgroup barriers.  Same Jacobi passes as the
+// reference's loop (shepseg.py:572-611): all scans of a pass read the state its applies have not
+// touched yet.
+template <int DT>
+__global__ __launch_bounds__(1024) void k_single_tail(
+    const void *__restrict__ img, int nb, uint32_t *seg, uint32_t *segsz, uint32_t *tgt_l, uint32_t n,
+    uint32_t nrows, uint32_t ncols, int four, const uint32_t *__restrict__ rest2,
+    const uint32_t *__restrict__ nrest2, const ImgGeom geom)
+{
+    __shared__ uint32_t s_merged;
+    const uint32_t nr = *nrest2;
+    for (;;) {
+        if (threadIdx.x == 0) s_merged = 0u;
+        __syncthreads();
+        for (uint32_t i = threadIdx.x; i < nr; i += 1024u) {
+            const uint32_t p = rest2[i];
+            uint32_t out = NO_TARGET;
+            if (L2LOAD(&segsz[L2LOAD(&seg[p])]) == 1u)
+                out = single_target<DT, true>(img, nb, seg, segsz, p, n, nrows, ncols, four, geom);
+            tgt_l[i] = out;                       // (read back by this thread only)
+        }
+        __threadfence();
+        __syncthreads();
+        bool any = false;
+        for (uint32_t i = threadIdx.x; i < nr; i += 1024u) {
+            const uint32_t t = tgt_l[i];
+            if (t == NO_TARGET) continue;
+            const uint32_t p = rest2[i];
+            const uint32_t old = L2LOAD(&seg[p]);
+            __hip_atomic_store(&seg[p], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&segsz[old], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            atomicAdd(&segsz[t], 1u);
+            any = true;
+        }
+        if (any) s_merged = 1u;
+        __threadfence();
+        __syncthreads();
+        const bool more = s_merged != 0u;
+        __syncthreads();
+        if (!more) break;
+    }
 }
 
 // relabelSegments (shepseg.py:739-777): newid[k] = k - #{1 <= j < k : segsz[j] == 0}
@@ -161,11 +228,19 @@ __global__ __launch_bounds__(256) void k_compact_sizes(const uint32_t *__restric
     else if (v != 0u) out[k - sub[k] - (boff ? boff[k / SCAN_ITEMS] : 0u)] = v;
 }
 
+// (sizes_out: the k_compact_sizes pass over the ns ids rides in the same launch)
 __global__ __launch_bounds__(256) void k_relabel(uint32_t *__restrict__ seg,
                                                  const uint32_t *__restrict__ sub, uint32_t n,
-                                                 const uint32_t *__restrict__ boff)
+                                                 const uint32_t *__restrict__ boff,
+                                                 const uint32_t *__restrict__ segsz, uint32_t ns,
+                                                 uint32_t *__restrict__ sizes_out)
 {
     const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    if (sizes_out && p < ns) {
+        const uint32_t v = segsz[p];
+        if (p == 0u) sizes_out[0] = v;
+        else if (v != 0u) sizes_out[p - sub[p] - (boff ? boff[p / SCAN_ITEMS] : 0u)] = v;
+    }
     if (p >= n) return;
     const uint32_t s = seg[p];
     seg[p] = s - sub[s] - (boff ? boff[s / SCAN_ITEMS] : 0u);
@@ -183,20 +258,15 @@ static int run_relabel(shp_ctx *ctx, uint32_t *d_seg, uint32_t n, const uint32_t
     uint32_t *tot = sub + ns;
     EmptyFn f{d_segsz};
     const uint32_t *boff = nullptr;
-    CHK(scan_exclusive(ctx, f, ns, sub, tot, bp<uint32_t>(ctx->scan_tmp), &boff));
-    if (n) {
-        hipLaunchKernelGGL(k_relabel, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, d_seg,
-                           sub, n, boff);
+    uint32_t *mir = ctx->h_pinned + PIN_MIRROR + MIR_RELABEL;        // the scan stores its total there
+    CHK(scan_exclusive(ctx, f, ns, sub, tot, bp<uint32_t>(ctx->scan_tmp), &boff, mir));
+    if (n || d_sizes_out) {
+        hipLaunchKernelGGL(k_relabel, dim3(grid_for(n > ns ? n : ns, 256)), dim3(256), 0, ctx->stream, d_seg,
+                           sub, n, boff, d_segsz, ns, d_sizes_out);
         KCHK(ctx);
     }
-    if (d_sizes_out) {
-        hipLaunchKernelGGL(k_compact_sizes, dim3(grid_for(ns, 256)), dim3(256), 0, ctx->stream,
-                           d_segsz, sub, ns, d_sizes_out, boff);
-        KCHK(ctx);
-    }
-    HIPCHK(ctx, hipMemcpyAsync(ctx->h_pinned, tot, 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    *new_max_host = max_id - ctx->h_pinned[0];
+    *new_max_host = max_id - *(volatile uint32_t *)mir;
     return 0;
 }
 
@@ -239,10 +309,20 @@ static int run_eliminate_single(shp_ctx *ctx, const void *d_img, int dtype, int 
     hipStream_t st = ctx->stream;
     uint32_t merged = 0, nr = 0;
     if (singles_ready) {
-        // the candidates are known: every pass (the first included) walks the list only
-        rest = bp<uint32_t>(ctx->singles);
-        nr = nsingles;
-        merged = 1;
+        // the candidates are known: the first pass walks the list and compacts what is left of it,
+        // one workgroup runs the later passes -- three commands, no host round trip
+        if (nsingles) {
+            const uint32_t *list = bp<uint32_t>(ctx->singles);
+            const unsigned gl = grid_for(nsingles, 256);
+            DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_single_scan_list<DT>, dim3(gl), dim3(256), 0, st, d_img, nb,
+                                                     d_seg, segsz, tgt, n, nrows, ncols, four, list, nsingles, nelim, geom));
+            KCHK(ctx);
+            hipLaunchKernelGGL(k_single_apply_list, dim3(gl), dim3(256), 0, st, d_seg, segsz, tgt, list, nsingles,
+                               nelim, rest); KCHK(ctx);
+            DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_single_tail<DT>, dim3(1), dim3(1024), 0, st, d_img, nb, d_seg,
+                                                     segsz, tgt, n, nrows, ncols, four, rest, nrest, geom));
+            KCHK(ctx);
+        }
     } else {
         HIPCHK(ctx, hipMemsetAsync(nelim, 0, 8, st));
         DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_single_scan<DT>, dim3(g), dim3(256), 0, st, d_img, nb, d_seg,
@@ -261,7 +341,7 @@ static int run_eliminate_single(shp_ctx *ctx, const void *d_img, int dtype, int 
                                                  d_seg, segsz, tgt, n, nrows, ncols, four, rest, nr, nelim, geom));
         KCHK(ctx);
         hipLaunchKernelGGL(k_single_apply_list, dim3(gl), dim3(256), 0, st, d_seg, segsz, tgt, rest, nr,
-                           nelim); KCHK(ctx);
+                           nelim, (uint32_t *)nullptr); KCHK(ctx);
         HIPCHK(ctx, hipMemcpyAsync(ctx->h_pinned, nelim, 4, hipMemcpyDeviceToHost, st));
         HIPCHK(ctx, hipStreamSynchronize(st));
         merged = ctx->h_pinned[0];

@@ -338,6 +338,7 @@ struct SmallCtl {
 
 struct SmallArgs {
     SmallCtl *ctl;
+    uint32_t *pin;      // the host's copy of *ctl (pinned block), written by the kernel when the loop is done
     uint32_t *hist;
     uint32_t *seg, *segsz;
     float *ssum;
@@ -646,7 +647,14 @@ __global__ __launch_bounds__(256) void k_small_loop(SmallArgs a)
             }
         }
         __syncthreads();
-        if (s_done) break;
+        if (s_done) {
+            // workgroup 0 hands the control block to the host (every other workgroup's counters
+            // reached the L2 before the last barrier)
+            if (blockIdx.x == 0)
+                for (uint32_t i = threadIdx.x; i < (uint32_t)(sizeof(SmallCtl) / 4); i += 256u)
+                    MIRROR_STORE(&a.pin[i], L2LOAD(&((const uint32_t *)ctl)[i]));
+            break;
+        }
         const uint32_t target = s_target;
         SmallCnt *cnt = &ctl->cnt[slot % 3u];
         // ---- find phase: sources = segments of the target size.  Every wavefront scans its own
@@ -864,6 +872,8 @@ static int run_eliminate_small(shp_ctx *ctx, const void *d_img, int dtype, int n
     args.poll = poll_env < 1 ? 1 : poll_env;
     static const int bar2_env = getenv("SHEPSEG_SMALL_BAR2") ? atoi(getenv("SHEPSEG_SMALL_BAR2")) : 1;
     args.bar2 = bar2_env;
+    args.pin = (uint32_t *)pin;
+    pin->done = 0; pin->fail = 0;       // (a loop that gives up at a barrier leaves them so)
     fill_release(ctx, true);            // the pass loop is a latency-bound phase
     {
         std::unique_lock<std::mutex> lk(g_small_mu);
@@ -879,7 +889,7 @@ static int run_eliminate_small(shp_ctx *ctx, const void *d_img, int dtype, int n
     hipLaunchKernelGGL(k_small_loop, dim3(small_blocks), dim3(256), 0, st, args);
     hipError_t lerr = hipGetLastError();
     prof_end(ctx, ps);
-    hipError_t cerr = hipMemcpyAsync(pin, ctl, sizeof(SmallCtl), hipMemcpyDeviceToHost, st);
+    hipError_t cerr = hipSuccess;
     hipError_t serr = hipStreamSynchronize(st);
     walk_end(ctx);
     {

@@ -175,7 +175,7 @@ static int launch_assign(shp_ctx *ctx, const void *d_img, int dtype, int nb, siz
 {
     if (k < 1 || k > 65534) SHP_FAIL(ctx, SHP_ERR_ARG, "numClusters %d out of range", k);
     const size_t hn = (size_t)k * nb + k;
-    if (hn * 8 + 64 > SHP_PINNED_BYTES) SHP_FAIL(ctx, SHP_ERR_ARG, "k * nbands too large (%d x %d)", k, nb);
+    if (hn * 8 + 64 + 512 > SHP_PINNED_BYTES) SHP_FAIL(ctx, SHP_ERR_ARG, "k * nbands too large (%d x %d)", k, nb);
     double *h = (double *)(ctx->h_pinned + 16);       // pinned staging (stream-ordered reuse)
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));   // earlier users of the staging area are done
     kmeans_prepare_host(centres, k, nb, h, h + (size_t)k * nb);

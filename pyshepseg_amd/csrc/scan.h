@@ -59,13 +59,17 @@ struct AgentArrFn {     // block totals written by other workgroups of the same 
 template <class F>
 __global__ __launch_bounds__(256) void k_scan_local(F f, uint32_t n, uint32_t *__restrict__ out,
                                                     uint32_t *bsum, uint32_t *total_out,
-                                                    uint32_t *boff, uint32_t *ctr)
+                                                    uint32_t *boff, uint32_t *ctr, uint32_t *total_host)
 {
     __shared__ uint32_t s_last;
     const uint32_t carry = scan_block(f, n, out, blockIdx.x);
     const uint32_t nb = gridDim.x;
     if (nb == 1u) {
-        if (threadIdx.x == 0) { bsum[0] = carry; if (total_out) *total_out = carry; }
+        if (threadIdx.x == 0) {
+            bsum[0] = carry;
+            if (total_out) *total_out = carry;
+            if (total_host) MIRROR_STORE(total_host, carry);
+        }
         return;
     }
     if (threadIdx.x == 0) {
@@ -85,6 +89,7 @@ __global__ __launch_bounds__(256) void k_scan_local(F f, uint32_t n, uint32_t *_
     const uint32_t tot = scan_block(g, nb, boff, 0u);
     if (threadIdx.x == 0) {
         if (total_out) *total_out = tot;
+        if (total_host) MIRROR_STORE(total_host, tot);
         __hip_atomic_store(ctr, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
@@ -119,13 +124,16 @@ static inline size_t scan_tmp_bytes(size_t n)
 // lazy_boff (optional): the add-back pass is skipped and *lazy_boff receives the per-block offsets
 // (nullptr when there is a single block): the consumer adds lazy_boff[i / SCAN_ITEMS] to out[i]
 // itself, one launch less on a stream where every launch queues behind other tiles' kernels.
+// total_host (optional): a word of the context's pinned block (see PIN_MIRROR) that receives the
+// total as well, readable after the next stream synchronisation.
 template <class F>
 static int scan_exclusive(shp_ctx *ctx, F f, uint32_t n, uint32_t *out, uint32_t *total_dev,
-                          uint32_t *tmp, const uint32_t **lazy_boff = nullptr)
+                          uint32_t *tmp, const uint32_t **lazy_boff = nullptr, uint32_t *total_host = nullptr)
 {
     if (lazy_boff) *lazy_boff = nullptr;
     if (n == 0) {
         if (total_dev) HIPCHK(ctx, hipMemsetAsync(total_dev, 0, 4, ctx->stream));
+        if (total_host) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); *total_host = 0; }
         return 0;
     }
     const uint32_t nb = (n + SCAN_ITEMS - 1) / SCAN_ITEMS;
@@ -135,12 +143,13 @@ static int scan_exclusive(shp_ctx *ctx, F f, uint32_t n, uint32_t *out, uint32_t
     const bool one_launch = one_env && nb > 1 && nb <= SCAN_ITEMS;    // the last workgroup scans the totals
     hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scan_local<F>), dim3(nb), dim3(256), 0, ctx->stream, f, n,
                        out, bsum, (nb == 1 || one_launch) ? total_dev : (uint32_t *)nullptr,
-                       one_launch ? boff : (uint32_t *)nullptr, ctx->scan_ctr);
+                       one_launch ? boff : (uint32_t *)nullptr, ctx->scan_ctr,
+                       (nb == 1 || one_launch) ? total_host : (uint32_t *)nullptr);
     KCHK(ctx);
     if (nb == 1) return 0;                   // the kernel wrote the total itself
     if (!one_launch) {
         ArrFn g{bsum};
-        CHK(scan_exclusive(ctx, g, nb, boff, total_dev, tmp + 2 * (size_t)nb + 2));
+        CHK(scan_exclusive(ctx, g, nb, boff, total_dev, tmp + 2 * (size_t)nb + 2, nullptr, total_host));
     }
     if (lazy_boff) { *lazy_boff = boff; return 0; }
     hipLaunchKernelGGL(k_scan_add, dim3(grid_for(n, 256)), dim3(256), 0, ctx->stream, out, n, boff);

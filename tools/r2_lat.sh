@@ -1,7 +1,7 @@
 # diagnostic: per-kernel median durations inside one bench step, with and without the walkers
 R=$PWD; cd /tmp && export TMPDIR=/tmp; cd $R
 i=0
-for spec in "A=0" "SHEPSEG_DBG_SKIP_DFS=1,SHEPSEG_DBG_SKIP_SMALL=1" "SHEPSEG_FILL_MAX=1" "SHEPSEG_FILL_MAX=2"; do
+for spec in ${LAT_SPECS:-"A=0" "SHEPSEG_DBG_SKIP_DFS=1,SHEPSEG_DBG_SKIP_SMALL=1" "SHEPSEG_FILL_MAX=1" "SHEPSEG_FILL_MAX=2"}; do
   i=$((i+1))
   for kv in $(echo "$spec" | tr ',' ' '); do export $kv; done
   rm -rf gpurun_out/tl
@@ -9,7 +9,7 @@ for spec in "A=0" "SHEPSEG_DBG_SKIP_DFS=1,SHEPSEG_DBG_SKIP_SMALL=1" "SHEPSEG_FIL
   for kv in $(echo "$spec" | tr ',' ' '); do unset ${kv%%=*}; done
   f=$(ls gpurun_out/tl/*kernel_trace.csv gpurun_out/tl/*/*kernel_trace.csv 2>/dev/null | head -1)
   echo "== $spec" >> gpurun_out/r2_lat.txt
-  tail -1 gpurun_out/tl.log | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['config']['step_s'])" >> gpurun_out/r2_lat.txt
+  grep "^{" gpurun_out/tl.log | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], d['config']['step_s'])" >> gpurun_out/r2_lat.txt
   python - "$f" >> gpurun_out/r2_lat.txt <<'PY'
 import csv, sys, collections
 d = collections.defaultdict(list)
