@@ -216,6 +216,20 @@ int shp_stitch_chain_dev(shp_ctx *ctx, const uint32_t *d_tile, int ys, int xs, i
                          uint32_t *d_meta, uint32_t *d_right_out, uint32_t *d_bottom_out,
                          uint32_t *d_out, int64_t out_pitch, int xout, int yout,
                          uint32_t top_cross_px, uint32_t left_cross_px /* 0xFFFFFFFF = unknown */);
+
+/* Parallel stitch of the sharded driver: every tile runs the chain step with a
+ * PROVISIONAL base (tile index * stride, in *d_max_seg_id) so that it depends on its two
+ * neighbours' strips only, not on the running maxSegId of all earlier tiles (reference
+ * tiling.py:1029-1043).  shp_stitch_counts_dev reports what the step did -- d_out2[0] = new ids
+ * handed out, d_out2[1] = the largest of them present in the trimmed window, both relative to
+ * base (asynchronous) -- and once every tile's count is known shp_renumber_dev maps
+ * id -> new_base[id / stride] + id % stride over a raster (new_base: ntiles host values;
+ * synchronous).  The result equals the sequential chain iff out2[0] == out2[1] for every tile;
+ * otherwise the driver reruns the sequential chain. */
+int shp_stitch_counts_dev(shp_ctx *ctx, const uint32_t *d_meta, uint32_t max_local, uint32_t base,
+                          uint32_t *d_out2);
+int shp_renumber_dev(shp_ctx *ctx, uint32_t *d_raster, int64_t npix, uint32_t stride,
+                     const uint32_t *new_base, int ntiles);
 /* one stitched, trimmed tile (w x h at xout, yout of the device raster) sub-sampled into one overview
  * layer exactly as SegmentationConcurrencyMgr.writeOverviews does tile by tile (tiling.py:1360-1383):
  * every level-th pixel from offset level / 2 of the tile, written at (xout / level, yout / level),

@@ -98,6 +98,8 @@ _SIGS = {
                                        _c.c_int]),
     'shp_stitch_prepare_dev': (_c.c_int, [_vp, _vp, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
                                           _c.c_uint32, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _vp, _vp]),
+    'shp_stitch_counts_dev': (_c.c_int, [_vp, _vp, _c.c_uint32, _c.c_uint32, _vp]),
+    'shp_renumber_dev': (_c.c_int, [_vp, _vp, _c.c_int64, _c.c_uint32, _vp, _c.c_int]),
     'shp_stitch_chain_dev': (_c.c_int, [_vp, _vp, _c.c_int, _c.c_int, _c.c_int, _vp, _c.c_int64,
                                         _vp, _c.c_int64, _c.c_uint32, _c.c_int, _vp, _c.c_int,
                                         _c.c_int, _c.c_int, _c.c_int, _vp, _vp, _vp, _vp, _c.c_int64,

@@ -849,6 +849,40 @@ API int shp_stitch_chain_dev(shp_ctx *ctx, const uint32_t *d_tile, int ys, int x
 
 // one trimmed tile's contribution to one overview layer; runs behind the tile's output write on the
 // context's side stream (shp_stitch_chain_dev), so the chain itself is not held up
+// Parallel stitch.  After shp_stitch_chain_dev ran with
+// *d_max_seg_id = base (the tile's provisional base): d_out2[0] = number of new ids the tile handed
+// out, d_out2[1] = the largest of them (minus base) present in its trimmed window.  Asynchronous.
+API int shp_stitch_counts_dev(shp_ctx *ctx, const uint32_t *d_meta, uint32_t max_local, uint32_t base,
+                              uint32_t *d_out2)
+{
+    CHK(enter(ctx));
+    if (!d_meta || !d_out2) SHP_FAIL(ctx, SHP_ERR_ARG, "NULL argument");
+    const uint32_t nseg = max_local + 1u;
+    HIPCHK(ctx, hipMemsetAsync(d_out2, 0, 8, ctx->stream));
+    hipLaunchKernelGGL(k_lut_counts, dim3(grid_for(nseg, 256)), dim3(256), 0, ctx->stream,
+                       d_meta + 3 * (size_t)nseg, d_meta, nseg, base, d_out2);
+    KCHK(ctx);
+    return 0;
+}
+
+// Provisional ids -> final ids over a device raster: id -> new_base[id / stride] + id % stride
+// (0 stays 0; new_base: ntiles host values).  Synchronous.
+API int shp_renumber_dev(shp_ctx *ctx, uint32_t *d_raster, int64_t npix, uint32_t stride,
+                         const uint32_t *new_base, int ntiles)
+{
+    CHK(enter(ctx));
+    if ((!d_raster && npix) || !new_base || ntiles < 1 || stride == 0 || npix < 0)
+        SHP_FAIL(ctx, SHP_ERR_ARG, "bad argument");
+    if (npix == 0) return 0;
+    CHK(buf_ensure(ctx, ctx->tlist, (size_t)ntiles * 4));
+    HIPCHK(ctx, hipMemcpyAsync(ctx->tlist.p, new_base, (size_t)ntiles * 4, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_renumber, dim3(grid_for((size_t)npix, 256)), dim3(256), 0, ctx->stream, d_raster,
+                       (size_t)npix, stride, bp<uint32_t>(ctx->tlist), (uint32_t)ntiles);
+    KCHK(ctx);
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return 0;
+}
+
 API int shp_overview_window_dev(shp_ctx *ctx, const uint32_t *d_raster, int64_t pitch, int xout, int yout,
                                 int w, int h, int level, uint32_t *d_ov, int ov_w, int ov_h)
 {

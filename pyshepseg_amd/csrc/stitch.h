@@ -626,6 +626,43 @@ static int run_stitch_chain(shp_ctx *ctx, const uint32_t *d_tile, uint32_t ys, u
     return 0;
 }
 
+// ---- parallel (provisional-id) stitch of the sharded driver -----------------------------------------
+// out[0] = largest new id the chain step handed out, minus base (= how many: they are base + 1 ..),
+// out[1] = the same over the segments present in the trimmed window.  With base = the tile's
+// provisional base every inherited id is below it.  out[] must be zero.
+__global__ __launch_bounds__(256) void k_lut_counts(const uint32_t *__restrict__ lut,
+                                                    const uint32_t *__restrict__ flags, uint32_t nseg,
+                                                    uint32_t base, uint32_t *out)
+{
+    const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t l = (s < nseg && s != 0u) ? lut[s] : 0u;
+    uint32_t a = l > base ? l - base : 0u;
+    uint32_t b = (a != 0u && (flags[s] & META_IN_TRIM)) ? a : 0u;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t oa = __shfl_xor(a, d, 64), ob = __shfl_xor(b, d, 64);
+        a = oa > a ? oa : a;
+        b = ob > b ? ob : b;
+    }
+    if (lane_id() == 0) {
+        if (a) atomicMax(&out[0], a);
+        if (b) atomicMax(&out[1], b);
+    }
+}
+
+// id -> table[id / stride] + id % stride (0 stays 0): provisional ids (tile index * stride + rank)
+// to the final ones once every tile's count is known
+__global__ __launch_bounds__(256) void k_renumber(uint32_t *__restrict__ ras, size_t n, uint32_t stride,
+                                                  const uint32_t *__restrict__ table, uint32_t ntiles)
+{
+    const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t v = ras[i];
+    if (v == 0u) return;
+    const uint32_t t = v / stride;
+    ras[i] = t < ntiles ? table[t] + (v - t * stride) : 0u;
+}
+
 // trimmed window of the tile through the LUT into the output raster, on the side stream
 static int run_stitch_finish(shp_ctx *ctx, const uint32_t *d_tile, uint32_t ys, uint32_t xs,
                              uint32_t max_local, uint32_t top, uint32_t bottom, uint32_t left,

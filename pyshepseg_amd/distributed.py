@@ -10,13 +10,24 @@ What shards and what does not
   path.
 * The cross-tile stitch is specified sequentially (reference stitchTiles, tiling.py:979-1043:
   every tile's new ids start after the largest id of all earlier tiles, and shared segments
-  take the id the tile above / to the left already gave them).  It is kept exactly that way:
-  rank r stitches its tiles as soon as it has received, from the rank holding the tiles before,
-  the running maxSegId, the recoded bottom overlap strips of that rank's last ncols tiles (the
-  top neighbours of this rank's first tiles) and, when this rank starts in the middle of a tile
-  row, the right strip of the tile before -- the one real exchange step (point-to-point
-  send/recv, <= 25 MB per strip) -- and passes its own on.  A final all-reduce sums the
-  per-rank histograms.
+  take the id the tile above / to the left already gave them).  Two forms, same result:
+  - sequential: rank r stitches its tiles once it has received, from the rank holding the tiles
+    before, the running maxSegId, the recoded bottom overlap strips of that rank's last ncols
+    tiles (the top neighbours of this rank's first tiles) and, when this rank starts in the middle
+    of a tile row, the right strip of the tile before -- point-to-point send/recv, <= 25 MB per
+    strip -- and passes its own on at the end;
+  - parallel (default with more than one rank): tile t numbers its new segments from a
+    PROVISIONAL base t * stride (stride = 2^32 / number of tiles), so its chain step needs the
+    strips of the tiles above and to the left only -- a rank starts as soon as the first strip of
+    the previous rank's last row arrives, strips travel tile by tile.  Every tile reports K_t =
+    ids handed out and R_t = the largest of them present in its trimmed window; an all-gather
+    later, if K_t == R_t everywhere, the sequential run would have found maxSegId = sum of the
+    earlier K (the reference advances it to trimmed.max()), the provisional ids are in the same
+    order as the final ones (ties in the mode are broken by id) and no two of them collide, so
+    id -> base[id / stride] + id % stride over the output gives the identical raster.  A tile
+    with K_t != R_t (the reference then reuses ids: tests/golden/stitch_quirk_empties) or with
+    more local segments than the stride sends every rank back to the sequential form.
+  A final all-reduce sums the per-rank histograms.
 * The k-means fit runs on rank 0 from the sub-sample gathered from every rank's slice; the
   centres (k x nBands float64) are broadcast.
 
@@ -153,12 +164,20 @@ class DistResult(object):
 def runDistributed(engine, comm, nRows, nCols, tileSize, overlapSize, minSegmentSize=50,
                    numClusters=60, subsamplePcnt=None, maxSpectralDiff='auto', imgNullVal=None,
                    fixedKMeansInit=True, fourConnected=True, simpleTileRecode=False,
-                   spectDistPcntile=50, kmeansObj=None):
+                   spectDistPcntile=50, kmeansObj=None, stitchMode=None):
     """Tiled segmentation of an (nRows x nCols) raster, its tiles sharded over comm.world ranks.
     ``engine`` owns this rank's slice of the raster and of the output (see HipEngine).  Returns a
     DistResult with maxSegId, hist (global), kmeans, maxSpectralDiff, tileRange (row-major tile
     indices of this rank), rowRange (the tile rows they touch) and outRows (image rows of the
-    output buffer this rank holds: its tiles' trimmed windows are written, the rest is 0)."""
+    output buffer this rank holds: its tiles' trimmed windows are written, the rest is 0) and
+    stitchMode ('sequential', 'parallel', or 'parallel->sequential' when the parallel form had to
+    be redone; argument / SHEPSEG_STITCH: None = parallel when comm.world > 1)."""
+    if stitchMode is None:
+        stitchMode = os.environ.get('SHEPSEG_STITCH') or ('parallel' if comm.world > 1 else 'sequential')
+    if stitchMode not in ('sequential', 'parallel'):
+        raise ValueError("stitchMode must be 'sequential' or 'parallel'")
+    if simpleTileRecode:
+        stitchMode = 'sequential'          # (no shared segments: nothing to gain)
     if (overlapSize % 2) != 0:
         raise tiling.PyShepSegTilingError("Overlap size must be an even number")
 
@@ -222,38 +241,103 @@ def runDistributed(engine, comm, nRows, nCols, tileSize, overlapSize, minSegment
     # ---- segment this rank's tiles (asynchronously) ----
     engine.startSegmentation(centres, msd, imgNullVal, fourConnected, minSegmentSize)
 
-    # ---- the stitch chain ----
-    maxSegId = 0
-    if haveTiles:
-        pos = nonEmpty.index(comm.rank)
-        prevRank = nonEmpty[pos - 1] if pos > 0 else None
-        nextRank = nonEmpty[pos + 1] if pos + 1 < len(nonEmpty) else None
-        fromPrev = {}
-        if prevRank is not None:
-            maxSegId, fromPrev = engine.recvBoundary(
-                comm, prevRank, boundaryPlan(tileInfo, shards, prevRank, overlapSize))
-        engine.setMaxSegId(maxSegId)
-        jobmap = {(j.col, j.row): j for j in jobs}
-        for j in jobs:
-            engine.waitTile(j)
-            win = _winOf(j.col, j.row)
-            top = left = None
-            if not simpleTileRecode:
-                if j.row > 0:
-                    a = jobmap.get((j.col, j.row - 1))
-                    top = engine.bottomStripOf(a) if a is not None else fromPrev[('b', j.col, j.row - 1)]
-                if j.col > 0:
-                    a = jobmap.get((j.col - 1, j.row))
-                    left = engine.rightStripOf(a) if a is not None else fromPrev[('r', j.col - 1, j.row)]
-            engine.stitchTile(j, top, left, win, simpleTileRecode)
-        maxSegId = engine.getMaxSegId()
-        if nextRank is not None:
-            plan = boundaryPlan(tileInfo, shards, comm.rank, overlapSize)
-            engine.sendBoundary(comm, nextRank, maxSegId,
-                                [(kind, jobmap[(c, r)], h, w) for (kind, c, r, h, w) in plan])
-    # final maxSegId lives on the last rank that has tiles
-    vals = comm.allgather_obj(int(maxSegId))
-    maxSegId = vals[nonEmpty[-1]] if nonEmpty else 0
+    # ---- the stitch ----
+    jobmap = {(j.col, j.row): j for j in jobs}
+    pos = nonEmpty.index(comm.rank) if haveTiles else -1
+    prevRank = nonEmpty[pos - 1] if pos > 0 else None
+    nextRank = nonEmpty[pos + 1] if haveTiles and pos + 1 < len(nonEmpty) else None
+
+    def _neighbours(j, fromPrev):
+        top = left = None
+        if not simpleTileRecode:
+            if j.row > 0:
+                a = jobmap.get((j.col, j.row - 1))
+                top = engine.bottomStripOf(a) if a is not None else fromPrev[('b', j.col, j.row - 1)]
+            if j.col > 0:
+                a = jobmap.get((j.col - 1, j.row))
+                left = engine.rightStripOf(a) if a is not None else fromPrev[('r', j.col - 1, j.row)]
+        return top, left
+
+    def _sequential():
+        maxSegId = 0
+        if haveTiles:
+            fromPrev = {}
+            if prevRank is not None:
+                maxSegId, fromPrev = engine.recvBoundary(
+                    comm, prevRank, boundaryPlan(tileInfo, shards, prevRank, overlapSize))
+            engine.setMaxSegId(maxSegId)
+            for j in jobs:
+                engine.waitTile(j)
+                (top, left) = _neighbours(j, fromPrev)
+                engine.stitchTile(j, top, left, _winOf(j.col, j.row), simpleTileRecode)
+            maxSegId = engine.getMaxSegId()
+            if nextRank is not None:
+                plan = boundaryPlan(tileInfo, shards, comm.rank, overlapSize)
+                engine.sendBoundary(comm, nextRank, maxSegId,
+                                    [(kind, jobmap[(c, r)], h, w) for (kind, c, r, h, w) in plan])
+        # final maxSegId lives on the last rank that has tiles
+        vals = comm.allgather_obj(int(maxSegId))
+        return vals[nonEmpty[-1]] if nonEmpty else 0
+
+    def _parallel():
+        """Returns the final maxSegId, or None when some tile makes the provisional form unsafe."""
+        ntAll = ncolsT * tileInfo.nrows
+        stride = 0xFFFFFFFF // max(ntAll, 1)
+        mine = []
+        if haveTiles:
+            # strips cross the rank boundary tile by tile, in the sender's tile order ('b' before 'r')
+            order = lambda plan: sorted(plan, key=lambda it: (it[2] * ncolsT + it[1], it[0] != 'b'))
+            planPrev = order(boundaryPlan(tileInfo, shards, prevRank, overlapSize)) if prevRank is not None else []
+            sendOf = {}
+            if nextRank is not None:
+                for it in order(boundaryPlan(tileInfo, shards, comm.rank, overlapSize)):
+                    sendOf.setdefault((it[1], it[2]), []).append(it)
+            fromPrev = {}
+            got = [0]
+
+            def need(key):
+                while key not in fromPrev:
+                    it = planPrev[got[0]]
+                    got[0] += 1
+                    fromPrev[(it[0], it[1], it[2])] = engine.recvStrip(comm, prevRank, it)
+            engine.beginProvisional(stride, ntAll)
+            for (slot, j) in enumerate(jobs):
+                if j.row > 0 and (j.col, j.row - 1) not in jobmap:
+                    need(('b', j.col, j.row - 1))
+                if j.col > 0 and (j.col - 1, j.row) not in jobmap:
+                    need(('r', j.col - 1, j.row))
+                engine.waitTile(j)
+                (top, left) = _neighbours(j, fromPrev)
+                t = j.row * ncolsT + j.col
+                engine.stitchTileAt(j, top, left, _winOf(j.col, j.row), t, stride, slot)
+                for it in sendOf.get((j.col, j.row), ()):
+                    engine.sendStrip(comm, nextRank, it, j)
+            while got[0] < len(planPrev):          # (every planned strip has a reader; be safe)
+                need((planPrev[got[0]][0], planPrev[got[0]][1], planPrev[got[0]][2]))
+            counts = engine.tileCounts(len(jobs))
+            mine = [(j.row * ncolsT + j.col, int(k), int(r), int(j.maxLocal))
+                    for (j, (k, r)) in zip(jobs, counts)]
+        everyone = [x for part in comm.allgather_obj(mine) for x in part]
+        K = numpy.zeros(ntAll, dtype=numpy.int64)
+        safe = len(everyone) == ntAll
+        for (t, k, r, mloc) in everyone:
+            K[t] = k
+            if k != r or mloc >= stride or k >= stride:
+                safe = False
+        if not safe or int(K.sum()) > 0xFFFFFFFF:
+            return None
+        base = numpy.concatenate(([0], numpy.cumsum(K)[:-1])).astype(numpy.uint32)
+        if haveTiles:
+            engine.renumber(stride, base)
+        return int(K.sum())
+
+    if stitchMode == 'parallel':
+        maxSegId = _parallel()
+        if maxSegId is None:
+            stitchMode = 'parallel->sequential'
+            maxSegId = _sequential()
+    else:
+        maxSegId = _sequential()
     hist = engine.histogram(maxSegId) if haveTiles else numpy.zeros(maxSegId + 1, numpy.int64)
     hist = comm.allreduce_sum_i64(numpy.asarray(hist, dtype=numpy.int64)).astype(numpy.uint32)
     hist[0] = 0
@@ -264,6 +348,7 @@ def runDistributed(engine, comm, nRows, nCols, tileSize, overlapSize, minSegment
     res.hist = hist
     res.kmeans = kmeansObj
     res.maxSpectralDiff = msd
+    res.stitchMode = stitchMode
     res.subsamplePcnt = subsamplePcnt
     res.rowRange = (r0, r1)
     res.tileRange = (t0, t1)
@@ -419,33 +504,87 @@ class HipEngine(object):
                 ctypes.c_void_p(self.d_strips.value + 4 * j.bottomOff), self.d_out, self.nCols, xout,
                 yout - self.outLo, j.crossPx[0], j.crossPx[1]))
 
+    # ---- parallel stitch: provisional bases, per-tile counts, eager strips ----
+    def beginProvisional(self, stride, ntAll):
+        bases = (numpy.arange(ntAll, dtype=numpy.uint64) * stride).astype(numpy.uint32)
+        self.nbBases = (ntAll + 2 * len(self.jobs) + 16) * 4
+        self.d_bases = tiling._devAlloc(self.c, self.nbBases)
+        self.c.check(self.L.shp_dev_memset(self.c.handle, self.d_bases, 0, self.nbBases))
+        self.c.check(self.L.shp_dev_upload(self.c.handle, self.d_bases, _lib.ptr(bases), ntAll * 4))
+        self.ntAll = ntAll
+
+    def stitchTileAt(self, j, top, left, win, t, stride, slot):
+        """The chain step of tile t with its provisional base (a device word of its own, so nothing
+        is uploaded or read back per tile), then its two counts into slot `slot`."""
+        (tt, b, l, r, xout, yout) = win
+        with self.timings.interval('stitchtiles'):
+            self.c.check(self.L.shp_stitch_chain_dev(
+                self.c.handle, ctypes.c_void_p(self.d_tiles.value + 4 * j.offset), j.ysize, j.xsize,
+                self.overlap, ctypes.c_void_p(top[0]) if top else None, top[1] if top else 0,
+                ctypes.c_void_p(left[0]) if left else None, left[1] if left else 0, j.maxLocal,
+                0, ctypes.c_void_p(self.d_bases.value + 4 * t), tt, b, l, r, ctypes.c_void_p(j.meta),
+                ctypes.c_void_p(self.d_strips.value + 4 * j.rightOff),
+                ctypes.c_void_p(self.d_strips.value + 4 * j.bottomOff), self.d_out, self.nCols, xout,
+                yout - self.outLo, j.crossPx[0], j.crossPx[1]))
+            self.c.check(self.L.shp_stitch_counts_dev(
+                self.c.handle, ctypes.c_void_p(j.meta), j.maxLocal, (t * stride) & 0xFFFFFFFF,
+                ctypes.c_void_p(self.d_bases.value + 4 * (self.ntAll + 2 * slot))))
+
+    def tileCounts(self, n):
+        a = numpy.zeros(2 * max(n, 1), dtype=numpy.uint32)
+        self.c.check(self.L.shp_sync(self.c.handle))
+        self.c.check(self.L.shp_dev_download(self.c.handle, _lib.ptr(a),
+                                             ctypes.c_void_p(self.d_bases.value + 4 * self.ntAll), 8 * max(n, 1)))
+        tiling._devRelease(self.c, self.d_bases, self.nbBases)
+        self.d_bases = None
+        return a[:2 * n].reshape(n, 2)
+
+    def renumber(self, stride, base):
+        self.c.check(self.L.shp_sync(self.c.handle))
+        base = numpy.ascontiguousarray(base, dtype=numpy.uint32)
+        self.c.check(self.L.shp_renumber_dev(self.c.handle, self.d_out, (self.outHi - self.outLo) * self.nCols,
+                                             int(stride), _lib.ptr(base), len(base)))
+
+    def sendStrip(self, comm, dst, item, a):
+        (kind, _c, _r, h, w) = item
+        self.c.check(self.L.shp_sync(self.c.handle))          # the chain step that wrote it is done
+        self._sendOne(comm, dst, kind, a, h * w)
+
+    def recvStrip(self, comm, src, item):
+        (kind, _c, _r, h, w) = item
+        return (self._recvOne(comm, src, h * w), w)
+
+    def _sendOne(self, comm, dst, kind, a, n):
+        (ptr, _pitch) = self.bottomStripOf(a) if kind == 'b' else self.rightStripOf(a)
+        if comm.onDevice:        # device memory straight into RCCL
+            comm.send_dev(ptr, n * 4, dst)
+        else:                    # ranks without a device transport: stage through host memory
+            buf = numpy.empty(n, dtype=numpy.uint32)
+            self.c.check(self.L.shp_dev_download(self.c.handle, _lib.ptr(buf), ctypes.c_void_p(ptr), n * 4))
+            comm.send_bytes(buf, dst)
+
+    def _recvOne(self, comm, src, n):
+        d = tiling._devAlloc(self.c, n * 4)
+        self.recvDev.append((d, n * 4))
+        if comm.onDevice:
+            comm.recv_dev(d.value, n * 4, src)
+        else:
+            buf = numpy.frombuffer(comm.recv_bytes(src), dtype=numpy.uint32)
+            self.c.check(self.L.shp_dev_upload(self.c.handle, d, _lib.ptr(numpy.ascontiguousarray(buf)), n * 4))
+        return d.value
+
     def sendBoundary(self, comm, dst, maxSegId, items):
         """items: (kind, job, h, w) from boundaryPlan; strips are dense h x w blocks."""
         self.c.check(self.L.shp_sync(self.c.handle))
         comm.send_obj(int(maxSegId), dst)
         for (kind, a, h, w) in items:
-            n = h * w
-            (ptr, _pitch) = self.bottomStripOf(a) if kind == 'b' else self.rightStripOf(a)
-            if comm.onDevice:        # device memory straight into RCCL
-                comm.send_dev(ptr, n * 4, dst)
-            else:                    # ranks without a device transport: stage through host memory
-                buf = numpy.empty(n, dtype=numpy.uint32)
-                self.c.check(self.L.shp_dev_download(self.c.handle, _lib.ptr(buf), ctypes.c_void_p(ptr), n * 4))
-                comm.send_bytes(buf, dst)
+            self._sendOne(comm, dst, kind, a, h * w)
 
     def recvBoundary(self, comm, src, plan):
         maxSegId = int(comm.recv_obj(src))
         strips = {}
         for (kind, col, row, h, w) in plan:
-            n = h * w
-            d = tiling._devAlloc(self.c, n * 4)
-            self.recvDev.append((d, n * 4))
-            if comm.onDevice:
-                comm.recv_dev(d.value, n * 4, src)
-            else:
-                buf = numpy.frombuffer(comm.recv_bytes(src), dtype=numpy.uint32)
-                self.c.check(self.L.shp_dev_upload(self.c.handle, d, _lib.ptr(numpy.ascontiguousarray(buf)), n * 4))
-            strips[(kind, col, row)] = (d.value, w)
+            strips[(kind, col, row)] = (self._recvOne(comm, src, h * w), w)
         return maxSegId, strips
 
     def histogram(self, maxSegId):
@@ -569,7 +708,8 @@ def bench_main(args, rank, world, local_rank):
                                       args.tile, args.overlap, world),
                        "tiles": r.numTileRows * r.numTileCols, "workers": args.workers,
                        "max_seg_id": int(r.maxSegId),
-                       "parallelism": "tiles sharded by area; stitch chain over ncclSend/ncclRecv (%s)"
+                       "stitch": r.stitchMode,
+                       "parallelism": "tiles sharded by area; overlap strips over ncclSend/ncclRecv (%s)"
                                       % type(comm).__name__},
             "roofline": {"bound": "hbm", "kernel": "whole path", "achieved": round(
                 value * 1e6 * (2 * nb + 4) / 1e9, 3), "peak": 8000.0 * world, "unit": "GB/s",

@@ -70,6 +70,39 @@ class OracleEngine(object):
                  xout:xout + trimmed.shape[1]] = trimmed
         self.maxSeg = max(self.maxSeg, int(trimmed.max()))
 
+    # ---- parallel stitch ----
+    def beginProvisional(self, stride, ntAll):
+        self.counts = {}
+
+    def stitchTileAt(self, j, top, left, win, t, stride, slot):
+        base = t * stride
+        self.maxSeg = base
+        self.stitchTile(j, top, left, win, False)
+        rec = self.recoded[(j.col, j.row)]
+        (tt, b, l, r, _x, _y) = win
+        k = max(0, int(rec.max()) - base)
+        trimmed = rec[tt:b, l:r]
+        rr = max(0, int(trimmed.max()) - base) if trimmed.size else 0
+        self.counts[slot] = (k, rr)
+
+    def tileCounts(self, n):
+        return [self.counts[i] for i in range(n)]
+
+    def renumber(self, stride, base):
+        v = self.out
+        t = (v // np.uint32(stride)).astype(np.int64)
+        self.out = np.where(v == 0, 0, base[np.minimum(t, len(base) - 1)] + (v % np.uint32(stride))).astype(np.uint32)
+
+    def sendStrip(self, comm, dst, item, a):
+        (kind, _c, _r, h, w) = item
+        s = self.bottomStripOf(a) if kind == 'b' else self.rightStripOf(a)
+        assert s.shape == (h, w)
+        comm.send_bytes(np.ascontiguousarray(s, dtype=np.uint32), dst)
+
+    def recvStrip(self, comm, src, item):
+        (_kind, _c, _r, h, w) = item
+        return np.frombuffer(comm.recv_bytes(src), dtype=np.uint32).reshape(h, w).copy()
+
     def sendBoundary(self, comm, dst, maxSegId, items):
         comm.send_obj(int(maxSegId), dst)
         for (kind, a, h, w) in items:

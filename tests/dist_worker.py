@@ -17,8 +17,25 @@ def main():
     from pyshepseg_amd import distributed
     from pyshepseg_amd import comm as shpcomm
     from dist_oracle_engine import OracleEngine
-    img = np.load(os.path.join(outdir, 'img.npy'))
     comm = shpcomm.SocketComm()
+    golden = sys.argv[5] if len(sys.argv) > 5 else None
+    if golden:
+        # a stitch fixture: the reference's own image, model and parameters; only the label mosaic is
+        # compared (by the test), so nothing else is written
+        from pyshepseg_amd import shepseg
+        g = np.load(golden, allow_pickle=True)
+        img = g['img']
+        eng = OracleEngine(img, oracle)
+        r = distributed.runDistributed(
+            eng, comm, img.shape[1], img.shape[2], int(g['tile_size']), int(g['overlap']),
+            minSegmentSize=int(g['min_seg']), maxSpectralDiff=float(g['msd']),
+            imgNullVal=(int(g['null_val']) if int(g['has_null']) else None),
+            fourConnected=bool(int(g['four'])), kmeansObj=shepseg.KMeansModel(g['centres']))
+        np.savez(os.path.join(outdir, 'rank%d.npz' % comm.rank), out=eng.out, outLo=r.outRows[0],
+                 outHi=r.outRows[1], maxSegId=r.maxSegId, hist=r.hist, mode=r.stitchMode)
+        comm.close()
+        return
+    img = np.load(os.path.join(outdir, 'img.npy'))
     eng = OracleEngine(img, oracle)
     r = distributed.runDistributed(eng, comm, img.shape[1], img.shape[2], tile, ov,
                                    minSegmentSize=12, numClusters=8, fixedKMeansInit=True,
@@ -30,7 +47,8 @@ def main():
     np.savez(os.path.join(outdir, 'stats%d.npz' % comm.rank), ic=ic, fc=fc)
     np.savez(os.path.join(outdir, 'rank%d.npz' % comm.rank), out=eng.out, outLo=r.outRows[0],
              outHi=r.outRows[1], maxSegId=r.maxSegId, hist=r.hist,
-             centres=r.kmeans.cluster_centers_, msd=r.maxSpectralDiff, rows=np.array(r.rowRange))
+             centres=r.kmeans.cluster_centers_, msd=r.maxSpectralDiff, rows=np.array(r.rowRange),
+             mode=r.stitchMode)
     comm.close()
 
 

@@ -34,7 +34,7 @@ def main():
     eng.releaseOutput()
     np.savez(os.path.join(outdir, 'rank%d.npz' % comm.rank), out=out, outLo=r.outRows[0],
              outHi=r.outRows[1], maxSegId=r.maxSegId, hist=r.hist,
-             centres=r.kmeans.cluster_centers_, msd=r.maxSpectralDiff)
+             centres=r.kmeans.cluster_centers_, msd=r.maxSpectralDiff, mode=r.stitchMode)
     comm.close()
 
 

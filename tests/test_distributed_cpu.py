@@ -100,13 +100,14 @@ def test_shard_plan_random_grids():
                     assert ('r', col - 1, row) in got
 
 
-def _run_ranks(world, argv, tmp_path, timeout=600):
+def _run_ranks(world, argv, tmp_path, timeout=600, extra_env=None):
     """start `world` rank processes with the environment a launcher sets; all must exit 0"""
     procs = []
     for r in range(world):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world),
                    MASTER_ADDR='127.0.0.1', MASTER_PORT='0', OMP_NUM_THREADS='1',
                    SHEPSEG_COMM_DIR=str(tmp_path / 'comm'))
+        env.update(extra_env or {})
         procs.append(subprocess.Popen([sys.executable] + argv, env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.PIPE, text=True))
     outs = [p.communicate(timeout=timeout) for p in procs]
@@ -114,16 +115,51 @@ def _run_ranks(world, argv, tmp_path, timeout=600):
         assert p.returncode == 0, e[-3000:]
 
 
-@pytest.mark.parametrize('world,simple,NR', [(2, 0, 330), (3, 0, 330), (2, 1, 330), (3, 0, 150)])
-def test_two_rank_chain_matches_single_process(world, simple, NR, tmp_path, oracle):
+STITCH_GOLDEN = ['stitch_2x2', 'stitch_3x3_null', 'stitch_3x4_8conn', 'stitch_quirk_empties',
+                 'stitch_quirk_zeros']
+
+
+@pytest.mark.parametrize('name', STITCH_GOLDEN)
+@pytest.mark.parametrize('world', [2, 3])
+def test_parallel_stitch_equals_reference_mosaic(name, world, tmp_path):
+    """The parallel (provisional-id) stitch of the sharded driver against the REFERENCE's own stitched
+    mosaics, both quirk fixtures included: where a tile hands out an id that its trimmed window
+    does not show (stitch_quirk_empties) the driver must notice and redo the stitch sequentially."""
+    path = os.path.join(ROOT, 'tests', 'golden', name + '.npz')
+    g = np.load(path, allow_pickle=True)
+    _run_ranks(world, [os.path.join(ROOT, 'tests', 'dist_worker.py'), str(tmp_path), '0', '0', '0', path],
+               tmp_path)
+    parts = [np.load(tmp_path / ('rank%d.npz' % r)) for r in range(world)]
+    want = g['mosaic']
+    got = np.zeros_like(want)
+    modes = set()
+    for q in parts:
+        lo, hi = int(q['outLo']), int(q['outHi'])
+        got[lo:hi] = np.maximum(got[lo:hi], q['out'])
+        assert int(q['maxSegId']) == int(g['max_seg_id'])
+        assert np.array_equal(q['hist'], g['hist'])
+        modes.add(str(q['mode']))
+    assert np.array_equal(got, want)
+    assert len(modes) == 1                       # every rank took the same decision
+    if name == 'stitch_quirk_empties':
+        assert modes == {'parallel->sequential'}
+    elif name in ('stitch_2x2', 'stitch_3x3_null', 'stitch_3x4_8conn'):
+        assert modes == {'parallel'}
+
+
+@pytest.mark.parametrize('world,simple,NR,mode', [(2, 0, 330, 'parallel'), (3, 0, 330, 'parallel'),
+                                                  (2, 1, 330, 'sequential'), (3, 0, 150, 'parallel'),
+                                                  (3, 0, 330, 'sequential')])
+def test_two_rank_chain_matches_single_process(world, simple, NR, mode, tmp_path, oracle):
     # NR = 150: two tile rows for three ranks -> whole-row shards and a rank without tiles
     img = oracle.synthimg(31, 3, NR, 260)
     img[:, :4, :] = 65535                      # a null border row band (nulls are not given here)
     np.save(tmp_path / 'img.npy', img)
     tile, ov = 96, 32
     _run_ranks(world, [os.path.join(ROOT, 'tests', 'dist_worker.py'), str(tmp_path), str(tile), str(ov),
-                       str(simple)], tmp_path)
+                       str(simple)], tmp_path, extra_env={'SHEPSEG_STITCH': mode})
     parts = [np.load(tmp_path / ('rank%d.npz' % r)) for r in range(world)]
+    assert {str(q['mode']).split('->')[0] for q in parts} == {mode}
     # single-process reference: oracle tiles + oracle stitch with the same centres
     centres, msd = parts[0]['centres'], float(parts[0]['msd'])
     for q in parts[1:]:
@@ -152,3 +188,35 @@ def test_two_rank_chain_matches_single_process(world, simple, NR, tmp_path, orac
         st = np.load(tmp_path / ('stats%d.npz' % r))
         assert np.array_equal(st['ic'], wic)
         assert np.array_equal(st['fc'].view(np.uint32), wfc.view(np.uint32))
+
+
+@pytest.mark.parametrize('seed', range(8))
+def test_parallel_stitch_fuzz_in_process(seed, oracle):
+    """One rank, both forms of the stitch on random small rasters with many tiles: identical mosaics,
+    maxSegId and histograms whichever way the parallel form ends (kept, or redone sequentially)."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    from dist_oracle_engine import OracleEngine
+    from pyshepseg_amd import distributed, shepseg
+    from pyshepseg_amd import comm as shpcomm
+    rng = np.random.default_rng(seed)
+    (nr, nc) = (int(rng.integers(120, 260)), int(rng.integers(120, 260)))
+    img = oracle.synthimg(100 + seed, 3, nr, nc)
+    if seed % 2:
+        img[:, : int(rng.integers(1, 9)), :] = 65535
+    (tile, ov) = [(48, 32), (64, 24), (80, 40), (56, 16)][seed % 4]
+    xs = shepseg._sample_rows(img, 100, 65535 if seed % 2 else None)
+    init = shepseg.diagonalClusterCentres(xs, 6).astype(np.float64)
+    centres, _l, _n = oracle.kmeans_fit(xs.astype(np.float64), init)
+    res = {}
+    for mode in ('sequential', 'parallel'):
+        eng = OracleEngine(img, oracle)
+        r = distributed.runDistributed(
+            eng, shpcomm.LocalComm(), nr, nc, tile, ov, minSegmentSize=int(rng.integers(8, 30)) if mode == 'x' else 14,
+            maxSpectralDiff='auto', imgNullVal=(65535 if seed % 2 else None), fourConnected=bool(seed % 3),
+            kmeansObj=shepseg.KMeansModel(centres), stitchMode=mode)
+        res[mode] = (eng.out.copy(), r.maxSegId, r.hist.copy(), r.stitchMode)
+    assert res['sequential'][3] == 'sequential'
+    assert res['parallel'][3] in ('parallel', 'parallel->sequential')
+    assert np.array_equal(res['sequential'][0], res['parallel'][0])
+    assert res['sequential'][1] == res['parallel'][1]
+    assert np.array_equal(res['sequential'][2], res['parallel'][2])

@@ -51,12 +51,16 @@ def test_rccl_comm_world_one(tmp_path):
     _run_ranks(1, ['-c', code], tmp_path, timeout=300)
 
 
-@pytest.mark.parametrize('world', [1, 2])
-def test_hip_engine_chain_matches_single_process(world, tmp_path):
+@pytest.mark.parametrize('world,mode', [(1, 'sequential'), (1, 'parallel'), (2, 'parallel'), (2, 'sequential')])
+def test_hip_engine_chain_matches_single_process(world, mode, tmp_path):
+    """both forms of the sharded stitch (sequential chain / provisional ids + renumber) against the
+    in-process tiled run"""
     from pyshepseg_amd import tiling
     _run_ranks(world, [os.path.join(ROOT, 'tests', 'dist_worker_gpu.py'), str(tmp_path),
-                       'socket' if world > 1 else 'rccl'], tmp_path)
+                       'socket' if world > 1 else 'rccl'], tmp_path, extra={'SHEPSEG_STITCH': mode})
     parts = [np.load(tmp_path / ('rank%d.npz' % r)) for r in range(world)]
+    assert {str(q['mode']).split('->')[0] for q in parts} == {mode}
+    print('stitch mode:', {str(q['mode']) for q in parts})
     from pyshepseg_amd import tilingstats
     from oracle import oracle
     ras = tiling.DeviceRaster.synth(11, 6, 1500, 1300)

@@ -105,9 +105,12 @@ def test_c3_fullsize_properties(oracle):
         from pyshepseg_amd import distributed
         eng = distributed.HipEngine(lambda yLo, yHi: tiling.DeviceRaster.synth(11, 6, yHi - yLo, N, y0=yLo),
                                     numWorkers=16)
+        # ... in the PARALLEL form of the stitch (provisional ids per tile, renumbered at the end): on
+        # this imagery no tile hides its last new id outside its trimmed window, so the form is kept
         d = distributed.runDistributed(eng, distributed.Comm(None), N, N, 4096, 1024, minSegmentSize=50,
-                                       numClusters=60, fixedKMeansInit=True)
+                                       numClusters=60, fixedKMeansInit=True, stitchMode='parallel')
         eng.ras.free()
+        assert d.stitchMode == 'parallel'
         assert d.maxSegId == mx and np.array_equal(np.asarray(d.hist).astype(np.int64), hist)
         assert np.array_equal(d.kmeans.cluster_centers_, centres)
 
