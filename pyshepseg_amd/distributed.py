@@ -86,16 +86,20 @@ def shardTileRows(tileInfo, world):
     return out
 
 
-def shardTiles(tileInfo, world):
+def shardTiles(tileInfo, world, wholeRows=False):
     """Contiguous ranges [t0, t1) of tiles (row-major index row * ncols + col) per rank, balanced
     by pixel area.  Every rank that has a successor holds at least ncols tiles, so a tile's top
-    neighbour is either local or in the previous rank; with fewer than ncols tiles per rank the
-    ranges are whole tile rows (shardTileRows), which has the same property."""
+    neighbour is either local or in the previous rank; with fewer than ncols tiles per rank, or
+    with wholeRows, the ranges are whole tile rows (shardTileRows), which has the same property.
+    Whole rows are what the parallel stitch wants: a rank whose range starts in the middle of a
+    tile row needs the right strip of the previous rank's LAST tile before its first chain step,
+    whereas a row's first tile only needs the tile above it, which the previous rank stitches at
+    the start of its last row -- the ranks then work one tile behind each other."""
     (ncols, nrows) = (tileInfo.ncols, tileInfo.nrows)
     nt = ncols * nrows
     if world <= 1:
         return [(0, nt)]
-    if nt // world < ncols:
+    if nt // world < ncols or wholeRows:
         return [(a * ncols, b * ncols) for (a, b) in shardTileRows(tileInfo, world)]
     weights = []
     for r in range(nrows):
@@ -185,7 +189,8 @@ def runDistributed(engine, comm, nRows, nCols, tileSize, overlapSize, minSegment
         RasterXSize, RasterYSize = nCols, nRows
     tileInfo = tiling.getTilesForFile(_Ds(), tileSize, overlapSize)
     ncolsT = tileInfo.ncols
-    shards = shardTiles(tileInfo, comm.world)
+    shardBy = os.environ.get('SHEPSEG_SHARD') or ('rows' if stitchMode == 'parallel' else 'tiles')
+    shards = shardTiles(tileInfo, comm.world, wholeRows=(shardBy == 'rows'))
     (t0, t1) = shards[comm.rank]
     haveTiles = t1 > t0
     myTiles = [(t % ncolsT, t // ncolsT) for t in range(t0, t1)]
