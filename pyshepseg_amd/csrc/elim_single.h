@@ -122,41 +122,48 @@ __global__ __launch_bounds__(256) void k_single_scan_list(
 }
 
 // rest2 (optional): the single pixels of the list that found no target are appended there, their
-// count in nelim[1] -- the candidates of the later passes
+// count in nelim[1] -- the candidates of the later passes.  A workgroup covers SINGLE_SPAN entries
+// and appends with ONE global atomic (atomics on one counter serialise at the L2: ~0.1 us each).
+#define SINGLE_SPAN 4096u
 __global__ __launch_bounds__(256) void k_single_apply_list(uint32_t *__restrict__ seg, uint32_t *segsz,
                                                            const uint32_t *__restrict__ tgt_l,
                                                            const uint32_t *__restrict__ rest,
                                                            uint32_t nrest,
                                                            uint32_t *nelim, uint32_t *__restrict__ rest2)
 {
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    const uint32_t t = i < nrest ? tgt_l[i] : NO_TARGET;
-    const uint32_t p = i < nrest ? rest[i] : 0u;
-    if (t != NO_TARGET) {
-        const uint32_t old = seg[p];
-        seg[p] = t;
-        segsz[old] = 0;
-        atomicAdd(&segsz[t], 1u);
-        *nelim = 1u;
-    }
-    if (rest2) {         // (one global atomic per workgroup: atomics on one counter serialise at the L2)
-        __shared__ uint32_t s_buf[256];
-        __shared__ uint32_t s_cnt, s_base;
-        if (threadIdx.x == 0) s_cnt = 0u;
-        __syncthreads();
-        const bool keep = i < nrest && t == NO_TARGET;
-        const unsigned long long m = __ballot(keep);
-        if (m != 0ull) {
-            uint32_t base = 0;
-            if (lane_id() == 0) base = atomicAdd(&s_cnt, (uint32_t)__popcll(m));
-            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-            if (keep) s_buf[base + (uint32_t)__popcll(m & lanemask_lt())] = p;
+    __shared__ uint32_t s_buf[SINGLE_SPAN];
+    __shared__ uint32_t s_cnt, s_base;
+    if (threadIdx.x == 0) s_cnt = 0u;
+    __syncthreads();
+    bool any = false;
+    for (uint32_t it = 0; it < SINGLE_SPAN / 256u; it++) {
+        const uint32_t i = blockIdx.x * SINGLE_SPAN + it * 256u + threadIdx.x;
+        const uint32_t t = i < nrest ? tgt_l[i] : NO_TARGET;
+        const uint32_t p = i < nrest ? rest[i] : 0u;
+        if (t != NO_TARGET) {
+            const uint32_t old = seg[p];
+            seg[p] = t;
+            segsz[old] = 0;
+            atomicAdd(&segsz[t], 1u);
+            any = true;
         }
-        __syncthreads();
-        if (threadIdx.x == 0) s_base = s_cnt ? atomicAdd(&nelim[1], s_cnt) : 0u;
-        __syncthreads();
-        if (threadIdx.x < s_cnt) rest2[s_base + threadIdx.x] = s_buf[threadIdx.x];
+        if (rest2) {
+            const bool keep = i < nrest && t == NO_TARGET;
+            const unsigned long long m = __ballot(keep);
+            if (m != 0ull) {
+                uint32_t base = 0;
+                if (lane_id() == 0) base = atomicAdd(&s_cnt, (uint32_t)__popcll(m));
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                if (keep) s_buf[base + (uint32_t)__popcll(m & lanemask_lt())] = p;
+            }
+        }
     }
+    if (__ballot(any) != 0ull && lane_id() == 0) *nelim = 1u;
+    if (!rest2) return;
+    __syncthreads();
+    if (threadIdx.x == 0) s_base = s_cnt ? atomicAdd(&nelim[1], s_cnt) : 0u;
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < s_cnt; i += 256u) rest2[s_base + i] = s_buf[i];
 }
 
 // Every later pass of the single-pixel stage in ONE workgroup: the candidates left after the first
@@ -317,8 +324,8 @@ static int run_eliminate_single(shp_ctx *ctx, const void *d_img, int dtype, int 
             DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_single_scan_list<DT>, dim3(gl), dim3(256), 0, st, d_img, nb,
                                                      d_seg, segsz, tgt, n, nrows, ncols, four, list, nsingles, nelim, geom));
             KCHK(ctx);
-            hipLaunchKernelGGL(k_single_apply_list, dim3(gl), dim3(256), 0, st, d_seg, segsz, tgt, list, nsingles,
-                               nelim, rest); KCHK(ctx);
+            hipLaunchKernelGGL(k_single_apply_list, dim3(grid_for(nsingles, SINGLE_SPAN)), dim3(256), 0, st, d_seg,
+                               segsz, tgt, list, nsingles, nelim, rest); KCHK(ctx);
             DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_single_tail<DT>, dim3(1), dim3(1024), 0, st, d_img, nb, d_seg,
                                                      segsz, tgt, n, nrows, ncols, four, rest, nrest, geom));
             KCHK(ctx);
@@ -340,8 +347,8 @@ static int run_eliminate_single(shp_ctx *ctx, const void *d_img, int dtype, int 
         DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_single_scan_list<DT>, dim3(gl), dim3(256), 0, st, d_img, nb,
                                                  d_seg, segsz, tgt, n, nrows, ncols, four, rest, nr, nelim, geom));
         KCHK(ctx);
-        hipLaunchKernelGGL(k_single_apply_list, dim3(gl), dim3(256), 0, st, d_seg, segsz, tgt, rest, nr,
-                           nelim, (uint32_t *)nullptr); KCHK(ctx);
+        hipLaunchKernelGGL(k_single_apply_list, dim3(grid_for(nr, SINGLE_SPAN)), dim3(256), 0, st, d_seg, segsz,
+                           tgt, rest, nr, nelim, (uint32_t *)nullptr); KCHK(ctx);
         HIPCHK(ctx, hipMemcpyAsync(ctx->h_pinned, nelim, 4, hipMemcpyDeviceToHost, st));
         HIPCHK(ctx, hipStreamSynchronize(st));
         merged = ctx->h_pinned[0];
