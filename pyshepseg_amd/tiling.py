@@ -376,8 +376,18 @@ def _readSubsampledImage(src, bandNumbers, subsampleProp):
             return out              # (consumed by fitSpectralClusters before the next call)
         return numpy.ascontiguousarray(out[bands])
     if isinstance(src, _ArraySource):
-        # the kept rows only (a memmap then touches 1/skip of the file, not all of it)
-        return numpy.ascontiguousarray(numpy.stack([src.arr[b][ry][:, rx] for b in bands]))
+        # the kept rows only (a memmap then touches 1/skip of the file, not all of it), a band per
+        # thread: the row gather of a 40000-column raster is 80 MB per band
+        out = numpy.empty((len(bands), len(ry), len(rx)), dtype=src.arr.dtype)
+
+        def one(i):
+            out[i] = src.arr[bands[i]][ry][:, rx]
+        ts = [threading.Thread(target=one, args=(i,)) for i in range(len(bands))]
+        for t in ts:
+            t.start()
+        for t in ts:
+            t.join()
+        return out
     rows = []
     for ypos in range(0, nlines, TILESIZE):
         ysize = min(TILESIZE, nlines - ypos)
@@ -589,8 +599,10 @@ class _RasterStreamer(object):
 
 class _NpyRowWriter(object):
     """A (nRows, nCols) uint32 .npy file written rows at a time with pwrite: storing into a fresh
-    memory map costs a page fault per 4 KiB (1 GB/s and worse from several threads), a write into
-    the page cache is one kernel copy."""
+    memory map costs a page fault per 4 KiB (1 GB/s and worse from several threads; populating the
+    map ahead of the data with madvise(MADV_POPULATE_WRITE) from background threads was slower
+    still: 3.2 s for 6.4 GB), a write into the page cache is one kernel copy.  Buffered writes to one
+    file serialise on its inode lock, so the sink tops out near 5 GB/s whatever the thread count."""
     def __init__(self, path, nrows, ncols):
         (self.nrows, self.ncols) = (nrows, ncols)
         with open(path, 'wb') as f:
