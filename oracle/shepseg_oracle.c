@@ -261,7 +261,13 @@ static void relabel_segments(uint32_t *seg, size_t npix, const uint32_t *seg_siz
     free(sub);
 }
 
-/* findNearestNeighbourPixel: shepseg.py:677-736 (N2: exact int64; N3: scan order; N4) */
+/* findNearestNeighbourPixel: shepseg.py:677-736 (N2; N3: scan order; N4).
+ * N2 precisely: numba evaluates dSqr as the int64 sum of the squared EXACT differences, wrapping
+ * modulo 2^64 (only 32-bit imagery can get there: |difference| >= 2^31.5 in a band, or the sum
+ * over the bands), and the reference compares it as written -- `minDsqr < 0 or dSqr < minDsqr` --
+ * so a sum that wrapped negative is taken and then counts as "unset" for the next candidate.
+ * Checked against the reference on 8000 limit-value cases: oracle/refgen/probe_dist_32bit.py,
+ * results/dist_probe_32bit.txt.  Unsigned arithmetic here: signed overflow is undefined in C. */
 static int find_nearest_nbr(const void *img, int dtype, int nbands, int nrows, int ncols,
                             const uint32_t *seg, int i, int j, const uint32_t *seg_size,
                             int four, int *oi, int *oj)
@@ -277,12 +283,13 @@ static int find_nearest_nbr(const void *img, int dtype, int nbands, int nrows, i
             if (!connected) continue;
             uint32_t nb = seg[(size_t)a * ncols + b];
             if (seg_size[nb] > 1) {
-                int64_t d = 0;
+                uint64_t du = 0;
                 for (int k = 0; k < nbands; k++) {
-                    int64_t t = px_get(img, dtype, (size_t)k * npix + (size_t)i * ncols + j) -
-                                px_get(img, dtype, (size_t)k * npix + (size_t)a * ncols + b);
-                    d += t * t;
+                    uint64_t t = (uint64_t)(px_get(img, dtype, (size_t)k * npix + (size_t)i * ncols + j) -
+                                            px_get(img, dtype, (size_t)k * npix + (size_t)a * ncols + b));
+                    du += t * t;
                 }
+                int64_t d = (int64_t)du;
                 if (min_d < 0 || d < min_d) { min_d = d; ii = a; jj = b; }
             }
         }

@@ -42,22 +42,27 @@ __device__ __forceinline__ uint32_t single_target(const void *__restrict__ img, 
     }
 #pragma unroll
     for (int k = 0; k < 9; k++) ok[k] = ok[k] && (COH ? L2LOAD(&segsz[sn[k]]) : segsz[sn[k]]) > 1u;
-    long long d[9];
+    // the reference's dSqr is an int64 that wraps (32-bit imagery can get there) and is compared
+    // as written, `minDsqr < 0 or dSqr < minDsqr`: a negative sum counts as "unset" for the next
+    // candidate.  Unsigned arithmetic, converted at the end: signed overflow is undefined.
+    unsigned long long d[9];
 #pragma unroll
     for (int k = 0; k < 9; k++) d[k] = 0;
     for (int b = 0; b < nb; b++) {
         const long long vp = ld_t<DT>(img, (size_t)b * g.bstride + qo[4]);
 #pragma unroll
         for (int k = 0; k < 9; k++) {
-            const long long t = vp - ld_t<DT>(img, (size_t)b * g.bstride + qo[k]);
+            const unsigned long long t = (unsigned long long)(vp - ld_t<DT>(img, (size_t)b * g.bstride + qo[k]));
             d[k] += t * t;
         }
     }
     uint32_t out = NO_TARGET;
     long long mind = -1;
 #pragma unroll
-    for (int k = 0; k < 9; k++)
-        if (ok[k] && (mind < 0 || d[k] < mind)) { mind = d[k]; out = sn[k]; }
+    for (int k = 0; k < 9; k++) {
+        const long long dk = (long long)d[k];
+        if (ok[k] && (mind < 0 || dk < mind)) { mind = dk; out = sn[k]; }
+    }
     return out;
 }
 
