@@ -4,9 +4,15 @@ parameters, runs the HIP path and the C oracle, and compares bit for bit:
   tile   shepseg.doShepherdSegmentation           vs oracle.segment_tile
   tiled  tiling.doTiledShepherdSegmentation        vs oracle tiles + oracle.stitch_tiles
   stats  tilingstats.calcPerSegmentStats           vs oracle.segstats
+  fit    shepseg._fit (device Lloyd)              vs oracle.kmeans_fit: n_iter_, partition, centres to 1e-8
+  subset subset.subsetImage                        vs oracle.subset_recode
+  spatial tilingstats.calcPerSegmentSpatialStats  vs oracle.spatialstats (edge counts, variogram, mean coordinates)
+  spectra shepseg.buildSegmentSpectra / makeSegmentLocations vs oracle
+  paged  tilingstats.calcPerSegmentStatsTiled in small chunks (RAT pages) vs the whole-raster statistics
   big    the same as tile on 1000-2600-pixel rasters with few value levels (components of 10^5-10^6
          pixels: the depth-first cut, its stack spills and the global-memory walk)
-usage: python tools/fuzz_gpu.py [ncases] [seed] [big]     (prints one line per failure and a summary)"""
+usage: python tools/fuzz_gpu.py [ncases] [seed] [big|more]     (prints one line per failure and a summary;
+       `more` runs the fit / subset / spatial / spectra / paged kinds instead of tile / tiled / stats)"""
 import os
 import sys
 import time
@@ -15,7 +21,7 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import oracle                                   # noqa: E402
-from pyshepseg_amd import shepseg, tiling, tilingstats      # noqa: E402
+from pyshepseg_amd import shepseg, tiling, tilingstats, subset      # noqa: E402
 
 DTYPES = [np.uint8, np.int16, np.uint16, np.int32, np.uint32]
 
@@ -108,17 +114,129 @@ def one_case(rng, kind):
     return ok, desc
 
 
+def label_raster(rng, nr, nc):
+    """scrambled block ids with holes (first-seen order differs from id order)"""
+    bh, bw = int(rng.integers(3, 40)), int(rng.integers(3, 40))
+    gr, gc = nr // bh + 1, nc // bw + 1
+    base = rng.permutation(np.arange(1, gr * gc + 1)).reshape(gr, gc).astype(np.uint32)
+    seg = np.kron(base, np.ones((bh, bw), dtype=np.uint32))[:nr, :nc].copy()
+    seg[rng.random(seg.shape) < 0.02] = 0
+    if rng.random() < 0.5:                       # leave some ids unused
+        seg[seg % np.uint32(7) == 3] = 0
+    return np.ascontiguousarray(seg)
+
+
+def more_case(rng, kind, tmpdir):
+    dtype = DTYPES[int(rng.integers(0, len(DTYPES)))]
+    if kind == 'fit':
+        nb = int(rng.integers(1, 11))
+        n = int(rng.integers(50, 40000))
+        k = int(rng.integers(2, 61))
+        img = make_image(rng, dtype, nb, 1, n).reshape(nb, n).T.astype(np.float64)
+        # real-valued jitter: on integer lattices with few levels exact distance ties decide the
+        # trajectory (DESIGN.md section 4: there the device, the oracle and sklearn's own thread counts
+        # legitimately part ways); without ties the three must agree
+        img = img + rng.random(img.shape) * float(rng.choice([0.5, 3.0, 40.0]))
+        if len(np.unique(img, axis=0)) < k:
+            return None
+        init = shepseg.diagonalClusterCentres(img, k).astype(np.float64)
+        want_c, want_l, want_n = oracle.kmeans_fit(img, init)
+        km = shepseg._fit(np.ascontiguousarray(img), init)
+        pairs = set(zip(km.labels_.tolist(), want_l.tolist()))
+        same_part = len(pairs) == len(set(km.labels_.tolist())) == len(set(want_l.tolist()))
+        a = km.cluster_centers_[np.lexsort(km.cluster_centers_.T[::-1])]
+        b = want_c[np.lexsort(want_c.T[::-1])]
+        cdiff = float(np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b))))
+        ok = km.n_iter_ == want_n and same_part and cdiff < 1e-9
+        moved = int((np.array([dict(pairs).get(x, -1) for x in km.labels_.tolist()]) != want_l).sum()) if not same_part else 0
+        return ok, 'fit %s n=%d nb=%d k=%d n_iter=%d/%d same_partition=%s rows_differing~%d max_rel_centre_diff=%.2e' % (
+            np.dtype(dtype).name, n, nb, k, km.n_iter_, want_n, same_part, moved, cdiff)
+    (nr, nc) = (int(rng.integers(30, 700)), int(rng.integers(30, 700)))
+    seg = label_raster(rng, nr, nc)
+    S = int(seg.max())
+    if kind == 'subset':
+        xs, ys = int(rng.integers(1, nc + 1)), int(rng.integers(1, nr + 1))
+        tlx, tly = int(rng.integers(0, nc - xs + 1)), int(rng.integers(0, nr - ys + 1))
+        m = (rng.random((ys, xs)) > 0.3).astype(np.uint8) if rng.random() < 0.5 else None
+        want, worig, whist = oracle.subset_recode(seg, tlx, tly, xs, ys, m, 1024)
+        np.save(os.path.join(tmpdir, 'seg.npy'), seg)
+        r = subset.subsetImage(os.path.join(tmpdir, 'seg.npy'), os.path.join(tmpdir, 'out.npy'), tlx, tly, xs, ys,
+                               maskImage=m)
+        ok = (np.array_equal(r.segimg, want) and np.array_equal(r.origSegIds, worig) and
+              np.array_equal(r.hist, whist))
+        return ok, 'subset %dx%d window (%d,%d,%d,%d) mask=%s' % (nr, nc, tlx, tly, xs, ys, m is not None)
+    band = make_image(rng, dtype, 1, nr, nc)[0]
+    nullv = int(band.flat[int(rng.integers(0, band.size))])
+    if kind == 'spatial':
+        ts = tilingstats
+        R, I = ts.GFT_Real, ts.GFT_Integer
+        which = int(rng.integers(0, 3))
+        if which == 0:
+            tr = np.array([float(rng.integers(0, 10 ** 6)), float(rng.integers(1, 30)), 0.0,
+                           float(rng.integers(0, 10 ** 7)), 0.0, -float(rng.integers(1, 30))])
+            _ic, fc = ts.calcPerSegmentSpatialStats(seg, band, [R, R], ts.userFuncMeanCoord, tr, nullv)
+            _wi, wf = oracle.spatialstats(seg, band, 'meancoord', tr, nullv, 0, 2, max_seg_id=S)
+            ok = bool(np.allclose(fc, wf, rtol=1e-6, atol=0))
+        elif which == 1:
+            four = bool(rng.integers(0, 2))
+            ic, _fc = ts.calcPerSegmentSpatialStats(seg, band, [I, I], ts.userFuncNumEdgePixels, four, nullv)
+            wi, _wf = oracle.spatialstats(seg, band, 'numedge', int(four), nullv, 2, 0, max_seg_id=S)
+            ok = np.array_equal(ic, wi)
+        else:
+            md = int(rng.integers(1, 9))
+            _ic, fc = ts.calcPerSegmentSpatialStats(seg, band, [R] * md, ts.userFuncVariogram, md, nullv)
+            _wi, wf = oracle.spatialstats(seg, band, 'variogram', md, nullv, 0, md, max_seg_id=S)
+            ok = np.array_equal(fc.view(np.uint32), wf.view(np.uint32))
+        return ok, 'spatial func %d %s %dx%d null=%d' % (which, np.dtype(dtype).name, nr, nc, nullv)
+    if kind == 'spectra':
+        nb = int(rng.integers(1, 11))
+        img = make_image(rng, dtype, nb, nr, nc)
+        got = shepseg.buildSegmentSpectra(seg, img, S)
+        want = oracle.build_segment_spectra(seg, img, S)
+        ok = np.array_equal(np.asarray(got).view(np.uint32), np.asarray(want).view(np.uint32))
+        segSize = np.bincount(seg.ravel(), minlength=S + 1).astype(np.uint32)
+        loc = shepseg.makeSegmentLocations(seg, segSize)
+        (woff, wrc) = oracle.segment_locations(seg, S)
+        for sid in rng.integers(1, S + 1, size=min(S, 20)):
+            a = np.asarray(loc[np.uint32(sid)].rowcols) if np.uint32(sid) in loc else np.zeros((0, 2), np.uint32)
+            b = wrc[woff[sid]:woff[sid + 1]]
+            ok = ok and np.array_equal(a.astype(np.int64), np.asarray(b).astype(np.int64))
+        return ok, 'spectra %s nb=%d %dx%d S=%d' % (np.dtype(dtype).name, nb, nr, nc, S)
+    # paged: the streaming form in small row chunks against the whole-raster statistics
+    sel = [('a', 'min'), ('b', 'max'), ('c', 'mean'), ('d', 'stddev'), ('e', 'median'), ('f', 'mode'),
+           ('g', 'percentile', int(rng.integers(0, 101))), ('h', 'pixcount')]
+    use_null = rng.random() < 0.5
+    wic, wfc, fast = tilingstats.calcPerSegmentStats(seg, band, sel, imgNullVal=nullv if use_null else None, maxSegId=S)
+    r = tilingstats.calcPerSegmentStatsTiled(band, 1, seg, sel, imgNullVal=nullv if use_null else None,
+                                             chunkPixels=int(rng.integers(nc, nr * nc + 1)))
+    ok = True
+    present = np.bincount(seg.ravel(), minlength=S + 1) > 0
+    for (i, row) in enumerate(fast):
+        name = sel[i][0]
+        col = np.asarray(r.columns[name])
+        ref = (wic if int(row[2]) == 0 else wfc)[int(row[3])]
+        ok = ok and np.array_equal(np.asarray(col)[present][1:] if False else np.asarray(col)[1:][present[1:]],
+                                   np.asarray(ref)[1:][present[1:]].astype(col.dtype))
+    return ok, 'paged %s %dx%d S=%d null=%s' % (np.dtype(dtype).name, nr, nc, S, use_null)
+
+
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     big = len(sys.argv) > 3 and sys.argv[3] == 'big'
+    more = len(sys.argv) > 3 and sys.argv[3] == 'more'
+    import tempfile
+    tmpdir = tempfile.mkdtemp()
     rng = np.random.default_rng(seed)
-    counts = {'tile': [0, 0], 'tiled': [0, 0], 'stats': [0, 0], 'big': [0, 0]}
+    counts = {'tile': [0, 0], 'tiled': [0, 0], 'stats': [0, 0], 'big': [0, 0], 'fit': [0, 0], 'subset': [0, 0],
+              'spatial': [0, 0], 'spectra': [0, 0], 'paged': [0, 0]}
     t0 = time.time()
     for i in range(n):
         kind = 'big' if big else ('tile', 'tile', 'tiled', 'stats')[i % 4]
+        if more:
+            kind = ('fit', 'subset', 'spatial', 'spectra', 'paged')[i % 5]
         try:
-            res = one_case(rng, kind)
+            res = more_case(rng, kind, tmpdir) if more else one_case(rng, kind)
         except Exception as e:                      # a raised error is a failure of the case too
             res = (False, '%s raised %r' % (kind, e))
         if res is None:
