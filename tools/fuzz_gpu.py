@@ -8,6 +8,8 @@ parameters, runs the HIP path and the C oracle, and compares bit for bit:
   subset subset.subsetImage                        vs oracle.subset_recode
   spatial tilingstats.calcPerSegmentSpatialStats  vs oracle.spatialstats (edge counts, variogram, mean coordinates)
   spectra shepseg.buildSegmentSpectra / makeSegmentLocations vs oracle
+  sharded distributed.runDistributed (HIP engine, one rank) in the sequential AND the parallel form of
+         the stitch vs oracle tiles + oracle.stitch_tiles
   paged  tilingstats.calcPerSegmentStatsTiled in small chunks (RAT pages) vs the whole-raster statistics
   big    the same as tile on 1000-2600-pixel rasters with few value levels (components of 10^5-10^6
          pixels: the depth-first cut, its stack spills and the global-memory walk)
@@ -151,6 +153,42 @@ def more_case(rng, kind, tmpdir):
         moved = int((np.array([dict(pairs).get(x, -1) for x in km.labels_.tolist()]) != want_l).sum()) if not same_part else 0
         return ok, 'fit %s n=%d nb=%d k=%d n_iter=%d/%d same_partition=%s rows_differing~%d max_rel_centre_diff=%.2e' % (
             np.dtype(dtype).name, n, nb, k, km.n_iter_, want_n, same_part, moved, cdiff)
+    if kind == 'sharded':
+        from pyshepseg_amd import distributed
+        from pyshepseg_amd import comm as shpcomm
+        nb = int(rng.integers(1, 7))
+        (nr, nc) = (int(rng.integers(150, 520)), int(rng.integers(150, 520)))
+        img = make_image(rng, dtype, nb, nr, nc)
+        k = int(rng.integers(2, 12))
+        four = bool(rng.integers(0, 2))
+        minseg = int(rng.integers(2, 60))
+        xs = shepseg._sample_rows(img, 100, None)
+        init = shepseg.diagonalClusterCentres(xs, k).astype(np.float64)
+        centres, _l, _n = oracle.kmeans_fit(xs.astype(np.float64), init, max_iter=10)
+        km = shepseg.KMeansModel(centres)
+        (tile, ov) = [(96, 32), (64, 32), (80, 24), (160, 64), (48, 32)][int(rng.integers(0, 5))]
+        tiles, ntc, ntr = oracle.get_tiles(nr, nc, tile, ov)
+        res = {}
+        for mode in ('sequential', 'parallel'):
+            eng = distributed.HipEngine(lambda yLo, yHi: tiling.DeviceRaster.fromArray(np.ascontiguousarray(img[:, yLo:yHi])),
+                                        numWorkers=int(rng.integers(1, 7)), keepOutput=True)
+            r = distributed.runDistributed(eng, shpcomm.LocalComm(), nr, nc, tile, ov, minSegmentSize=minseg,
+                                           fourConnected=four, kmeansObj=km, stitchMode=mode)
+            out = eng.localOutput()
+            eng.releaseOutput()
+            eng.ras.free()
+            res[mode] = (out, int(r.maxSegId), np.asarray(r.hist).copy(), r.stitchMode, float(r.maxSpectralDiff))
+        local = {}
+        for (c, rr), (x, y, xsz, ysz) in tiles.items():
+            sub = np.ascontiguousarray(img[:, y:y + ysz, x:x + xsz])
+            local[(c, rr)] = oracle.segment_tile(sub, centres, minseg, res['sequential'][4], None, four)['segimg']
+        want, mx, hist = oracle.stitch_tiles(local, tiles, ntc, ntr, nr, nc, ov)
+        ok = True
+        for mode in ('sequential', 'parallel'):
+            (out, m, h, _sm, _msd) = res[mode]
+            ok = ok and np.array_equal(out, want) and m == int(mx) and np.array_equal(h, hist)
+        return ok, 'sharded %s nb=%d %dx%d tile=%d/%d k=%d minseg=%d -> %s' % (
+            np.dtype(dtype).name, nb, nr, nc, tile, ov, k, minseg, res['parallel'][3])
     (nr, nc) = (int(rng.integers(30, 700)), int(rng.integers(30, 700)))
     seg = label_raster(rng, nr, nc)
     S = int(seg.max())
@@ -229,12 +267,14 @@ def main():
     tmpdir = tempfile.mkdtemp()
     rng = np.random.default_rng(seed)
     counts = {'tile': [0, 0], 'tiled': [0, 0], 'stats': [0, 0], 'big': [0, 0], 'fit': [0, 0], 'subset': [0, 0],
-              'spatial': [0, 0], 'spectra': [0, 0], 'paged': [0, 0]}
+              'spatial': [0, 0], 'spectra': [0, 0], 'paged': [0, 0], 'sharded': [0, 0]}
     t0 = time.time()
     for i in range(n):
         kind = 'big' if big else ('tile', 'tile', 'tiled', 'stats')[i % 4]
         if more:
-            kind = ('fit', 'subset', 'spatial', 'spectra', 'paged')[i % 5]
+            kind = ('fit', 'subset', 'spatial', 'spectra', 'paged', 'sharded')[i % 6]
+        if len(sys.argv) > 4:
+            kind = sys.argv[4]
         try:
             res = more_case(rng, kind, tmpdir) if more else one_case(rng, kind)
         except Exception as e:                      # a raised error is a failure of the case too
