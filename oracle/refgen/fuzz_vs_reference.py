@@ -1,6 +1,9 @@
 """Pin the C oracle against the unmodified reference on many random inputs.
 
-    /opt/conda/bin/python3.9 oracle/refgen/fuzz_vs_reference.py [ncases]
+    /opt/conda/bin/python3.9 oracle/refgen/fuzz_vs_reference.py [ncases] [wide]
+
+`wide`: 32-bit imagery (uint32 and int32) over the types' whole range and at their limits, where
+the reference's integer arithmetic wraps (findNearestNeighbourPixel) and float32 sums are inexact.
 
 Stage by stage (assign, clump, single-pixel elimination, small-segment
 elimination, k-means fit partition) the oracle must equal the reference bit
@@ -19,6 +22,36 @@ from oracle import oracle
 class FakeKM(object):
     def __init__(self, centres):
         self.cluster_centers_ = centres
+
+
+def make_img_wide(rng, case):
+    dt = np.uint32 if case % 2 == 0 else np.int32
+    info = np.iinfo(dt)
+    nb = int(rng.choice([1, 2, 3, 6, 8]))
+    nr = int(rng.randint(5, 110))
+    nc = int(rng.randint(5, 110))
+    kind = (case // 2) % 4
+    levels = np.array([info.min, info.min + 1, int(info.min) // 2 + int(info.max) // 2, info.max - 1, info.max],
+                      dtype=np.int64)
+    if kind == 0:      # blocks of limit values with single-pixel noise of limit values
+        base = levels[rng.randint(0, 5, size=(nb, nr // 5 + 1, nc // 5 + 1))]
+        img = np.kron(base, np.ones((1, 5, 5), dtype=np.int64))[:, :nr, :nc]
+        m = rng.rand(nr, nc) < 0.15
+        img = np.where(m[None], levels[rng.randint(0, 5, size=(nb, nr, nc))], img)
+    elif kind == 1:    # the whole range, uniformly
+        img = rng.randint(info.min, int(info.max) + 1, size=(nb, nr, nc), dtype=np.int64)
+    elif kind == 2:    # smooth, scaled to the range
+        img = oracle.synthimg(int(rng.randint(1, 1000)), nb, nr, nc).astype(np.int64)
+        img = img * ((int(info.max) - int(info.min)) // 65536) + int(info.min)
+    else:              # few levels far apart + small noise
+        img = levels[rng.randint(0, 5, size=(nb, nr, nc))] // 3 * 2 + rng.randint(0, 4, size=(nb, nr, nc))
+    img = np.clip(img, info.min, info.max).astype(dt)
+    null_val = None
+    if rng.rand() < 0.5:
+        null_val = int(info.max) if rng.rand() < 0.7 else int(info.min)
+        m = rng.rand(nr, nc) < rng.choice([0.01, 0.1])
+        img[rng.randint(0, nb)][m] = null_val
+    return np.ascontiguousarray(img), null_val
 
 
 def make_img(rng, case):
@@ -64,11 +97,12 @@ def make_img(rng, case):
 
 def main():
     ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-    rng = np.random.RandomState(12345)
+    wide = len(sys.argv) > 2 and sys.argv[2] == 'wide'
+    rng = np.random.RandomState(54321 if wide else 12345)
     nfail = 0
     t0 = time.time()
     for case in range(ncases):
-        img, null_val = make_img(rng, case)
+        img, null_val = make_img_wide(rng, case) if wide else make_img(rng, case)
         nb, nr, nc = img.shape
         k = int(rng.choice([2, 5, 10, 60]))
         min_seg = int(rng.choice([2, 5, 20, 50]))
