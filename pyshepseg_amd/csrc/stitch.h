@@ -553,6 +553,125 @@ __global__ __launch_bounds__(256) void k_recode_window(const uint32_t *__restric
     out[(size_t)r * opitch + c] = lut[tile[(r0 + r) * xs + c0 + c]];
 }
 
+// ---- the chain step's kernels: both strips per launch (blockIdx.y = 0 top strip, 1 left strip) ----
+struct StripArgs {
+    const uint32_t *B;              // the neighbour's recoded strip (nullptr: this tile has none)
+    size_t pitch;
+    uint32_t srows, scols, bit;
+    unsigned long long *keys;       // hsize slots
+    uint32_t *cnts;
+    unsigned long long *best;       // nseg entries
+};
+
+__global__ __launch_bounds__(256) void k_pair_count2(const uint32_t *__restrict__ tile, uint32_t xs,
+                                                     const uint32_t *__restrict__ flags,
+                                                     const StripArgs a0, const StripArgs a1, uint32_t hmask)
+{
+    const StripArgs &a = blockIdx.y ? a1 : a0;
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (!a.B || blockIdx.x * 256u >= a.srows * a.scols) return;         // (uniform per workgroup)
+    const bool inb = i < a.srows * a.scols;
+    unsigned long long key = 0;
+    if (inb) {
+        const uint32_t r = i / a.scols, c = i - r * a.scols;
+        const uint32_t s = tile[r * xs + c];
+        if (s != 0 && (flags[s] & a.bit))
+            key = ((unsigned long long)s << 32) | (unsigned long long)a.B[(size_t)r * a.pitch + c];
+    }
+    const unsigned lane = lane_id();
+    const unsigned long long pk = __shfl_up(key, 1, 64);
+    const bool head = lane == 0 || pk != key;
+    const unsigned long long heads = __ballot(head);
+    if (head && key != 0) {
+        const unsigned long long nxt = (lane == 63) ? 0ull : (heads & ~((2ull << lane) - 1ull));
+        const uint32_t len = (nxt ? (unsigned)__builtin_ctzll(nxt) : 64u) - lane;
+        uint32_t h = hash64(key) & hmask;
+        for (;;) {
+            const unsigned long long old = atomicCAS(&a.keys[h], 0ull, key);
+            if (old == 0ull || old == key) { atomicAdd(&a.cnts[h], len); break; }
+            h = (h + 1u) & hmask;
+        }
+    }
+}
+
+// best[seg] = max over the table of (count << 32 | ~value): most frequent, smallest on ties
+__global__ __launch_bounds__(256) void k_pair_best2(const StripArgs a0, const StripArgs a1, uint32_t hsize)
+{
+    const StripArgs &a = blockIdx.y ? a1 : a0;
+    const uint32_t h = blockIdx.x * 256u + threadIdx.x;
+    if (!a.B || h >= hsize) return;
+    const unsigned long long k = a.keys[h];
+    if (k == 0ull) return;
+    const uint32_t s = (uint32_t)(k >> 32), v = (uint32_t)k;
+    atomicMax(&a.best[s], ((unsigned long long)a.cnts[h] << 32) | (unsigned long long)(~v));
+}
+
+// a segment keeps its own (new) id when neither strip recodes it and its bounding-box corner lies in
+// the trimmed window
+struct OwnFn2 {
+    const unsigned long long *best_top, *best_left;
+    const uint32_t *segtop, *segleft;
+    uint32_t top, bottom, left, right;
+    __device__ __forceinline__ uint32_t operator()(uint32_t s) const
+    {
+        if (s == 0 || best_top[s] != 0ull || best_left[s] != 0ull) return 0u;
+        const uint32_t t = segtop[s], l = segleft[s];
+        return (l >= left && t >= top && l < right && t < bottom) ? 1u : 0u;
+    }
+};
+
+// the LUT: the left strip's mode overrides the top strip's (recodeSharedSegments runs top first, then
+// left, tiling.py:1129-1203), owned segments get max_seg_id + rank + 1, the rest 0
+__global__ __launch_bounds__(256) void k_build_lut2(OwnFn2 own, const uint32_t *__restrict__ rank,
+                                                    const uint32_t *__restrict__ rank_boff,
+                                                    const uint32_t *__restrict__ max_seg_id,
+                                                    uint32_t nseg, uint32_t *__restrict__ lut)
+{
+    const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+    if (s >= nseg) return;
+    uint32_t v = 0;
+    if (s != 0) {
+        const unsigned long long bl = own.best_left[s], bt = own.best_top[s];
+        if (bl != 0ull) v = ~(uint32_t)bl;
+        else if (bt != 0ull) v = ~(uint32_t)bt;
+        else if (own(s)) v = *max_seg_id + rank[s] + (rank_boff ? rank_boff[s / SCAN_ITEMS] : 0u) + 1u;
+    }
+    lut[s] = v;
+}
+
+// maxSegId = max(maxSegId, largest recoded id among the segments present in the trimmed window)
+__global__ __launch_bounds__(256) void k_tmax_into(const uint32_t *__restrict__ lut,
+                                                   const uint32_t *__restrict__ flags, uint32_t nseg,
+                                                   uint32_t *max_seg_id)
+{
+    const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+    uint32_t m = (s < nseg && s != 0 && (flags[s] & META_IN_TRIM)) ? lut[s] : 0u;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t o = __shfl_xor(m, d, 64);
+        m = o > m ? o : m;
+    }
+    if (lane_id() == 0 && m != 0) atomicMax(max_seg_id, m);
+}
+
+// the recoded right strip (ys x an_cols) and bottom strip (an_rows x xs) in one launch
+__global__ __launch_bounds__(256) void k_recode_strips(const uint32_t *__restrict__ tile, uint32_t ys, uint32_t xs,
+                                                       uint32_t an_rows, uint32_t an_cols,
+                                                       const uint32_t *__restrict__ lut,
+                                                       uint32_t *__restrict__ right_out,
+                                                       uint32_t *__restrict__ bottom_out)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (blockIdx.y == 0) {
+        if (!right_out || i >= ys * an_cols) return;
+        const uint32_t r = i / an_cols, c = i - r * an_cols;
+        right_out[i] = lut[tile[r * xs + xs - an_cols + c]];
+    } else {
+        if (!bottom_out || i >= an_rows * xs) return;
+        bottom_out[i] = lut[tile[(ys - an_rows) * xs + i]];
+    }
+}
+
 static int run_stitch_chain(shp_ctx *ctx, const uint32_t *d_tile, uint32_t ys, uint32_t xs,
                             uint32_t overlap, const uint32_t *d_top_b, size_t top_pitch,
                             const uint32_t *d_left_b, size_t left_pitch, uint32_t max_local, int simple,
@@ -568,61 +687,53 @@ static int run_stitch_chain(shp_ctx *ctx, const uint32_t *d_tile, uint32_t ys, u
     uint32_t *flags = d_meta, *segtop = d_meta + nseg, *segleft = d_meta + 2 * (size_t)nseg;
     uint32_t *lut = d_meta + 3 * (size_t)nseg;
     const uint32_t an_rows = overlap < ys ? overlap : ys, an_cols = overlap < xs ? overlap : xs;
-    CHK(buf_ensure(ctx, ctx->small, 4096));
-    uint32_t *tmax = bp<uint32_t>(ctx->small) + 32;
-    HIPCHK(ctx, hipMemsetAsync(tmax, 0, 4, st));
     if (simple) {
         hipLaunchKernelGGL(k_lut_simple, dim3(grid_for(nseg, 256)), dim3(256), 0, st, lut, nseg, d_max_seg_id); KCHK(ctx);
     } else {
-        // the pair table holds one entry per distinct (crossing segment, neighbour id): at most the
+        // Nine commands per tile (twenty-one before: under load every command of this one sequential
+        // stream queues behind the other streams' kernels, and the chain fell 120 tiles behind):
+        // one clear of every table, both strips per launch, the modes folded into the LUT build.
+        // The pair table holds one entry per distinct (crossing segment, neighbour id): at most the
         // strip's pixels of crossing segments, which the prepare step counted (else the whole strip)
         uint32_t maxstrip = 0;
         if (d_top_b) maxstrip = top_cross_px < an_rows * xs ? top_cross_px : an_rows * xs;
         if (d_left_b) {
-            const uint32_t b = left_cross_px < ys * an_cols ? left_cross_px : ys * an_cols;
-            if (b > maxstrip) maxstrip = b;
+            const uint32_t bb = left_cross_px < ys * an_cols ? left_cross_px : ys * an_cols;
+            if (bb > maxstrip) maxstrip = bb;
         }
         uint32_t hsize = 1024;
         while (hsize < 2u * maxstrip) hsize <<= 1;
-        CHK(buf_ensure(ctx, ctx->aux, (size_t)nseg * 4 * 6 + 256));
-        CHK(buf_ensure(ctx, ctx->aux2, (size_t)hsize * 12 + 256));
+        const size_t zbytes = (size_t)nseg * 16 + (size_t)hsize * 24;
+        CHK(buf_ensure(ctx, ctx->aux, (size_t)nseg * 4 + 256));
+        CHK(buf_ensure(ctx, ctx->aux2, zbytes + 256));
         CHK(buf_ensure(ctx, ctx->scan_tmp, scan_tmp_bytes(nseg)));
-        uint32_t *w = bp<uint32_t>(ctx->aux);
-        uint32_t *in_dict = w, *recode = w + nseg, *rank = w + 2 * (size_t)nseg;
-        unsigned long long *best = (unsigned long long *)(w + 4 * (size_t)nseg);
-        unsigned long long *keys = bp<unsigned long long>(ctx->aux2);
-        uint32_t *cnts = (uint32_t *)(keys + hsize);
-        HIPCHK(ctx, hipMemsetAsync(in_dict, 0, (size_t)nseg * 4, st));
-        for (int pass = 0; pass < 2; pass++) {
-            const int horizontal = pass == 0;
-            const uint32_t *B = horizontal ? d_top_b : d_left_b;
-            if (!B) continue;
-            const uint32_t srows = horizontal ? an_rows : ys, scols = horizontal ? xs : an_cols;
-            const uint32_t npx = srows * scols;
-            if (npx == 0) continue;
-            HIPCHK(ctx, hipMemsetAsync(best, 0, (size_t)nseg * 8, st));
-            HIPCHK(ctx, hipMemsetAsync(keys, 0, (size_t)hsize * 8, st));
-            HIPCHK(ctx, hipMemsetAsync(cnts, 0, (size_t)hsize * 4, st));
-            hipLaunchKernelGGL(k_pair_count_flag, dim3(grid_for(npx, 256)), dim3(256), 0, st, d_tile, xs, srows,
-                               scols, B, horizontal ? top_pitch : left_pitch, flags,
-                               horizontal ? META_CROSS_TOP : META_CROSS_LEFT, keys, cnts, hsize - 1u); KCHK(ctx);
-            hipLaunchKernelGGL(k_pair_best, dim3(grid_for(hsize, 256)), dim3(256), 0, st, keys, cnts, hsize, best); KCHK(ctx);
-            hipLaunchKernelGGL(k_best_to_dict, dim3(grid_for(nseg, 256)), dim3(256), 0, st, best, nseg, in_dict, recode); KCHK(ctx);
+        uint32_t *rank = bp<uint32_t>(ctx->aux);
+        unsigned long long *best_top = bp<unsigned long long>(ctx->aux2), *best_left = best_top + nseg;
+        unsigned long long *keys0 = best_left + nseg, *keys1 = keys0 + hsize;
+        uint32_t *cnts0 = (uint32_t *)(keys1 + hsize), *cnts1 = cnts0 + hsize;
+        HIPCHK(ctx, hipMemsetAsync(ctx->aux2.p, 0, zbytes, st));
+        const StripArgs a0{d_top_b, top_pitch, an_rows, xs, META_CROSS_TOP, keys0, cnts0, best_top};
+        const StripArgs a1{d_left_b, left_pitch, ys, an_cols, META_CROSS_LEFT, keys1, cnts1, best_left};
+        if (d_top_b || d_left_b) {
+            const uint32_t n0 = d_top_b ? an_rows * xs : 0u, n1 = d_left_b ? ys * an_cols : 0u;
+            hipLaunchKernelGGL(k_pair_count2, dim3(grid_for(n0 > n1 ? n0 : n1, 256), 2), dim3(256), 0, st, d_tile, xs,
+                               flags, a0, a1, hsize - 1u); KCHK(ctx);
+            hipLaunchKernelGGL(k_pair_best2, dim3(grid_for(hsize, 256), 2), dim3(256), 0, st, a0, a1, hsize); KCHK(ctx);
         }
-        OwnFn own{in_dict, segtop, segleft, top, bottom, left, right};
-        CHK(scan_exclusive(ctx, own, nseg, rank, nullptr, bp<uint32_t>(ctx->scan_tmp)));
-        hipLaunchKernelGGL(k_build_lut, dim3(grid_for(nseg, 256)), dim3(256), 0, st, own, rank, recode,
+        OwnFn2 own{best_top, best_left, segtop, segleft, top, bottom, left, right};
+        const uint32_t *rank_boff = nullptr;
+        CHK(scan_exclusive(ctx, own, nseg, rank, nullptr, bp<uint32_t>(ctx->scan_tmp), &rank_boff));
+        hipLaunchKernelGGL(k_build_lut2, dim3(grid_for(nseg, 256)), dim3(256), 0, st, own, rank, rank_boff,
                            d_max_seg_id, nseg, lut); KCHK(ctx);
     }
-    hipLaunchKernelGGL(k_tmax_segments, dim3(grid_for(nseg, 256)), dim3(256), 0, st, lut, flags, nseg, tmax); KCHK(ctx);
-    hipLaunchKernelGGL(k_max_merge, dim3(1), dim3(64), 0, st, d_max_seg_id, tmax); KCHK(ctx);
+    hipLaunchKernelGGL(k_tmax_into, dim3(grid_for(nseg, 256)), dim3(256), 0, st, lut, flags, nseg, d_max_seg_id); KCHK(ctx);
     // the recoded overlap strips that the tiles to the right / below will read
-    if (d_right_out && an_cols)
-        { hipLaunchKernelGGL(k_recode_window, dim3(grid_for(ys * an_cols, 256)), dim3(256), 0, st, d_tile, xs, 0u,
-                             xs - an_cols, ys, an_cols, lut, d_right_out, (size_t)an_cols); KCHK(ctx); }
-    if (d_bottom_out && an_rows)
-        { hipLaunchKernelGGL(k_recode_window, dim3(grid_for(an_rows * xs, 256)), dim3(256), 0, st, d_tile, xs,
-                             ys - an_rows, 0u, an_rows, xs, lut, d_bottom_out, (size_t)xs); KCHK(ctx); }
+    uint32_t *ro = (d_right_out && an_cols) ? d_right_out : nullptr, *bo = (d_bottom_out && an_rows) ? d_bottom_out : nullptr;
+    if (ro || bo) {
+        const uint32_t n0 = ro ? ys * an_cols : 0u, n1 = bo ? an_rows * xs : 0u;
+        hipLaunchKernelGGL(k_recode_strips, dim3(grid_for(n0 > n1 ? n0 : n1, 256), 2), dim3(256), 0, st, d_tile, ys, xs,
+                           an_rows, an_cols, lut, ro, bo); KCHK(ctx);
+    }
     return 0;
 }
 

@@ -27,8 +27,8 @@ def cover(iv, lo, hi):
         else: cur[1] = max(cur[1], e)
     if cur: tot += cur[1] - cur[0]
     return tot
-F = [(s, e) for s, e, n, q, b in rows if b >= 1024 and not n.startswith(('k_dfs_split', 'k_small_loop'))]
-Lt = [(s, e) for s, e, n, q, b in rows if n.startswith(('k_dfs_split', 'k_small_loop'))]
+F = [(s, e) for s, e, n, q, b in rows if b >= 1024 and not n.startswith(('k_dfs_split', 'k_dfs_pool', 'k_small_loop'))]
+Lt = [(s, e) for s, e, n, q, b in rows if n.startswith(('k_dfs_split', 'k_dfs_pool', 'k_small_loop'))]
 print('step span %.1f ms; sum of GPU-filling kernel durations %.1f ms; union %.1f ms' % (
     (t1 - t0) / 1e6, sum(e - s for s, e in F) / 1e6, cover(F, t0, t1) / 1e6))
 for i in range(nb):
@@ -37,3 +37,13 @@ for i in range(nb):
     nl = sum(1 for s, e in Lt if e > lo and s < hi)
     print('%5.0f ms  queues %2d  latency-bound kernels in flight %2d  filling-union %.2f  sum-of-filling %.2f' % (
         (lo - t0) / 1e6, nq, nl, cover(F, lo, hi) / (hi - lo), sum(min(e, hi) - max(s, lo) for s, e in F if e > lo and s < hi) / (hi - lo)))
+# what runs at the very end of the step (after the last latency-bound kernel has finished)
+lastwalk = max([e for s, e in Lt] or [t0])
+tail = collections.defaultdict(lambda: [0, 0.0])
+for s, e, n, q, b in rows:
+    if s >= lastwalk:
+        k = tail[n.split('(')[0][:44]]
+        k[0] += 1; k[1] += (e - s) / 1e6
+print('after the last walker (%.1f ms before the end):' % ((t1 - lastwalk) / 1e6))
+for n, (c, ms) in sorted(tail.items(), key=lambda kv: -kv[1][1])[:12]:
+    print('   %-46s %4d launches %8.2f ms' % (n, c, ms))
