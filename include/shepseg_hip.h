@@ -84,6 +84,15 @@ int shp_kmeans_fit(shp_ctx *ctx, const double *xsample, int64_t nrows, int nband
 int shp_kmeans_fit_typed(shp_ctx *ctx, const void *xsample, int dtype, int64_t nrows, int nbands,
                          int k, const double *init_centres, int max_iter, double tol_rel,
                          double *centres_out, int32_t *labels_out, int *n_iter_out);
+/* The same from the BAND-PLANAR sub-sample (nbands planes of npix pixels, as shp_dev_subsample
+ * returns it): rows with null_val in any band are dropped when has_null, init_centres == NULL means
+ * the reference's diagonalClusterCentres (shepseg.py:364-397) of the rows kept; *nrows_out = rows the
+ * model was fitted on (labels_out, optional, receives that many).  Identical arithmetic (each band's
+ * sums are one chain in row order), prepared by one host thread per band, no host transposition. */
+int shp_kmeans_fit_planar(shp_ctx *ctx, const void *planes, int dtype, int64_t npix, int nbands,
+                          int has_null, int64_t null_val, int k, const double *init_centres,
+                          int max_iter, double tol_rel, double *centres_out, int32_t *labels_out,
+                          int *n_iter_out, int64_t *nrows_out);
 
 /* replaces shepseg.applySpectralClusters (shepseg.py:317-361) + KMeans.predict:
  * clusters_out[nrows*ncols] int32, 1..k, 0 where any band == null_val. */

@@ -45,6 +45,9 @@ _SIGS = {
                                   _c.c_double, _vp, _vp, _c.POINTER(_c.c_int)]),
     'shp_kmeans_fit_typed': (_c.c_int, [_vp, _vp, _c.c_int, _c.c_int64, _c.c_int, _c.c_int, _vp,
                                         _c.c_int, _c.c_double, _vp, _vp, _c.POINTER(_c.c_int)]),
+    'shp_kmeans_fit_planar': (_c.c_int, [_vp, _vp, _c.c_int, _c.c_int64, _c.c_int, _c.c_int, _c.c_int64, _c.c_int,
+                                         _vp, _c.c_int, _c.c_double, _vp, _vp, _c.POINTER(_c.c_int),
+                                         _c.POINTER(_c.c_int64)]),
     'shp_kmeans_assign': (_c.c_int, [_vp, _vp, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _vp,
                                      _c.c_int, _c.c_int, _c.c_int64, _vp]),
     'shp_clump': (_c.c_int, [_vp, _vp, _c.c_int, _c.c_int, _c.c_int, _vp,

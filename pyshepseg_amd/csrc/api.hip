@@ -199,6 +199,24 @@ API int shp_kmeans_fit_typed(shp_ctx *ctx, const void *xsample, int dtype, int64
                           centres_out, labels_out, n_iter_out);
 }
 
+// The whole-image model of the tiled driver from the sub-sample as it leaves the device: nbands
+// planes of npix pixels.  Rows with the null value in any band are dropped, the initial centres are
+// diagonalClusterCentres of what is left (init_centres == NULL) or given; *nrows_out = rows fitted
+// (labels_out, optional, holds that many).  Same arithmetic as shp_kmeans_fit_typed on the
+// transposed rows, prepared by one host thread per band.
+API int shp_kmeans_fit_planar(shp_ctx *ctx, const void *planes, int dtype, int64_t npix, int nbands,
+                              int has_null, int64_t null_val, int k, const double *init_centres,
+                              int max_iter, double tol_rel, double *centres_out, int32_t *labels_out,
+                              int *n_iter_out, int64_t *nrows_out)
+{
+    CHK(enter(ctx));
+    if (!planes || !centres_out) SHP_FAIL(ctx, SHP_ERR_ARG, "NULL argument");
+    if (dtype_size(dtype) == 0) SHP_FAIL(ctx, SHP_ERR_ARG, "bad pixel type %d", dtype);
+    if (nrows_out) *nrows_out = 0;
+    return run_kmeans_fit(ctx, planes, dtype, npix, nbands, k, init_centres, max_iter, tol_rel, centres_out,
+                          labels_out, n_iter_out, true, has_null, (long long)null_val, nrows_out);
+}
+
 API int shp_kmeans_assign(shp_ctx *ctx, const void *img, int dtype, int nbands, int nrows, int ncols,
                           const double *centres, int k, int has_null, int64_t null_val,
                           int32_t *clusters_out)

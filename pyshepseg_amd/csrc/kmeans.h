@@ -16,6 +16,7 @@
 #include "common.h"
 #include <algorithm>
 #include <chrono>
+#include <thread>
 
 #define ASSIGN_PPT 4   // pixels per thread (amortises the scalar centroid loads)
 
@@ -575,18 +576,131 @@ static void fit_centre_rows(const T *xin, uint32_t n, int nb, double *X, std::ve
         }
 }
 
+
+// ---- sample preparation from the BAND-PLANAR form (the tiled driver's sub-sample as it leaves the
+//      device: nb planes of m pixels), a host thread per band.  The same arithmetic as fit_centre_rows
+//      -- every band's sums are one chain in row order, and the bands never mix -- without the
+//      (m x nb) transposition on the host (5 ms for the benchmark's 10^6-row sample) and with the
+//      three passes over the sample spread over nb cores (8 ms -> ~2 ms).  The centred sample is
+//      written band-planar too (threads do not share cache lines) and transposed on the device.
+struct PlanarPrep {
+    uint32_t n = 0;                     // rows kept (non-null)
+    std::vector<double> mu, var_sum;    // per band: mean, sum of squared deviations of the centred column
+    std::vector<long long> vmin, vmax;  // per band, over the kept rows
+};
+
+template <class T>
+static void planar_band(const T *plane, const uint32_t *idx, uint32_t n, double *Xb, double *mu_out,
+                        double *var_out, long long *mn_out, long long *mx_out)
+{
+    double acc = 0.0;
+    T mn = plane[idx ? idx[0] : 0], mx = mn;
+    for (uint32_t i = 0; i < n; i++) {
+        const T v = plane[idx ? idx[i] : i];
+        acc += (double)v;
+        mn = v < mn ? v : mn;
+        mx = v > mx ? v : mx;
+    }
+    const double mu = acc / (double)n;
+    acc = 0.0;
+    for (uint32_t i = 0; i < n; i++) {
+        const double xv = (double)plane[idx ? idx[i] : i] - mu;
+        Xb[i] = xv;
+        acc += xv;
+    }
+    const double m2 = acc / (double)n;
+    double acc2 = 0.0;
+    for (uint32_t i = 0; i < n; i++) { const double d = Xb[i] - m2; acc2 += d * d; }
+    *mu_out = mu; *var_out = acc2; *mn_out = (long long)mn; *mx_out = (long long)mx;
+}
+
+// rows whose every band differs from the null value, in order (shepseg.py:283-299)
+template <class T>
+static void planar_keep(const T *planes, size_t m, int nb, long long null_val, std::vector<uint32_t> &idx)
+{
+    const unsigned nt = std::max(1u, std::min(8u, std::thread::hardware_concurrency()));
+    std::vector<std::vector<uint32_t>> part(nt);
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nt; t++)
+        th.emplace_back([&, t] {
+            const size_t lo = m * t / nt, hi = m * (t + 1) / nt;
+            std::vector<uint32_t> &out = part[t];
+            for (size_t i = lo; i < hi; i++) {
+                bool ok = true;
+                for (int b = 0; b < nb && ok; b++) ok = (long long)planes[(size_t)b * m + i] != null_val;
+                if (ok) out.push_back((uint32_t)i);
+            }
+        });
+    for (auto &t : th) t.join();
+    size_t tot = 0;
+    for (auto &v : part) tot += v.size();
+    idx.reserve(tot);
+    for (auto &v : part) idx.insert(idx.end(), v.begin(), v.end());
+}
+
+// diagonalClusterCentres (shepseg.py:364-397) as numpy evaluates it on a sample of pixel type T:
+// (max - min) in T (wrapping), / (k + 1) in float64, min + (j + 1) * step in float64, truncated to T
+template <class T>
+static void planar_diag_init(const PlanarPrep &pp, int nb, int k, double *init)
+{
+    typedef typename std::make_unsigned<T>::type UT;
+    for (int b = 0; b < nb; b++) {
+        const T mn = (T)pp.vmin[b], mx = (T)pp.vmax[b];
+        const T diff = (T)(UT)((UT)mx - (UT)mn);
+        const double step = (double)diff / (double)(k + 1);
+        for (int j = 0; j < k; j++) {
+            const double v = (double)mn + (double)(j + 1) * step;
+            init[j * nb + b] = (double)(T)v;
+        }
+    }
+}
+
+// Xp (nb planes of n) -> X (n rows of nb)
+__global__ __launch_bounds__(256) void k_fit_transpose(const double *__restrict__ Xp, uint32_t n, int nb,
+                                                       double *__restrict__ X)
+{
+    const size_t i = (size_t)blockIdx.x * 256u + threadIdx.x;
+    if (i >= (size_t)n * nb) return;
+    const uint32_t r = (uint32_t)(i / nb), b = (uint32_t)(i - (size_t)r * nb);
+    X[i] = Xp[(size_t)b * n + r];
+}
+
 #define FIT_DT_F64 100        // xin holds float64 rows (shp_kmeans_fit); else one of the SHP_* pixel types
+// planar: xin_any holds nb planes of nrows pixels (a pixel type, not FIT_DT_F64); rows with a null in
+// any band are dropped when has_null; init == nullptr: diagonalClusterCentres of the kept rows;
+// *nrows_kept_out = rows the model was fitted on (labels_out holds that many).
 static int run_kmeans_fit(shp_ctx *ctx, const void *xin_any, int xdtype, int64_t nrows, int nb, int k,
                           const double *init, int max_iter, double tol_rel, double *centres_out,
-                          int32_t *labels_out, int *n_iter_out)
+                          int32_t *labels_out, int *n_iter_out, bool planar = false, int has_null = 0,
+                          long long null_val = 0, int64_t *nrows_kept_out = nullptr)
 {
     if (nrows < 1 || nrows > 0x7fffffffll || nb < 1 || k < 1)
         SHP_FAIL(ctx, SHP_ERR_ARG, "kmeans_fit: bad shape");
-    if (nrows < k) SHP_FAIL(ctx, SHP_ERR_ARG, "n_samples=%lld should be >= n_clusters=%d",
-                            (long long)nrows, k);
-    const uint32_t n = (uint32_t)nrows;
+    if (!planar && nrows < k) SHP_FAIL(ctx, SHP_ERR_ARG, "n_samples=%lld should be >= n_clusters=%d",
+                                       (long long)nrows, k);
+    uint32_t n = (uint32_t)nrows;
     const int kn = k * nb;
     const auto t_begin = std::chrono::steady_clock::now();
+    PlanarPrep pp;
+    std::vector<uint32_t> keep_idx;
+    std::vector<double> init_diag;
+    if (planar) {
+        // rows kept first (the buffers below are sized by them)
+        if (has_null) {
+            switch (xdtype) {
+            case SHP_U8: planar_keep((const uint8_t *)xin_any, (size_t)nrows, nb, null_val, keep_idx); break;
+            case SHP_I16: planar_keep((const int16_t *)xin_any, (size_t)nrows, nb, null_val, keep_idx); break;
+            case SHP_U16: planar_keep((const uint16_t *)xin_any, (size_t)nrows, nb, null_val, keep_idx); break;
+            case SHP_I32: planar_keep((const int32_t *)xin_any, (size_t)nrows, nb, null_val, keep_idx); break;
+            case SHP_U32: planar_keep((const uint32_t *)xin_any, (size_t)nrows, nb, null_val, keep_idx); break;
+            default: SHP_FAIL(ctx, SHP_ERR_ARG, "kmeans_fit: bad sample type %d", xdtype);
+            }
+            n = (uint32_t)keep_idx.size();
+        }
+        if (nrows_kept_out) *nrows_kept_out = (int64_t)n;
+        if ((int64_t)n < (int64_t)k) SHP_FAIL(ctx, SHP_ERR_ARG, "n_samples=%lld should be >= n_clusters=%d",
+                                              (long long)n, k);
+    }
     // centre the data on the host (sklearn: X -= X.mean(axis=0)); rows outer / bands inner keeps
     // each band's additions in row order while nb independent chains are in flight.  X lives in
     // a pinned, grow-only buffer of the context: no page faults after the first call and the
@@ -601,18 +715,56 @@ static int run_kmeans_fit(shp_ctx *ctx, const void *xin_any, int xdtype, int64_t
     }
     double *X = ctx->h_fit;
     std::vector<double> mu(nb, 0.0), acc(nb, 0.0), acc2(nb, 0.0);
-    switch (xdtype) {
-    case FIT_DT_F64: fit_centre_rows((const double *)xin_any, n, nb, X, mu, acc); break;
-    case SHP_U8: fit_centre_rows((const uint8_t *)xin_any, n, nb, X, mu, acc); break;
-    case SHP_I16: fit_centre_rows((const int16_t *)xin_any, n, nb, X, mu, acc); break;
-    case SHP_U16: fit_centre_rows((const uint16_t *)xin_any, n, nb, X, mu, acc); break;
-    case SHP_I32: fit_centre_rows((const int32_t *)xin_any, n, nb, X, mu, acc); break;
-    case SHP_U32: fit_centre_rows((const uint32_t *)xin_any, n, nb, X, mu, acc); break;
-    default: SHP_FAIL(ctx, SHP_ERR_ARG, "kmeans_fit: bad sample type %d", xdtype);
+    if (planar) {
+        const uint32_t *ix = has_null ? keep_idx.data() : (const uint32_t *)nullptr;
+        pp.n = n;
+        pp.mu.assign(nb, 0.0); pp.var_sum.assign(nb, 0.0); pp.vmin.assign(nb, 0); pp.vmax.assign(nb, 0);
+        std::vector<std::thread> th;
+#define PLANAR_BANDS(T)                                                                              \
+        for (int b = 0; b < nb; b++)                                                                     \
+            th.emplace_back([&, b] {                                                                     \
+                planar_band((const T *)xin_any + (size_t)b * (size_t)nrows, ix, n, X + (size_t)b * n,   \
+                            &pp.mu[b], &pp.var_sum[b], &pp.vmin[b], &pp.vmax[b]);                        \
+            })
+        switch (xdtype) {
+        case SHP_U8: PLANAR_BANDS(uint8_t); break;
+        case SHP_I16: PLANAR_BANDS(int16_t); break;
+        case SHP_U16: PLANAR_BANDS(uint16_t); break;
+        case SHP_I32: PLANAR_BANDS(int32_t); break;
+        case SHP_U32: PLANAR_BANDS(uint32_t); break;
+        default: SHP_FAIL(ctx, SHP_ERR_ARG, "kmeans_fit: bad sample type %d", xdtype);
+        }
+#undef PLANAR_BANDS
+        for (auto &t : th) t.join();
+        for (int b = 0; b < nb; b++) { mu[b] = pp.mu[b]; acc2[b] = pp.var_sum[b]; }
+        if (!init) {
+            init_diag.resize(kn);
+            switch (xdtype) {
+            case SHP_U8: planar_diag_init<uint8_t>(pp, nb, k, init_diag.data()); break;
+            case SHP_I16: planar_diag_init<int16_t>(pp, nb, k, init_diag.data()); break;
+            case SHP_U16: planar_diag_init<uint16_t>(pp, nb, k, init_diag.data()); break;
+            case SHP_I32: planar_diag_init<int32_t>(pp, nb, k, init_diag.data()); break;
+            default: planar_diag_init<uint32_t>(pp, nb, k, init_diag.data()); break;
+            }
+            init = init_diag.data();
+        }
+    } else {
+        switch (xdtype) {
+        case FIT_DT_F64: fit_centre_rows((const double *)xin_any, n, nb, X, mu, acc); break;
+        case SHP_U8: fit_centre_rows((const uint8_t *)xin_any, n, nb, X, mu, acc); break;
+        case SHP_I16: fit_centre_rows((const int16_t *)xin_any, n, nb, X, mu, acc); break;
+        case SHP_U16: fit_centre_rows((const uint16_t *)xin_any, n, nb, X, mu, acc); break;
+        case SHP_I32: fit_centre_rows((const int32_t *)xin_any, n, nb, X, mu, acc); break;
+        case SHP_U32: fit_centre_rows((const uint32_t *)xin_any, n, nb, X, mu, acc); break;
+        default: SHP_FAIL(ctx, SHP_ERR_ARG, "kmeans_fit: bad sample type %d", xdtype);
+        }
+        for (int b = 0; b < nb; b++) acc[b] /= (double)n;
+        for (uint32_t i = 0; i < n; i++)
+            for (int b = 0; b < nb; b++) { const double d = X[(size_t)i * nb + b] - acc[b]; acc2[b] += d * d; }
     }
-    for (int b = 0; b < nb; b++) acc[b] /= (double)n;
-    for (uint32_t i = 0; i < n; i++)
-        for (int b = 0; b < nb; b++) { const double d = X[(size_t)i * nb + b] - acc[b]; acc2[b] += d * d; }
+    if (!init) SHP_FAIL(ctx, SHP_ERR_ARG, "kmeans_fit: no initial centres");
+    // (host X is row-major, or band-planar in the planar form)
+    auto Xat = [&](uint32_t i, int b) -> double { return planar ? X[(size_t)b * n + i] : X[(size_t)i * nb + b]; };
     double tol = 0.0;
     for (int b = 0; b < nb; b++) tol += acc2[b] / (double)n;
     tol = tol / nb * tol_rel;
@@ -646,7 +798,14 @@ static int run_kmeans_fit(shp_ctx *ctx, const void *xin_any, int xdtype, int64_t
     double *pin_up = (double *)(ctx->h_pinned + 16);
     double *pin_dn = pin_up + (2 * kn + k);
     HIPCHK(ctx, hipStreamSynchronize(st));           // earlier users of the staging area are done
-    HIPCHK(ctx, hipMemcpyAsync(dX, X, xbytes, hipMemcpyHostToDevice, st));
+    if (planar) {
+        CHK(buf_ensure(ctx, ctx->aux, xbytes));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->aux.p, X, xbytes, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(k_fit_transpose, dim3(grid_for((size_t)n * nb, 256)), dim3(256), 0, st,
+                           bp<double>(ctx->aux), n, nb, dX); KCHK(ctx);
+    } else {
+        HIPCHK(ctx, hipMemcpyAsync(dX, X, xbytes, hipMemcpyHostToDevice, st));
+    }
     HIPCHK(ctx, hipMemsetAsync(dlabB, 0xff, (size_t)n * 4, st));        // labels_old = -1
     const unsigned g = grid_for(n, 256u * FIT_RPT);
     auto upload_centres = [&](const std::vector<double> &cc) -> int {
@@ -727,8 +886,8 @@ static int run_kmeans_fit(shp_ctx *ctx, const void *xin_any, int xdtype, int64_t
             const uint32_t f = order[r];
             const int e = empties[r], old = hl[f];
             for (int b = 0; b < nb; b++) {
-                Cn[old * nb + b] -= X[(size_t)f * nb + b];
-                Cn[e * nb + b] = X[(size_t)f * nb + b];
+                Cn[old * nb + b] -= Xat(f, b);
+                Cn[e * nb + b] = Xat(f, b);
             }
             w[e] = 1.0; w[old] -= 1.0;
         }

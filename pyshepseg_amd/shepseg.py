@@ -9,6 +9,7 @@ sample selection and initial centres of ``fitSpectralClusters`` and ``autoMaxSpe
 There is no CPU fallback: without the HIP library or a GPU every compute call raises.
 """
 import ctypes
+import os
 import time
 
 import numpy
@@ -183,11 +184,36 @@ def _fit(xSample, init, max_iter=300, tol=1e-4, wantInertia=False):
     return KMeansModel(centres, nit.value, labels, inertia)
 
 
+def _fit_planar(img, numClusters, imgNullVal, init=None, max_iter=300, tol=1e-4):
+    img = numpy.ascontiguousarray(img)
+    nb = img.shape[0]
+    npix = int(img.size // max(nb, 1))
+    centres = numpy.empty((numClusters, nb), dtype=numpy.float64)
+    labels = numpy.empty(max(npix, 1), dtype=numpy.int32)
+    nit = ctypes.c_int(0)
+    nrows = ctypes.c_int64(0)
+    if init is not None:
+        init = numpy.ascontiguousarray(init, dtype=numpy.float64)
+    c = _lib.ctx()
+    c.check(c._L.shp_kmeans_fit_planar(
+        c.handle, _lib.ptr(img), _lib.SHP_DTYPES[img.dtype], npix, nb, int(imgNullVal is not None),
+        0 if imgNullVal is None else int(imgNullVal), int(numClusters),
+        None if init is None else _lib.ptr(init), int(max_iter), float(tol), _lib.ptr(centres),
+        _lib.ptr(labels), ctypes.byref(nit), ctypes.byref(nrows)))
+    return KMeansModel(centres, nit.value, labels[:nrows.value], None)
+
+
 def fitSpectralClusters(img, numClusters, subsamplePcnt, imgNullVal, fixedKMeansInit):
     """First step of Shepherd segmentation: k-means on a subsample of the pixels
     (reference shepseg.py:252-314).  Lloyd iterations run on the GPU (shp_kmeans_fit).
     Returns a fitted :class:`KMeansModel`."""
     img = numpy.asarray(img)
+    if (fixedKMeansInit and img.ndim == 3 and img.dtype in _lib.SHP_DTYPES and
+            int(round(100. / subsamplePcnt)) == 1 and os.environ.get('SHEPSEG_FIT_PLANAR', '1') != '0'):
+        # every pixel of img is a sample: the band-planar array goes down as it is (null rows are
+        # dropped, the diagonal initial centres taken and the sample centred by one host thread per
+        # band inside the library: the same arithmetic as the row form below, no transposition)
+        return _fit_planar(img, numClusters, imgNullVal)
     xSample, minmax = _sample_rows(img, subsamplePcnt, imgNullVal, wantMinMax=True)
     if fixedKMeansInit:
         init = diagonalClusterCentres(xSample, numClusters, minmax)

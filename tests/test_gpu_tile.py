@@ -391,3 +391,34 @@ def test_ctx_reserve_and_argument_errors(shepseg):
         assert rc == 0 and mx.value == seg.max() and seg.min() >= 1
     finally:
         c.close()
+
+
+@pytest.mark.parametrize('case', range(8))
+def test_planar_fit_equals_row_fit(case, shepseg, oracle):
+    """fitSpectralClusters' band-planar form (threaded sample preparation inside the library, no host
+    transposition) against the row form: the same rows kept, the same diagonal initial centres, the
+    same centres / n_iter_ / labels bit for bit."""
+    rng = np.random.RandomState(100 + case)
+    dt = [np.uint16, np.uint8, np.int16, np.int32, np.uint32, np.uint16, np.int16, np.uint8][case]
+    nb = [6, 3, 4, 2, 5, 1, 10, 7][case]
+    (nr, nc) = [(300, 257), (64, 90), (120, 33), (77, 200), (90, 90), (400, 50), (55, 81), (1, 700)][case]
+    base = oracle.synthimg(case + 3, nb, nr, nc).astype(np.int64)
+    info = np.iinfo(dt)
+    span = (int(info.max) - int(info.min)) * 3 // 4
+    img = base * span // 65535 + int(info.min)
+    img = np.clip(img + rng.randint(0, 5, size=img.shape), info.min, info.max).astype(dt)
+    null = None
+    if case in (1, 2, 4, 6):
+        null = int(info.max) if case != 2 else int(img.flat[17])
+        img[rng.randint(0, nb), rng.rand(nr, nc) < 0.07] = null
+    k = [60, 7, 12, 5, 30, 9, 20, 4][case]
+    import os
+    a = shepseg.fitSpectralClusters(img, k, 100, null, True)
+    os.environ['SHEPSEG_FIT_PLANAR'] = '0'
+    try:
+        b = shepseg.fitSpectralClusters(img, k, 100, null, True)
+    finally:
+        del os.environ['SHEPSEG_FIT_PLANAR']
+    assert a.n_iter_ == b.n_iter_
+    assert np.array_equal(a.cluster_centers_.view(np.uint64), b.cluster_centers_.view(np.uint64))
+    assert np.array_equal(a.labels_, b.labels_)

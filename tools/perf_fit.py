@@ -1,15 +1,20 @@
-"""Timings of the whole-image k-means model: device sub-sample, host sample preparation, Lloyd fit
-(set SHEPSEG_FIT_TIMING=1 for the split inside shp_kmeans_fit)."""
+"""Timings of the whole-image k-means model: device sub-sample, sample preparation, Lloyd fit, in the
+row form (host transposition + single-threaded centring) and the band-planar form (threaded
+preparation inside the library).  SHEPSEG_FIT_TIMING=1 prints the split inside the library."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from pyshepseg_amd import tiling, shepseg, _lib
 size = int(sys.argv[1]) if len(sys.argv) > 1 else 40000
-ras = tiling.DeviceRaster.synth(11, 6, size, size)
-for rep in range(3):
-    t0 = time.time(); img = tiling.readSubsampledImage(ras, [1, 2, 3, 4, 5, 6], np.sqrt(1e6 / (size * size))); t1 = time.time()
-    xs, mm = shepseg._sample_rows(img, 100, None, wantMinMax=True); t2 = time.time()
-    init = shepseg.diagonalClusterCentres(xs, 60, mm); t3 = time.time()
-    km = shepseg._fit(xs, init); t4 = time.time()
-    print('subsample %.1f ms  sample_rows+minmax %.1f ms  diag init %.1f ms  _fit %.1f ms  n_iter %d  rows %d'
-          % ((t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t4 - t3) * 1e3, km.n_iter_, xs.shape[0]))
+nb = int(sys.argv[2]) if len(sys.argv) > 2 else 6
+ras = tiling.DeviceRaster.synth(11, nb, size, size)
+for rep in range(6):
+    mode = 'planar' if rep % 2 else 'rows'
+    os.environ['SHEPSEG_FIT_PLANAR'] = '1' if mode == 'planar' else '0'
+    t0 = time.time()
+    img = tiling.readSubsampledImage(ras, list(range(1, nb + 1)), np.sqrt(1e6 / (size * size)))
+    t1 = time.time()
+    km = shepseg.fitSpectralClusters(img, 60, 100, None, True)
+    t2 = time.time()
+    print('%-6s subsample %.1f ms  fitSpectralClusters %.1f ms  n_iter %d  rows %d'
+          % (mode, (t1 - t0) * 1e3, (t2 - t1) * 1e3, km.n_iter_, img.shape[1] * img.shape[2]))
