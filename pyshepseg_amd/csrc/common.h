@@ -268,6 +268,12 @@ static inline int buf_ensure(shp_ctx *ctx, DevBuf &b, size_t bytes)
 {
     if (bytes == 0) bytes = 16;
     if (b.cap >= bytes) return 0;
+    static const bool regrow_log = getenv("SHEPSEG_REGROW_LOG") != nullptr;      // diagnostic: which workspace still grows
+    if (regrow_log) {
+        int which = -1;
+        for (size_t i = 0; i < ctx->bufs.size(); i++) if (ctx->bufs[i] == &b) which = (int)i;
+        fprintf(stderr, "regrow: ctx %p buffer #%d %zu -> %zu bytes\n", (void *)ctx, which, b.cap, bytes);
+    }
     if (b.p) {
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         HIPCHK(ctx, hipFree(b.p));
