@@ -1050,7 +1050,9 @@ ORC_API int orc_spatialstats(const uint32_t *seg, const void *band, int dtype, i
                             const int64_t dist = (int64_t)sqrt((double)(yo * yo + xo * xo));
                             if (dist <= maxd && dist > 0) {
                                 counts[dist - 1]++;
-                                sums[dist - 1] += (double)((val - val2) * (val - val2));
+                                /* numba: an int64 product that wraps (32-bit imagery only), then float64 */
+                                const uint64_t du = (uint64_t)(val - val2);
+                                sums[dist - 1] += (double)(int64_t)(du * du);
                             }
                         }
                 }
