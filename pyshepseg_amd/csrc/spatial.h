@@ -115,9 +115,9 @@ __global__ __launch_bounds__(256) void k_spatial_vario(SpatialGeom g, const uint
         if (row + yo < g.nrows && col + xo < g.ncols) {
             const uint32_t q = p + yo * g.ncols + xo;
             if (spatial_member(g, q) == s) {
-                const long long d = v - ld_px(g.band, g.dtype, q);
+                const unsigned long long d = (unsigned long long)(v - ld_px(g.band, g.dtype, q));
                 c++;
-                acc += (unsigned long long)(d * d);
+                acc += d * d;                 // (unsigned: the square of a 32-bit difference may wrap)
             }
         }
     }
