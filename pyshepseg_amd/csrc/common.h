@@ -125,6 +125,8 @@ static inline void stream_take(shp_ctx *ctx, int cls)
                 ctx->stream = s;
                 break;
             }
+            (void)hipGetLastError();
+            if (g_streams.made[cls] == 0) return;      // no stream of this class at all: stay on the idle stream
         }
         g_streams.cv.wait(lk);
     }
