@@ -153,12 +153,12 @@ static int run_segstats(shp_ctx *ctx, const uint32_t *d_seg, const void *d_band,
     }
     // sort by value (payload: segment key), then stably by segment key (payload: value)
     uint32_t *k1 = nullptr, *v1 = nullptr, *k2 = nullptr, *v2 = nullptr;
-    CHK(sort_pairs(ctx, kval, kseg, n, valbits, &k1, &v1));            // k1 = values, v1 = seg keys
+    CHK(sort_pairs(ctx, kval, kseg, n, valbits, &k1, &v1, true));            // k1 = values, v1 = seg keys
     if (n) {
         HIPCHK(ctx, hipMemcpyAsync(kval, k1, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
         HIPCHK(ctx, hipMemcpyAsync(kseg, v1, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
     }
-    CHK(sort_pairs(ctx, kseg, kval, n, bits_for(S), &k2, &v2));        // k2 = seg keys, v2 = values
+    CHK(sort_pairs(ctx, kseg, kval, n, bits_for(S), &k2, &v2, true));        // k2 = seg keys, v2 = values
     CHK(buf_ensure(ctx, ctx->scan_tmp, scan_tmp_bytes(ns)));
     HIPCHK(ctx, hipMemsetAsync(cnt, 0, ns * 4, st));
     if (n) {

@@ -50,6 +50,8 @@ __device__ __forceinline__ unsigned long long match_digit(uint32_t d, bool valid
     return peers;
 }
 
+// Direct form: every item goes straight to its place (label keys come in runs, so the lanes of a
+// digit already write neighbouring addresses; 4 KiB of LDS per workgroup).
 __global__ __launch_bounds__(256) void k_sort_scatter(
     const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
     uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, uint32_t n, int shift,
@@ -109,6 +111,101 @@ __global__ __launch_bounds__(256) void k_sort_scatter(
     }
 }
 
+// Staged form of the scatter (keys without locality: the statistics' (value, segment) sorts).
+// The scatter goes through LDS: the workgroup's 2048 items are first put in digit order there (the
+// per-wave ranks give every item its place), then written out in that order, so that consecutive
+// lanes write consecutive addresses within a digit's run -- with random digits a direct scatter
+// issued 4-byte writes to 2048 unrelated addresses per workgroup, the staged one writes ~256 runs of
+// 8 items (and whole 256-byte spans when the keys come in runs, as labels do).
+__global__ __launch_bounds__(256) void k_sort_scatter_staged(
+    const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
+    uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, uint32_t n, int shift,
+    const uint32_t *__restrict__ histscan, uint32_t nblk, const uint32_t *__restrict__ boff)
+{
+    __shared__ uint32_t wcount[4][256];
+    __shared__ uint32_t gdelta[256];        // global position - position in the workgroup's digit order
+    __shared__ uint32_t wtot[4];
+    __shared__ uint32_t skeys[SORT_TILE], svals[SORT_TILE];
+    const unsigned w = threadIdx.x >> 6, lane = lane_id();
+    const uint32_t base = blockIdx.x * SORT_TILE + w * SORT_ROWS * 64u + lane;
+    uint32_t k[SORT_ROWS], v[SORT_ROWS];
+#pragma unroll
+    for (unsigned r = 0; r < SORT_ROWS; r++) {
+        const uint32_t idx = base + r * 64u;
+        k[r] = (idx < n) ? keys_in[idx] : 0u;
+        v[r] = (idx < n) ? (vals_in ? vals_in[idx] : idx) : 0u;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; i++) wcount[i][threadIdx.x] = 0;
+    __syncthreads();
+    const unsigned long long lt = lanemask_lt();
+    // per row: the lanes sharing this lane's digit (peers) and how many items of that digit the
+    // wave's earlier rows hold (rowbase); the leader of each group bumps the wave's digit count
+    unsigned long long peers[SORT_ROWS];
+    uint32_t rowbase[SORT_ROWS];
+#pragma unroll
+    for (unsigned r = 0; r < SORT_ROWS; r++) {
+        const bool valid = (base + r * 64u) < n;
+        const uint32_t d = (k[r] >> shift) & 255u;
+        peers[r] = match_digit(d, valid);
+        uint32_t rb = 0;
+        if (valid) rb = wcount[w][d];
+        __builtin_amdgcn_wave_barrier();
+        if (valid && (peers[r] & lt) == 0ull) wcount[w][d] = rb + (uint32_t)__popcll(peers[r]);
+        __builtin_amdgcn_wave_barrier();
+        rowbase[r] = rb;
+    }
+    __syncthreads();
+    {
+        // thread d: the workgroup's count of digit d, its exclusive scan over the digits (the digit's
+        // first place in the staged order), and where each wave's items of that digit start
+        const uint32_t c0 = wcount[0][threadIdx.x], c1 = wcount[1][threadIdx.x], c2 = wcount[2][threadIdx.x],
+                       c3 = wcount[3][threadIdx.x];
+        const uint32_t tot = c0 + c1 + c2 + c3;
+        uint32_t incl = tot;
+#pragma unroll
+        for (int dd = 1; dd < 64; dd <<= 1) {
+            const uint32_t t = __shfl_up(incl, dd, 64);
+            if (lane >= (unsigned)dd) incl += t;
+        }
+        if (lane == 63) wtot[w] = incl;
+        __syncthreads();
+        uint32_t lstart = incl - tot;
+        for (unsigned i = 0; i < w; i++) lstart += wtot[i];
+        const size_t hi = (size_t)threadIdx.x * nblk + blockIdx.x;
+        const uint32_t gbase = histscan[hi] + (boff ? boff[hi / SCAN_ITEMS] : 0u);      // lazy add-back of the scan
+        gdelta[threadIdx.x] = gbase - lstart;
+        wcount[0][threadIdx.x] = lstart;
+        wcount[1][threadIdx.x] = lstart + c0;
+        wcount[2][threadIdx.x] = lstart + c0 + c1;
+        wcount[3][threadIdx.x] = lstart + c0 + c1 + c2;
+    }
+    __syncthreads();
+#pragma unroll
+    for (unsigned r = 0; r < SORT_ROWS; r++) {
+        const bool valid = (base + r * 64u) < n;
+        const uint32_t d = (k[r] >> shift) & 255u;
+        if (valid) {
+            const uint32_t lp = wcount[w][d] + rowbase[r] + (uint32_t)__popcll(peers[r] & lt);
+            skeys[lp] = k[r];
+            svals[lp] = v[r];
+        }
+    }
+    __syncthreads();
+    const uint32_t tile0 = blockIdx.x * SORT_TILE;
+    const uint32_t nvalid = tile0 < n ? (n - tile0 < SORT_TILE ? n - tile0 : SORT_TILE) : 0u;
+#pragma unroll
+    for (unsigned j = 0; j < SORT_TILE / 256u; j++) {
+        const uint32_t i = threadIdx.x + j * 256u;
+        if (i < nvalid) {
+            const uint32_t key = skeys[i];
+            const uint32_t pos = i + gdelta[(key >> shift) & 255u];
+            if (keys_out) keys_out[pos] = key;
+            vals_out[pos] = svals[i];
+        }
+    }
+}
+
 static inline int bits_for(uint32_t maxval)      // significant bits of the largest key
 {
     int b = 1;
@@ -122,7 +219,7 @@ static inline int bits_for(uint32_t maxval)      // significant bits of the larg
 // (vals always end up in ctx->pix or ctx->sort_v1).  keys_sorted == nullptr: the caller only wants
 // the values, the last pass does not write the keys.
 static int sort_pairs(shp_ctx *ctx, const uint32_t *keys_in, const uint32_t *vals_in, uint32_t n,
-                      int bits, uint32_t **keys_sorted, uint32_t **vals_sorted)
+                      int bits, uint32_t **keys_sorted, uint32_t **vals_sorted, bool staged = false)
 {
     const uint32_t nblk = (n + SORT_TILE - 1) / SORT_TILE;
     int passes = (bits + 7) / 8;
@@ -150,8 +247,12 @@ static int sort_pairs(shp_ctx *ctx, const uint32_t *keys_in, const uint32_t *val
         ArrFn f{hist};
         const uint32_t *boff = nullptr;
         CHK(scan_exclusive(ctx, f, (uint32_t)nh, hscan, nullptr, bp<uint32_t>(ctx->scan_tmp), &boff));
-        hipLaunchKernelGGL(k_sort_scatter, dim3(nblk), dim3(256), 0, ctx->stream, kin, vin, kout,
-                           vout, n, p * 8, hscan, nblk, boff);
+        if (staged)
+            hipLaunchKernelGGL(k_sort_scatter_staged, dim3(nblk), dim3(256), 0, ctx->stream, kin, vin, kout,
+                               vout, n, p * 8, hscan, nblk, boff);
+        else
+            hipLaunchKernelGGL(k_sort_scatter, dim3(nblk), dim3(256), 0, ctx->stream, kin, vin, kout,
+                               vout, n, p * 8, hscan, nblk, boff);
         KCHK(ctx);
         kin = kout; vin = vout;
     }
