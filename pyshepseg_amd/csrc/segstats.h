@@ -35,6 +35,7 @@ __global__ __launch_bounds__(256) void k_stats_keys(const uint32_t *__restrict__
     kval[p] = (uint32_t)(v - bias);
 }
 
+#define SEGSTATS_STAGE 3072u     // values a wavefront stages in LDS (12 KiB; 48 KiB per workgroup)
 // one thread per segment over its ascending value run
 __global__ __launch_bounds__(256) void k_seg_stats(const uint32_t *__restrict__ vals,
                                                    const uint32_t *__restrict__ off,
@@ -44,7 +45,21 @@ __global__ __launch_bounds__(256) void k_seg_stats(const uint32_t *__restrict__ 
                                                    long long *__restrict__ intcols,
                                                    float *__restrict__ fltcols)
 {
+    // The 64 segments of a wavefront hold one contiguous span of the value array.  When that span is
+    // short (many small segments: 50 M segments of 32 pixels in the C5 workload) the wavefront loads
+    // it into LDS with coalesced reads and every thread walks its own run there; a thread reading
+    // its 128 bytes straight from memory, twice, moved a cache line per load.
+    __shared__ uint32_t stage[4][SEGSTATS_STAGE];
     const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+    const unsigned lane = lane_id(), wv = threadIdx.x >> 6;
+    const uint32_t s_first = s - lane, s_last = s_first + 63u < S ? s_first + 63u : S;
+    const uint32_t span0 = s_first <= S ? off[s_first] : 0u;
+    const uint32_t span1 = s_first <= S ? off[s_last] + cnt[s_last] : 0u;
+    const bool staged = span1 - span0 <= SEGSTATS_STAGE;          // (uniform per wavefront)
+    if (staged) {
+        for (uint32_t i = lane; i < span1 - span0; i += 64u) stage[wv][i] = vals[span0 + i];
+        __builtin_amdgcn_wave_barrier();
+    }
     if (s > S) return;
     const size_t ns = (size_t)S + 1;
     if (s == 0) {                       // null segment row: zeros (RatPage :1992-1996)
@@ -55,7 +70,7 @@ __global__ __launch_bounds__(256) void k_seg_stats(const uint32_t *__restrict__ 
         return;
     }
     const uint32_t n = cnt[s];
-    const uint32_t *a = vals + off[s];
+    const uint32_t *a = staged ? &stage[wv][off[s] - span0] : vals + off[s];
     long long vmin = missing, vmax = missing, vmode = missing;
     float mean = (float)missing, stddev = (float)missing;
     if (n > 0) {
@@ -154,11 +169,20 @@ static int run_segstats(shp_ctx *ctx, const uint32_t *d_seg, const void *d_band,
     // sort by value (payload: segment key), then stably by segment key (payload: value)
     uint32_t *k1 = nullptr, *v1 = nullptr, *k2 = nullptr, *v2 = nullptr;
     CHK(sort_pairs(ctx, kval, kseg, n, valbits, &k1, &v1, true));            // k1 = values, v1 = seg keys
-    if (n) {
-        HIPCHK(ctx, hipMemcpyAsync(kval, k1, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
-        HIPCHK(ctx, hipMemcpyAsync(kseg, v1, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
+    // the second sort reads the first one's result where it lies unless its own first pass would
+    // write into the same ping-pong buffers (that depends on the two pass counts' parities)
+    const uint32_t *in_seg = v1, *in_val = k1;
+    {
+        const int passes2 = (bits_for(S) + 7) / 8;
+        const uint32_t *out_k = bp<uint32_t>(ctx->sort_k0);
+        const uint32_t *out_v = (passes2 & 1) ? bp<uint32_t>(ctx->pix) : bp<uint32_t>(ctx->sort_v1);
+        if (n && (k1 == out_k || k1 == out_v || v1 == out_k || v1 == out_v)) {
+            HIPCHK(ctx, hipMemcpyAsync(kval, k1, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
+            HIPCHK(ctx, hipMemcpyAsync(kseg, v1, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
+            in_seg = kseg; in_val = kval;
+        }
     }
-    CHK(sort_pairs(ctx, kseg, kval, n, bits_for(S), &k2, &v2, true));        // k2 = seg keys, v2 = values
+    CHK(sort_pairs(ctx, in_seg, in_val, n, bits_for(S), &k2, &v2, true));    // k2 = seg keys, v2 = values
     CHK(buf_ensure(ctx, ctx->scan_tmp, scan_tmp_bytes(ns)));
     HIPCHK(ctx, hipMemsetAsync(cnt, 0, ns * 4, st));
     if (n) {
