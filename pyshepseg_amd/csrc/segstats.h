@@ -35,6 +35,42 @@ __global__ __launch_bounds__(256) void k_stats_keys(const uint32_t *__restrict__
     kval[p] = (uint32_t)(v - bias);
 }
 
+// the statistics of one segment into their columns (a: its ascending value run, n values)
+__device__ __forceinline__ void seg_stats_emit(uint32_t s, uint32_t n, const uint32_t *a, long long bias,
+                                               const uint32_t *__restrict__ sel, int nstats, long long missing,
+                                               long long *__restrict__ intcols, float *__restrict__ fltcols,
+                                               size_t ns, long long vmin, long long vmax, long long vmode,
+                                               float mean, float stddev)
+{
+    for (int i = 0; i < nstats; i++) {
+        const uint32_t stat = sel[i * 5 + 1], ctype = sel[i * 5 + 2], cidx = sel[i * 5 + 3];
+        const uint32_t param = sel[i * 5 + 4];
+        double val = 0.0;
+        if (stat == 4u || stat == 6u) {
+            if (n == 0) val = (double)missing;
+            else {
+                const double pc = (stat == 4u) ? 50.0 : (double)param;
+                const double t = (double)n * (pc / 100.0);
+                uint32_t idx = n - 1;                            // t == 0: loop never runs
+                if (t > 0.0) {
+                    double ct = ceil(t);
+                    if (ct > (double)n) ct = (double)n;
+                    idx = (uint32_t)ct - 1u;
+                }
+                val = (double)((long long)a[idx] + bias);
+            }
+        } else if (stat == 0u) val = (double)vmin;
+        else if (stat == 1u) val = (double)vmax;
+        else if (stat == 2u) val = (double)mean;
+        else if (stat == 3u) val = (double)stddev;
+        else if (stat == 5u) val = (double)vmode;
+        else if (stat == 7u) val = (double)n;
+        if (ctype == 0u) intcols[(size_t)cidx * ns + s] = (long long)val;
+        else fltcols[(size_t)cidx * ns + s] = (float)val;
+    }
+}
+
+#define SEGSTATS_BIG 4096u       // segments above this many valid pixels go to k_seg_stats_big
 #define SEGSTATS_STAGE 3072u     // values a wavefront stages in LDS (12 KiB; 48 KiB per workgroup)
 // one thread per segment over its ascending value run
 __global__ __launch_bounds__(256) void k_seg_stats(const uint32_t *__restrict__ vals,
@@ -43,7 +79,7 @@ __global__ __launch_bounds__(256) void k_seg_stats(const uint32_t *__restrict__ 
                                                    long long bias, const uint32_t *__restrict__ sel,
                                                    int nstats, long long missing,
                                                    long long *__restrict__ intcols,
-                                                   float *__restrict__ fltcols)
+                                                   float *__restrict__ fltcols, uint32_t *biglist)
 {
     // The 64 segments of a wavefront hold one contiguous span of the value array.  When that span is
     // short (many small segments: 50 M segments of 32 pixels in the C5 workload) the wavefront loads
@@ -70,6 +106,10 @@ __global__ __launch_bounds__(256) void k_seg_stats(const uint32_t *__restrict__ 
         return;
     }
     const uint32_t n = cnt[s];
+    if (n > SEGSTATS_BIG) {             // a long run is a wavefront's work (k_seg_stats_big), not a thread's
+        biglist[1u + atomicAdd(&biglist[0], 1u)] = s;
+        return;
+    }
     const uint32_t *a = staged ? &stage[wv][off[s] - span0] : vals + off[s];
     long long vmin = missing, vmax = missing, vmode = missing;
     float mean = (float)missing, stddev = (float)missing;
@@ -94,31 +134,69 @@ __global__ __launch_bounds__(256) void k_seg_stats(const uint32_t *__restrict__ 
         }
         stddev = (float)sqrt((double)var / (double)n);
     }
-    for (int i = 0; i < nstats; i++) {
-        const uint32_t stat = sel[i * 5 + 1], ctype = sel[i * 5 + 2], cidx = sel[i * 5 + 3];
-        const uint32_t param = sel[i * 5 + 4];
-        double val = 0.0;
-        if (stat == 4u || stat == 6u) {
-            if (n == 0) val = (double)missing;
-            else {
-                const double pc = (stat == 4u) ? 50.0 : (double)param;
-                const double t = (double)n * (pc / 100.0);
-                uint32_t idx = n - 1;                            // t == 0: loop never runs
-                if (t > 0.0) {
-                    double ct = ceil(t);
-                    if (ct > (double)n) ct = (double)n;
-                    idx = (uint32_t)ct - 1u;
-                }
-                val = (double)((long long)a[idx] + bias);
+    seg_stats_emit(s, n, a, bias, sel, nstats, missing, intcols, fltcols, ns, vmin, vmax, vmode, mean, stddev);
+}
+
+// Segments with long value runs, one wavefront each (a persistent grid over biglist: [0] = count,
+// ids from [1]).  The sum is a parallel integer sum; the variance and the mode need the runs of equal
+// values IN ORDER (the reference adds one float32 term per distinct value, ascending): the wavefront
+// reads 64 values a step, finds the run boundaries with one ballot and closes the runs that end in
+// the step one after the other -- at most one per distinct value in all, whatever the pixel count.
+__global__ __launch_bounds__(256) void k_seg_stats_big(const uint32_t *__restrict__ vals,
+                                                       const uint32_t *__restrict__ off,
+                                                       const uint32_t *__restrict__ cnt, uint32_t S,
+                                                       long long bias, const uint32_t *__restrict__ sel,
+                                                       int nstats, long long missing,
+                                                       long long *__restrict__ intcols,
+                                                       float *__restrict__ fltcols, const uint32_t *biglist)
+{
+    const unsigned lane = lane_id();
+    const uint32_t nbig = biglist[0];
+    const size_t ns = (size_t)S + 1;
+    for (uint32_t e = blockIdx.x * 4u + (threadIdx.x >> 6); e < nbig; e += gridDim.x * 4u) {
+        const uint32_t s = (uint32_t)__builtin_amdgcn_readfirstlane((int)biglist[1u + e]);
+        const uint32_t n = (uint32_t)__builtin_amdgcn_readfirstlane((int)cnt[s]);
+        const uint32_t *a = vals + (uint32_t)__builtin_amdgcn_readfirstlane((int)off[s]);
+        long long sum = 0;
+        for (uint32_t i = lane; i < n; i += 64u) sum += (long long)a[i] + bias;
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, 64);
+        const float mean = (float)((double)sum / (double)n);
+        float var = 0.0f;
+        uint32_t bestc = 0, curx = (uint32_t)__builtin_amdgcn_readfirstlane((int)a[0]), curc = 0;
+        long long vmode = missing;
+        for (uint32_t base = 0; base < n; base += 64u) {
+            const uint32_t i = base + lane;
+            const bool valid = i < n;
+            const uint32_t x = valid ? a[i] : 0u;
+            uint32_t prev = __shfl_up(x, 1, 64);
+            if (lane == 0) prev = curx;
+            unsigned long long heads = __ballot(valid && x != prev);
+            const uint32_t nvalid = n - base < 64u ? n - base : 64u;
+            uint32_t start = 0;
+            while (heads) {
+                const uint32_t h = (uint32_t)__builtin_ctzll(heads);
+                heads &= heads - 1ull;
+                curc += h - start;
+                const double dd = (double)((long long)curx + bias) - (double)mean;
+                var = var + (float)((double)curc * (dd * dd));
+                if (curc > bestc) { bestc = curc; vmode = (long long)curx + bias; }
+                curx = (uint32_t)__builtin_amdgcn_readlane((int)x, (int)h);
+                curc = 0;
+                start = h;
             }
-        } else if (stat == 0u) val = (double)vmin;
-        else if (stat == 1u) val = (double)vmax;
-        else if (stat == 2u) val = (double)mean;
-        else if (stat == 3u) val = (double)stddev;
-        else if (stat == 5u) val = (double)vmode;
-        else if (stat == 7u) val = (double)n;
-        if (ctype == 0u) intcols[(size_t)cidx * ns + s] = (long long)val;
-        else fltcols[(size_t)cidx * ns + s] = (float)val;
+            curc += nvalid - start;
+        }
+        {
+            const double dd = (double)((long long)curx + bias) - (double)mean;
+            var = var + (float)((double)curc * (dd * dd));
+            if (curc > bestc) { bestc = curc; vmode = (long long)curx + bias; }
+        }
+        if (lane == 0) {
+            const float stddev = (float)sqrt((double)var / (double)n);
+            seg_stats_emit(s, n, a, bias, sel, nstats, missing, intcols, fltcols, ns, (long long)a[0] + bias,
+                           (long long)a[n - 1] + bias, vmode, mean, stddev);
+        }
     }
 }
 
@@ -190,8 +268,13 @@ static int run_segstats(shp_ctx *ctx, const uint32_t *d_seg, const void *d_band,
     }
     ArrFn cf{cnt};
     CHK(scan_exclusive(ctx, cf, (uint32_t)ns, off, nullptr, bp<uint32_t>(ctx->scan_tmp)));
+    // (the list of long segments: in the first sort's key buffer, free by now)
+    uint32_t *biglist = kval;
+    HIPCHK(ctx, hipMemsetAsync(biglist, 0, 4, st));
     hipLaunchKernelGGL(k_seg_stats, dim3(grid_for(ns, 256)), dim3(256), 0, st, v2, off, cnt, S, bias, d_sel,
-                       nstats, (long long)missing, d_int, d_flt); KCHK(ctx);
+                       nstats, (long long)missing, d_int, d_flt, biglist); KCHK(ctx);
+    hipLaunchKernelGGL(k_seg_stats_big, dim3(512), dim3(256), 0, st, v2, off, cnt, S, bias, d_sel, nstats,
+                       (long long)missing, d_int, d_flt, biglist); KCHK(ctx);
     prof_end(ctx, ps);
     if (nint) HIPCHK(ctx, hipMemcpyAsync(intcols_out, d_int, (size_t)nint * ns * 8, hipMemcpyDeviceToHost, st));
     if (nflt) HIPCHK(ctx, hipMemcpyAsync(fltcols_out, d_flt, (size_t)nflt * ns * 4, hipMemcpyDeviceToHost, st));

@@ -208,3 +208,23 @@ def test_stats_on_device_resident_rasters(oracle):
     for name in ('p', 'n', 'mo'):
         assert np.array_equal(got.columns[name], want.columns[name])
     assert np.array_equal(got.columns['n'], wi[1]) and np.array_equal(got.columns['m'].view(np.uint32), wf[0].view(np.uint32))
+
+
+def test_stats_giant_segment_vs_oracle(oracle):
+    """a segment of 1.9 M pixels among small ones: its value run is one wavefront's work
+    (k_seg_stats_big: parallel sum, runs of equal values closed in order), same columns as the oracle"""
+    from pyshepseg_amd import tilingstats
+    rng = np.random.RandomState(12)
+    seg = np.ones((1500, 1500), dtype=np.uint32)
+    seg[:250] = (np.arange(250 * 1500).reshape(250, 1500) // 300 + 2).astype(np.uint32)
+    seg[700:720, 100:900] = 0
+    band = rng.randint(0, 900, size=seg.shape).astype(np.uint16)          # few distinct values: long runs
+    band[300:1400:7] = 65535
+    sel = [('a', 'min'), ('b', 'max'), ('c', 'mean'), ('d', 'stddev'), ('e', 'median'), ('f', 'mode'),
+           ('g', 'percentile', 90), ('h', 'percentile', 0), ('i', 'pixcount')]
+    S = int(seg.max())
+    for null in (None, 65535):
+        ic, fc, _fast = tilingstats.calcPerSegmentStats(seg, band, sel, imgNullVal=null, maxSegId=S)
+        wic, wfc = oracle.segstats(seg, band, sel, null, -9999, max_seg_id=S)
+        assert np.array_equal(ic, wic)
+        assert np.array_equal(fc.view(np.uint32), wfc.view(np.uint32))
