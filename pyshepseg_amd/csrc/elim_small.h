@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void k_spectra_big(
     constexpr bool WIDE = DT == SHP_I32 || DT == SHP_U32;
     typedef typename std::conditional<WIDE, long long, int>::type IT;
     typedef typename std::conditional<WIDE, double, float>::type FT;
-    __shared__ FT tv[4][BG][65];     // 65: lanes (= bands) read down their rows conflict-free
+    __shared__ __attribute__((aligned(16))) FT tv[4][BG][68];     // 68: rows 16-byte aligned, lanes (= bands) read theirs conflict-free
     const unsigned lane = lane_id(), wv = threadIdx.x >> 6;
     const uint32_t nbig = list[0];
     const IT LIM = (IT)1 << 24;
@@ -207,6 +207,20 @@ __global__ __launch_bounds__(256) void k_spectra_big(
                     if (lane < (unsigned)bg) {
                         const FT *row = tv[wv][lane];
                         uint32_t q = 0;
+                        if (!WIDE && cnt == 64u) {
+                            // a whole step: the row comes in as sixteen 16-byte LDS reads issued together
+                            // (eight separate waits for eight values each made the 64 dependent adds a
+                            // 3000-cycle step: the 10000-pixel pieces of the depth-first cut, ~150 steps
+                            // for one wavefront, set this kernel's duration)
+                            float4 r4[16];
+#pragma unroll
+                            for (int u = 0; u < 16; u++) r4[u] = ((const float4 *)row)[u];
+#pragma unroll
+                            for (int u = 0; u < 16; u++) {
+                                acc = acc + r4[u].x; acc = acc + r4[u].y; acc = acc + r4[u].z; acc = acc + r4[u].w;
+                            }
+                            q = 64u;
+                        }
                         for (; q + 8u <= cnt; q += 8u) {
                             FT r[8];
 #pragma unroll
