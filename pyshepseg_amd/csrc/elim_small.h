@@ -48,6 +48,8 @@ __device__ __forceinline__ float f32_acc(float acc, long long v)
 // WIDE = 32-bit pixel types, whose values need the float64 form of the reference's
 // `float32 + pixel` (N5); for 8/16-bit types a float32 add is the same correctly rounded sum.
 #define SPECTRA_BG 8        // bands per pass
+#define SPECTRA_VAL 4       // ordered phase: image values are loaded this many 64-pixel steps ahead of their chain,
+#define SPECTRA_PIX 3       // their pixel indices this many steps ahead of the values (SPECTRA_PIX + 1 == SPECTRA_VAL)
 #define SPECTRA_GRID 4096   // workgroups of the persistent k_spectra_big (latency-bound: fill the wave slots)
 template <typename T> __device__ __forceinline__ T wave_sum_t(T v)
 {
@@ -185,59 +187,79 @@ __global__ __launch_bounds__(256) void k_spectra_big(
             }
             // ---- ordered phase: list order float32 additions, lane = band ----
             if (i0 < bm) {
-                IT cur[BG];
+                // Two-stage software pipeline.  A step's image values hang on its pixel indices (two
+                // dependent memory round trips): issued together once per step they cost the
+                // wavefront a full memory latency per 64 pixels -- and the 10000-pixel pieces of the
+                // depth-first cut, ~150 such steps for ONE wavefront, are this kernel's duration.  So
+                // the indices are loaded SPECTRA_PIX steps before the values that need them, the
+                // values SPECTRA_VAL steps before the chain that adds them.
+                IT V[SPECTRA_VAL][BG];
+                uint32_t P[SPECTRA_VAL];              // (ring of SPECTRA_PIX + 1 = SPECTRA_VAL slots)
+                const uint32_t last = bm - 1u;
+#define SP_PIX(cs) pix[bo + ((cs) + lane < bm ? (cs) + lane : last)]
+#define SP_VAL(dst, p)                                                                   \
+                { const size_t ix_ = geom_off(g, (p));                                    \
+                  _Pragma("unroll") for (int j = 0; j < BG; j++) dst[j] = (IT)ld_t<DT>(img, boff[j] + ix_); }
                 {
-                    const bool valid = i0 + lane < bm;
-                    const size_t ix = geom_off(g, pix[bo + (valid ? i0 + lane : i0)]);
+                    uint32_t p0[SPECTRA_VAL];
 #pragma unroll
-                    for (int j = 0; j < BG; j++) cur[j] = (IT)ld_t<DT>(img, boff[j] + ix);
+                    for (int d = 0; d < SPECTRA_VAL; d++) p0[d] = SP_PIX(i0 + (uint32_t)d * 64u);
+#pragma unroll
+                    for (int d = 0; d < SPECTRA_PIX; d++) P[d] = SP_PIX(i0 + (uint32_t)(SPECTRA_VAL + d) * 64u);
+#pragma unroll
+                    for (int d = 0; d < SPECTRA_VAL; d++) SP_VAL(V[d], p0[d]);
                 }
-                for (uint32_t c0 = i0; c0 < bm; c0 += 64u) {
+                for (uint32_t c0 = i0; c0 < bm; c0 += 64u * SPECTRA_VAL) {
 #pragma unroll
-                    for (int j = 0; j < BG; j++) tv[wv][j][lane] = (FT)cur[j];
-                    __builtin_amdgcn_wave_barrier();
-                    const uint32_t nx = c0 + 64u;
-                    if (nx < bm) {                   // next step's gathers overlap this step's chain
-                        const bool valid = nx + lane < bm;
-                        const size_t ix = geom_off(g, pix[bo + (valid ? nx + lane : nx)]);
+                    for (int d = 0; d < SPECTRA_VAL; d++) {
+                        const uint32_t cs = c0 + (uint32_t)d * 64u;
+                        if (cs >= bm) break;                         // (uniform)
 #pragma unroll
-                        for (int j = 0; j < BG; j++) cur[j] = (IT)ld_t<DT>(img, boff[j] + ix);
-                    }
-                    const uint32_t cnt = bm - c0 < 64u ? bm - c0 : 64u;      // lanes >= cnt staged junk
-                    if (lane < (unsigned)bg) {
-                        const FT *row = tv[wv][lane];
-                        uint32_t q = 0;
-                        if (!WIDE && cnt == 64u) {
-                            // a whole step: the row comes in as sixteen 16-byte LDS reads issued together
-                            // (eight separate waits for eight values each made the 64 dependent adds a
-                            // 3000-cycle step: the 10000-pixel pieces of the depth-first cut, ~150 steps
-                            // for one wavefront, set this kernel's duration)
-                            float4 r4[16];
+                        for (int j = 0; j < BG; j++) tv[wv][j][lane] = (FT)V[d][j];
+                        __builtin_amdgcn_wave_barrier();
+                        // indices of step s + VAL + PIX into the slot its predecessor just left, values of
+                        // step s + VAL from the indices loaded PIX steps ago
+                        const uint32_t pnow = P[d];
+                        P[(d + SPECTRA_PIX) % SPECTRA_VAL] = SP_PIX(cs + (uint32_t)(SPECTRA_VAL + SPECTRA_PIX) * 64u);
+                        SP_VAL(V[d], pnow);
+                        const uint32_t cnt = bm - cs < 64u ? bm - cs : 64u;      // lanes >= cnt staged junk
+                        if (lane < (unsigned)bg) {
+                            const FT *row = tv[wv][lane];
+                            uint32_t q = 0;
+                            if (!WIDE && cnt == 64u) {
+                                // a whole step: the row comes in as sixteen 16-byte LDS reads issued together
+                                // (eight separate waits for eight values each made the 64 dependent adds a
+                                // 3000-cycle step: the 10000-pixel pieces of the depth-first cut, ~150 steps
+                                // for one wavefront, set this kernel's duration)
+                                float4 r4[16];
 #pragma unroll
-                            for (int u = 0; u < 16; u++) r4[u] = ((const float4 *)row)[u];
+                                for (int u = 0; u < 16; u++) r4[u] = ((const float4 *)row)[u];
 #pragma unroll
-                            for (int u = 0; u < 16; u++) {
-                                acc = acc + r4[u].x; acc = acc + r4[u].y; acc = acc + r4[u].z; acc = acc + r4[u].w;
+                                for (int u = 0; u < 16; u++) {
+                                    acc = acc + r4[u].x; acc = acc + r4[u].y; acc = acc + r4[u].z; acc = acc + r4[u].w;
+                                }
+                                q = 64u;
                             }
-                            q = 64u;
-                        }
-                        for (; q + 8u <= cnt; q += 8u) {
-                            FT r[8];
+                            for (; q + 8u <= cnt; q += 8u) {
+                                FT r[8];
 #pragma unroll
-                            for (int u = 0; u < 8; u++) r[u] = row[q + u];
+                                for (int u = 0; u < 8; u++) r[u] = row[q + u];
 #pragma unroll
-                            for (int u = 0; u < 8; u++) {
-                                if (WIDE) acc = (float)((double)acc + (double)r[u]);
-                                else acc = acc + (float)r[u];
+                                for (int u = 0; u < 8; u++) {
+                                    if (WIDE) acc = (float)((double)acc + (double)r[u]);
+                                    else acc = acc + (float)r[u];
+                                }
+                            }
+                            for (; q < cnt; q++) {
+                                if (WIDE) acc = (float)((double)acc + (double)row[q]);
+                                else acc = acc + (float)row[q];
                             }
                         }
-                        for (; q < cnt; q++) {
-                            if (WIDE) acc = (float)((double)acc + (double)row[q]);
-                            else acc = acc + (float)row[q];
-                        }
+                        __builtin_amdgcn_wave_barrier();
                     }
-                    __builtin_amdgcn_wave_barrier();
                 }
+#undef SP_PIX
+#undef SP_VAL
             }
             if (lane < (unsigned)bg) ssum[(size_t)bs * nb + b0 + lane] = acc;
         }
