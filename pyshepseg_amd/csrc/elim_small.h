@@ -79,13 +79,26 @@ __global__ __launch_bounds__(256) void k_spectra_small(
         float acc[BG];
 #pragma unroll
         for (int j = 0; j < BG; j++) acc[j] = 0.0f;
-        for (uint32_t i = 0; i < m; i++) {
-            const size_t idx = geom_off(g, pix[o + i]);
-            long long v[BG];
+        // (the pixel index is loaded two pixels ahead of its values, the values one pixel ahead of their
+        //  additions: a pixel otherwise costs two dependent memory round trips)
+        uint32_t p1 = pix[o], p2 = pix[o + (m > 1u ? 1u : 0u)];
+        long long v[BG];
+        {
+            const size_t idx = geom_off(g, p1);
 #pragma unroll
             for (int j = 0; j < BG; j++) v[j] = ld_t<DT>(img, base + (size_t)(j < bg ? j : 0) * g.bstride + idx);
+        }
+        for (uint32_t i = 0; i < m; i++) {
+            const uint32_t p3 = pix[o + (i + 2u < m ? i + 2u : m - 1u)];
+            long long vn[BG];
+            const size_t idx = geom_off(g, p2);
+#pragma unroll
+            for (int j = 0; j < BG; j++) vn[j] = ld_t<DT>(img, base + (size_t)(j < bg ? j : 0) * g.bstride + idx);
 #pragma unroll
             for (int j = 0; j < BG; j++) acc[j] = WIDE ? f32_acc(acc[j], v[j]) : acc[j] + (float)(int)v[j];
+#pragma unroll
+            for (int j = 0; j < BG; j++) v[j] = vn[j];
+            p2 = p3;
         }
 #pragma unroll
         for (int j = 0; j < BG; j++)
