@@ -12,7 +12,8 @@ parameters, runs the HIP path and the C oracle, and compares bit for bit:
          the stitch vs oracle tiles + oracle.stitch_tiles
   paged  tilingstats.calcPerSegmentStatsTiled in small chunks (RAT pages) vs the whole-raster statistics
   big    the same as tile on 1000-2600-pixel rasters with few value levels (components of 10^5-10^6
-         pixels: the depth-first cut, its stack spills and the global-memory walk)
+         pixels: the depth-first cut, its stack spills and the global-memory walk), alternating with
+         tiled runs of 1400-3200-pixel rasters (several cluster-map blocks, up to 23 workers)
 usage: python tools/fuzz_gpu.py [ncases] [seed] [big|more]     (prints one line per failure and a summary;
        `more` runs the fit / subset / spatial / spectra / paged kinds instead of tile / tiled / stats)"""
 import os
@@ -52,6 +53,9 @@ def one_case(rng, kind):
     if kind == 'big':
         (nr, nc) = (int(rng.integers(1000, 2600)), int(rng.integers(1000, 2600)))
         nb = int(rng.integers(1, 4))
+    elif kind == 'bigtiled':
+        (nr, nc) = (int(rng.integers(1400, 3200)), int(rng.integers(1400, 3200)))
+        nb = int(rng.integers(1, 7))
     elif kind == 'tiled':
         (nr, nc) = (int(rng.integers(150, 420)), int(rng.integers(150, 420)))
     elif shape_kind < 0.1:
@@ -60,7 +64,7 @@ def one_case(rng, kind):
         (nr, nc) = (int(rng.integers(1, 500)), 1)
     else:
         (nr, nc) = (int(rng.integers(2, 400)), int(rng.integers(2, 400)))
-    img = make_image(rng, dtype, nb, nr, nc, 5 if kind == 'big' else 40)
+    img = make_image(rng, dtype, nb, nr, nc, 5 if kind == 'big' else 12 if kind == 'bigtiled' else 40)
     nullv = None
     if rng.random() < 0.4:
         nullv = int(img.flat[int(rng.integers(0, img.size))]) if rng.random() < 0.5 else int(np.iinfo(dtype).max)
@@ -68,6 +72,8 @@ def one_case(rng, kind):
             r0 = int(rng.integers(0, nr))
             img[:, r0:r0 + int(rng.integers(1, 8)), :] = nullv
     k = int(rng.integers(2, 6 if kind == 'big' else 25))
+    if kind == 'bigtiled':
+        k = int(rng.integers(4, 16))
     four = bool(rng.integers(0, 2))
     minseg = int(rng.integers(1, 70))
     xs = shepseg._sample_rows(img, 100, nullv)
@@ -89,10 +95,12 @@ def one_case(rng, kind):
         if kind == 'big':
             desc += ' clumps=%d' % int(want['numClumps'])
         return ok, desc
-    if kind == 'tiled':
+    if kind in ('tiled', 'bigtiled'):
         (tile, ov) = [(96, 32), (128, 48), (80, 24), (160, 64)][int(rng.integers(0, 4))]
+        if kind == 'bigtiled':          # several cluster-map blocks, many tiles in flight
+            (tile, ov) = [(512, 128), (640, 192), (1024, 256), (768, 64)][int(rng.integers(0, 4))]
         cfg = tiling.SegmentationConcurrencyConfig(concurrencyType=tiling.CONC_THREADS,
-                                                   numWorkers=int(rng.integers(1, 6)))
+                                                   numWorkers=int(rng.integers(1, 6 if kind == 'tiled' else 24)))
         r = tiling.doTiledShepherdSegmentation(img, None, tileSize=tile, overlapSize=ov, minSegmentSize=minseg,
                                                numClusters=k, maxSpectralDiff=msd, imgNullVal=nullv,
                                                fourConnected=four, kmeansObj=km, concurrencyCfg=cfg)
@@ -266,11 +274,11 @@ def main():
     import tempfile
     tmpdir = tempfile.mkdtemp()
     rng = np.random.default_rng(seed)
-    counts = {'tile': [0, 0], 'tiled': [0, 0], 'stats': [0, 0], 'big': [0, 0], 'fit': [0, 0], 'subset': [0, 0],
+    counts = {'tile': [0, 0], 'tiled': [0, 0], 'stats': [0, 0], 'big': [0, 0], 'bigtiled': [0, 0], 'fit': [0, 0], 'subset': [0, 0],
               'spatial': [0, 0], 'spectra': [0, 0], 'paged': [0, 0], 'sharded': [0, 0]}
     t0 = time.time()
     for i in range(n):
-        kind = 'big' if big else ('tile', 'tile', 'tiled', 'stats')[i % 4]
+        kind = ('big', 'bigtiled')[i % 2] if big else ('tile', 'tile', 'tiled', 'stats')[i % 4]
         if more:
             kind = ('fit', 'subset', 'spatial', 'spectra', 'paged', 'sharded')[i % 6]
         if len(sys.argv) > 4:
