@@ -14,7 +14,7 @@ parameters, runs the HIP path and the C oracle, and compares bit for bit:
   big    the same as tile on 1000-2600-pixel rasters with few value levels (components of 10^5-10^6
          pixels: the depth-first cut, its stack spills and the global-memory walk), alternating with
          tiled runs of 1400-3200-pixel rasters (several cluster-map blocks, up to 23 workers)
-usage: python tools/fuzz_gpu.py [ncases] [seed] [big|more]     (prints one line per failure and a summary;
+usage: python tests/fuzz_gpu.py [ncases] [seed] [big|more]     (prints one line per failure and a summary;
        `more` runs the fit / subset / spatial / spectra / paged kinds instead of tile / tiled / stats)"""
 import os
 import sys

@@ -1,12 +1,11 @@
-"""Stage timings of one tile on the GPU (+ optional oracle parity check)."""
+"""Stage timings of one tile on the GPU (parity against the oracle lives in tests/: test_gpu_tile.py,
+tests/fuzz_gpu.py)."""
 import sys, time, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from pyshepseg_amd import shepseg, _lib
-from oracle import oracle
 
 size = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
-check = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 nb, k, minseg = 6, 60, 50
 c = _lib.ctx()
 img = np.empty((nb, size, size), dtype=np.uint16)
@@ -17,7 +16,3 @@ for rep in range(3):
     r = shepseg.doShepherdSegmentation(img, minSegmentSize=minseg, kmeansObj=km)
     dt = time.time() - t
     print('rep %d wall %.3fs  %.1f Mpix/s  segs %d  timings(ms) %s' % (rep, dt, size * size / dt / 1e6, r.segimg.max(), {k2: round(v, 2) for k2, v in r.timings.items()}))
-if check:
-    t = time.time()
-    want = oracle.segment_tile(img, km.cluster_centers_, minseg, float(r.maxSpectralDiff), None, True)
-    print('oracle %.2fs  equal=%s clumps %d' % (time.time() - t, np.array_equal(want['segimg'], r.segimg), want['numClumps']))

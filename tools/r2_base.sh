@@ -1,6 +1,6 @@
 # round-2 baseline: single-tile stage timings with the pass-loop phase breakdown, then a kernel trace of one default step
 R=$PWD; cd /tmp && export TMPDIR=/tmp; cd $R
-SHEPSEG_SMALL_TIMING=1 timeout -k 10 300 python tools/perf_tile.py 4096 0 > gpurun_out/r2_tile.log 2>&1; tail -12 gpurun_out/r2_tile.log
+SHEPSEG_SMALL_TIMING=1 timeout -k 10 300 python tools/perf_tile.py 4096 > gpurun_out/r2_tile.log 2>&1; tail -12 gpurun_out/r2_tile.log
 rm -rf gpurun_out/tl
 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/tl -o run -- python bench.py --steps 1 --warmup 1 --cpu-sample 0 > gpurun_out/tl.log 2>&1 &&
 f=$(ls gpurun_out/tl/*kernel_trace.csv gpurun_out/tl/*/*kernel_trace.csv 2>/dev/null | head -1) &&

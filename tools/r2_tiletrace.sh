@@ -1,7 +1,7 @@
 # kernel trace of ONE tile run alone (no contention): per-kernel duration and the gaps between launches
 R=$PWD; cd /tmp && export TMPDIR=/tmp; cd $R
 rm -rf gpurun_out/tt
-timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/tt -o run -- python tools/perf_tile.py 4096 ${TT_CHECK:-0} > gpurun_out/tt.log 2>&1 &&
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/tt -o run -- python tools/perf_tile.py 4096 > gpurun_out/tt.log 2>&1 &&
 f=$(ls gpurun_out/tt/*kernel_trace.csv gpurun_out/tt/*/*kernel_trace.csv 2>/dev/null | head -1) &&
 python - "$f" <<'PY'
 import csv, sys
