@@ -19,7 +19,9 @@ What shards and what does not
   - parallel (default with more than one rank): tile t numbers its new segments from a
     PROVISIONAL base t * stride (stride = 2^32 / number of tiles), so its chain step needs the
     strips of the tiles above and to the left only -- a rank starts as soon as the first strip of
-    the previous rank's last row arrives, strips travel tile by tile.  Every tile reports K_t =
+    the previous rank's last row arrives, strips travel tile by tile, and a rank takes its tiles
+    along anti-diagonals so that the tiles of its last row are ready two steps apart instead of a
+    row apart (SHEPSEG_CHAIN_ORDER=rowmajor: the old order).  Every tile reports K_t =
     ids handed out and R_t = the largest of them present in its trimmed window; an all-gather
     later, if K_t == R_t everywhere, the sequential run would have found maxSegId = sum of the
     earlier K (the reference advances it to trimmed.max()), the provisional ids are in the same
@@ -290,8 +292,14 @@ def runDistributed(engine, comm, nRows, nCols, tileSize, overlapSize, minSegment
         stride = 0xFFFFFFFF // max(ntAll, 1)
         mine = []
         if haveTiles:
-            # strips cross the rank boundary tile by tile, in the sender's tile order ('b' before 'r')
-            order = lambda plan: sorted(plan, key=lambda it: (it[2] * ncolsT + it[1], it[0] != 'b'))
+            # With provisional ids a chain step needs its two neighbours only, so a rank takes its
+            # tiles along anti-diagonals (row + col ascending): the tiles of its LAST row are then
+            # done two steps apart instead of a row apart, and the next rank, which waits for them
+            # one by one, follows two steps behind instead of a row behind.  Strips cross the rank
+            # boundary tile by tile in that order ('b' before 'r'); both sides derive it.
+            wave = os.environ.get('SHEPSEG_CHAIN_ORDER', 'diagonal') != 'rowmajor'
+            tkey = (lambda c, r: (r + c, r)) if wave else (lambda c, r: (r * ncolsT + c, 0))
+            order = lambda plan: sorted(plan, key=lambda it: tkey(it[1], it[2]) + (it[0] != 'b',))
             planPrev = order(boundaryPlan(tileInfo, shards, prevRank, overlapSize)) if prevRank is not None else []
             sendOf = {}
             if nextRank is not None:
@@ -306,7 +314,7 @@ def runDistributed(engine, comm, nRows, nCols, tileSize, overlapSize, minSegment
                     got[0] += 1
                     fromPrev[(it[0], it[1], it[2])] = engine.recvStrip(comm, prevRank, it)
             engine.beginProvisional(stride, ntAll)
-            for (slot, j) in enumerate(jobs):
+            for (slot, j) in sorted(enumerate(jobs), key=lambda sj: tkey(sj[1].col, sj[1].row)):
                 if j.row > 0 and (j.col, j.row - 1) not in jobmap:
                     need(('b', j.col, j.row - 1))
                 if j.col > 0 and (j.col - 1, j.row) not in jobmap:

@@ -147,18 +147,22 @@ def test_parallel_stitch_equals_reference_mosaic(name, world, tmp_path):
         assert modes == {'parallel'}
 
 
-@pytest.mark.parametrize('world,simple,NR,mode,shard', [
-    (2, 0, 330, 'parallel', 'rows'), (3, 0, 330, 'parallel', 'tiles'), (2, 1, 330, 'sequential', 'tiles'),
-    (3, 0, 150, 'parallel', 'rows'), (3, 0, 330, 'sequential', 'tiles'), (2, 0, 330, 'parallel', 'tiles'),
-    (3, 0, 330, 'sequential', 'rows')])
-def test_two_rank_chain_matches_single_process(world, simple, NR, mode, shard, tmp_path, oracle):
+@pytest.mark.parametrize('world,simple,NR,mode,shard,order', [
+    (2, 0, 330, 'parallel', 'rows', 'diagonal'), (3, 0, 330, 'parallel', 'tiles', 'diagonal'),
+    (2, 1, 330, 'sequential', 'tiles', 'diagonal'), (3, 0, 150, 'parallel', 'rows', 'diagonal'),
+    (3, 0, 330, 'sequential', 'tiles', 'diagonal'), (2, 0, 330, 'parallel', 'tiles', 'rowmajor'),
+    (3, 0, 330, 'sequential', 'rows', 'diagonal'), (2, 0, 330, 'parallel', 'rows', 'rowmajor'),
+    (2, 0, 330, 'parallel', 'tiles', 'diagonal')])
+def test_two_rank_chain_matches_single_process(world, simple, NR, mode, shard, order, tmp_path, oracle):
+    # order: a rank's chain steps of the parallel stitch along anti-diagonals or in row-major order
     # NR = 150: two tile rows for three ranks -> whole-row shards and a rank without tiles
     img = oracle.synthimg(31, 3, NR, 260)
     img[:, :4, :] = 65535                      # a null border row band (nulls are not given here)
     np.save(tmp_path / 'img.npy', img)
     tile, ov = 96, 32
     _run_ranks(world, [os.path.join(ROOT, 'tests', 'dist_worker.py'), str(tmp_path), str(tile), str(ov),
-                       str(simple)], tmp_path, extra_env={'SHEPSEG_STITCH': mode, 'SHEPSEG_SHARD': shard})
+                       str(simple)], tmp_path,
+               extra_env={'SHEPSEG_STITCH': mode, 'SHEPSEG_SHARD': shard, 'SHEPSEG_CHAIN_ORDER': order})
     parts = [np.load(tmp_path / ('rank%d.npz' % r)) for r in range(world)]
     assert {str(q['mode']).split('->')[0] for q in parts} == {mode}
     # single-process reference: oracle tiles + oracle stitch with the same centres
