@@ -152,7 +152,10 @@ def segment_tile(img, centres, min_seg_size, max_spectral_diff, null_val=None, f
                 smallSegmentsEliminated=s2.value, numClumps=ncl.value)
 
 
-def kmeans_fit(xsample, init, max_iter=300, tol=1e-4):
+def kmeans_fit(xsample, init, max_iter=300, tol=1e-4, mstep='rows', algorithm='full'):
+    """algorithm='full': Lloyd; 'elkan': what sklearn 0.24.2's KMeans(algorithm='auto') runs for k > 1.
+    mstep='rows': sklearn's one-thread summation order; 'device': the sums of the M-step
+    associated as the HIP fit does (chunks of min(256, 4096 // nBands) rows, groups of 64 chunks)"""
     x = np.ascontiguousarray(xsample, dtype=np.float64)
     init = np.ascontiguousarray(init, dtype=np.float64)
     n, nb = x.shape
@@ -160,8 +163,10 @@ def kmeans_fit(xsample, init, max_iter=300, tol=1e-4):
     centres = np.empty((k, nb), dtype=np.float64)
     labels = np.empty(n, dtype=np.int32)
     nit = ctypes.c_int(0)
-    rc = lib().orc_kmeans_fit(_p(x), ctypes.c_int64(n), nb, k, _p(init), int(max_iter),
-                              ctypes.c_double(tol), _p(centres), _p(labels), ctypes.byref(nit))
+    (chunk, group) = (min(256, 4096 // nb), 64) if mstep == 'device' else (0, 0)
+    fn = lib().orc_kmeans_fit_elkan if (algorithm == 'elkan' and k > 1) else lib().orc_kmeans_fit_assoc
+    rc = fn(_p(x), ctypes.c_int64(n), nb, k, _p(init), int(max_iter), ctypes.c_double(tol), chunk, group,
+            _p(centres), _p(labels), ctypes.byref(nit))
     assert rc == 0
     return centres, labels, nit.value
 

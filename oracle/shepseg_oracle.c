@@ -555,8 +555,228 @@ static void lloyd_assign(const double *X, size_t n, int nb, const double *C, int
     free(cn); free(m2c);
 }
 
-ORC_API int orc_kmeans_fit(const double *xin, int64_t nrows, int nbands, int k,
+/* ---- two pieces of numpy 1.26 that decide which samples an empty cluster is moved to
+ * (_k_means_fast.pyx _relocate_empty_clusters_dense: distances = ((X - centers_old[labels])**2).sum(axis=1);
+ *  far_from_centers = np.argpartition(distances, -n_empty)[:-n_empty-1:-1]), restated because on
+ * lattice-valued imagery many samples are equally far and the choice among them steers the rest of the
+ * fit.  Both pinned against numpy itself by oracle/refgen/probe_elkan.py (experiments 3 and 4). ---- */
+
+/* DOUBLE_pairwise_sum (numpy/core/src/umath/loops_utils.h.src) of a contiguous run: what a float64
+ * .sum() over the last axis evaluates.  Plain left-to-right below 8 elements. */
+static double np_pairwise_sum(const double *a, size_t n)
+{
+    if (n < 8) {
+        double res = 0.0;
+        for (size_t i = 0; i < n; i++) res += a[i];
+        return res;
+    }
+    if (n <= 128) {
+        double r[8];
+        size_t i;
+        for (int j = 0; j < 8; j++) r[j] = a[j];
+        for (i = 8; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; j++) r[j] += a[i + j];
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; i++) res += a[i];
+        return res;
+    }
+    size_t n2 = n / 2;
+    n2 -= n2 % 8;
+    return np_pairwise_sum(a, n2) + np_pairwise_sum(a + n2, n - n2);
+}
+
+/* np.argpartition(v, kth) for float64 without NaNs: numpy/core/src/npysort/selection.cpp
+ * introselect_<npy::double_tag, arg=true> (median-of-3 quickselect, median of medians of 5 once the
+ * depth limit is spent, selection by repeated minimum when kth is within 3 of the low end), the
+ * index array starting as 0..num-1.  No pivot cache (a single kth). */
+#define ASWAP(a, b) do { int64_t t_ = (a); (a) = (b); (b) = t_; } while (0)
+static void np_aintroselect(const double *v, int64_t *t, int64_t num, int64_t kth);
+static int64_t np_amedian5(const double *v, int64_t *t)
+{
+    if (v[t[1]] < v[t[0]]) ASWAP(t[1], t[0]);
+    if (v[t[4]] < v[t[3]]) ASWAP(t[4], t[3]);
+    if (v[t[3]] < v[t[0]]) ASWAP(t[3], t[0]);
+    if (v[t[4]] < v[t[1]]) ASWAP(t[4], t[1]);
+    if (v[t[2]] < v[t[1]]) ASWAP(t[2], t[1]);
+    if (v[t[3]] < v[t[2]]) return (v[t[3]] < v[t[1]]) ? 1 : 3;
+    return 2;
+}
+static int64_t np_amedian_of_median5(const double *v, int64_t *t, int64_t num)
+{
+    const int64_t right = num - 1, nmed = (right + 1) / 5;
+    for (int64_t i = 0, subleft = 0; i < nmed; i++, subleft += 5) {
+        const int64_t m = np_amedian5(v, t + subleft);
+        ASWAP(t[subleft + m], t[i]);
+    }
+    if (nmed > 2) np_aintroselect(v, t, nmed, nmed / 2);
+    return nmed / 2;
+}
+static void np_aintroselect(const double *v, int64_t *t, int64_t num, int64_t kth)
+{
+    int64_t low = 0, high = num - 1;
+    if (kth - low < 3) {                                   /* dumb_select_ */
+        const int64_t n2 = high - low + 1;
+        for (int64_t i = 0; i <= kth - low; i++) {
+            int64_t minidx = i;
+            double minval = v[t[low + i]];
+            for (int64_t q = i + 1; q < n2; q++)
+                if (v[t[low + q]] < minval) { minidx = q; minval = v[t[low + q]]; }
+            ASWAP(t[low + i], t[low + minidx]);
+        }
+        return;
+    }
+    if (kth == num - 1) {
+        int64_t maxidx = low;
+        double maxval = v[t[low]];
+        for (int64_t q = low + 1; q < num; q++)
+            if (!(v[t[q]] < maxval)) { maxidx = q; maxval = v[t[q]]; }
+        ASWAP(t[kth], t[maxidx]);
+        return;
+    }
+    int depth_limit = 0;
+    for (uint64_t u = (uint64_t)num >> 1; u; u >>= 1) depth_limit++;      /* npy_get_msb */
+    depth_limit *= 2;
+    for (; low + 1 < high;) {
+        int64_t ll = low + 1, hh = high;
+        if (depth_limit > 0 || hh - ll < 5) {
+            const int64_t mid = low + (high - low) / 2;    /* median3_swap_ */
+            if (v[t[high]] < v[t[mid]]) ASWAP(t[high], t[mid]);
+            if (v[t[high]] < v[t[low]]) ASWAP(t[high], t[low]);
+            if (v[t[low]] < v[t[mid]]) ASWAP(t[low], t[mid]);
+            ASWAP(t[mid], t[low + 1]);
+        } else {
+            const int64_t mid = ll + np_amedian_of_median5(v, t + ll, hh - ll);
+            ASWAP(t[mid], t[low]);
+            ll--; hh++;
+        }
+        depth_limit--;
+        const double pivot = v[t[low]];
+        for (;;) {                                         /* unguarded_partition_ */
+            do ll++; while (v[t[ll]] < pivot);
+            do hh--; while (pivot < v[t[hh]]);
+            if (hh < ll) break;
+            ASWAP(t[hh], t[ll]);
+        }
+        ASWAP(t[low], t[hh]);
+        if (hh >= kth) high = hh - 1;
+        if (hh <= kth) low = ll;
+    }
+    if (high == low + 1 && v[t[high]] < v[t[low]]) ASWAP(t[high], t[low]);
+}
+ORC_API void orc_np_argpartition(const double *v, int64_t num, int64_t kth, int64_t *out)
+{
+    for (int64_t i = 0; i < num; i++) out[i] = i;
+    if (num > 0) np_aintroselect(v, out, num, kth);
+}
+ORC_API double orc_np_pairwise_sum(const double *a, int64_t n) { return np_pairwise_sum(a, (size_t)n); }
+
+/* ---- Elkan's variant (what KMeans(algorithm="auto") runs for k > 1 in sklearn 0.24.2:
+ * _kmeans.py:824-825, _kmeans_single_elkan :300-428, _k_means_elkan.pyx init_bounds_dense /
+ * elkan_iter_chunked_dense / _update_chunk_dense).  In exact arithmetic it visits the partitions of
+ * Lloyd's algorithm; in float64 it differs wherever a sample is (nearly) equidistant from two
+ * centres: distances are the direct sqrt(sum (x - c)^2) of _euclidean_dense_dense instead of the
+ * dgemm expansion, a sample keeps its label unless another centre is STRICTLY closer, and the
+ * triangle-inequality bounds decide which distances are looked at at all.  Restated operation by
+ * operation, bounds included, so that exact ties fall the way the reference's do. ---- */
+static double elk_dist(const double *a, const double *b, int nf)          /* _euclidean_dense_dense, squared=False */
+{
+    int n4 = nf / 4, rem = nf % 4;
+    double result = 0.0;
+    for (int i = 0; i < n4; i++) {
+        result += ((a[0] - b[0]) * (a[0] - b[0]) + (a[1] - b[1]) * (a[1] - b[1]) +
+                   (a[2] - b[2]) * (a[2] - b[2]) + (a[3] - b[3]) * (a[3] - b[3]));
+        a += 4; b += 4;
+    }
+    for (int i = 0; i < rem; i++) result += (a[i] - b[i]) * (a[i] - b[i]);
+    return sqrt(result);
+}
+
+/* center_half_distances = euclidean_distances(centers) / 2 (sklearn.metrics.pairwise: -2 X.X^T + |x|^2
+ * + |y|^2, clipped at 0, zero diagonal, sqrt; the k x k product as this stack's BLAS evaluates it for
+ * these shapes: products and sums one after the other in band order, no fma -- pinned by
+ * oracle/refgen/probe_elkan.py) and distance_next_center = np.partition(half, 1, axis=0)[1] */
+static void elk_half_distances(const double *C, int k, int nb, double *half, double *next)
+{
+    double *xx = (double *)malloc(sizeof(double) * k);
+    for (int a = 0; a < k; a++) xx[a] = orc_sqnorm(C + (size_t)a * nb, nb);
+    for (int a = 0; a < k; a++)
+        for (int b = 0; b < k; b++) {
+            double d = 0.0;
+            for (int t = 0; t < nb; t++) d = d + C[(size_t)a * nb + t] * C[(size_t)b * nb + t];
+            double v = -2.0 * d;
+            v = v + xx[a];
+            v = v + xx[b];
+            if (!(v > 0.0)) v = 0.0;
+            if (a == b) v = 0.0;
+            half[(size_t)a * k + b] = sqrt(v) / 2.0;
+        }
+    for (int l = 0; l < k; l++) {          /* second smallest of column l (the diagonal zero is the smallest) */
+        double m0 = half[l], m1 = -1.0;
+        for (int a = 1; a < k; a++) {
+            const double v = half[(size_t)a * k + l];
+            if (v < m0) { m1 = m0; m0 = v; }
+            else if (m1 < 0.0 || v < m1) m1 = v;
+        }
+        next[l] = k > 1 ? m1 : m0;
+    }
+    free(xx);
+}
+
+static void elk_init_bounds(const double *X, size_t n, int nb, const double *C, int k, const double *half,
+                            int32_t *lab, double *ub, double *lb)
+{
+    for (size_t i = 0; i < n; i++) {
+        int best = 0;
+        double min_dist = elk_dist(X + i * nb, C, nb);
+        lb[i * k] = min_dist;
+        for (int j = 1; j < k; j++)
+            if (min_dist > half[(size_t)best * k + j]) {
+                const double dist = elk_dist(X + i * nb, C + (size_t)j * nb, nb);
+                lb[i * k + j] = dist;
+                if (dist < min_dist) { min_dist = dist; best = j; }
+            }
+        lab[i] = best;
+        ub[i] = min_dist;
+    }
+}
+
+static void elk_estep(const double *X, size_t n, int nb, const double *C, int k, const double *half,
+                      const double *next, int32_t *lab, double *ub, double *lb)
+{
+    for (size_t i = 0; i < n; i++) {
+        double upper = ub[i];
+        int tight = 0, label = lab[i];
+        if (!(next[label] >= upper)) {
+            for (int j = 0; j < k; j++)
+                if (j != label && upper > lb[i * k + j] && upper > half[(size_t)label * k + j]) {
+                    if (!tight) {
+                        upper = elk_dist(X + i * nb, C + (size_t)label * nb, nb);
+                        lb[i * k + label] = upper;
+                        tight = 1;
+                    }
+                    if (upper > lb[i * k + j] || upper > half[(size_t)label * k + j]) {
+                        const double dist = elk_dist(X + i * nb, C + (size_t)j * nb, nb);
+                        lb[i * k + j] = dist;
+                        if (dist < upper) { label = j; upper = dist; }
+                    }
+                }
+            lab[i] = label;
+            ub[i] = upper;
+        }
+    }
+}
+
+/* chunk_rows == 0: the M-step sums rows one after the other, as sklearn does with one OpenMP
+ * thread (_kmeans_lloyd.pyx lloyd_iter_chunked_dense / _update_chunk_dense; with more threads
+ * sklearn adds per-thread partial sums in whatever order the threads finish, so the association
+ * of these sums is not fixed by the reference).  chunk_rows > 0: the sums are associated as
+ * the HIP fit does (kmeans.h k_fit_partial / k_fit_reduce1 / k_fit_update): per chunk of
+ * chunk_rows rows in row order, the chunks of a group of group_chunks in chunk order, the groups
+ * in order.  Everything else is identical; tests use the second form to show that where the
+ * device and the row-order oracle part ways the association of these sums is the only cause. */
+static int kmeans_fit_impl(const double *xin, int64_t nrows, int nbands, int k,
                            const double *init, int max_iter, double tol_rel,
+                           int chunk_rows, int group_chunks, int elkan,
                            double *centres_out, int32_t *labels_out, int *n_iter_out)
 {
     size_t n = (size_t)nrows;
@@ -589,40 +809,72 @@ ORC_API int orc_kmeans_fit(const double *xin, int64_t nrows, int nbands, int k,
     }
     tol = tol / nb * tol_rel;
     int strict = 0, it = 0, have_old = 0;
+    double *half = NULL, *next = NULL, *ub = NULL, *lb = NULL, *cshift = NULL;
+    if (elkan) {
+        half = (double *)malloc(sizeof(double) * k * k);
+        next = (double *)malloc(sizeof(double) * k);
+        cshift = (double *)malloc(sizeof(double) * k);
+        ub = (double *)calloc(n ? n : 1, sizeof(double));
+        lb = (double *)calloc((n ? n : 1) * (size_t)k, sizeof(double));
+        elk_half_distances(C, k, nb, half, next);
+        elk_init_bounds(X, n, nb, C, k, half, lab, ub, lb);
+    }
     for (it = 1; it <= max_iter; it++) {
-        lloyd_assign(X, n, nb, C, k, lab);
+        if (elkan) elk_estep(X, n, nb, C, k, half, next, lab, ub, lb);
+        else lloyd_assign(X, n, nb, C, k, lab);
         memset(Cn, 0, sizeof(double) * k * nb);
         memset(w, 0, sizeof(double) * k);
-        for (size_t i = 0; i < n; i++) {
-            w[lab[i]] += 1.0;
-            for (int b = 0; b < nb; b++) Cn[lab[i] * nb + b] += X[i * nb + b];
+        if (chunk_rows <= 0) {
+            for (size_t i = 0; i < n; i++) {
+                w[lab[i]] += 1.0;
+                for (int b = 0; b < nb; b++) Cn[lab[i] * nb + b] += X[i * nb + b];
+            }
+        } else {
+            const int kn = k * nb;
+            double *P = (double *)malloc(sizeof(double) * kn), *P2 = (double *)malloc(sizeof(double) * kn);
+            const size_t gl = (size_t)chunk_rows * (size_t)(group_chunks > 0 ? group_chunks : 1);
+            for (size_t g0 = 0; g0 < n; g0 += gl) {
+                const size_t g1 = g0 + gl < n ? g0 + gl : n;
+                for (int t = 0; t < kn; t++) P2[t] = 0.0;
+                for (size_t c0 = g0; c0 < g1; c0 += (size_t)chunk_rows) {
+                    const size_t c1 = c0 + (size_t)chunk_rows < g1 ? c0 + (size_t)chunk_rows : g1;
+                    for (int t = 0; t < kn; t++) P[t] = 0.0;
+                    for (size_t i = c0; i < c1; i++) {
+                        w[lab[i]] += 1.0;
+                        for (int b = 0; b < nb; b++) P[lab[i] * nb + b] += X[i * nb + b];
+                    }
+                    for (int t = 0; t < kn; t++) P2[t] += P[t];
+                }
+                for (int t = 0; t < kn; t++) Cn[t] += P2[t];
+            }
+            free(P); free(P2);
         }
         int n_empty = 0;
         for (int j = 0; j < k; j++) n_empty += (w[j] == 0.0);
         if (n_empty > 0) {
             /* _relocate_empty_clusters_dense: farthest samples from their OLD centres */
             double *dist = (double *)malloc(sizeof(double) * n);
+            double *sq = (double *)malloc(sizeof(double) * nb);
             double dmax = 0.0;
             for (size_t i = 0; i < n; i++) {
-                double d = 0.0;
                 for (int b = 0; b < nb; b++) {
                     double t = X[i * nb + b] - C[lab[i] * nb + b];
-                    d += t * t;
+                    sq[b] = t * t;
                 }
+                const double d = np_pairwise_sum(sq, (size_t)nb);
                 dist[i] = d; if (d > dmax) dmax = d;
             }
+            free(sq);
             if (ORC_RELOCATE_GUARD == 0 || dmax > 0.0) {
-                /* empty_clusters is taken once, ascending (np.where), before any move */
+                /* empty_clusters is taken once, ascending (np.where), before any move; the r-th of
+                 * them gets far_from_centers[r] = np.argpartition(distances, -n_empty)[n - 1 - r] */
                 int *empties = (int *)malloc(sizeof(int) * n_empty);
+                int64_t *part = (int64_t *)malloc(sizeof(int64_t) * n);
                 int ne = 0;
                 for (int j = 0; j < k; j++) if (w[j] == 0.0) empties[ne++] = j;
+                orc_np_argpartition(dist, (int64_t)n, (int64_t)n - n_empty, part);
                 for (int r = 0; r < n_empty; r++) {
-                    /* r-th farthest sample: distance descending, index ascending on ties
-                     * (np.argpartition leaves the order among the n_empty farthest
-                     * implementation-defined; it only permutes cluster indices, N12) */
-                    size_t f = 0; double fd = -1.0;
-                    for (size_t i = 0; i < n; i++) if (dist[i] > fd) { fd = dist[i]; f = i; }
-                    dist[f] = -2.0;
+                    const size_t f = (size_t)part[n - 1 - (size_t)r];
                     int e = empties[r];
                     int old = lab[f];
                     for (int b = 0; b < nb; b++) {
@@ -631,7 +883,7 @@ ORC_API int orc_kmeans_fit(const double *xin, int64_t nrows, int nbands, int k,
                     }
                     w[e] = 1.0; w[old] -= 1.0;
                 }
-                free(empties);
+                free(empties); free(part);
             }
             free(dist);
         }
@@ -653,7 +905,9 @@ ORC_API int orc_kmeans_fit(const double *xin, int64_t nrows, int nbands, int k,
         }
         /* center_shift[j] = euclidean norm (4-way unrolled in sklearn's
          * _euclidean_dense_dense), center_shift_tot = sum(center_shift**2) */
+        /* ... center_shift_tot = (center_shift**2).sum(): numpy's pairwise sum */
         double shift = 0.0;
+        double *shsq = (double *)malloc(sizeof(double) * k);
         for (int j = 0; j < k; j++) {
             const double *a = &Cn[j * nb], *c = &C[j * nb];
             double r = 0.0;
@@ -664,7 +918,21 @@ ORC_API int orc_kmeans_fit(const double *xin, int64_t nrows, int nbands, int k,
                       (a[b + 3] - c[b + 3]) * (a[b + 3] - c[b + 3]));
             for (; b < nb; b++) r += (a[b] - c[b]) * (a[b] - c[b]);
             double s = sqrt(r);
-            shift += s * s;
+            shsq[j] = s * s;
+            if (elkan) cshift[j] = s;
+        }
+        shift = np_pairwise_sum(shsq, (size_t)k);
+        free(shsq);
+        if (elkan) {
+            /* end of elkan_iter: the bounds follow the centres; then the new centres' half distances */
+            for (size_t i = 0; i < n; i++) {
+                ub[i] += cshift[lab[i]];
+                for (int j = 0; j < k; j++) {
+                    lb[i * k + j] -= cshift[j];
+                    if (lb[i * k + j] < 0) lb[i * k + j] = 0;
+                }
+            }
+            elk_half_distances(Cn, k, nb, half, next);
         }
         memcpy(C, Cn, sizeof(double) * k * nb);
         if (have_old && memcmp(lab, lab_old, sizeof(int32_t) * n) == 0) { strict = 1; break; }
@@ -672,13 +940,43 @@ ORC_API int orc_kmeans_fit(const double *xin, int64_t nrows, int nbands, int k,
         memcpy(lab_old, lab, sizeof(int32_t) * n); have_old = 1;
     }
     if (it > max_iter) it = max_iter;
-    if (!strict) lloyd_assign(X, n, nb, C, k, lab);
+    if (!strict) {
+        if (elkan) elk_estep(X, n, nb, C, k, half, next, lab, ub, lb);
+        else lloyd_assign(X, n, nb, C, k, lab);
+    }
+    free(half); free(next); free(ub); free(lb); free(cshift);
     for (int j = 0; j < k; j++)
         for (int b = 0; b < nb; b++) centres_out[j * nb + b] = C[j * nb + b] + mu[b];
     if (labels_out) memcpy(labels_out, lab, sizeof(int32_t) * n);
     if (n_iter_out) *n_iter_out = it;
     free(X); free(mu); free(C); free(Cn); free(w); free(lab); free(lab_old);
     return 0;
+}
+
+ORC_API int orc_kmeans_fit(const double *xin, int64_t nrows, int nbands, int k,
+                           const double *init, int max_iter, double tol_rel,
+                           double *centres_out, int32_t *labels_out, int *n_iter_out)
+{
+    return kmeans_fit_impl(xin, nrows, nbands, k, init, max_iter, tol_rel, 0, 0, 0, centres_out, labels_out,
+                           n_iter_out);
+}
+
+ORC_API int orc_kmeans_fit_assoc(const double *xin, int64_t nrows, int nbands, int k,
+                                 const double *init, int max_iter, double tol_rel,
+                                 int chunk_rows, int group_chunks,
+                                 double *centres_out, int32_t *labels_out, int *n_iter_out)
+{
+    return kmeans_fit_impl(xin, nrows, nbands, k, init, max_iter, tol_rel, chunk_rows, group_chunks, 0,
+                           centres_out, labels_out, n_iter_out);
+}
+
+ORC_API int orc_kmeans_fit_elkan(const double *xin, int64_t nrows, int nbands, int k,
+                                 const double *init, int max_iter, double tol_rel,
+                                 int chunk_rows, int group_chunks,
+                                 double *centres_out, int32_t *labels_out, int *n_iter_out)
+{
+    return kmeans_fit_impl(xin, nrows, nbands, k, init, max_iter, tol_rel, chunk_rows, group_chunks, 1,
+                           centres_out, labels_out, n_iter_out);
 }
 
 /* ------------------------------------------------------------------ */

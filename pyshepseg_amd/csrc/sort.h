@@ -10,6 +10,7 @@
 #define SORT_ROWS 8u
 #define SORT_TILE (4u * SORT_ROWS * 64u)   // items per 256-thread workgroup
 
+template <unsigned ROWS>
 __global__ __launch_bounds__(256) void k_sort_hist(const uint32_t *__restrict__ keys, uint32_t n,
                                                    int shift, uint32_t *__restrict__ hist,
                                                    uint32_t nblk)
@@ -18,15 +19,15 @@ __global__ __launch_bounds__(256) void k_sort_hist(const uint32_t *__restrict__ 
     h[threadIdx.x] = 0;
     __syncthreads();
     const unsigned w = threadIdx.x >> 6, lane = lane_id();
-    const uint32_t base = blockIdx.x * SORT_TILE + w * SORT_ROWS * 64u + lane;
-    uint32_t d[SORT_ROWS];
+    const uint32_t base = blockIdx.x * (4u * ROWS * 64u) + w * ROWS * 64u + lane;
+    uint32_t d[ROWS];
 #pragma unroll
-    for (unsigned r = 0; r < SORT_ROWS; r++) {
+    for (unsigned r = 0; r < ROWS; r++) {
         const uint32_t idx = base + r * 64u;
         d[r] = (idx < n) ? ((keys[idx] >> shift) & 255u) : 256u;
     }
 #pragma unroll
-    for (unsigned r = 0; r < SORT_ROWS; r++) {
+    for (unsigned r = 0; r < ROWS; r++) {
         // label rasters come in runs: the lanes that share the first lane's digit add once (64
         // LDS atomics on one address would serialise), the others one by one
         const uint32_t d0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)d[r]);
@@ -117,20 +118,22 @@ __global__ __launch_bounds__(256) void k_sort_scatter(
 // lanes write consecutive addresses within a digit's run -- with random digits a direct scatter
 // issued 4-byte writes to 2048 unrelated addresses per workgroup, the staged one writes ~256 runs of
 // 8 items (and whole 256-byte spans when the keys come in runs, as labels do).
+template <unsigned ROWS>
 __global__ __launch_bounds__(256) void k_sort_scatter_staged(
     const uint32_t *__restrict__ keys_in, const uint32_t *__restrict__ vals_in,
     uint32_t *__restrict__ keys_out, uint32_t *__restrict__ vals_out, uint32_t n, int shift,
     const uint32_t *__restrict__ histscan, uint32_t nblk, const uint32_t *__restrict__ boff)
 {
+    constexpr unsigned TILE = 4u * ROWS * 64u;
     __shared__ uint32_t wcount[4][256];
     __shared__ uint32_t gdelta[256];        // global position - position in the workgroup's digit order
     __shared__ uint32_t wtot[4];
-    __shared__ uint32_t skeys[SORT_TILE], svals[SORT_TILE];
+    __shared__ uint32_t skeys[TILE], svals[TILE];
     const unsigned w = threadIdx.x >> 6, lane = lane_id();
-    const uint32_t base = blockIdx.x * SORT_TILE + w * SORT_ROWS * 64u + lane;
-    uint32_t k[SORT_ROWS], v[SORT_ROWS];
+    const uint32_t base = blockIdx.x * TILE + w * ROWS * 64u + lane;
+    uint32_t k[ROWS], v[ROWS];
 #pragma unroll
-    for (unsigned r = 0; r < SORT_ROWS; r++) {
+    for (unsigned r = 0; r < ROWS; r++) {
         const uint32_t idx = base + r * 64u;
         k[r] = (idx < n) ? keys_in[idx] : 0u;
         v[r] = (idx < n) ? (vals_in ? vals_in[idx] : idx) : 0u;
@@ -141,10 +144,10 @@ __global__ __launch_bounds__(256) void k_sort_scatter_staged(
     const unsigned long long lt = lanemask_lt();
     // per row: the lanes sharing this lane's digit (peers) and how many items of that digit the
     // wave's earlier rows hold (rowbase); the leader of each group bumps the wave's digit count
-    unsigned long long peers[SORT_ROWS];
-    uint32_t rowbase[SORT_ROWS];
+    unsigned long long peers[ROWS];
+    uint32_t rowbase[ROWS];
 #pragma unroll
-    for (unsigned r = 0; r < SORT_ROWS; r++) {
+    for (unsigned r = 0; r < ROWS; r++) {
         const bool valid = (base + r * 64u) < n;
         const uint32_t d = (k[r] >> shift) & 255u;
         peers[r] = match_digit(d, valid);
@@ -182,7 +185,7 @@ __global__ __launch_bounds__(256) void k_sort_scatter_staged(
     }
     __syncthreads();
 #pragma unroll
-    for (unsigned r = 0; r < SORT_ROWS; r++) {
+    for (unsigned r = 0; r < ROWS; r++) {
         const bool valid = (base + r * 64u) < n;
         const uint32_t d = (k[r] >> shift) & 255u;
         if (valid) {
@@ -192,10 +195,10 @@ __global__ __launch_bounds__(256) void k_sort_scatter_staged(
         }
     }
     __syncthreads();
-    const uint32_t tile0 = blockIdx.x * SORT_TILE;
-    const uint32_t nvalid = tile0 < n ? (n - tile0 < SORT_TILE ? n - tile0 : SORT_TILE) : 0u;
+    const uint32_t tile0 = blockIdx.x * TILE;
+    const uint32_t nvalid = tile0 < n ? (n - tile0 < TILE ? n - tile0 : TILE) : 0u;
 #pragma unroll
-    for (unsigned j = 0; j < SORT_TILE / 256u; j++) {
+    for (unsigned j = 0; j < TILE / 256u; j++) {
         const uint32_t i = threadIdx.x + j * 256u;
         if (i < nvalid) {
             const uint32_t key = skeys[i];
@@ -221,7 +224,11 @@ static inline int bits_for(uint32_t maxval)      // significant bits of the larg
 static int sort_pairs(shp_ctx *ctx, const uint32_t *keys_in, const uint32_t *vals_in, uint32_t n,
                       int bits, uint32_t **keys_sorted, uint32_t **vals_sorted, bool staged = false)
 {
-    const uint32_t nblk = (n + SORT_TILE - 1) / SORT_TILE;
+    // the staged form takes 4096 items per workgroup: half the block histograms to scan and re-read,
+    // and a digit's run in the staged order is 16 items (64 bytes) instead of 8 when the digits are random
+    static const bool wide = !getenv("SHEPSEG_SORT_WIDE") || atoi(getenv("SHEPSEG_SORT_WIDE")) != 0;
+    const uint32_t tile = (staged && wide) ? 2u * SORT_TILE : SORT_TILE;
+    const uint32_t nblk = (n + tile - 1) / tile;
     int passes = (bits + 7) / 8;
     if (passes < 1) passes = 1;
     CHK(buf_ensure(ctx, ctx->sort_k0, (size_t)n * 4));
@@ -241,14 +248,19 @@ static int sort_pairs(shp_ctx *ctx, const uint32_t *keys_in, const uint32_t *val
     if (n == 0) { if (keys_sorted) *keys_sorted = kbuf[0]; *vals_sorted = bp<uint32_t>(ctx->pix); return 0; }
     for (int p = 0; p < passes; p++) {
         uint32_t *kout = (!keys_sorted && p == passes - 1) ? nullptr : kbuf[p & 1], *vout = vbuf[p & 1];
-        hipLaunchKernelGGL(k_sort_hist, dim3(nblk), dim3(256), 0, ctx->stream, kin, n, p * 8, hist,
-                           nblk);
+        if (tile == SORT_TILE)
+            hipLaunchKernelGGL(k_sort_hist<SORT_ROWS>, dim3(nblk), dim3(256), 0, ctx->stream, kin, n, p * 8, hist, nblk);
+        else
+            hipLaunchKernelGGL(k_sort_hist<2u * SORT_ROWS>, dim3(nblk), dim3(256), 0, ctx->stream, kin, n, p * 8, hist, nblk);
         KCHK(ctx);
         ArrFn f{hist};
         const uint32_t *boff = nullptr;
         CHK(scan_exclusive(ctx, f, (uint32_t)nh, hscan, nullptr, bp<uint32_t>(ctx->scan_tmp), &boff));
-        if (staged)
-            hipLaunchKernelGGL(k_sort_scatter_staged, dim3(nblk), dim3(256), 0, ctx->stream, kin, vin, kout,
+        if (staged && tile != SORT_TILE)
+            hipLaunchKernelGGL(k_sort_scatter_staged<2u * SORT_ROWS>, dim3(nblk), dim3(256), 0, ctx->stream, kin, vin,
+                               kout, vout, n, p * 8, hscan, nblk, boff);
+        else if (staged)
+            hipLaunchKernelGGL(k_sort_scatter_staged<SORT_ROWS>, dim3(nblk), dim3(256), 0, ctx->stream, kin, vin, kout,
                                vout, n, p * 8, hscan, nblk, boff);
         else
             hipLaunchKernelGGL(k_sort_scatter, dim3(nblk), dim3(256), 0, ctx->stream, kin, vin, kout,

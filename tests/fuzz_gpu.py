@@ -159,6 +159,9 @@ def more_case(rng, kind, tmpdir):
         cdiff = float(np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b))))
         ok = km.n_iter_ == want_n and same_part and cdiff < 1e-9
         moved = int((np.array([dict(pairs).get(x, -1) for x in km.labels_.tolist()]) != want_l).sum()) if not same_part else 0
+        if not ok and os.environ.get('SHEPSEG_FUZZ_DUMP'):      # keep the case for a post-mortem on the CPU
+            np.savez_compressed(os.path.join(os.environ['SHEPSEG_FUZZ_DUMP'], 'fit_fail_%d_%d.npz' % (n, k)), img=img,
+                                init=init, dev_centres=km.cluster_centers_, dev_labels=km.labels_, dev_n_iter=km.n_iter_)
         return ok, 'fit %s n=%d nb=%d k=%d n_iter=%d/%d same_partition=%s rows_differing~%d max_rel_centre_diff=%.2e' % (
             np.dtype(dtype).name, n, nb, k, km.n_iter_, want_n, same_part, moved, cdiff)
     if kind == 'sharded':
