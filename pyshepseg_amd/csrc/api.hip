@@ -93,7 +93,7 @@ static int ctx_create(int device, int high_priority, shp_ctx **out, bool shared)
                  &ctx->scan_tmp, &ctx->sort_k0, &ctx->sort_k1, &ctx->sort_v1, &ctx->sort_hist,
                  &ctx->pix, &ctx->segsz, &ctx->origsz, &ctx->off, &ctx->ssum, &ctx->chnext,
                  &ctx->chtail, &ctx->mergeto, &ctx->tcount, &ctx->toff, &ctx->tfill, &ctx->tlist,
-                 &ctx->tsorted, &ctx->small, &ctx->cen, &ctx->fit_x, &ctx->fit_lab, &ctx->fit_part,
+                 &ctx->tsorted, &ctx->small, &ctx->cen, &ctx->fit_x, &ctx->fit_lab, &ctx->fit_part, &ctx->fit_lb,
                  &ctx->big, &ctx->srclist, &ctx->tgtlist, &ctx->bigbits, &ctx->singles, &ctx->dbg};
     *out = ctx;
     return SHP_OK;
@@ -177,6 +177,8 @@ static float ev_ms(shp_ctx *ctx, int a, int b)
 }
 
 // ---- k-means --------------------------------------------------------------------------------
+API int shp_last_fit_path(const shp_ctx *ctx) { return ctx ? ctx->fit_path : -1; }
+
 API int shp_kmeans_fit(shp_ctx *ctx, const double *xsample, int64_t nrows, int nbands, int k,
                        const double *init_centres, int max_iter, double tol_rel,
                        double *centres_out, int32_t *labels_out, int *n_iter_out)

@@ -1,0 +1,434 @@
+// fit_elkan.h -- the reference's own k-means fit, operation by operation (included by kmeans.h).
+//
+// shepseg.fitSpectralClusters (shepseg.py:305-312) calls KMeans(n_init=1, init=<array>).fit with
+// sklearn's default algorithm="auto", which in the reference's stack (sklearn 0.24.2, _kmeans.py:824)
+// is ELKAN's variant for k > 1: _kmeans_single_elkan (:300-428) over _k_means_elkan.pyx
+// init_bounds_dense / elkan_iter_chunked_dense.  In exact arithmetic it visits the partitions of
+// Lloyd's algorithm.  In float64 it does not wherever a sample is (nearly) equidistant from two
+// centres: distances are the direct sqrt(sum (x - c)^2), a sample keeps its label unless another
+// centre is STRICTLY closer, and triangle-inequality bounds decide which distances are looked at at
+// all -- on lattice-valued imagery (8-bit, few bands) exact ties are common and steer the whole fit
+// (oracle/refgen/probe_elkan.py: the Lloyd restatement differs from the reference on 67 of 357 such
+// fits, this one on none).
+//
+// run_kmeans_fit therefore has two paths with the same result where both apply:
+//  * the fast one (kmeans.h: Lloyd E-step in the dgemm order, chunked M-step sums, 8 iterations per
+//    host round trip) with a guard: an E-step that meets a sample whose two nearest centres are
+//    within FIT_TIE_EPS (relative) raises FitCtl::near.  Without such a sample every label is decided
+//    by a margin far above the rounding of either evaluation, so both algorithms visit the same
+//    partitions and stop after the same iteration;
+//  * this one, taken when the guard fires (SHEPSEG_FIT_ALGO=elkan: always): bounds kept per sample and
+//    centre (k x n float64, cluster-major), M-step sums in ROW order per cluster (sklearn with one
+//    OpenMP thread; row lists by one stable radix pass over the labels), the k x nb sized tail of an
+//    iteration on the host, one host round trip per iteration.  Bit-identical to the oracle's
+//    orc_kmeans_fit_elkan, i.e. to the reference with OMP_NUM_THREADS=1 (with more threads sklearn
+//    adds per-thread partial sums in the order the threads finish: not reproducible run to run).
+// Shared by both: empty-cluster relocation as numpy evaluates it (pairwise row sums, np.argpartition's
+// introselect), center_shift_tot as numpy's pairwise sum.
+#pragma once
+
+#define FIT_TIE_EPS 1e-12
+
+// DOUBLE_pairwise_sum (numpy/core/src/umath/loops_utils.h.src): what a float64 .sum() over a
+// contiguous run evaluates; plain left to right below 8 elements.  get(i) yields element i.
+template <class Get>
+__host__ __device__ inline double np_pairwise_sum_fn(Get get, size_t lo, size_t n)
+{
+    if (n < 8) {
+        double res = 0.0;
+        for (size_t i = 0; i < n; i++) res += get(lo + i);
+        return res;
+    }
+    if (n <= 128) {
+        double r[8];
+        size_t i;
+        for (int j = 0; j < 8; j++) r[j] = get(lo + j);
+        for (i = 8; i < n - (n % 8); i += 8)
+            for (int j = 0; j < 8; j++) r[j] += get(lo + i + j);
+        double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+        for (; i < n; i++) res += get(lo + i);
+        return res;
+    }
+    size_t n2 = n / 2;
+    n2 -= n2 % 8;
+    return np_pairwise_sum_fn(get, lo, n2) + np_pairwise_sum_fn(get, lo + n2, n - n2);
+}
+__host__ __device__ inline double np_pairwise_sum(const double *a, size_t n)
+{
+    return np_pairwise_sum_fn([a](size_t i) { return a[i]; }, 0, n);
+}
+
+// np.argpartition(v, kth) for float64 without NaNs: numpy/core/src/npysort/selection.cpp
+// introselect_<double, arg> from the index array 0..num-1 (oracle: np_aintroselect, pinned there)
+static void np_aintroselect(const double *v, int64_t *t, int64_t num, int64_t kth);
+static int64_t np_amedian5(const double *v, int64_t *t)
+{
+    if (v[t[1]] < v[t[0]]) std::swap(t[1], t[0]);
+    if (v[t[4]] < v[t[3]]) std::swap(t[4], t[3]);
+    if (v[t[3]] < v[t[0]]) std::swap(t[3], t[0]);
+    if (v[t[4]] < v[t[1]]) std::swap(t[4], t[1]);
+    if (v[t[2]] < v[t[1]]) std::swap(t[2], t[1]);
+    if (v[t[3]] < v[t[2]]) return (v[t[3]] < v[t[1]]) ? 1 : 3;
+    return 2;
+}
+static int64_t np_amedian_of_median5(const double *v, int64_t *t, int64_t num)
+{
+    const int64_t nmed = num / 5;
+    for (int64_t i = 0, subleft = 0; i < nmed; i++, subleft += 5) {
+        const int64_t m = np_amedian5(v, t + subleft);
+        std::swap(t[subleft + m], t[i]);
+    }
+    if (nmed > 2) np_aintroselect(v, t, nmed, nmed / 2);
+    return nmed / 2;
+}
+static void np_aintroselect(const double *v, int64_t *t, int64_t num, int64_t kth)
+{
+    int64_t low = 0, high = num - 1;
+    if (kth - low < 3) {
+        const int64_t n2 = high - low + 1;
+        for (int64_t i = 0; i <= kth - low; i++) {
+            int64_t minidx = i;
+            double minval = v[t[low + i]];
+            for (int64_t q = i + 1; q < n2; q++)
+                if (v[t[low + q]] < minval) { minidx = q; minval = v[t[low + q]]; }
+            std::swap(t[low + i], t[low + minidx]);
+        }
+        return;
+    }
+    if (kth == num - 1) {
+        int64_t maxidx = low;
+        double maxval = v[t[low]];
+        for (int64_t q = low + 1; q < num; q++)
+            if (!(v[t[q]] < maxval)) { maxidx = q; maxval = v[t[q]]; }
+        std::swap(t[kth], t[maxidx]);
+        return;
+    }
+    int depth_limit = 0;
+    for (uint64_t u = (uint64_t)num >> 1; u; u >>= 1) depth_limit++;
+    depth_limit *= 2;
+    for (; low + 1 < high;) {
+        int64_t ll = low + 1, hh = high;
+        if (depth_limit > 0 || hh - ll < 5) {
+            const int64_t mid = low + (high - low) / 2;
+            if (v[t[high]] < v[t[mid]]) std::swap(t[high], t[mid]);
+            if (v[t[high]] < v[t[low]]) std::swap(t[high], t[low]);
+            if (v[t[low]] < v[t[mid]]) std::swap(t[low], t[mid]);
+            std::swap(t[mid], t[low + 1]);
+        } else {
+            const int64_t mid = ll + np_amedian_of_median5(v, t + ll, hh - ll);
+            std::swap(t[mid], t[low]);
+            ll--; hh++;
+        }
+        depth_limit--;
+        const double pivot = v[t[low]];
+        for (;;) {
+            do ll++; while (v[t[ll]] < pivot);
+            do hh--; while (pivot < v[t[hh]]);
+            if (hh < ll) break;
+            std::swap(t[hh], t[ll]);
+        }
+        std::swap(t[low], t[hh]);
+        if (hh >= kth) high = hh - 1;
+        if (hh <= kth) low = ll;
+    }
+    if (high == low + 1 && v[t[high]] < v[t[low]]) std::swap(t[high], t[low]);
+}
+
+// dist[i] = ((X_i - C[lab_i])**2).sum() as numpy sums a row (empty-cluster relocation)
+__global__ __launch_bounds__(256) void k_fit_dist(const double *__restrict__ X, uint32_t n, int nb,
+                                                  const int32_t *__restrict__ lab,
+                                                  const double *__restrict__ C,
+                                                  double *__restrict__ dist)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const double *x = X + (size_t)i * nb, *c = C + (size_t)lab[i] * nb;
+    dist[i] = np_pairwise_sum_fn([x, c](size_t b) { const double t = x[b] - c[b]; return t * t; }, 0, (size_t)nb);
+}
+
+// The tail of an M-step on the host (k x nb numbers; both paths): empty clusters take the samples
+// farthest from their OLD centres (_relocate_empty_clusters_dense: empty clusters ascending, the r-th
+// gets np.argpartition(distances, -n_empty)[n - 1 - r]), centres = sums * (1 / weight)
+// (_average_centers), shifts (_center_shift: _euclidean_dense_dense) and their squared sum.
+// Cn: the cluster sums in, the new centres out.  fetch(dist, labels) brings the n distances and labels
+// from the device when a cluster is empty.
+template <class XAt, class Fetch>
+static int fit_mstep_tail(int k, int nb, uint32_t n, std::vector<double> &Cn, std::vector<double> &w,
+                          const std::vector<double> &C, XAt Xat, Fetch fetch, std::vector<double> &cshift,
+                          double *shift_tot)
+{
+    std::vector<int> empties;
+    for (int j = 0; j < k; j++) if (w[j] == 0.0) empties.push_back(j);
+    const int n_empty = (int)empties.size();
+    if (n_empty > 0) {
+        std::vector<double> dist;
+        std::vector<int32_t> hl;
+        const int rc = fetch(dist, hl);
+        if (rc) return rc;
+        std::vector<int64_t> part(n);
+        for (uint32_t i = 0; i < n; i++) part[i] = i;
+        np_aintroselect(dist.data(), part.data(), (int64_t)n, (int64_t)n - n_empty);
+        for (int r = 0; r < n_empty; r++) {
+            const uint32_t f = (uint32_t)part[n - 1u - (uint32_t)r];
+            const int e = empties[r], old = hl[f];
+            for (int b = 0; b < nb; b++) {
+                Cn[old * nb + b] -= Xat(f, b);
+                Cn[e * nb + b] = Xat(f, b);
+            }
+            w[e] = 1.0; w[old] -= 1.0;
+        }
+    }
+    for (int j = 0; j < k; j++)
+        if (w[j] > 0.0) { const double alpha = 1.0 / w[j]; for (int b = 0; b < nb; b++) Cn[j * nb + b] *= alpha; }
+    cshift.resize(k);
+    std::vector<double> sq(k);
+    for (int j = 0; j < k; j++) {
+        const double *a = &Cn[j * nb], *c = &C[j * nb];
+        double r = 0.0; int b = 0;
+        for (; b + 4 <= nb; b += 4)
+            r += ((a[b] - c[b]) * (a[b] - c[b]) + (a[b + 1] - c[b + 1]) * (a[b + 1] - c[b + 1]) +
+                  (a[b + 2] - c[b + 2]) * (a[b + 2] - c[b + 2]) + (a[b + 3] - c[b + 3]) * (a[b + 3] - c[b + 3]));
+        for (; b < nb; b++) r += (a[b] - c[b]) * (a[b] - c[b]);
+        const double s = __builtin_sqrt(r);
+        cshift[j] = s;
+        sq[j] = s * s;
+    }
+    *shift_tot = np_pairwise_sum(sq.data(), (size_t)k);
+    return 0;
+}
+
+// ---- Elkan's E-step ---------------------------------------------------------------------------
+// _euclidean_dense_dense(x, c, nf, squared=False)
+__host__ __device__ inline double elk_dist(const double *a, const double *b, int nf)
+{
+    const int n4 = nf / 4, rem = nf % 4;
+    double result = 0.0;
+    for (int i = 0; i < n4; i++) {
+        result += ((a[0] - b[0]) * (a[0] - b[0]) + (a[1] - b[1]) * (a[1] - b[1]) +
+                   (a[2] - b[2]) * (a[2] - b[2]) + (a[3] - b[3]) * (a[3] - b[3]));
+        a += 4; b += 4;
+    }
+    for (int i = 0; i < rem; i++) result += (a[i] - b[i]) * (a[i] - b[i]);
+    return __builtin_sqrt(result);
+}
+
+// center_half_distances = euclidean_distances(centres) / 2 (-2 C.C^T + |c|^2 + |c|^2 clipped at 0, zero
+// diagonal, sqrt; the product's terms multiplied and added one after the other in band order, as the
+// reference stack's BLAS does for these shapes) and distance_next_center = the second smallest of every
+// column (np.partition(half, 1, axis=0)[1]).  Host: k x k numbers.
+static void elk_half_distances(const double *C, int k, int nb, double *half, double *next)
+{
+    std::vector<double> xx(k);
+    for (int a = 0; a < k; a++) xx[a] = kmeans_sqnorm(C + (size_t)a * nb, nb);
+    for (int a = 0; a < k; a++)
+        for (int b = 0; b < k; b++) {
+            double d = 0.0;
+            for (int t = 0; t < nb; t++) d = d + C[(size_t)a * nb + t] * C[(size_t)b * nb + t];
+            double v = -2.0 * d;
+            v = v + xx[a];
+            v = v + xx[b];
+            if (!(v > 0.0)) v = 0.0;
+            if (a == b) v = 0.0;
+            half[(size_t)a * k + b] = __builtin_sqrt(v) / 2.0;
+        }
+    for (int l = 0; l < k; l++) {
+        double m0 = half[l], m1 = -1.0;
+        for (int a = 1; a < k; a++) {
+            const double v = half[(size_t)a * k + l];
+            if (v < m0) { m1 = m0; m0 = v; }
+            else if (m1 < 0.0 || v < m1) m1 = v;
+        }
+        next[l] = k > 1 ? m1 : m0;
+    }
+}
+
+// init_bounds_dense: lb is cluster-major (lb[j * n + i]), zero-filled by the caller
+__global__ __launch_bounds__(256) void k_elk_init(const double *__restrict__ X, uint32_t n, int nb,
+                                                  const double *__restrict__ C, int k,
+                                                  const double *__restrict__ half,
+                                                  int32_t *__restrict__ lab, double *__restrict__ ub,
+                                                  double *__restrict__ lb)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= n) return;
+    const double *x = X + (size_t)i * nb;
+    int best = 0;
+    double min_dist = elk_dist(x, C, nb);
+    lb[i] = min_dist;
+    for (int j = 1; j < k; j++)
+        if (min_dist > half[(size_t)best * k + j]) {
+            const double dist = elk_dist(x, C + (size_t)j * nb, nb);
+            lb[(size_t)j * n + i] = dist;
+            if (dist < min_dist) { min_dist = dist; best = j; }
+        }
+    lab[i] = best;
+    ub[i] = min_dist;
+}
+
+// The bounds update that ends elkan_iter (upper += shift of the own centre, lower -= shift, clipped at
+// 0) for the previous iteration when cshift != nullptr, then _update_chunk_dense's relabelling.
+// *ndiff += labels changed.
+__global__ __launch_bounds__(256) void k_elk_estep(const double *__restrict__ X, uint32_t n, int nb,
+                                                   const double *__restrict__ C, int k,
+                                                   const double *__restrict__ half,
+                                                   const double *__restrict__ next,
+                                                   const double *__restrict__ cshift,
+                                                   int32_t *__restrict__ lab, double *__restrict__ ub,
+                                                   double *__restrict__ lb, uint32_t *ndiff)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    uint32_t changed = 0;
+    if (i < n) {
+        const double *x = X + (size_t)i * nb;
+        int label = lab[i];
+        const int label0 = label;
+        double upper = ub[i];
+        if (cshift) {
+            upper += cshift[label];
+            for (int j = 0; j < k; j++) {
+                double v = lb[(size_t)j * n + i] - cshift[j];
+                if (v < 0) v = 0;
+                lb[(size_t)j * n + i] = v;
+            }
+        }
+        bool tight = false;
+        if (!(next[label] >= upper)) {
+            for (int j = 0; j < k; j++)
+                if (j != label && upper > lb[(size_t)j * n + i] && upper > half[(size_t)label * k + j]) {
+                    if (!tight) {
+                        upper = elk_dist(x, C + (size_t)label * nb, nb);
+                        lb[(size_t)label * n + i] = upper;
+                        tight = true;
+                    }
+                    if (upper > lb[(size_t)j * n + i] || upper > half[(size_t)label * k + j]) {
+                        const double dist = elk_dist(x, C + (size_t)j * nb, nb);
+                        lb[(size_t)j * n + i] = dist;
+                        if (dist < upper) { label = j; upper = dist; }
+                    }
+                }
+            lab[i] = label;
+        }
+        ub[i] = upper;
+        changed = label != label0;
+    }
+    const unsigned long long m = __ballot(changed != 0u);
+    if (m != 0ull && lane_id() == 0) atomicAdd(ndiff, (uint32_t)__popcll(m));
+}
+
+// off[j] = first position of label j in the sorted labels (off[k] = n)
+__global__ __launch_bounds__(256) void k_elk_offsets(const uint32_t *__restrict__ keys, uint32_t n, int k,
+                                                     uint32_t *__restrict__ off)
+{
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j > k) return;
+    uint32_t lo = 0, hi = n;
+    while (lo < hi) {
+        const uint32_t mid = lo + (hi - lo) / 2u;
+        if (keys[mid] < (uint32_t)j) lo = mid + 1u; else hi = mid;
+    }
+    off[j] = lo;
+}
+
+// S[j][b] = sum of X[row][b] over the rows of cluster j in ROW order (rows: the stable sort of the row
+// numbers by label), one chain per (cluster, band): a lane per band, FIT_ROWS_AHEAD independent loads in
+// flight, the additions one after the other.  grid (k, ceil(nb / 64)).
+#define FIT_ROWS_AHEAD 32
+__global__ __launch_bounds__(64) void k_fit_sum_lists(const double *__restrict__ X, int nb,
+                                                      const uint32_t *__restrict__ rows,
+                                                      const uint32_t *__restrict__ off,
+                                                      double *__restrict__ S, double *__restrict__ cnt)
+{
+    const int j = blockIdx.x, b = blockIdx.y * 64 + threadIdx.x;
+    const uint32_t q0 = off[j], q1 = off[j + 1];
+    if (b == 0) cnt[j] = (double)(q1 - q0);
+    if (b >= nb) return;
+    double acc = 0.0;
+    for (uint32_t q = q0; q < q1; q += FIT_ROWS_AHEAD) {
+        double v[FIT_ROWS_AHEAD];
+#pragma unroll
+        for (int u = 0; u < FIT_ROWS_AHEAD; u++) {
+            const uint32_t qq = q + (uint32_t)u < q1 ? q + (uint32_t)u : q1 - 1u;
+            v[u] = X[(size_t)rows[qq] * nb + b];
+        }
+#pragma unroll
+        for (int u = 0; u < FIT_ROWS_AHEAD; u++)
+            if (q + (uint32_t)u < q1) acc += v[u];
+    }
+    S[(size_t)j * nb + b] = acc;
+}
+
+// The faithful path.  dX: the centred sample on the device (n rows of nb); X: the same on the host
+// through Xat; C: the centred initial centres in, the final centred centres out; dlab: n labels out.
+template <class XAt>
+static int run_fit_elkan(shp_ctx *ctx, const double *dX, XAt Xat, uint32_t n, int nb, int k,
+                         std::vector<double> &C, int max_iter, double tol, int32_t *dlab, double *ddist,
+                         int *n_iter_out)
+{
+    const int kn = k * nb;
+    hipStream_t st = ctx->stream;
+    CHK(buf_ensure(ctx, ctx->fit_lb, ((size_t)k * n + n) * 8));
+    const size_t small_doubles = (size_t)kn * 2 + (size_t)k * k + 4 * (size_t)k + 8;
+    CHK(buf_ensure(ctx, ctx->fit_part, small_doubles * 8 + ((size_t)k + 2) * 4 + 64));
+    double *dlb = bp<double>(ctx->fit_lb), *dub = dlb + (size_t)k * n;
+    double *dC = bp<double>(ctx->fit_part), *dS = dC + kn, *dhalf = dS + kn, *dnext = dhalf + (size_t)k * k,
+           *dcshift = dnext + k, *dcnt = dcshift + k;
+    uint32_t *doff = (uint32_t *)(dcnt + k + 2), *dnd = doff + k + 1;
+    std::vector<double> half((size_t)k * k), next(k), cshift, Cn(kn), w(k), up;
+    auto upload = [&](bool with_shift) -> int {
+        // C | half | next | cshift in one staged copy (pageable: a few KiB per iteration)
+        up.assign(C.begin(), C.end());
+        HIPCHK(ctx, hipMemcpyAsync(dC, up.data(), (size_t)kn * 8, hipMemcpyHostToDevice, st));
+        HIPCHK(ctx, hipMemcpyAsync(dhalf, half.data(), (size_t)k * k * 8, hipMemcpyHostToDevice, st));
+        HIPCHK(ctx, hipMemcpyAsync(dnext, next.data(), (size_t)k * 8, hipMemcpyHostToDevice, st));
+        if (with_shift) HIPCHK(ctx, hipMemcpyAsync(dcshift, cshift.data(), (size_t)k * 8, hipMemcpyHostToDevice, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));      // the host vectors change before the copies would be read
+        return 0;
+    };
+    elk_half_distances(C.data(), k, nb, half.data(), next.data());
+    CHK(upload(false));
+    HIPCHK(ctx, hipMemsetAsync(dlb, 0, (size_t)k * n * 8, st));
+    const unsigned g = grid_for(n, 256);
+    hipLaunchKernelGGL(k_elk_init, dim3(g), dim3(256), 0, st, dX, n, nb, dC, k, dhalf, dlab, dub, dlb); KCHK(ctx);
+    bool strict = false, pending = false;
+    int it = 0;
+    for (it = 1; it <= max_iter; it++) {
+        HIPCHK(ctx, hipMemsetAsync(dnd, 0, 4, st));
+        hipLaunchKernelGGL(k_elk_estep, dim3(g), dim3(256), 0, st, dX, n, nb, dC, k, dhalf, dnext,
+                           pending ? dcshift : (const double *)nullptr, dlab, dub, dlb, dnd); KCHK(ctx);
+        // row lists: the row numbers sorted stably by label
+        uint32_t *ks = nullptr, *rows = nullptr;
+        CHK(sort_pairs(ctx, (const uint32_t *)dlab, nullptr, n, bits_for((uint32_t)(k - 1)), &ks, &rows));
+        hipLaunchKernelGGL(k_elk_offsets, dim3(grid_for((size_t)k + 1, 256)), dim3(256), 0, st, ks, n, k, doff); KCHK(ctx);
+        hipLaunchKernelGGL(k_fit_sum_lists, dim3(k, (nb + 63) / 64), dim3(64), 0, st, dX, nb, rows, doff, dS, dcnt); KCHK(ctx);
+        uint32_t nd = 0;
+        HIPCHK(ctx, hipMemcpyAsync(Cn.data(), dS, (size_t)kn * 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipMemcpyAsync(w.data(), dcnt, (size_t)k * 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipMemcpyAsync(&nd, dnd, 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        double shift_tot = 0.0;
+        auto fetch = [&](std::vector<double> &dist, std::vector<int32_t> &hl) -> int {
+            hipLaunchKernelGGL(k_fit_dist, dim3(g), dim3(256), 0, st, dX, n, nb, dlab, dC, ddist); KCHK(ctx);
+            dist.resize(n); hl.resize(n);
+            HIPCHK(ctx, hipMemcpyAsync(dist.data(), ddist, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+            HIPCHK(ctx, hipMemcpyAsync(hl.data(), dlab, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+            HIPCHK(ctx, hipStreamSynchronize(st));
+            return 0;
+        };
+        CHK(fit_mstep_tail(k, nb, n, Cn, w, C, Xat, fetch, cshift, &shift_tot));
+        elk_half_distances(Cn.data(), k, nb, half.data(), next.data());
+        C = Cn;
+        CHK(upload(true));
+        pending = true;
+        if (it >= 2 && nd == 0u) { strict = true; break; }
+        if (shift_tot <= tol) break;
+    }
+    if (it > max_iter) it = max_iter;
+    if (!strict) {
+        HIPCHK(ctx, hipMemsetAsync(dnd, 0, 4, st));
+        hipLaunchKernelGGL(k_elk_estep, dim3(g), dim3(256), 0, st, dX, n, nb, dC, k, dhalf, dnext,
+                           pending ? dcshift : (const double *)nullptr, dlab, dub, dlb, dnd); KCHK(ctx);
+    }
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    *n_iter_out = it;
+    return 0;
+}

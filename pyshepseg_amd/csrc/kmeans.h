@@ -244,9 +244,11 @@ struct FitCtl {
                         // the host finishes this iteration; 3 centre shift <= tol
     uint32_t iters;     // completed iterations
     uint32_t ndiff;     // labels changed by the E-step of the running iteration
-    uint32_t pad;
+    uint32_t near;      // E-steps that met a sample with two centres within FIT_TIE_EPS (fit_elkan.h)
     double shift;
 };
+
+#include "fit_elkan.h"
 
 #define FIT_RPT 4        // sample rows per thread in the E-step (independent fma chains in flight)
 template <int NB>
@@ -260,20 +262,22 @@ __global__ __launch_bounds__(256) void k_fit_assign(const double *__restrict__ X
     if (ctl && ctl->stop) return;               // the loop has ended: the rest of the batch is a no-op
     const int nb = (NB > 0) ? NB : nb_rt;
     const uint32_t i0 = blockIdx.x * (256u * FIT_RPT) + threadIdx.x;
-    uint32_t ndiff = 0;
+    uint32_t ndiff = 0, near = 0;
     if (NB > 0) {
-        double x[FIT_RPT][(NB > 0) ? NB : 1], bestd[FIT_RPT];
+        double x[FIT_RPT][(NB > 0) ? NB : 1], bestd[FIT_RPT], second[FIT_RPT];
         int best[FIT_RPT];
+        double cnmax = 0.0;
 #pragma unroll
         for (int r = 0; r < FIT_RPT; r++) {
             const uint32_t i = i0 + (uint32_t)r * 256u;
             const uint32_t ic = i < n ? i : n - 1u;      // clamped: branch-free loads
 #pragma unroll
             for (int b = 0; b < NB; b++) x[r][b] = X[(size_t)ic * NB + b];
-            best[r] = 0; bestd[r] = 0.0;
+            best[r] = 0; bestd[r] = 0.0; second[r] = __builtin_inf();
         }
         for (int j = 0; j < k; j++) {
             const double cn = cnorm[j];
+            cnmax = cn > cnmax ? cn : cnmax;
             double d[FIT_RPT];
 #pragma unroll
             for (int r = 0; r < FIT_RPT; r++) d[r] = (NB == 1) ? cn : 0.0;       // (see k_assign)
@@ -291,6 +295,9 @@ __global__ __launch_bounds__(256) void k_fit_assign(const double *__restrict__ X
             for (int r = 0; r < FIT_RPT; r++) {
                 if (j == 0) { bestd[r] = d[r]; best[r] = 0; }
                 else {
+                    // (the runner-up, for the tie guard: the larger of d and the best so far, if smaller)
+                    const double loser = d[r] < bestd[r] ? bestd[r] : d[r];
+                    second[r] = assign_min(loser, second[r]);
                     best[r] = d[r] < bestd[r] ? j : best[r];
                     bestd[r] = assign_min(d[r], bestd[r]);
                 }
@@ -302,6 +309,11 @@ __global__ __launch_bounds__(256) void k_fit_assign(const double *__restrict__ X
             if (i < n) {
                 lab[i] = best[r];
                 if (lab_old && lab_old[i] != best[r]) ndiff++;
+                double xn = 0.0;
+#pragma unroll
+                for (int b = 0; b < NB; b++) xn = __builtin_fma(x[r][b], x[r][b], xn);
+                const double scale = __builtin_fabs(bestd[r]) + __builtin_fabs(second[r]) + xn + cnmax;
+                if (k > 1 && second[r] - bestd[r] <= FIT_TIE_EPS * scale) near++;
             }
         }
     } else {
@@ -309,21 +321,27 @@ __global__ __launch_bounds__(256) void k_fit_assign(const double *__restrict__ X
             const uint32_t i = i0 + (uint32_t)r * 256u;
             if (i >= n) continue;
             int best = 0;
-            double bestd = 0.0;
+            double bestd = 0.0, second = __builtin_inf(), cnmax = 0.0, xn = 0.0;
             for (int j = 0; j < k; j++) {
                 double d = nb == 1 ? cnorm[j] : 0.0;
                 for (int b = 0; b < nb; b++) d = __builtin_fma(X[(size_t)i * nb + b], m2c[j * nb + b], d);
                 if (nb != 1) d = cnorm[j] + d;
-                if (j == 0 || d < bestd) { bestd = d; best = j; }
+                cnmax = cnorm[j] > cnmax ? cnorm[j] : cnmax;
+                if (j == 0) { bestd = d; best = 0; }
+                else if (d < bestd) { second = bestd; bestd = d; best = j; }
+                else if (d < second) second = d;
             }
             lab[i] = best;
             if (lab_old && lab_old[i] != best) ndiff++;
+            for (int b = 0; b < nb; b++) xn = __builtin_fma(X[(size_t)i * nb + b], X[(size_t)i * nb + b], xn);
+            if (k > 1 && second - bestd <= FIT_TIE_EPS * (__builtin_fabs(bestd) + __builtin_fabs(second) + xn + cnmax)) near++;
         }
     }
     // one atomic per wavefront
 #pragma unroll
     for (int s = 32; s >= 1; s >>= 1) ndiff += __shfl_xor(ndiff, s, 64);
     if (ndiff != 0u && lane_id() == 0 && ctl) atomicAdd(&ctl->ndiff, ndiff);
+    if (__ballot(near != 0u) != 0ull && lane_id() == 0 && ctl) atomicAdd(&ctl->near, 1u);
 }
 
 static void launch_fit_assign(shp_ctx *ctx, unsigned g, const double *dX, uint32_t n, int nb,
@@ -518,16 +536,7 @@ __global__ __launch_bounds__(256) void k_fit_update(const double *__restrict__ p
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-        double shift = 0.0;
-        int j = 0;                                   // in index order; eight loads in flight
-        for (; j + 8 <= k; j += 8) {
-            double v[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) v[u] = w[j + u];
-#pragma unroll
-            for (int u = 0; u < 8; u++) shift += v[u];
-        }
-        for (; j < k; j++) shift += w[j];
+        const double shift = np_pairwise_sum(w, (size_t)k);      // (center_shift**2).sum()
         const uint32_t nd = ctl->ndiff;
         ctl->shift = shift;
         ctl->iters = it;
@@ -540,23 +549,6 @@ __global__ __launch_bounds__(256) void k_fit_update(const double *__restrict__ p
         for (int b = 0; b < nb; b++) m2c[j * nb + b] = -2.0 * S[j * nb + b];
         cnorm[j] = kmeans_sqnorm(&S[j * nb], nb);
     }
-}
-
-// dist[i] = |X_i - C[lab_i]|^2 (for empty-cluster relocation, rare)
-__global__ __launch_bounds__(256) void k_fit_dist(const double *__restrict__ X, uint32_t n, int nb,
-                                                  const int32_t *__restrict__ lab,
-                                                  const double *__restrict__ C,
-                                                  double *__restrict__ dist)
-{
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i >= n) return;
-    const int j = lab[i];
-    double d = 0.0;
-    for (int b = 0; b < nb; b++) {
-        const double t = X[(size_t)i * nb + b] - C[j * nb + b];
-        d += t * t;
-    }
-    dist[i] = d;
 }
 
 // sklearn's X -= X.mean(axis=0) on rows of pixel type T (converted to float64 as the reference's
@@ -828,9 +820,16 @@ static int run_kmeans_fit(shp_ctx *ctx, const void *xin_any, int xdtype, int64_t
     const auto t_prep = std::chrono::steady_clock::now();
     bool strict = false, finished = false;
     int it_done = 0;
+    // SHEPSEG_FIT_ALGO: auto (the fast path unless its tie guard fires; sklearn runs Lloyd for k == 1),
+    // lloyd (never leave the fast path), elkan (always the reference's algorithm): fit_elkan.h
+    const char *algo_env = getenv("SHEPSEG_FIT_ALGO");
+    const bool force_lloyd = k == 1 || (algo_env && !strcmp(algo_env, "lloyd"));
+    bool elkan = !force_lloyd && algo_env && !strcmp(algo_env, "elkan");
+    const std::vector<double> C0 = C;
+    ctx->fit_path = 0;
     CHK(upload_centres(C));
     CHK(upload_ctl(0));
-    while (it_done < max_iter && !finished) {
+    while (it_done < max_iter && !finished && !elkan) {
         const int b_end = it_done + FIT_BATCH < max_iter ? it_done + FIT_BATCH : max_iter;
         for (int it = it_done + 1; it <= b_end; it++) {
             int32_t *dlab = (it & 1) ? dlabA : dlabB, *dlab_old = (it & 1) ? dlabB : dlabA;
@@ -850,6 +849,7 @@ static int run_kmeans_fit(shp_ctx *ctx, const void *xin_any, int xdtype, int64_t
         HIPCHK(ctx, hipMemcpyAsync(pin_ctl, dctl, sizeof(FitCtl), hipMemcpyDeviceToHost, st));
         HIPCHK(ctx, hipStreamSynchronize(st));
         const uint32_t stop = pin_ctl->stop;
+        if (pin_ctl->near != 0u && !force_lloyd) { elkan = true; break; }    // a (near) tie decided a label
         if (stop == 0u) { it_done = b_end; continue; }
         if (stop == 1u || stop == 3u) {
             it_done = (int)pin_ctl->iters;
@@ -858,52 +858,26 @@ static int run_kmeans_fit(shp_ctx *ctx, const void *xin_any, int xdtype, int64_t
             break;
         }
         // stop == 2: iteration `it` found an empty cluster after its E-step and level-2 sums; the
-        // host finishes it (_relocate_empty_clusters_dense: farthest samples from their OLD centres)
+        // host finishes it (fit_mstep_tail: relocation, averaging, shifts)
         const int it = (int)pin_ctl->iters + 1;
         const uint32_t nd = pin_ctl->ndiff;
         int32_t *dlab = (it & 1) ? dlabA : dlabB;
         HIPCHK(ctx, hipMemcpyAsync(pin_dn, dS, (size_t)(kn + k) * 8, hipMemcpyDeviceToHost, st));
         HIPCHK(ctx, hipMemcpyAsync(pin_up, dC, (size_t)kn * 8, hipMemcpyDeviceToHost, st));
-        hipLaunchKernelGGL(k_fit_dist, dim3(grid_for(n, 256)), dim3(256), 0, st, dX, n, nb, dlab, dC, ddist); KCHK(ctx);
-        std::vector<double> dist(n);
-        std::vector<int32_t> hl(n);
-        HIPCHK(ctx, hipMemcpyAsync(dist.data(), ddist, (size_t)n * 8, hipMemcpyDeviceToHost, st));
-        HIPCHK(ctx, hipMemcpyAsync(hl.data(), dlab, (size_t)n * 4, hipMemcpyDeviceToHost, st));
         HIPCHK(ctx, hipStreamSynchronize(st));
         for (int t = 0; t < kn; t++) { Cn[t] = pin_dn[t]; C[t] = pin_up[t]; }
         for (int j = 0; j < k; j++) w[j] = pin_dn[kn + j];
-        std::vector<int> empties;
-        for (int j = 0; j < k; j++) if (w[j] == 0.0) empties.push_back(j);
-        const int n_empty = (int)empties.size();
-        // the n_empty farthest samples, distance descending / index ascending on ties
-        std::vector<uint32_t> order(n);
-        for (uint32_t i = 0; i < n; i++) order[i] = i;
-        std::partial_sort(order.begin(), order.begin() + n_empty, order.end(),
-                          [&dist](uint32_t a, uint32_t b) {
-                              return dist[a] > dist[b] || (dist[a] == dist[b] && a < b);
-                          });
-        for (int r = 0; r < n_empty; r++) {
-            const uint32_t f = order[r];
-            const int e = empties[r], old = hl[f];
-            for (int b = 0; b < nb; b++) {
-                Cn[old * nb + b] -= Xat(f, b);
-                Cn[e * nb + b] = Xat(f, b);
-            }
-            w[e] = 1.0; w[old] -= 1.0;
-        }
-        for (int j = 0; j < k; j++)
-            if (w[j] > 0.0) { const double alpha = 1.0 / w[j]; for (int b = 0; b < nb; b++) Cn[j * nb + b] *= alpha; }
+        auto fetch = [&](std::vector<double> &dist, std::vector<int32_t> &hl) -> int {
+            hipLaunchKernelGGL(k_fit_dist, dim3(grid_for(n, 256)), dim3(256), 0, st, dX, n, nb, dlab, dC, ddist); KCHK(ctx);
+            dist.resize(n); hl.resize(n);
+            HIPCHK(ctx, hipMemcpyAsync(dist.data(), ddist, (size_t)n * 8, hipMemcpyDeviceToHost, st));
+            HIPCHK(ctx, hipMemcpyAsync(hl.data(), dlab, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+            HIPCHK(ctx, hipStreamSynchronize(st));
+            return 0;
+        };
+        std::vector<double> cshift;
         double shift = 0.0;
-        for (int j = 0; j < k; j++) {
-            const double *a = &Cn[j * nb], *c = &C[j * nb];
-            double r = 0.0; int b = 0;
-            for (; b + 4 <= nb; b += 4)
-                r += ((a[b] - c[b]) * (a[b] - c[b]) + (a[b + 1] - c[b + 1]) * (a[b + 1] - c[b + 1]) +
-                      (a[b + 2] - c[b + 2]) * (a[b + 2] - c[b + 2]) + (a[b + 3] - c[b + 3]) * (a[b + 3] - c[b + 3]));
-            for (; b < nb; b++) r += (a[b] - c[b]) * (a[b] - c[b]);
-            const double sq = __builtin_sqrt(r);
-            shift += sq * sq;
-        }
+        CHK(fit_mstep_tail(k, nb, n, Cn, w, C, Xat, fetch, cshift, &shift));
         C = Cn;
         it_done = it;
         CHK(upload_centres(C));
@@ -914,7 +888,15 @@ static int run_kmeans_fit(shp_ctx *ctx, const void *xin_any, int xdtype, int64_t
     int it = it_done;
     int32_t *dlab = (it_done & 1) ? dlabA : dlabB;
     if (it_done == 0) dlab = dlabA;                  // max_iter < 1: labels of the initial centres
-    if (!strict) {
+    if (elkan) {
+        // the reference's algorithm from the initial centres (whatever the fast path did is dropped)
+        C = C0;
+        dlab = dlabA;
+        CHK(run_fit_elkan(ctx, dX, Xat, n, nb, k, C, max_iter, tol, dlab, ddist, &it));
+        ctx->fit_path = 1;
+        HIPCHK(ctx, hipMemcpyAsync(dC, C.data(), (size_t)kn * 8, hipMemcpyHostToDevice, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+    } else if (!strict) {
         // extra E-step so that the labels match the final centres (the device already holds their
         // m2c | cnorm; either label buffer will do)
         launch_fit_assign(ctx, g, dX, n, nb, dm2c, dcn, k, dlab, (const int32_t *)nullptr, (FitCtl *)nullptr); KCHK(ctx);

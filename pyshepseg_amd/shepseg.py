@@ -181,7 +181,9 @@ def _fit(xSample, init, max_iter=300, tol=1e-4, wantInertia=False):
                                     float(tol), _lib.ptr(centres), _lib.ptr(labels),
                                     ctypes.byref(nit)))
     inertia = float(((x - centres[labels]) ** 2).sum()) if wantInertia else None
-    return KMeansModel(centres, nit.value, labels, inertia)
+    km = KMeansModel(centres, nit.value, labels, inertia)
+    km.fit_path_ = ('lloyd', 'elkan')[c._L.shp_last_fit_path(c.handle)]
+    return km
 
 
 def _fit_planar(img, numClusters, imgNullVal, init=None, max_iter=300, tol=1e-4):
@@ -200,7 +202,9 @@ def _fit_planar(img, numClusters, imgNullVal, init=None, max_iter=300, tol=1e-4)
         0 if imgNullVal is None else int(imgNullVal), int(numClusters),
         None if init is None else _lib.ptr(init), int(max_iter), float(tol), _lib.ptr(centres),
         _lib.ptr(labels), ctypes.byref(nit), ctypes.byref(nrows)))
-    return KMeansModel(centres, nit.value, labels[:nrows.value], None)
+    km = KMeansModel(centres, nit.value, labels[:nrows.value], None)
+    km.fit_path_ = ('lloyd', 'elkan')[c._L.shp_last_fit_path(c.handle)]
+    return km
 
 
 def fitSpectralClusters(img, numClusters, subsamplePcnt, imgNullVal, fixedKMeansInit):

@@ -16,5 +16,5 @@ for rep in range(6):
     t1 = time.time()
     km = shepseg.fitSpectralClusters(img, 60, 100, None, True)
     t2 = time.time()
-    print('%-6s subsample %.1f ms  fitSpectralClusters %.1f ms  n_iter %d  rows %d'
-          % (mode, (t1 - t0) * 1e3, (t2 - t1) * 1e3, km.n_iter_, img.shape[1] * img.shape[2]))
+    print('%-6s subsample %.1f ms  fitSpectralClusters %.1f ms  n_iter %d  rows %d  path %s'
+          % (mode, (t1 - t0) * 1e3, (t2 - t1) * 1e3, km.n_iter_, img.shape[1] * img.shape[2], getattr(km, 'fit_path_', '?')))
