@@ -265,9 +265,17 @@ __global__ __launch_bounds__(256) void k_elk_init(const double *__restrict__ X, 
     ub[i] = min_dist;
 }
 
-// The bounds update that ends elkan_iter (upper += shift of the own centre, lower -= shift, clipped at
-// 0) for the previous iteration when cshift != nullptr, then _update_chunk_dense's relabelling.
+// _update_chunk_dense's relabelling, preceded by the bounds update that ends elkan_iter for the previous
+// iteration when cshift != nullptr (upper += shift of the own centre; lower -= shift, clipped at 0), in
+// ONE pass over the sample's k lower bounds (cluster-major: consecutive lanes read consecutive
+// addresses), ELK_AHEAD loads in flight.  The reference updates all bounds first and relabels afterwards; the
+// only place where the order shows is the write of the tightened upper bound into lb[label] while the
+// scan is still below `label`: that entry is then already final when the scan reaches it (`fresh`).
+// (A lazy form -- replaying the missed shifts only for samples whose upper bound does not clear the
+// nearest other centre -- was tried: on the benchmark sample most samples fail that test in every
+// iteration, and the replay's dependent loads made the kernel three times slower.)
 // *ndiff += labels changed.
+#define ELK_AHEAD 8
 __global__ __launch_bounds__(256) void k_elk_estep(const double *__restrict__ X, uint32_t n, int nb,
                                                    const double *__restrict__ C, int k,
                                                    const double *__restrict__ half,
@@ -283,31 +291,49 @@ __global__ __launch_bounds__(256) void k_elk_estep(const double *__restrict__ X,
         int label = lab[i];
         const int label0 = label;
         double upper = ub[i];
-        if (cshift) {
-            upper += cshift[label];
-            for (int j = 0; j < k; j++) {
-                double v = lb[(size_t)j * n + i] - cshift[j];
-                if (v < 0) v = 0;
-                lb[(size_t)j * n + i] = v;
-            }
-        }
+        if (cshift) upper += cshift[label];
+        const bool open = !(next[label] >= upper);
         bool tight = false;
-        if (!(next[label] >= upper)) {
-            for (int j = 0; j < k; j++)
-                if (j != label && upper > lb[(size_t)j * n + i] && upper > half[(size_t)label * k + j]) {
+        int fresh = -1;
+        double fresh_val = 0.0;
+        double *lbi = lb + i;
+        for (int j0 = 0; j0 < k; j0 += ELK_AHEAD) {
+            double pre[ELK_AHEAD];
+#pragma unroll
+            for (int u = 0; u < ELK_AHEAD; u++) {
+                const int jj = j0 + u < k ? j0 + u : k - 1;
+                pre[u] = lbi[(size_t)jj * n];
+            }
+#pragma unroll
+            for (int u = 0; u < ELK_AHEAD; u++) {
+                const int j = j0 + u;
+                if (j >= k) break;
+                double v;
+                if (j == fresh) v = fresh_val;          // (pre[u] may predate the write)
+                else {
+                    v = pre[u];
+                    if (cshift) {
+                        v -= cshift[j];
+                        if (v < 0) v = 0;
+                        lbi[(size_t)j * n] = v;
+                    }
+                }
+                if (open && j != label && upper > v && upper > half[(size_t)label * k + j]) {
                     if (!tight) {
                         upper = elk_dist(x, C + (size_t)label * nb, nb);
-                        lb[(size_t)label * n + i] = upper;
+                        lbi[(size_t)label * n] = upper;
+                        if (label > j) { fresh = label; fresh_val = upper; }
                         tight = true;
                     }
-                    if (upper > lb[(size_t)j * n + i] || upper > half[(size_t)label * k + j]) {
+                    if (upper > v || upper > half[(size_t)label * k + j]) {
                         const double dist = elk_dist(x, C + (size_t)j * nb, nb);
-                        lb[(size_t)j * n + i] = dist;
+                        lbi[(size_t)j * n] = dist;
                         if (dist < upper) { label = j; upper = dist; }
                     }
                 }
-            lab[i] = label;
+            }
         }
+        if (open) lab[i] = label;
         ub[i] = upper;
         changed = label != label0;
     }
@@ -315,11 +341,12 @@ __global__ __launch_bounds__(256) void k_elk_estep(const double *__restrict__ X,
     if (m != 0ull && lane_id() == 0) atomicAdd(ndiff, (uint32_t)__popcll(m));
 }
 
-// off[j] = first position of label j in the sorted labels (off[k] = n)
+// off[j] = first position of label j in the sorted labels (off[k] = n); *zero_me = 0
 __global__ __launch_bounds__(256) void k_elk_offsets(const uint32_t *__restrict__ keys, uint32_t n, int k,
-                                                     uint32_t *__restrict__ off)
+                                                     uint32_t *__restrict__ off, uint32_t *zero_me)
 {
     const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j == 0) *zero_me = 0u;          // the next E-step's change counter
     if (j > k) return;
     uint32_t lo = 0, hi = n;
     while (lo < hi) {
@@ -357,6 +384,69 @@ __global__ __launch_bounds__(64) void k_fit_sum_lists(const double *__restrict__
     S[(size_t)j * nb + b] = acc;
 }
 
+// The same for nb <= 64 with the rows staged through LDS: a workgroup per cluster gathers the next
+// B = FIT_STAGE_DOUBLES / nb rows of its list with all 256 threads (row numbers first, then the values,
+// all loads unconditional and in flight together; the loads of block i + 1 are issued before block i is
+// summed), laid out band-major in LDS (band b's values of consecutive rows are adjacent), then one lane
+// per band adds them in order, two rows per 128-bit LDS read.  What remains is the chain of dependent
+// additions of the largest cluster.
+#define FIT_STAGE_DOUBLES 6144u       // 48 KiB
+#define FIT_STAGE_PER_THREAD (FIT_STAGE_DOUBLES / 256u)
+__global__ __launch_bounds__(256) void k_fit_sum_lists_staged(const double *__restrict__ X, int nb,
+                                                             const uint32_t *__restrict__ rows,
+                                                             const uint32_t *__restrict__ off,
+                                                             double *__restrict__ S, double *__restrict__ cnt)
+{
+    __shared__ __attribute__((aligned(16))) double sx[FIT_STAGE_DOUBLES + 2u * 64u];
+    const int j = blockIdx.x;
+    const uint32_t q0 = off[j], q1 = off[j + 1];
+    const uint32_t unb = (uint32_t)nb;
+    const uint32_t B = (FIT_STAGE_DOUBLES / unb) & ~1u;          // rows per block (even: 16-byte reads)
+    const uint32_t pitch = B + 2u;                               // doubles between two bands' runs
+    if (threadIdx.x == 0) cnt[j] = (double)(q1 - q0);
+    double v[FIT_STAGE_PER_THREAD];
+    // element e = threadIdx.x + 256 u of a block is band eb[u] of its row er[u] (the same in every block);
+    // rows past the end of the list are clamped to its last one
+    uint32_t er[FIT_STAGE_PER_THREAD], eb[FIT_STAGE_PER_THREAD];
+#pragma unroll
+    for (uint32_t u = 0; u < FIT_STAGE_PER_THREAD; u++) {
+        const uint32_t e = threadIdx.x + u * 256u;
+        er[u] = e / unb; eb[u] = e - er[u] * unb;
+    }
+    auto gather = [&](uint32_t q) {
+        const uint32_t last = ((q1 - q < B) ? (q1 - q) : B) - 1u;
+        uint32_t idx[FIT_STAGE_PER_THREAD];
+#pragma unroll
+        for (uint32_t u = 0; u < FIT_STAGE_PER_THREAD; u++) idx[u] = rows[q + (er[u] < last ? er[u] : last)];
+#pragma unroll
+        for (uint32_t u = 0; u < FIT_STAGE_PER_THREAD; u++) v[u] = X[(size_t)idx[u] * unb + eb[u]];
+    };
+    double acc = 0.0;
+    if (q0 < q1) gather(q0);
+    for (uint32_t q = q0; q < q1; q += B) {
+        const uint32_t nrows = (q1 - q < B) ? (q1 - q) : B;
+#pragma unroll
+        for (uint32_t u = 0; u < FIT_STAGE_PER_THREAD; u++)
+            if (er[u] < nrows) sx[eb[u] * pitch + er[u]] = v[u];
+        __syncthreads();
+        if (q + B < q1) gather(q + B);
+        if (threadIdx.x < unb) {
+            const double *p = sx + threadIdx.x * pitch;
+            uint32_t r = 0;
+            for (; r + 16u <= nrows; r += 16u) {
+                double2 t[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) t[u] = *(const double2 *)(p + r + 2u * (uint32_t)u);
+#pragma unroll
+                for (int u = 0; u < 8; u++) { acc += t[u].x; acc += t[u].y; }
+            }
+            for (; r < nrows; r++) acc += p[r];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < unb) S[(size_t)j * unb + threadIdx.x] = acc;
+}
+
 // The faithful path.  dX: the centred sample on the device (n rows of nb); X: the same on the host
 // through Xat; C: the centred initial centres in, the final centred centres out; dlab: n labels out.
 template <class XAt>
@@ -367,44 +457,62 @@ static int run_fit_elkan(shp_ctx *ctx, const double *dX, XAt Xat, uint32_t n, in
     const int kn = k * nb;
     hipStream_t st = ctx->stream;
     CHK(buf_ensure(ctx, ctx->fit_lb, ((size_t)k * n + n) * 8));
-    const size_t small_doubles = (size_t)kn * 2 + (size_t)k * k + 4 * (size_t)k + 8;
-    CHK(buf_ensure(ctx, ctx->fit_part, small_doubles * 8 + ((size_t)k + 2) * 4 + 64));
+    // small device block: what an iteration sends down (C | half | next | cshift, one copy) and what it
+    // brings back (S | cnt | nd[2], one copy); nd alternates between two counters so that the one an
+    // E-step adds to was zeroed an iteration earlier (k_elk_offsets) and read back in between
+    const size_t up_doubles = (size_t)kn + (size_t)k * k + 2 * (size_t)k, dn_doubles = (size_t)kn + k + 1;
+    CHK(buf_ensure(ctx, ctx->fit_part, (up_doubles + dn_doubles) * 8 + ((size_t)k + 2) * 4 + 64));
     double *dlb = bp<double>(ctx->fit_lb), *dub = dlb + (size_t)k * n;
-    double *dC = bp<double>(ctx->fit_part), *dS = dC + kn, *dhalf = dS + kn, *dnext = dhalf + (size_t)k * k,
-           *dcshift = dnext + k, *dcnt = dcshift + k;
-    uint32_t *doff = (uint32_t *)(dcnt + k + 2), *dnd = doff + k + 1;
-    std::vector<double> half((size_t)k * k), next(k), cshift, Cn(kn), w(k), up;
-    auto upload = [&](bool with_shift) -> int {
-        // C | half | next | cshift in one staged copy (pageable: a few KiB per iteration)
-        up.assign(C.begin(), C.end());
-        HIPCHK(ctx, hipMemcpyAsync(dC, up.data(), (size_t)kn * 8, hipMemcpyHostToDevice, st));
-        HIPCHK(ctx, hipMemcpyAsync(dhalf, half.data(), (size_t)k * k * 8, hipMemcpyHostToDevice, st));
-        HIPCHK(ctx, hipMemcpyAsync(dnext, next.data(), (size_t)k * 8, hipMemcpyHostToDevice, st));
-        if (with_shift) HIPCHK(ctx, hipMemcpyAsync(dcshift, cshift.data(), (size_t)k * 8, hipMemcpyHostToDevice, st));
-        HIPCHK(ctx, hipStreamSynchronize(st));      // the host vectors change before the copies would be read
+    double *dC = bp<double>(ctx->fit_part), *dhalf = dC + kn, *dnext = dhalf + (size_t)k * k, *dcshift = dnext + k;
+    double *dS = dcshift + k, *dcnt = dS + kn;
+    uint32_t *dnd = (uint32_t *)(dcnt + k), *doff = dnd + 2;
+    // host staging: two upload halves (alternating: a half is rewritten two iterations later, after a
+    // stream synchronisation in between) and one download area, pinned when they fit the context's block
+    const size_t stage_bytes = (2 * up_doubles + dn_doubles) * 8;
+    std::vector<double> pageable;
+    double *stage = (double *)ctx->h_pinned;
+    const bool pinned = stage_bytes + 256 <= (size_t)PIN_MIRROR * 4u;
+    if (!pinned) { pageable.resize(2 * up_doubles + dn_doubles); stage = pageable.data(); }
+    double *h_dn = stage + 2 * up_doubles;
+    std::vector<double> half((size_t)k * k), next(k), cshift(k, 0.0), Cn(kn), w(k);
+    int up_turn = 0;
+    auto upload = [&]() -> int {
+        double *h = stage + (size_t)(up_turn++ & 1) * up_doubles;
+        memcpy(h, C.data(), (size_t)kn * 8);
+        memcpy(h + kn, half.data(), (size_t)k * k * 8);
+        memcpy(h + kn + (size_t)k * k, next.data(), (size_t)k * 8);
+        memcpy(h + kn + (size_t)k * k + k, cshift.data(), (size_t)k * 8);
+        HIPCHK(ctx, hipMemcpyAsync(dC, h, up_doubles * 8, hipMemcpyHostToDevice, st));
+        if (!pinned) HIPCHK(ctx, hipStreamSynchronize(st));
         return 0;
     };
+    HIPCHK(ctx, hipStreamSynchronize(st));          // earlier users of the pinned block are done
     elk_half_distances(C.data(), k, nb, half.data(), next.data());
-    CHK(upload(false));
+    CHK(upload());
     HIPCHK(ctx, hipMemsetAsync(dlb, 0, (size_t)k * n * 8, st));
+    HIPCHK(ctx, hipMemsetAsync(dnd, 0, 8, st));
     const unsigned g = grid_for(n, 256);
     hipLaunchKernelGGL(k_elk_init, dim3(g), dim3(256), 0, st, dX, n, nb, dC, k, dhalf, dlab, dub, dlb); KCHK(ctx);
     bool strict = false, pending = false;
     int it = 0;
     for (it = 1; it <= max_iter; it++) {
-        HIPCHK(ctx, hipMemsetAsync(dnd, 0, 4, st));
         hipLaunchKernelGGL(k_elk_estep, dim3(g), dim3(256), 0, st, dX, n, nb, dC, k, dhalf, dnext,
-                           pending ? dcshift : (const double *)nullptr, dlab, dub, dlb, dnd); KCHK(ctx);
+                           pending ? dcshift : (const double *)nullptr, dlab, dub, dlb, dnd + (it & 1)); KCHK(ctx);
         // row lists: the row numbers sorted stably by label
         uint32_t *ks = nullptr, *rows = nullptr;
         CHK(sort_pairs(ctx, (const uint32_t *)dlab, nullptr, n, bits_for((uint32_t)(k - 1)), &ks, &rows));
-        hipLaunchKernelGGL(k_elk_offsets, dim3(grid_for((size_t)k + 1, 256)), dim3(256), 0, st, ks, n, k, doff); KCHK(ctx);
-        hipLaunchKernelGGL(k_fit_sum_lists, dim3(k, (nb + 63) / 64), dim3(64), 0, st, dX, nb, rows, doff, dS, dcnt); KCHK(ctx);
-        uint32_t nd = 0;
-        HIPCHK(ctx, hipMemcpyAsync(Cn.data(), dS, (size_t)kn * 8, hipMemcpyDeviceToHost, st));
-        HIPCHK(ctx, hipMemcpyAsync(w.data(), dcnt, (size_t)k * 8, hipMemcpyDeviceToHost, st));
-        HIPCHK(ctx, hipMemcpyAsync(&nd, dnd, 4, hipMemcpyDeviceToHost, st));
+        hipLaunchKernelGGL(k_elk_offsets, dim3(grid_for((size_t)k + 1, 256)), dim3(256), 0, st, ks, n, k, doff,
+                           dnd + ((it + 1) & 1)); KCHK(ctx);
+        if (nb <= 64)
+            hipLaunchKernelGGL(k_fit_sum_lists_staged, dim3(k), dim3(256), 0, st, dX, nb, rows, doff, dS, dcnt);
+        else
+            hipLaunchKernelGGL(k_fit_sum_lists, dim3(k, (nb + 63) / 64), dim3(64), 0, st, dX, nb, rows, doff, dS, dcnt);
+        KCHK(ctx);
+        HIPCHK(ctx, hipMemcpyAsync(h_dn, dS, dn_doubles * 8, hipMemcpyDeviceToHost, st));
         HIPCHK(ctx, hipStreamSynchronize(st));
+        memcpy(Cn.data(), h_dn, (size_t)kn * 8);
+        memcpy(w.data(), h_dn + kn, (size_t)k * 8);
+        const uint32_t nd = ((const uint32_t *)(h_dn + kn + k))[it & 1];
         double shift_tot = 0.0;
         auto fetch = [&](std::vector<double> &dist, std::vector<int32_t> &hl) -> int {
             hipLaunchKernelGGL(k_fit_dist, dim3(g), dim3(256), 0, st, dX, n, nb, dlab, dC, ddist); KCHK(ctx);
@@ -417,17 +525,15 @@ static int run_fit_elkan(shp_ctx *ctx, const double *dX, XAt Xat, uint32_t n, in
         CHK(fit_mstep_tail(k, nb, n, Cn, w, C, Xat, fetch, cshift, &shift_tot));
         elk_half_distances(Cn.data(), k, nb, half.data(), next.data());
         C = Cn;
-        CHK(upload(true));
+        CHK(upload());
         pending = true;
         if (it >= 2 && nd == 0u) { strict = true; break; }
         if (shift_tot <= tol) break;
     }
     if (it > max_iter) it = max_iter;
-    if (!strict) {
-        HIPCHK(ctx, hipMemsetAsync(dnd, 0, 4, st));
+    if (!strict)
         hipLaunchKernelGGL(k_elk_estep, dim3(g), dim3(256), 0, st, dX, n, nb, dC, k, dhalf, dnext,
                            pending ? dcshift : (const double *)nullptr, dlab, dub, dlb, dnd); KCHK(ctx);
-    }
     HIPCHK(ctx, hipStreamSynchronize(st));
     *n_iter_out = it;
     return 0;

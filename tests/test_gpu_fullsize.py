@@ -9,6 +9,7 @@ interior 4096 x 4096 tile windows is compared with the oracle bit for bit.  C4 (
 bands) and C5 (per-segment statistics over 1.6 Gpx / 50 M segments) go through the same kind of
 properties plus one oracle-checked window each."""
 import ctypes
+import os
 
 import numpy as np
 import pytest
@@ -97,6 +98,12 @@ def test_c3_fullsize_properties(oracle):
         # the reference's stitch can leave a few ids empty; flag and histogram agree
         assert bool(r.hasEmptySegments) == bool((hist[1:] == 0).any())
         assert (hist[1:] == 0).sum() < 1e-3 * mx
+        # the whole-image k-means model is the REFERENCE's, bit for bit: tests/golden/c3_fit_reference.npz
+        # holds shepseg.fitSpectralClusters' centres for this raster's sub-sample (sklearn 0.24.2, Elkan's
+        # algorithm, all 300 iterations; oracle/refgen/gen_golden_c3_fit.py)
+        ref = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'c3_fit_reference.npz'))
+        assert r.kmeans.n_iter_ == int(ref['n_iter'])
+        assert np.array_equal(centres.view(np.uint64), ref['centres'].view(np.uint64))
         # deterministic run to run: same model, same ids, same histogram
         assert runs[1][0] == mx and np.array_equal(runs[1][1], hist)
         assert np.array_equal(runs[1][2], centres) and runs[1][3] == msd
@@ -105,12 +112,14 @@ def test_c3_fullsize_properties(oracle):
         from pyshepseg_amd import distributed
         eng = distributed.HipEngine(lambda yLo, yHi: tiling.DeviceRaster.synth(11, 6, yHi - yLo, N, y0=yLo),
                                     numWorkers=16)
-        # ... in the PARALLEL form of the stitch (provisional ids per tile, renumbered at the end): on
-        # this imagery no tile hides its last new id outside its trimmed window, so the form is kept
+        # ... in the PARALLEL form of the stitch (provisional ids per tile, renumbered at the end).  Whether
+        # the form is kept depends on the segmentation: with the reference's model for this raster one of
+        # the 144 tiles hides its last new id outside its trimmed window (the reference then reuses the
+        # id), the driver notices and redoes the chain sequentially -- either way the same result
         d = distributed.runDistributed(eng, distributed.Comm(None), N, N, 4096, 1024, minSegmentSize=50,
                                        numClusters=60, fixedKMeansInit=True, stitchMode='parallel')
         eng.ras.free()
-        assert d.stitchMode == 'parallel'
+        assert d.stitchMode in ('parallel', 'parallel->sequential')
         assert d.maxSegId == mx and np.array_equal(np.asarray(d.hist).astype(np.int64), hist)
         assert np.array_equal(d.kmeans.cluster_centers_, centres)
 
@@ -162,7 +171,10 @@ def test_c4_fullsize_properties(oracle):
         hist = np.asarray(r.hist).astype(np.int64)
         mx = int(r.maxSegId)
         assert mx == len(hist) - 1 and mx > 100000
-        assert hist[0] == 0 and N * N - 64 <= int(hist.sum()) <= N * N      # (see the C3 test)
+        # (see the C3 test; with the reference's model for this raster the stitch quirk blanks the 3431 pixels
+        # that one 10 716-pixel segment of tile (5, 2), crossing both midlines, has in its trimmed window:
+        # tests/diag_c4_zeros.py)
+        assert hist[0] == 0 and N * N - 20000 <= int(hist.sum()) <= N * N
         assert r.numTileRows == 12 and r.numTileCols == 12
         assert r.kmeans.cluster_centers_.shape == (60, 10)
         assert bool(r.hasEmptySegments) == bool((hist[1:] == 0).any())
