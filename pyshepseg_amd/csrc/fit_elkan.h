@@ -31,8 +31,12 @@
 
 // DOUBLE_pairwise_sum (numpy/core/src/umath/loops_utils.h.src): what a float64 .sum() over a
 // contiguous run evaluates; plain left to right below 8 elements.  get(i) yields element i.
-template <class Get>
-__host__ __device__ inline double np_pairwise_sum_fn(Get get, size_t lo, size_t n)
+// (the halving above 128 elements is numpy's recursion; here its depth is a template parameter, so that
+//  device code gets plain nested calls instead of a recursive function on a dynamic stack -- the
+//  recursive form made k_fit_update, the one kernel that called it out of line, read its loop control
+//  back wrongly.  LEVELS = 10 covers 131072 elements: k <= 65534 centres, nb <= 4096 bands.)
+template <int LEVELS, class Get>
+__host__ __device__ inline double np_pairwise_sum_lv(Get get, size_t lo, size_t n)
 {
     if (n < 8) {
         double res = 0.0;
@@ -49,9 +53,18 @@ __host__ __device__ inline double np_pairwise_sum_fn(Get get, size_t lo, size_t 
         for (; i < n; i++) res += get(lo + i);
         return res;
     }
-    size_t n2 = n / 2;
-    n2 -= n2 % 8;
-    return np_pairwise_sum_fn(get, lo, n2) + np_pairwise_sum_fn(get, lo + n2, n - n2);
+    if constexpr (LEVELS > 0) {
+        size_t n2 = n / 2;
+        n2 -= n2 % 8;
+        return np_pairwise_sum_lv<LEVELS - 1>(get, lo, n2) + np_pairwise_sum_lv<LEVELS - 1>(get, lo + n2, n - n2);
+    } else {
+        return __builtin_nan("");           // more than 128 * 2^10 elements: no caller gets here
+    }
+}
+template <class Get>
+__host__ __device__ inline double np_pairwise_sum_fn(Get get, size_t lo, size_t n)
+{
+    return np_pairwise_sum_lv<10>(get, lo, n);
 }
 __host__ __device__ inline double np_pairwise_sum(const double *a, size_t n)
 {

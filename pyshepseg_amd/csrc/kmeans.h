@@ -760,7 +760,7 @@ static int run_kmeans_fit(shp_ctx *ctx, const void *xin_any, int xdtype, int64_t
     double tol = 0.0;
     for (int b = 0; b < nb; b++) tol += acc2[b] / (double)n;
     tol = tol / nb * tol_rel;
-    std::vector<double> C(kn), Cn(kn), w(k), hm((size_t)kn + k);
+    std::vector<double> C(kn);
     for (int t = 0; t < kn; t++) C[t] = init[t] - mu[t % nb];
 
     uint32_t chunk = FIT_LDS_DOUBLES / (uint32_t)nb;
@@ -785,10 +785,9 @@ static int run_kmeans_fit(shp_ctx *ctx, const void *xin_any, int xdtype, int64_t
     uint32_t *dpc2 = dpc + (size_t)nchunks * k;
     double *dm2c = bp<double>(ctx->cen), *dcn = dm2c + kn, *dC = dcn + k;
     hipStream_t st = ctx->stream;
-    // pinned staging: [0..] FitCtl, then m2c|cnorm|C (2kn+k doubles), then S|w (kn+k doubles)
+    // pinned staging: [0..] FitCtl, then m2c|cnorm|C (2kn+k doubles)
     FitCtl *pin_ctl = (FitCtl *)ctx->h_pinned;
     double *pin_up = (double *)(ctx->h_pinned + 16);
-    double *pin_dn = pin_up + (2 * kn + k);
     HIPCHK(ctx, hipStreamSynchronize(st));           // earlier users of the staging area are done
     if (planar) {
         CHK(buf_ensure(ctx, ctx->aux, xbytes));
@@ -824,7 +823,7 @@ static int run_kmeans_fit(shp_ctx *ctx, const void *xin_any, int xdtype, int64_t
     // lloyd (never leave the fast path), elkan (always the reference's algorithm): fit_elkan.h
     const char *algo_env = getenv("SHEPSEG_FIT_ALGO");
     const bool force_lloyd = k == 1 || (algo_env && !strcmp(algo_env, "lloyd"));
-    bool elkan = !force_lloyd && algo_env && !strcmp(algo_env, "elkan");
+    bool elkan = k > 1 && !force_lloyd && algo_env && !strcmp(algo_env, "elkan");
     const std::vector<double> C0 = C;
     ctx->fit_path = 0;
     CHK(upload_centres(C));
@@ -849,6 +848,9 @@ static int run_kmeans_fit(shp_ctx *ctx, const void *xin_any, int xdtype, int64_t
         HIPCHK(ctx, hipMemcpyAsync(pin_ctl, dctl, sizeof(FitCtl), hipMemcpyDeviceToHost, st));
         HIPCHK(ctx, hipStreamSynchronize(st));
         const uint32_t stop = pin_ctl->stop;
+        if (getenv("SHEPSEG_FIT_TIMING"))
+            fprintf(stderr, "kmeans fit: batch to %d: stop %u iters %u ndiff %u near %u shift %.17g tol %.17g\n", b_end, stop,
+                    pin_ctl->iters, pin_ctl->ndiff, pin_ctl->near, pin_ctl->shift, tol);
         if (pin_ctl->near != 0u && !force_lloyd) { elkan = true; break; }    // a (near) tie decided a label
         if (stop == 0u) { it_done = b_end; continue; }
         if (stop == 1u || stop == 3u) {
@@ -857,33 +859,12 @@ static int run_kmeans_fit(shp_ctx *ctx, const void *xin_any, int xdtype, int64_t
             finished = true;
             break;
         }
-        // stop == 2: iteration `it` found an empty cluster after its E-step and level-2 sums; the
-        // host finishes it (fit_mstep_tail: relocation, averaging, shifts)
-        const int it = (int)pin_ctl->iters + 1;
-        const uint32_t nd = pin_ctl->ndiff;
-        int32_t *dlab = (it & 1) ? dlabA : dlabB;
-        HIPCHK(ctx, hipMemcpyAsync(pin_dn, dS, (size_t)(kn + k) * 8, hipMemcpyDeviceToHost, st));
-        HIPCHK(ctx, hipMemcpyAsync(pin_up, dC, (size_t)kn * 8, hipMemcpyDeviceToHost, st));
-        HIPCHK(ctx, hipStreamSynchronize(st));
-        for (int t = 0; t < kn; t++) { Cn[t] = pin_dn[t]; C[t] = pin_up[t]; }
-        for (int j = 0; j < k; j++) w[j] = pin_dn[kn + j];
-        auto fetch = [&](std::vector<double> &dist, std::vector<int32_t> &hl) -> int {
-            hipLaunchKernelGGL(k_fit_dist, dim3(grid_for(n, 256)), dim3(256), 0, st, dX, n, nb, dlab, dC, ddist); KCHK(ctx);
-            dist.resize(n); hl.resize(n);
-            HIPCHK(ctx, hipMemcpyAsync(dist.data(), ddist, (size_t)n * 8, hipMemcpyDeviceToHost, st));
-            HIPCHK(ctx, hipMemcpyAsync(hl.data(), dlab, (size_t)n * 4, hipMemcpyDeviceToHost, st));
-            HIPCHK(ctx, hipStreamSynchronize(st));
-            return 0;
-        };
-        std::vector<double> cshift;
-        double shift = 0.0;
-        CHK(fit_mstep_tail(k, nb, n, Cn, w, C, Xat, fetch, cshift, &shift));
-        C = Cn;
-        it_done = it;
-        CHK(upload_centres(C));
-        CHK(upload_ctl((uint32_t)it));
-        if (nd == 0) { strict = true; finished = true; }
-        else if (shift <= tol) finished = true;
+        // stop == 2: an iteration found an empty cluster.  Relocations are the reference algorithm's
+        // business (which samples move where depends on its distances and on numpy's partition order,
+        // and what follows on Elkan's bounds): start over on that path (fit_elkan.h)
+        if (force_lloyd && k > 1) SHP_FAIL(ctx, SHP_ERR_ARG, "kmeans_fit: an empty cluster needs SHEPSEG_FIT_ALGO=auto or elkan");
+        elkan = true;
+        break;
     }
     int it = it_done;
     int32_t *dlab = (it_done & 1) ? dlabA : dlabB;

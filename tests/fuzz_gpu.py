@@ -4,7 +4,7 @@ parameters, runs the HIP path and the C oracle, and compares bit for bit:
   tile   shepseg.doShepherdSegmentation           vs oracle.segment_tile
   tiled  tiling.doTiledShepherdSegmentation        vs oracle tiles + oracle.stitch_tiles
   stats  tilingstats.calcPerSegmentStats           vs oracle.segstats
-  fit    shepseg._fit (device Lloyd)              vs oracle.kmeans_fit: n_iter_, partition, centres to 1e-8
+  fit    shepseg._fit                             vs oracle.kmeans_fit(algorithm='elkan'): n_iter_, labels_, centres (bit for bit on the Elkan path)
   subset subset.subsetImage                        vs oracle.subset_recode
   spatial tilingstats.calcPerSegmentSpatialStats  vs oracle.spatialstats (edge counts, variogram, mean coordinates)
   spectra shepseg.buildSegmentSpectra / makeSegmentLocations vs oracle
@@ -150,20 +150,27 @@ def more_case(rng, kind, tmpdir):
         if len(np.unique(img, axis=0)) < k:
             return None
         init = shepseg.diagonalClusterCentres(img, k).astype(np.float64)
-        want_c, want_l, want_n = oracle.kmeans_fit(img, init)
+        if rng.random() < 0.5:                   # half of the cases on the lattice itself: exact ties, empty clusters
+            img = np.floor(img)
+            if len(np.unique(img, axis=0)) < k:
+                return None
+            init = shepseg.diagonalClusterCentres(img, k).astype(np.float64)
+        # the reference's algorithm (Elkan's k-means as sklearn 0.24.2 evaluates it, row-order sums)
+        want_c, want_l, want_n = oracle.kmeans_fit(img, init, algorithm='elkan')
         km = shepseg._fit(np.ascontiguousarray(img), init)
-        pairs = set(zip(km.labels_.tolist(), want_l.tolist()))
-        same_part = len(pairs) == len(set(km.labels_.tolist())) == len(set(want_l.tolist()))
-        a = km.cluster_centers_[np.lexsort(km.cluster_centers_.T[::-1])]
-        b = want_c[np.lexsort(want_c.T[::-1])]
-        cdiff = float(np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b))))
-        ok = km.n_iter_ == want_n and same_part and cdiff < 1e-9
-        moved = int((np.array([dict(pairs).get(x, -1) for x in km.labels_.tolist()]) != want_l).sum()) if not same_part else 0
-        if not ok and os.environ.get('SHEPSEG_FUZZ_DUMP'):      # keep the case for a post-mortem on the CPU
-            np.savez_compressed(os.path.join(os.environ['SHEPSEG_FUZZ_DUMP'], 'fit_fail_%d_%d.npz' % (n, k)), img=img,
+        if km.fit_path_ == 'elkan':              # a (near) tie was met: the device ran the same algorithm -> bit for bit
+            ok = (km.n_iter_ == want_n and np.array_equal(km.labels_, want_l) and
+                  np.array_equal(km.cluster_centers_.view(np.uint64), want_c.view(np.uint64)))
+        else:                                    # no label hung on a tie: Lloyd iterations, chunked sums -> same
+            ok = (km.n_iter_ == want_n and np.array_equal(km.labels_, want_l) and      # partitions, centres to rounding
+                  np.allclose(km.cluster_centers_, want_c, rtol=1e-11, atol=1e-9))
+        cdiff = float(np.max(np.abs(km.cluster_centers_ - want_c) / np.maximum(1.0, np.abs(want_c))))
+        dump = os.environ.get('SHEPSEG_FUZZ_DUMP')     # keep (a few small) failing cases for a post-mortem on the CPU
+        if not ok and dump and img.size < 100000 and len([f for f in os.listdir(dump) if f.startswith('fit_fail_')]) < 6:
+            np.savez_compressed(os.path.join(dump, 'fit_fail_%d_%d.npz' % (n, k)), img=img,
                                 init=init, dev_centres=km.cluster_centers_, dev_labels=km.labels_, dev_n_iter=km.n_iter_)
-        return ok, 'fit %s n=%d nb=%d k=%d n_iter=%d/%d same_partition=%s rows_differing~%d max_rel_centre_diff=%.2e' % (
-            np.dtype(dtype).name, n, nb, k, km.n_iter_, want_n, same_part, moved, cdiff)
+        return ok, 'fit %s n=%d nb=%d k=%d path=%s n_iter=%d/%d labels_equal=%s max_rel_centre_diff=%.2e' % (
+            np.dtype(dtype).name, n, nb, k, km.fit_path_, km.n_iter_, want_n, np.array_equal(km.labels_, want_l), cdiff)
     if kind == 'sharded':
         from pyshepseg_amd import distributed
         from pyshepseg_amd import comm as shpcomm
