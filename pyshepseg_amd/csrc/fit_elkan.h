@@ -354,6 +354,97 @@ __global__ __launch_bounds__(256) void k_elk_estep(const double *__restrict__ X,
     if (m != 0ull && lane_id() == 0) atomicAdd(ndiff, (uint32_t)__popcll(m));
 }
 
+// The same for k <= 64 in two phases, the reference's own order: first every lower bound is updated in a
+// branch-free streaming pass that also notes, one bit per centre, where the (shifted) upper bound exceeds
+// both the lower bound and the half distance from the sample's centre (the centres' half distances sit in
+// LDS: a per-lane gather); then only those centres are visited, in index order, with the reference's
+// tests on the current values.  The set is a superset of the centres the reference's scan stops at while
+// the label stands, because the upper bound only falls during the scan -- except when the tightened
+// distance comes out a rounding above the bound it replaces; after that, and after a relabelling (the half
+// distances are then the new centre's), the rest of the set is rebuilt.  In the one-pass form nearly
+// every centre's branch was taken by some lane of a wavefront; here a wavefront runs as many distance
+// evaluations as its busiest lane needs.
+__global__ __launch_bounds__(256) void k_elk_estep64(const double *__restrict__ X, uint32_t n, int nb,
+                                                     const double *__restrict__ C, int k,
+                                                     const double *__restrict__ half,
+                                                     const double *__restrict__ next,
+                                                     const double *__restrict__ cshift,
+                                                     int32_t *__restrict__ lab, double *__restrict__ ub,
+                                                     double *__restrict__ lb, uint32_t *ndiff)
+{
+    __shared__ double sh[64 * 64];
+    for (int t = threadIdx.x; t < k * k; t += 256) sh[t] = half[t];
+    __syncthreads();
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    uint32_t changed = 0;
+    if (i < n) {
+        const double *x = X + (size_t)i * nb;
+        int label = lab[i];
+        const int label0 = label;
+        double upper = ub[i];
+        if (cshift) upper += cshift[label];
+        double *lbi = lb + i;
+        const double *hrow = sh + label * k;
+        unsigned long long cand = 0ull;
+        for (int j0 = 0; j0 < k; j0 += ELK_AHEAD) {
+            double pre[ELK_AHEAD];
+#pragma unroll
+            for (int u = 0; u < ELK_AHEAD; u++) {
+                const int jj = j0 + u < k ? j0 + u : k - 1;
+                pre[u] = lbi[(size_t)jj * n];
+            }
+#pragma unroll
+            for (int u = 0; u < ELK_AHEAD; u++) {
+                const int j = j0 + u;
+                if (j < k) {
+                    double v = pre[u];
+                    if (cshift) {
+                        v -= cshift[j];
+                        if (v < 0) v = 0;
+                        lbi[(size_t)j * n] = v;
+                    }
+                    cand |= (upper > v && upper > hrow[j]) ? (1ull << j) : 0ull;
+                }
+            }
+        }
+        if (!(next[label] >= upper)) {
+            bool tight = false;
+            cand &= ~(1ull << label);
+            // the centres after j that can pass the reference's first test with the current label and bound
+            auto rebuild = [&](int j) {
+                unsigned long long c2 = 0ull;
+                for (int q = j + 1; q < k; q++)
+                    if (q != label && upper > lbi[(size_t)q * n] && upper > sh[label * k + q]) c2 |= 1ull << q;
+                return c2;
+            };
+            while (cand) {
+                const int j = __builtin_ctzll(cand);
+                cand &= cand - 1ull;
+                if (j == label) continue;
+                if (upper > lbi[(size_t)j * n] && upper > sh[label * k + j]) {
+                    if (!tight) {
+                        const double was = upper;
+                        upper = elk_dist(x, C + (size_t)label * nb, nb);
+                        lbi[(size_t)label * n] = upper;
+                        tight = true;
+                        if (upper > was) cand = rebuild(j);        // a rounding above the bound it replaces
+                    }
+                    if (upper > lbi[(size_t)j * n] || upper > sh[label * k + j]) {
+                        const double dist = elk_dist(x, C + (size_t)j * nb, nb);
+                        lbi[(size_t)j * n] = dist;
+                        if (dist < upper) { label = j; upper = dist; cand = rebuild(j); }
+                    }
+                }
+            }
+            lab[i] = label;
+        }
+        ub[i] = upper;
+        changed = label != label0;
+    }
+    const unsigned long long m = __ballot(changed != 0u);
+    if (m != 0ull && lane_id() == 0) atomicAdd(ndiff, (uint32_t)__popcll(m));
+}
+
 // off[j] = first position of label j in the sorted labels (off[k] = n); *zero_me = 0
 __global__ __launch_bounds__(256) void k_elk_offsets(const uint32_t *__restrict__ keys, uint32_t n, int k,
                                                      uint32_t *__restrict__ off, uint32_t *zero_me)
@@ -509,8 +600,13 @@ static int run_fit_elkan(shp_ctx *ctx, const double *dX, XAt Xat, uint32_t n, in
     bool strict = false, pending = false;
     int it = 0;
     for (it = 1; it <= max_iter; it++) {
-        hipLaunchKernelGGL(k_elk_estep, dim3(g), dim3(256), 0, st, dX, n, nb, dC, k, dhalf, dnext,
-                           pending ? dcshift : (const double *)nullptr, dlab, dub, dlb, dnd + (it & 1)); KCHK(ctx);
+        if (k <= 64)
+            hipLaunchKernelGGL(k_elk_estep64, dim3(g), dim3(256), 0, st, dX, n, nb, dC, k, dhalf, dnext,
+                               pending ? dcshift : (const double *)nullptr, dlab, dub, dlb, dnd + (it & 1));
+        else
+            hipLaunchKernelGGL(k_elk_estep, dim3(g), dim3(256), 0, st, dX, n, nb, dC, k, dhalf, dnext,
+                               pending ? dcshift : (const double *)nullptr, dlab, dub, dlb, dnd + (it & 1));
+        KCHK(ctx);
         // row lists: the row numbers sorted stably by label
         uint32_t *ks = nullptr, *rows = nullptr;
         CHK(sort_pairs(ctx, (const uint32_t *)dlab, nullptr, n, bits_for((uint32_t)(k - 1)), &ks, &rows));
@@ -544,9 +640,15 @@ static int run_fit_elkan(shp_ctx *ctx, const double *dX, XAt Xat, uint32_t n, in
         if (shift_tot <= tol) break;
     }
     if (it > max_iter) it = max_iter;
-    if (!strict)
-        hipLaunchKernelGGL(k_elk_estep, dim3(g), dim3(256), 0, st, dX, n, nb, dC, k, dhalf, dnext,
-                           pending ? dcshift : (const double *)nullptr, dlab, dub, dlb, dnd); KCHK(ctx);
+    if (!strict) {
+        if (k <= 64)
+            hipLaunchKernelGGL(k_elk_estep64, dim3(g), dim3(256), 0, st, dX, n, nb, dC, k, dhalf, dnext,
+                               pending ? dcshift : (const double *)nullptr, dlab, dub, dlb, dnd);
+        else
+            hipLaunchKernelGGL(k_elk_estep, dim3(g), dim3(256), 0, st, dX, n, nb, dC, k, dhalf, dnext,
+                               pending ? dcshift : (const double *)nullptr, dlab, dub, dlb, dnd);
+        KCHK(ctx);
+    }
     HIPCHK(ctx, hipStreamSynchronize(st));
     *n_iter_out = it;
     return 0;
