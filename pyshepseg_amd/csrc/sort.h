@@ -224,9 +224,10 @@ static inline int bits_for(uint32_t maxval)      // significant bits of the larg
 static int sort_pairs(shp_ctx *ctx, const uint32_t *keys_in, const uint32_t *vals_in, uint32_t n,
                       int bits, uint32_t **keys_sorted, uint32_t **vals_sorted, bool staged = false)
 {
-    // the staged form takes 4096 items per workgroup: half the block histograms to scan and re-read,
-    // and a digit's run in the staged order is 16 items (64 bytes) instead of 8 when the digits are random
-    static const bool wide = !getenv("SHEPSEG_SORT_WIDE") || atoi(getenv("SHEPSEG_SORT_WIDE")) != 0;
+    // SHEPSEG_SORT_WIDE=1: the staged form with 4096 items per workgroup (half the block histograms, 64-byte
+    // runs per digit).  Measured on C5: histogram passes 3.8 -> 3.2 ms, scatter passes 9.2 -> 11.2 ms (116
+    // VGPRs, 38 KiB of LDS: four workgroups per CU): slower overall, so off by default.
+    static const bool wide = getenv("SHEPSEG_SORT_WIDE") && atoi(getenv("SHEPSEG_SORT_WIDE")) != 0;
     const uint32_t tile = (staged && wide) ? 2u * SORT_TILE : SORT_TILE;
     const uint32_t nblk = (n + tile - 1) / tile;
     int passes = (bits + 7) / 8;
