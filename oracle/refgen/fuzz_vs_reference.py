@@ -5,9 +5,9 @@
 `wide`: 32-bit imagery (uint32 and int32) over the types' whole range and at their limits, where
 the reference's integer arithmetic wraps (findNearestNeighbourPixel) and float32 sums are inexact.
 
-Stage by stage (assign, clump, single-pixel elimination, small-segment
-elimination, k-means fit partition) the oracle must equal the reference bit
-for bit.  Build container only; see refenv.py.
+Stage by stage (assign, clump, single-pixel elimination, small-segment elimination, and the
+k-means fit: n_iter_, labels_, cluster_centers_) the oracle must equal the reference bit for
+bit.  Run with OMP_NUM_THREADS=1 (the fit's sums).  Build container only; see refenv.py.
 """
 import sys
 import time
@@ -139,19 +139,19 @@ def main():
         full = oracle.segment_tile(img, c, min_seg, float(ref['msd']), null_val, four)
         if not np.array_equal(full['segimg'], ref['seg_final']):
             print('FULL MISMATCH', tag); ok = False
-        # k-means fit: same partition + n_iter as sklearn (labels up to permutation, N12/N14)
+        # k-means fit, the reference's algorithm (Elkan's, sklearn 0.24.2 algorithm="auto"): n_iter_, labels_ and
+        # cluster_centers_ bit for bit.  Needs OMP_NUM_THREADS=1 (with more threads sklearn's M-step sums are
+        # added in the order its threads finish).
         x = np.transpose(img, (1, 2, 0)).reshape(nr * nc, nb)
         if null_val is not None:
             x = x[(x != null_val).all(axis=1)]
         xs = x[::int(round(100. / pcnt))]
         init = shepseg.diagonalClusterCentres(xs, k)
-        cfit, lab, nit = oracle.kmeans_fit(xs.astype(np.float64), init.astype(np.float64))
-        rl = km.labels_
-        pairs = set(zip(lab.tolist(), rl.tolist()))
-        if nit != km.n_iter_ or len(pairs) != len(set(lab.tolist())) or \
-                len(pairs) != len(set(rl.tolist())):
-            print('KMFIT MISMATCH', tag, nit, km.n_iter_, len(pairs), len(set(lab.tolist())),
-                  len(set(rl.tolist())))
+        cfit, lab, nit = oracle.kmeans_fit(xs.astype(np.float64), init.astype(np.float64), algorithm='elkan')
+        if nit != km.n_iter_ or not np.array_equal(lab, km.labels_) or \
+                not np.array_equal(cfit.view(np.uint64), np.asarray(km.cluster_centers_, dtype=np.float64).view(np.uint64)):
+            print('KMFIT MISMATCH', tag, nit, km.n_iter_, int((lab != km.labels_).sum()),
+                  float(np.abs(cfit - km.cluster_centers_).max()))
             ok = False
         nfail += (not ok)
         if case % 20 == 0:

@@ -93,7 +93,8 @@ def test_device_fit_equals_reference_on_ties(ties, shepseg):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize('n,nb,k', [(20000, 6, 60), (5000, 1, 12), (9000, 10, 30), (700, 3, 300), (130000, 4, 25)])
+@pytest.mark.parametrize('n,nb,k', [(20000, 6, 60), (5000, 1, 12), (9000, 10, 30), (700, 3, 300), (130000, 4, 25),
+                                    (3000, 70, 5), (64, 2, 64), (4000, 8, 65)])
 def test_device_elkan_path_equals_oracle(n, nb, k, shepseg, oracle, monkeypatch):
     """SHEPSEG_FIT_ALGO=elkan on integer samples with a few hundred distinct rows (ties, empty
     clusters): the device's Elkan path against the oracle's, bit for bit; and without the override the
@@ -140,3 +141,17 @@ def test_device_fast_path_equals_elkan_when_guard_is_quiet(seed, shepseg, oracle
     km_e = shepseg._fit(xs, init)
     assert km_e.n_iter_ == ne and np.array_equal(km_e.labels_, le)
     assert np.array_equal(km_e.cluster_centers_.view(np.uint64), ce.view(np.uint64))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('max_iter', [1, 2, 3, 7])
+def test_device_elkan_path_stops_at_max_iter(max_iter, shepseg, oracle, monkeypatch):
+    """the iteration limit on the Elkan path: same labels (the final E-step included) and centres as the oracle"""
+    rng = np.random.RandomState(max_iter)
+    xs = rng.randint(0, 40, size=(6000, 3)).astype(np.uint8)
+    init = shepseg.diagonalClusterCentres(xs, 12).astype(np.float64)
+    want_c, want_l, want_n = oracle.kmeans_fit(xs.astype(np.float64), init, max_iter=max_iter, algorithm='elkan')
+    monkeypatch.setenv('SHEPSEG_FIT_ALGO', 'elkan')
+    km = shepseg._fit(xs, init, max_iter=max_iter)
+    assert km.n_iter_ == want_n and np.array_equal(km.labels_, want_l)
+    assert np.array_equal(km.cluster_centers_.view(np.uint64), want_c.view(np.uint64))
