@@ -9,8 +9,16 @@
  *
  * Parity status: PINNED.  Every function below is checked against the
  * unmodified reference run under real numba 0.54.1 / sklearn 0.24.2 in the
- * build container (oracle/refgen/gen_golden.py -> tests/golden/, and
- * oracle/refgen/fuzz_vs_reference.py).
+ * build container (oracle/refgen/gen_golden*.py -> tests/golden/, and
+ * oracle/refgen/fuzz_vs_reference.py: 400 + 300 random cases, every stage and
+ * the k-means fit bit for bit).  The fit the reference runs is ELKAN's
+ * k-means (sklearn 0.24.2 algorithm="auto"): orc_kmeans_fit_elkan, pinned on
+ * top by oracle/refgen/probe_elkan.py with one OpenMP thread -- the only
+ * reproducible setting of the reference itself.  orc_kmeans_fit /
+ * orc_kmeans_fit_assoc restate Lloyd's algorithm (what the HIP fit runs while no
+ * label hangs on a tie) and are pinned through it: same partitions, iteration
+ * count and, with the row-order sums, centres as Elkan's wherever no sample is
+ * equidistant from two centres.
  *
  * Each function cites the reference file:line it restates.  Numeric typing
  * follows SURVEY.md section 8(a0) (facts N1..N14, established by running the
