@@ -622,6 +622,7 @@ static int run_fit_elkan(shp_ctx *ctx, const double *dX, XAt Xat, uint32_t n, in
         memcpy(Cn.data(), h_dn, (size_t)kn * 8);
         memcpy(w.data(), h_dn + kn, (size_t)k * 8);
         const uint32_t nd = ((const uint32_t *)(h_dn + kn + k))[it & 1];
+        if (getenv("SHEPSEG_FIT_TRACE")) fprintf(stderr, "elkan it %d: labels changed %u\n", it, nd);
         double shift_tot = 0.0;
         auto fetch = [&](std::vector<double> &dist, std::vector<int32_t> &hl) -> int {
             hipLaunchKernelGGL(k_fit_dist, dim3(g), dim3(256), 0, st, dX, n, nb, dlab, dC, ddist); KCHK(ctx);
