@@ -172,7 +172,7 @@ def stats_cases():
                                                         ('med', 'median'), ('mode', 'mode')])
 
 
-def stitch_case(name, img, tile_size, overlap, k, min_seg, null_val, four):
+def stitch_case(name, img, tile_size, overlap, k, min_seg, null_val, four, pcnt=5):
     """tiling.stitchTiles loop (tiling.py:979-1043) driven through the reference's own
     recodeTile / recodeSharedSegments / relabelSegments / crossesMidline, in memory."""
     from pyshepseg import tiling
@@ -184,7 +184,7 @@ def stitch_case(name, img, tile_size, overlap, k, min_seg, null_val, four):
     class FakeMgr(object):
         pass
     ti = tiling.getTilesForFile(FakeDs(), tile_size, overlap)
-    km = shepseg.fitSpectralClusters(img, k, 5, null_val, True)
+    km = shepseg.fitSpectralClusters(img, k, pcnt, null_val, True)
     cache = {}
     mgr = FakeMgr()
     mgr.overlapSize = overlap
@@ -233,6 +233,7 @@ def stitch_case(name, img, tile_size, overlap, k, min_seg, null_val, four):
          min_seg=np.int64(min_seg), null_val=np.int64(-1 if null_val is None else null_val),
          has_null=np.int64(null_val is not None), four=np.int64(four),
          centres=np.asarray(km.cluster_centers_, dtype=np.float64), msd=np.float64(msd),
+         n_iter=np.int64(km.n_iter_), pcnt=np.int64(pcnt),
          ntcols=np.int64(ti.ncols), ntrows=np.int64(ti.nrows), mosaic=out,
          max_seg_id=np.int64(max_seg), hist=hist.hist.astype(np.uint32), **arrs)
     print('   tiles %dx%d maxSegId %d empty ids %d' % (ti.ncols, ti.nrows, max_seg,

@@ -71,6 +71,29 @@ def test_oracle_elkan_equals_lloyd_without_ties(oracle):
         assert np.array_equal(ce, cl)           # same partitions, same row-order sums
 
 
+@pytest.mark.parametrize('name', ['e2e_ties_a', 'e2e_ties_b'])
+def test_oracle_end_to_end_model_included(name, golden, oracle):
+    """the reference's whole job on rasters where the model hangs on ties (oracle/refgen/gen_golden_e2e_ties.py):
+    Elkan fit of the whole raster -> tiles -> stitch, all through the oracle, against the reference's mosaic"""
+    from pyshepseg_amd import shepseg as host          # host-side sample selection / diagonal init only
+    g = golden(name)
+    img = g['img']
+    null = int(g['null_val']) if int(g['has_null']) else None
+    xs = host._sample_rows(img, 100, null)
+    init = host.diagonalClusterCentres(xs, int(g['k'])).astype(np.float64)
+    c, _l, nit = oracle.kmeans_fit(xs.astype(np.float64), init, algorithm='elkan')
+    assert nit == int(g['n_iter']) and np.array_equal(c.view(np.uint64), g['centres'].view(np.uint64))
+    c2, _l2, _n2 = oracle.kmeans_fit(xs.astype(np.float64), init, algorithm='full')
+    assert not np.array_equal(c2, g['centres'])         # the fixture is one where Lloyd's model differs
+    tiles, ntc, ntr = oracle.get_tiles(img.shape[1], img.shape[2], int(g['tile_size']), int(g['overlap']))
+    local = {}
+    for (col, row), (x, y, xs_, ys_) in tiles.items():
+        sub = np.ascontiguousarray(img[:, y:y + ys_, x:x + xs_])
+        local[(col, row)] = oracle.segment_tile(sub, c, int(g['min_seg']), float(g['msd']), null, bool(g['four']))['segimg']
+    want, mx, hist = oracle.stitch_tiles(local, tiles, ntc, ntr, img.shape[1], img.shape[2], int(g['overlap']))
+    assert mx == int(g['max_seg_id']) and np.array_equal(want, g['mosaic']) and np.array_equal(hist, g['hist'])
+
+
 # ---- GPU ----------------------------------------------------------------------------------------
 
 @pytest.fixture(scope='module')

@@ -12,6 +12,28 @@ pytestmark = pytest.mark.gpu
 STITCH = sorted(os.path.basename(p)[:-4] for p in glob.glob(os.path.join(GOLDEN, 'stitch_*.npz')))
 
 
+@pytest.mark.parametrize('name', ['e2e_ties_a', 'e2e_ties_b'])
+def test_golden_tiled_end_to_end_model_included(name, golden):
+    """The whole job with NO model handed in: the k-means fit of the whole raster, the tiles, the stitch,
+    against goldens whose model is the reference's own fitSpectralClusters on rasters where Elkan's
+    algorithm (what the reference runs) and Lloyd's end in different models
+    (oracle/refgen/gen_golden_e2e_ties.py): centres and n_iter_ bit for bit, then the mosaic."""
+    from pyshepseg_amd import tiling
+    g = golden(name)
+    null = int(g['null_val']) if int(g['has_null']) else None
+    cfg = tiling.SegmentationConcurrencyConfig(concurrencyType=tiling.CONC_THREADS, numWorkers=2)
+    r = tiling.doTiledShepherdSegmentation(
+        g['img'], None, tileSize=int(g['tile_size']), overlapSize=int(g['overlap']),
+        minSegmentSize=int(g['min_seg']), numClusters=int(g['k']), imgNullVal=null,
+        fourConnected=bool(g['four']), fixedKMeansInit=True, concurrencyCfg=cfg)
+    assert r.kmeans.n_iter_ == int(g['n_iter'])
+    assert np.array_equal(r.kmeans.cluster_centers_.view(np.uint64), g['centres'].view(np.uint64))
+    assert r.maxSpectralDiff == g['msd']
+    assert r.maxSegId == int(g['max_seg_id'])
+    assert np.array_equal(r.segimg, g['mosaic'])
+    assert np.array_equal(r.hist, g['hist'])
+
+
 @pytest.mark.parametrize('name', STITCH)
 @pytest.mark.parametrize('workers', [1, 3])
 def test_golden_tiled(name, workers, golden):
