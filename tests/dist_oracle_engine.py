@@ -32,7 +32,7 @@ class OracleEngine(object):
         from pyshepseg_amd import shepseg
         xs = shepseg._sample_rows(img, 100, imgNullVal)
         init = shepseg.diagonalClusterCentres(xs, numClusters).astype(np.float64)
-        c, _l, _n = self.orc.kmeans_fit(xs.astype(np.float64), init)
+        c, _l, _n = self.orc.kmeans_fit(xs.astype(np.float64), init, algorithm='elkan')     # the reference's algorithm
         return _KM(c)
 
     def startSegmentation(self, centres, msd, imgNullVal, fourConnected, minSegmentSize):

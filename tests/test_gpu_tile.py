@@ -282,13 +282,14 @@ def test_tiny_min_segment_size_patch_tables(four, shepseg, oracle):
 
 @pytest.mark.parametrize('k,n', [(300, 9000), (7, 5000), (60, 700)])
 def test_kmeans_fit_vs_oracle_shapes(k, n, shepseg, oracle):
-    """Lloyd fit against the oracle's sklearn-0.24.2 restatement: k above the in-LDS counting sort's
-    limit (plain partial-sum kernel), small k, and fewer than three chunks of rows."""
+    """The fit against the oracle's sklearn-0.24.2 restatement: k above the in-LDS counting sort's limit (plain
+    partial-sum kernel on the Lloyd path, the generic bounds kernel on the Elkan path), small k, and fewer
+    than three chunks of rows."""
     rng = np.random.RandomState(k)
     cent = rng.randint(500, 60000, size=(k, 4))
     xs = (cent[rng.randint(0, k, size=n)] + rng.randint(-200, 200, size=(n, 4))).astype(np.uint16)
     init = shepseg.diagonalClusterCentres(xs, k).astype(np.float64)
-    want_c, want_l, want_n = oracle.kmeans_fit(xs.astype(np.float64), init)
+    want_c, want_l, want_n = oracle.kmeans_fit(xs.astype(np.float64), init, algorithm='elkan')   # the reference's
     km = shepseg._fit(xs, init)
     assert km.n_iter_ == want_n
     assert np.allclose(km.cluster_centers_, want_c, rtol=0, atol=1e-8)
