@@ -102,6 +102,9 @@ def test_c3_fullsize_properties(oracle):
         # holds shepseg.fitSpectralClusters' centres for this raster's sub-sample (sklearn 0.24.2, Elkan's
         # algorithm, all 300 iterations; oracle/refgen/gen_golden_c3_fit.py)
         ref = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'c3_fit_reference.npz'))
+        import zlib
+        sample = tiling.readSubsampledImage(ras, list(range(1, 7)), np.sqrt(1e6 / (N * N)))
+        assert zlib.crc32(np.ascontiguousarray(sample).tobytes()) == int(ref['sample_crc32'])    # the fixture's input
         assert r.kmeans.n_iter_ == int(ref['n_iter'])
         assert np.array_equal(centres.view(np.uint64), ref['centres'].view(np.uint64))
         # deterministic run to run: same model, same ids, same histogram
