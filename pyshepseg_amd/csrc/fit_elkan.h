@@ -20,7 +20,8 @@
 //  * this one, taken when the guard fires (SHEPSEG_FIT_ALGO=elkan: always): bounds kept per sample and
 //    centre (k x n float64, cluster-major), M-step sums in ROW order per cluster (sklearn with one
 //    OpenMP thread; row lists by one stable radix pass over the labels), the k x nb sized tail of an
-//    iteration on the host, one host round trip per iteration.  Bit-identical to the oracle's
+//    iteration in a one-workgroup kernel (k_elk_update), eight iterations per host round trip; an
+//    iteration that leaves a cluster empty is finished on the host.  Bit-identical to the oracle's
 //    orc_kmeans_fit_elkan, i.e. to the reference with OMP_NUM_THREADS=1 (with more threads sklearn
 //    adds per-thread partial sums in the order the threads finish: not reproducible run to run).
 // Shared by both: empty-cluster relocation as numpy evaluates it (pairwise row sums, np.argpartition's
@@ -295,8 +296,10 @@ __global__ __launch_bounds__(256) void k_elk_estep(const double *__restrict__ X,
                                                    const double *__restrict__ next,
                                                    const double *__restrict__ cshift,
                                                    int32_t *__restrict__ lab, double *__restrict__ ub,
-                                                   double *__restrict__ lb, uint32_t *ndiff)
+                                                   double *__restrict__ lb, uint32_t *ndiff,
+                                                   const uint32_t *stop)
 {
+    if (stop && *stop) return;                  // the loop has ended: the rest of the batch is a no-op
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     uint32_t changed = 0;
     if (i < n) {
@@ -372,8 +375,10 @@ __global__ __launch_bounds__(256) void k_elk_estep64(const double *__restrict__ 
                                                      const double *__restrict__ next,
                                                      const double *__restrict__ cshift,
                                                      int32_t *__restrict__ lab, double *__restrict__ ub,
-                                                     double *__restrict__ lb, uint32_t *ndiff)
+                                                     double *__restrict__ lb, uint32_t *ndiff,
+                                                     const uint32_t *stop)
 {
+    if (stop && *stop) return;
     __shared__ double sh[64 * 64];
     for (int t = threadIdx.x; t < k * k; t += 256) sh[t] = half[t];
     __syncthreads();
@@ -449,8 +454,10 @@ __global__ __launch_bounds__(256) void k_elk_estep64(const double *__restrict__ 
 
 // off[j] = first position of label j in the sorted labels (off[k] = n); *zero_me = 0
 __global__ __launch_bounds__(256) void k_elk_offsets(const uint32_t *__restrict__ keys, uint32_t n, int k,
-                                                     uint32_t *__restrict__ off, uint32_t *zero_me)
+                                                     uint32_t *__restrict__ off, uint32_t *zero_me,
+                                                     const uint32_t *stop)
 {
+    if (stop && *stop) return;
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j == 0) *zero_me = 0u;          // the next E-step's change counter
     if (j > k) return;
@@ -469,8 +476,10 @@ __global__ __launch_bounds__(256) void k_elk_offsets(const uint32_t *__restrict_
 __global__ __launch_bounds__(64) void k_fit_sum_lists(const double *__restrict__ X, int nb,
                                                       const uint32_t *__restrict__ rows,
                                                       const uint32_t *__restrict__ off,
-                                                      double *__restrict__ S, double *__restrict__ cnt)
+                                                      double *__restrict__ S, double *__restrict__ cnt,
+                                                      const uint32_t *stop)
 {
+    if (stop && *stop) return;
     const int j = blockIdx.x, b = blockIdx.y * 64 + threadIdx.x;
     const uint32_t q0 = off[j], q1 = off[j + 1];
     if (b == 0) cnt[j] = (double)(q1 - q0);
@@ -501,8 +510,10 @@ __global__ __launch_bounds__(64) void k_fit_sum_lists(const double *__restrict__
 __global__ __launch_bounds__(256) void k_fit_sum_lists_staged(const double *__restrict__ X, int nb,
                                                              const uint32_t *__restrict__ rows,
                                                              const uint32_t *__restrict__ off,
-                                                             double *__restrict__ S, double *__restrict__ cnt)
+                                                             double *__restrict__ S, double *__restrict__ cnt,
+                                                             const uint32_t *stop)
 {
+    if (stop && *stop) return;
     __shared__ __attribute__((aligned(16))) double sx[FIT_STAGE_DOUBLES + 2u * 64u];
     const int j = blockIdx.x;
     const uint32_t q0 = off[j], q1 = off[j + 1];
@@ -553,8 +564,102 @@ __global__ __launch_bounds__(256) void k_fit_sum_lists_staged(const double *__re
     if (threadIdx.x < unb) S[(size_t)j * unb + threadIdx.x] = acc;
 }
 
+// loop control of the Elkan iterations, owned by the device between host synchronisations
+struct ElkCtl {
+    uint32_t stop;      // 0 running; 1 labels unchanged (strict convergence); 2 an empty cluster: the host
+                        // finishes this iteration; 3 centre shift <= tol
+    uint32_t iters;     // completed iterations
+    uint32_t nd[2];     // labels changed by the E-step of iteration it: nd[it & 1]
+    double shift_tot;
+};
+
+// The end of an iteration in one workgroup, unless a cluster came out empty (left to the host:
+// fit_mstep_tail): centres = sums * (1 / weight), the centres' shifts and their squared sum, the new
+// centres' half distances and nearest-centre distances, sklearn's two convergence tests.  Every float64
+// operation and its order are those of fit_mstep_tail / elk_half_distances.  C: the old centres in, the
+// new ones out.
+__global__ __launch_bounds__(1024) void k_elk_update(double *__restrict__ S, const double *__restrict__ cnt,
+                                                    int k, int nb, double *__restrict__ C,
+                                                    double *__restrict__ cshift, double *__restrict__ half,
+                                                    double *__restrict__ next, double *__restrict__ scratch,
+                                                    ElkCtl *ctl, double tol, uint32_t it)
+{
+    if (ctl->stop) return;
+    __shared__ int s_empty;
+    const int kn = k * nb;
+    if (threadIdx.x == 0) s_empty = 0;
+    __syncthreads();
+    for (int j = threadIdx.x; j < k; j += 1024) if (cnt[j] == 0.0) s_empty = 1;
+    __syncthreads();
+    if (s_empty) {
+        if (threadIdx.x == 0) ctl->stop = 2u;
+        return;
+    }
+    for (int t = threadIdx.x; t < kn; t += 1024) {
+        const double alpha = 1.0 / cnt[t / nb];
+        S[t] = S[t] * alpha;                                 // the new centres
+    }
+    __syncthreads();
+    double *sq = scratch, *xx = scratch + k;
+    for (int j = threadIdx.x; j < k; j += 1024) {
+        const double *a = &S[j * nb], *c = &C[j * nb];
+        double r = 0.0;
+        int b = 0;
+        for (; b + 4 <= nb; b += 4)
+            r += ((a[b] - c[b]) * (a[b] - c[b]) + (a[b + 1] - c[b + 1]) * (a[b + 1] - c[b + 1]) +
+                  (a[b + 2] - c[b + 2]) * (a[b + 2] - c[b + 2]) + (a[b + 3] - c[b + 3]) * (a[b + 3] - c[b + 3]));
+        for (; b < nb; b++) r += (a[b] - c[b]) * (a[b] - c[b]);
+        const double sh = __builtin_sqrt(r);
+        cshift[j] = sh;
+        sq[j] = sh * sh;
+        xx[j] = kmeans_sqnorm(a, nb);
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < k * k; e += 1024) {
+        const int a = e / k, b = e - a * k;
+        double d = 0.0;
+        for (int t = 0; t < nb; t++) d = d + S[(size_t)a * nb + t] * S[(size_t)b * nb + t];
+        double v = -2.0 * d;
+        v = v + xx[a];
+        v = v + xx[b];
+        if (!(v > 0.0)) v = 0.0;
+        if (a == b) v = 0.0;
+        half[e] = __builtin_sqrt(v) / 2.0;
+    }
+    for (int t = threadIdx.x; t < kn; t += 1024) C[t] = S[t];
+    __syncthreads();
+    for (int l = threadIdx.x; l < k; l += 1024) {
+        double m0 = half[l], m1 = -1.0;
+        for (int a0 = 1; a0 < k; a0 += 8) {          // eight loads in flight, the comparisons in order
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = half[(size_t)(a0 + u < k ? a0 + u : k - 1) * k + l];
+#pragma unroll
+            for (int u = 0; u < 8; u++)
+                if (a0 + u < k) {
+                    if (v[u] < m0) { m1 = m0; m0 = v[u]; }
+                    else if (m1 < 0.0 || v[u] < m1) m1 = v[u];
+                }
+        }
+        next[l] = k > 1 ? m1 : m0;
+    }
+    if (threadIdx.x == 0) {
+        const double shift_tot = np_pairwise_sum(sq, (size_t)k);
+        const uint32_t nd = ctl->nd[it & 1u];
+        ctl->shift_tot = shift_tot;
+        ctl->iters = it;
+        if (it >= 2u && nd == 0u) ctl->stop = 1u;
+        else if (shift_tot <= tol) ctl->stop = 3u;
+    }
+}
+
+#define ELK_BATCH 8                 // iterations enqueued between two host synchronisations
+
 // The faithful path.  dX: the centred sample on the device (n rows of nb); X: the same on the host
 // through Xat; C: the centred initial centres in, the final centred centres out; dlab: n labels out.
+// Iterations run in batches of ELK_BATCH without a host round trip (k_elk_update owns the convergence
+// tests; once it raises ctl->stop the kernels still queued behind it return at once); an iteration that
+// leaves a cluster empty is finished on the host.
 template <class XAt>
 static int run_fit_elkan(shp_ctx *ctx, const double *dX, XAt Xat, uint32_t n, int nb, int k,
                          std::vector<double> &C, int max_iter, double tol, int32_t *dlab, double *ddist,
@@ -563,68 +668,99 @@ static int run_fit_elkan(shp_ctx *ctx, const double *dX, XAt Xat, uint32_t n, in
     const int kn = k * nb;
     hipStream_t st = ctx->stream;
     CHK(buf_ensure(ctx, ctx->fit_lb, ((size_t)k * n + n) * 8));
-    // small device block: what an iteration sends down (C | half | next | cshift, one copy) and what it
-    // brings back (S | cnt | nd[2], one copy); nd alternates between two counters so that the one an
-    // E-step adds to was zeroed an iteration earlier (k_elk_offsets) and read back in between
-    const size_t up_doubles = (size_t)kn + (size_t)k * k + 2 * (size_t)k, dn_doubles = (size_t)kn + k + 1;
-    CHK(buf_ensure(ctx, ctx->fit_part, (up_doubles + dn_doubles) * 8 + ((size_t)k + 2) * 4 + 64));
+    // small device block: C | cshift | half | next | S | cnt | scratch (2k) | ctl | off (k + 1)
+    const size_t small_doubles = (size_t)kn + k + (size_t)k * k + k + kn + k + 2 * (size_t)k;
+    CHK(buf_ensure(ctx, ctx->fit_part, small_doubles * 8 + sizeof(ElkCtl) + ((size_t)k + 2) * 4 + 64));
     double *dlb = bp<double>(ctx->fit_lb), *dub = dlb + (size_t)k * n;
-    double *dC = bp<double>(ctx->fit_part), *dhalf = dC + kn, *dnext = dhalf + (size_t)k * k, *dcshift = dnext + k;
-    double *dS = dcshift + k, *dcnt = dS + kn;
-    uint32_t *dnd = (uint32_t *)(dcnt + k), *doff = dnd + 2;
-    // host staging: two upload halves (alternating: a half is rewritten two iterations later, after a
-    // stream synchronisation in between) and one download area, pinned when they fit the context's block
-    const size_t stage_bytes = (2 * up_doubles + dn_doubles) * 8;
+    double *dC = bp<double>(ctx->fit_part), *dcshift = dC + kn, *dhalf = dcshift + k, *dnext = dhalf + (size_t)k * k;
+    double *dS = dnext + k, *dcnt = dS + kn, *dscr = dcnt + k;
+    ElkCtl *dctl = (ElkCtl *)(dscr + 2 * (size_t)k);
+    uint32_t *doff = (uint32_t *)(dctl + 1);
+    uint32_t *dstop = &dctl->stop;
+    // host staging (pinned when it fits the context's block): C | cshift | half | next up, S | cnt down, ctl
+    const size_t up_doubles = (size_t)kn + k + (size_t)k * k + k, dn_doubles = (size_t)kn + k;
     std::vector<double> pageable;
     double *stage = (double *)ctx->h_pinned;
-    const bool pinned = stage_bytes + 256 <= (size_t)PIN_MIRROR * 4u;
-    if (!pinned) { pageable.resize(2 * up_doubles + dn_doubles); stage = pageable.data(); }
-    double *h_dn = stage + 2 * up_doubles;
+    const bool pinned = (up_doubles + dn_doubles) * 8 + sizeof(ElkCtl) + 256 <= (size_t)PIN_MIRROR * 4u;
+    if (!pinned) { pageable.resize(up_doubles + dn_doubles + 8); stage = pageable.data(); }
+    double *h_up = stage, *h_dn = stage + up_doubles;
+    ElkCtl *h_ctl = (ElkCtl *)(h_dn + dn_doubles);
     std::vector<double> half((size_t)k * k), next(k), cshift(k, 0.0), Cn(kn), w(k);
-    int up_turn = 0;
-    auto upload = [&]() -> int {
-        double *h = stage + (size_t)(up_turn++ & 1) * up_doubles;
-        memcpy(h, C.data(), (size_t)kn * 8);
-        memcpy(h + kn, half.data(), (size_t)k * k * 8);
-        memcpy(h + kn + (size_t)k * k, next.data(), (size_t)k * 8);
-        memcpy(h + kn + (size_t)k * k + k, cshift.data(), (size_t)k * 8);
-        HIPCHK(ctx, hipMemcpyAsync(dC, h, up_doubles * 8, hipMemcpyHostToDevice, st));
-        if (!pinned) HIPCHK(ctx, hipStreamSynchronize(st));
+    auto upload = [&]() -> int {                    // (the stream is idle whenever this runs)
+        memcpy(h_up, C.data(), (size_t)kn * 8);
+        memcpy(h_up + kn, cshift.data(), (size_t)k * 8);
+        memcpy(h_up + kn + k, half.data(), (size_t)k * k * 8);
+        memcpy(h_up + kn + k + (size_t)k * k, next.data(), (size_t)k * 8);
+        HIPCHK(ctx, hipMemcpyAsync(dC, h_up, up_doubles * 8, hipMemcpyHostToDevice, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        return 0;
+    };
+    auto upload_ctl = [&](uint32_t iters, uint32_t nd0, uint32_t nd1) -> int {
+        memset(h_ctl, 0, sizeof(ElkCtl));
+        h_ctl->iters = iters; h_ctl->nd[0] = nd0; h_ctl->nd[1] = nd1;
+        HIPCHK(ctx, hipMemcpyAsync(dctl, h_ctl, sizeof(ElkCtl), hipMemcpyHostToDevice, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
         return 0;
     };
     HIPCHK(ctx, hipStreamSynchronize(st));          // earlier users of the pinned block are done
     elk_half_distances(C.data(), k, nb, half.data(), next.data());
-    CHK(upload());
+    CHK(upload());                                  // (cshift = 0: the first E-step's bounds update changes nothing)
+    CHK(upload_ctl(0, 0, 0));
     HIPCHK(ctx, hipMemsetAsync(dlb, 0, (size_t)k * n * 8, st));
-    HIPCHK(ctx, hipMemsetAsync(dnd, 0, 8, st));
     const unsigned g = grid_for(n, 256);
     hipLaunchKernelGGL(k_elk_init, dim3(g), dim3(256), 0, st, dX, n, nb, dC, k, dhalf, dlab, dub, dlb); KCHK(ctx);
-    bool strict = false, pending = false;
-    int it = 0;
-    for (it = 1; it <= max_iter; it++) {
+    auto estep = [&](uint32_t *nd, const uint32_t *stop) -> int {
         if (k <= 64)
-            hipLaunchKernelGGL(k_elk_estep64, dim3(g), dim3(256), 0, st, dX, n, nb, dC, k, dhalf, dnext,
-                               pending ? dcshift : (const double *)nullptr, dlab, dub, dlb, dnd + (it & 1));
+            hipLaunchKernelGGL(k_elk_estep64, dim3(g), dim3(256), 0, st, dX, n, nb, dC, k, dhalf, dnext, dcshift, dlab,
+                               dub, dlb, nd, stop);
         else
-            hipLaunchKernelGGL(k_elk_estep, dim3(g), dim3(256), 0, st, dX, n, nb, dC, k, dhalf, dnext,
-                               pending ? dcshift : (const double *)nullptr, dlab, dub, dlb, dnd + (it & 1));
+            hipLaunchKernelGGL(k_elk_estep, dim3(g), dim3(256), 0, st, dX, n, nb, dC, k, dhalf, dnext, dcshift, dlab,
+                               dub, dlb, nd, stop);
         KCHK(ctx);
-        // row lists: the row numbers sorted stably by label
-        uint32_t *ks = nullptr, *rows = nullptr;
-        CHK(sort_pairs(ctx, (const uint32_t *)dlab, nullptr, n, bits_for((uint32_t)(k - 1)), &ks, &rows));
-        hipLaunchKernelGGL(k_elk_offsets, dim3(grid_for((size_t)k + 1, 256)), dim3(256), 0, st, ks, n, k, doff,
-                           dnd + ((it + 1) & 1)); KCHK(ctx);
-        if (nb <= 64)
-            hipLaunchKernelGGL(k_fit_sum_lists_staged, dim3(k), dim3(256), 0, st, dX, nb, rows, doff, dS, dcnt);
-        else
-            hipLaunchKernelGGL(k_fit_sum_lists, dim3(k, (nb + 63) / 64), dim3(64), 0, st, dX, nb, rows, doff, dS, dcnt);
-        KCHK(ctx);
+        return 0;
+    };
+    bool strict = false, finished = false;
+    int it_done = 0;
+    while (it_done < max_iter && !finished) {
+        const int b_end = it_done + ELK_BATCH < max_iter ? it_done + ELK_BATCH : max_iter;
+        for (int it = it_done + 1; it <= b_end; it++) {
+            CHK(estep(&dctl->nd[it & 1], dstop));
+            // row lists: the row numbers sorted stably by label
+            uint32_t *ks = nullptr, *rows = nullptr;
+            CHK(sort_pairs(ctx, (const uint32_t *)dlab, nullptr, n, bits_for((uint32_t)(k - 1)), &ks, &rows));
+            hipLaunchKernelGGL(k_elk_offsets, dim3(grid_for((size_t)k + 1, 256)), dim3(256), 0, st, ks, n, k, doff,
+                               &dctl->nd[(it + 1) & 1], dstop); KCHK(ctx);
+            if (nb <= 64)
+                hipLaunchKernelGGL(k_fit_sum_lists_staged, dim3(k), dim3(256), 0, st, dX, nb, rows, doff, dS, dcnt, dstop);
+            else
+                hipLaunchKernelGGL(k_fit_sum_lists, dim3(k, (nb + 63) / 64), dim3(64), 0, st, dX, nb, rows, doff, dS, dcnt,
+                                   dstop);
+            KCHK(ctx);
+            hipLaunchKernelGGL(k_elk_update, dim3(1), dim3(1024), 0, st, dS, dcnt, k, nb, dC, dcshift, dhalf, dnext, dscr,
+                               dctl, tol, (uint32_t)it); KCHK(ctx);
+        }
+        HIPCHK(ctx, hipMemcpyAsync(h_ctl, dctl, sizeof(ElkCtl), hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        const uint32_t stop = h_ctl->stop;
+        if (getenv("SHEPSEG_FIT_TRACE"))
+            fprintf(stderr, "elkan batch to %d: stop %u iters %u labels changed %u / %u shift %.17g\n", b_end, stop,
+                    h_ctl->iters, h_ctl->nd[0], h_ctl->nd[1], h_ctl->shift_tot);
+        if (stop == 0u) { it_done = b_end; continue; }
+        if (stop == 1u || stop == 3u) {
+            it_done = (int)h_ctl->iters;
+            strict = stop == 1u;
+            finished = true;
+            break;
+        }
+        // stop == 2: iteration `it` left a cluster empty after its E-step and sums; the host finishes it
+        const int it = (int)h_ctl->iters + 1;
+        const uint32_t nd = h_ctl->nd[it & 1], nd_other = h_ctl->nd[(it + 1) & 1];
         HIPCHK(ctx, hipMemcpyAsync(h_dn, dS, dn_doubles * 8, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipMemcpyAsync(h_up, dC, (size_t)kn * 8, hipMemcpyDeviceToHost, st));
         HIPCHK(ctx, hipStreamSynchronize(st));
         memcpy(Cn.data(), h_dn, (size_t)kn * 8);
         memcpy(w.data(), h_dn + kn, (size_t)k * 8);
-        const uint32_t nd = ((const uint32_t *)(h_dn + kn + k))[it & 1];
-        if (getenv("SHEPSEG_FIT_TRACE")) fprintf(stderr, "elkan it %d: labels changed %u\n", it, nd);
+        memcpy(C.data(), h_up, (size_t)kn * 8);             // the centres this iteration started from
         double shift_tot = 0.0;
         auto fetch = [&](std::vector<double> &dist, std::vector<int32_t> &hl) -> int {
             hipLaunchKernelGGL(k_fit_dist, dim3(g), dim3(256), 0, st, dX, n, nb, dlab, dC, ddist); KCHK(ctx);
@@ -638,21 +774,17 @@ static int run_fit_elkan(shp_ctx *ctx, const double *dX, XAt Xat, uint32_t n, in
         elk_half_distances(Cn.data(), k, nb, half.data(), next.data());
         C = Cn;
         CHK(upload());
-        pending = true;
-        if (it >= 2 && nd == 0u) { strict = true; break; }
-        if (shift_tot <= tol) break;
+        // (the counter the next E-step adds to was zeroed by this iteration's k_elk_offsets)
+        CHK(upload_ctl((uint32_t)it, (it & 1) ? nd_other : nd, (it & 1) ? nd : nd_other));
+        it_done = it;
+        if (it >= 2 && nd == 0u) { strict = true; finished = true; }
+        else if (shift_tot <= tol) finished = true;
     }
-    if (it > max_iter) it = max_iter;
-    if (!strict) {
-        if (k <= 64)
-            hipLaunchKernelGGL(k_elk_estep64, dim3(g), dim3(256), 0, st, dX, n, nb, dC, k, dhalf, dnext,
-                               pending ? dcshift : (const double *)nullptr, dlab, dub, dlb, dnd);
-        else
-            hipLaunchKernelGGL(k_elk_estep, dim3(g), dim3(256), 0, st, dX, n, nb, dC, k, dhalf, dnext,
-                               pending ? dcshift : (const double *)nullptr, dlab, dub, dlb, dnd);
-        KCHK(ctx);
-    }
+    if (!strict) CHK(estep(&dctl->nd[0], nullptr));
+    // the final centres
+    HIPCHK(ctx, hipMemcpyAsync(h_up, dC, (size_t)kn * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipStreamSynchronize(st));
-    *n_iter_out = it;
+    memcpy(C.data(), h_up, (size_t)kn * 8);
+    *n_iter_out = it_done;
     return 0;
 }
