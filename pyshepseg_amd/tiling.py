@@ -590,6 +590,13 @@ class _RasterStreamer(object):
         self.full.put(None)
         for t in self.threads:
             t.join(timeout=60.0)
+        if any(t.is_alive() for t in self.threads):
+            # a reader still blocked in a slow file / GDAL read would later write into a buffer
+            # that the pool had handed to the next run, or the uploader would use a destroyed
+            # context: leak both (as the tiled driver does for a stuck worker)
+            self.stuck = True
+            self.bufs = []
+            return
         self.cUp.check(self.cUp._L.shp_sync(self.cUp.handle))
         for b in self.bufs:
             _pinnedPut(b)
@@ -1183,9 +1190,17 @@ def doTiledShepherdSegmentation(infile, outfile, tileSize=DFLT_TILESIZE,
                     def sink(y0, y1, v, dest=dest):
                         dest[y0:y1] = v
                 else:
-                    def sink(y0, y1, v, band=gdalOut[1]):
-                        band.WriteArray(v, 0, y0)
-                writer = _OutputWriter(d_out, inYsize, inXsize, sink, timings)
+                    # one GDAL dataset handle is not safe for concurrent calls (the SWIG layer drops
+                    # the GIL, the KEA / GTiff drivers behind it keep unguarded state): the row
+                    # blocks go to the band one at a time, as the reference's single WriteArray
+                    # per tile does (tiling.py:1032-1034)
+                    gdalLock = threading.Lock()
+
+                    def sink(y0, y1, v, band=gdalOut[1], lock=gdalLock):
+                        with lock:
+                            band.WriteArray(v, 0, y0)
+                writer = _OutputWriter(d_out, inYsize, inXsize, sink, timings,
+                                       nCopiers=1 if gdalOut is not None else None)
             rowsWritten = 0
             ovLevels = overviewLevels(inXsize, inYsize) if outfile is not _KEEP_ON_DEVICE else []
             ovDev = []
@@ -1291,7 +1306,7 @@ def doTiledShepherdSegmentation(infile, outfile, tileSize=DFLT_TILESIZE,
                     writer.finish()
                 except Exception:
                     pass
-            stuck = False
+            stuck = bool(streamer is not None and getattr(streamer, 'stuck', False))
             for t in threads:
                 t.join(timeout=None if ok else 120.0)
                 stuck = stuck or t.is_alive()
