@@ -94,7 +94,7 @@ static int ctx_create(int device, int high_priority, shp_ctx **out, bool shared)
                  &ctx->pix, &ctx->segsz, &ctx->origsz, &ctx->off, &ctx->ssum, &ctx->chnext,
                  &ctx->chtail, &ctx->mergeto, &ctx->tcount, &ctx->toff, &ctx->tfill, &ctx->tlist,
                  &ctx->tsorted, &ctx->small, &ctx->cen, &ctx->fit_x, &ctx->fit_lab, &ctx->fit_part, &ctx->fit_lb,
-                 &ctx->big, &ctx->srclist, &ctx->tgtlist, &ctx->bigbits, &ctx->singles, &ctx->dbg};
+                 &ctx->big, &ctx->srclist, &ctx->tgtlist, &ctx->bigbits, &ctx->singles, &ctx->dbg, &ctx->snap};
     *out = ctx;
     return SHP_OK;
 }
@@ -1154,6 +1154,11 @@ static ReservePlan reserve_plan(int dtype, int nbands, size_t n)
     pl.push_back({&shp_ctx::singles, (n + 2) * 4});
     pl.push_back({&shp_ctx::bigbits, (n / 32 + 2) * 4});
     pl.push_back({&shp_ctx::big, (size_t)maxbig * (sizeof(BigInfo) + 4) + 128});
+    {       // the replay's bitmap snapshots: a walker-pool-sized slot per walker (run_clump)
+        const size_t walkers = ((size_t)maxbig + DFS_WAVES - 1) / DFS_WAVES * DFS_WAVES;
+        const size_t cap = (size_t)DFS_MAX_BLOCKS * DFS_WAVES;
+        pl.push_back({&shp_ctx::snap, (walkers < cap ? walkers : cap) * DFS_POOL_GRANS_DEFAULT * DFS_GRAN_WORDS * 4});
+    }
     pl.push_back({&shp_ctx::sort_hist, 2 * nh * 4});
     pl.push_back({&shp_ctx::scan_tmp, scan_tmp_bytes(n > nh ? n : nh)});
     DevBuf shp_ctx::*perseg[] = {&shp_ctx::origsz, &shp_ctx::chnext, &shp_ctx::chtail, &shp_ctx::mergeto,

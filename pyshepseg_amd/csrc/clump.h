@@ -430,6 +430,7 @@ __device__ __forceinline__ void dfs_split_global(uint32_t *lab, const BigInfo &B
 // (stack pointers travel by value, packed sp_l | sp_g << 32: a reference parameter of an
 // out-of-line function would pin them to scratch memory in the walk)
 #define UNI(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))      // wave-uniform by construction
+#define UNI64(x) ((unsigned long long)UNI((uint32_t)(x)) | ((unsigned long long)UNI((uint32_t)((x) >> 32)) << 32))
 __device__ __noinline__ unsigned long long dfs_spill(uint32_t *sw, uint32_t *gstack, uint32_t sp_l, uint32_t sp_g)
 {
     const unsigned lane = lane_id();
@@ -465,7 +466,8 @@ __device__ __forceinline__ unsigned long long dfs_bitmap_words(const BigInfo &B,
 {
     const uint32_t minr = B.root / ncols;
     const uint32_t H = B.maxr - minr + 1u, W = B.maxc - B.minc + 1u;
-    return (unsigned long long)(H + 2u) * ((W + 2u + 31u) >> 5);
+    const uint32_t wpr = (W + 2u + 31u) >> 5;
+    return (unsigned long long)(H + 2u) * (wpr < 2u ? 2u : wpr);      // (a tile row of the walk is two words)
 }
 
 __device__ __forceinline__ void dfs_split_lds(uint32_t *lab, const BigInfo &B, uint32_t *bm,
@@ -612,6 +614,408 @@ __device__ __forceinline__ void dfs_split_lds(uint32_t *lab, const BigInfo &B, u
     }
 }
 
+// ---- the replay with its neighbourhood in registers ------------------------------------------------
+// The walk above pays an LDS round trip and ~45 dependent instructions per step.  A walker is one
+// wavefront on one dependent chain, so it is paced by instruction ISSUE: 4.3-4.5 cycles per scalar
+// or vector instruction for a lone wave, ~10 for a conditional branch that falls through, ~25 for
+// a taken one, 8.8 for a v_readlane, 52 for an LDS round trip (tools/ubench/issue.hip).  Here:
+//   * the walker keeps a 64 x 64-bit TILE of its bitmap in two VGPRs (lane i = padded row tr0 + i,
+//     bits = padded columns 32 * twc .. + 63) and the three rows around the current position
+//     (U, C, D) in SGPR pairs.  A step is scalar bit arithmetic on U / C / D -- which neighbours
+//     are unvisited members, clear them, move to the last one pushed; a vertical move shifts the
+//     window with one v_readlane pair (entering row) and one v_writelane pair (leaving row), a
+//     horizontal move costs nothing; LDS is read only when the tile is re-centred;
+//   * for 4-connectivity the steps run inside ONE assembly block (dfs_walk4_asm.h, generated by
+//     tools/gen_dfs_walk4.py): the 4-bit neighbour mask indexes a table of 16 code blocks that know
+//     statically what to clear, stack and where to move, each ending in the next step's table
+//     jump.  It returns on a dead end or when its GUARD runs out: a budget, decremented by the
+//     pixels each step marks, that is the minimum of what is left of the 10000-pixel cap, of the
+//     room in the stack window and of the distance to the tile's rim -- one untaken branch per step
+//     instead of three tests;
+//   * labels are NOT stored per step.  A piece's pixels are exactly the bits it cleared, so at the
+//     piece's end the rows it stood on are swept once with all 64 lanes: a pixel that still holds
+//     the component's root in `lab` and whose bit is gone belongs to this piece (coalesced loads;
+//     pixels of earlier pieces already carry their seed);
+//   * a dead end does not pop one entry at a time: the 64 entries on top of the stack are tested
+//     together, one lane each, and everything above the topmost entry that still has an unvisited
+//     neighbour is dropped at once -- popping a dead entry has no effect in the reference either
+//     (shepseg.py:507-536: nothing is marked, clumpSize stands), and most stacked pixels are dead
+//     by the time they surface (mean run of 6-7 dead pops).
+// Bit-exact replay of shepseg.py:490-539 like the walk above.
+#include "dfs_walk4_asm.h"
+template <bool FOUR>
+__device__ __forceinline__ void dfs_split_win(uint32_t *lab, const BigInfo &B, uint32_t *bm,
+                                              uint32_t *sw, uint32_t *stackbuf, uint32_t ncols,
+                                              uint32_t *singles, uint32_t *nsingles, uint32_t *csize,
+                                              uint32_t *snap, unsigned long long *prof)
+{
+    typedef unsigned long long u64;
+#ifdef DFS_PROF     // diagnostic build (make PROF=1): cycles per phase and event counts per component
+    u64 pf_t = __builtin_readcyclecounter(), pf_build = 0, pf_dead = 0, pf_label = 0, pf_seed = 0, pf_rim = 0, pf_walk = 0, pf_asm = 0;
+    u64 pf_nstep = 0, pf_ndead = 0, pf_nbulk = 0, pf_nrim = 0, pf_npiece = 0, pf_nrun = 0;
+#define PF_LAP(acc) do { const u64 t_ = __builtin_readcyclecounter(); acc += t_ - pf_t; pf_t = t_; } while (0)
+#define PF_CNT(c) (c)++
+#define PF_ADD(c, n) (c) += (n)
+#else
+#define PF_LAP(acc) do { } while (0)
+#define PF_CNT(c) do { } while (0)
+#define PF_ADD(c, n) do { } while (0)
+#endif
+    const uint32_t root = B.root;
+    uint32_t *gstack = stackbuf + B.off;
+    const unsigned lane = lane_id();
+    const uint32_t minr = root / ncols, minc = B.minc;
+    const uint32_t H = B.maxr - minr + 1u, W = B.maxc - minc + 1u;
+    uint32_t wpr_ = (W + 2u + 31u) >> 5;
+    if (wpr_ < 2u) wpr_ = 2u;                   // a tile row is two words
+    const uint32_t wpr = wpr_;
+    const uint32_t nprow = H + 2u, nwords = nprow * wpr;
+    const uint32_t gbase = (minr - 1u) * ncols + minc - 1u;
+    // ---- member bitmap from the flattened CCL labels (eight row loads in flight) ----
+    for (uint32_t pr0 = 0; pr0 < nprow; pr0 += 8u) {
+        for (uint32_t c0 = 0; c0 < wpr * 32u; c0 += 64u) {
+            const uint32_t bc = c0 + lane;
+            const bool cin = bc >= 1u && bc <= W;
+            uint32_t v[8];
+#pragma unroll
+            for (uint32_t u = 0; u < 8u; u++) {
+                const uint32_t pr = pr0 + u;
+                v[u] = (cin && pr >= 1u && pr <= H) ? lab[gbase + pr * ncols + bc] : NULL_LAB;
+            }
+#pragma unroll
+            for (uint32_t u = 0; u < 8u; u++) {
+                const uint32_t pr = pr0 + u;
+                const u64 mm = __ballot(v[u] == root);
+                if (pr < nprow && lane < 2u && (c0 >> 5) + lane < wpr) {
+                    const uint32_t wv = lane ? (uint32_t)(mm >> 32) : (uint32_t)mm;
+                    bm[pr * wpr + (c0 >> 5) + lane] = wv;
+                    snap[pr * wpr + (c0 >> 5) + lane] = wv;       // the bitmap as of the last piece's end
+                }
+            }
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t wpr_inv = 0xFFFFFFFFu / wpr + 1u;              // __umulhi(i, wpr_inv) == i / wpr for i < 2^32 / wpr
+    // per-lane constants (8-connectivity and the dead-end test): lanes 0..nq-1 own the neighbours in
+    // the reference's push order (cx outer, cy inner); dpk = offset in packed (row << 16 | col) form
+    constexpr uint32_t NQ = FOUR ? 4u : 8u;
+    int dy = 0, dx = 0;
+    if (FOUR) {
+        dy = (lane == 1) ? -1 : (lane == 2) ? 1 : 0;
+        dx = (lane == 0) ? -1 : (lane == 3) ? 1 : 0;
+    } else if (lane < 8u) {
+        dx = (lane < 3u) ? -1 : (lane < 5u) ? 0 : 1;
+        dy = (lane == 0u || lane == 3u || lane == 5u) ? -1 : (lane == 1u || lane == 6u) ? 0 : 1;
+    }
+    if (lane >= NQ) { dy = 0; dx = 0; }
+    const uint32_t dpk = (uint32_t)(dy * 65536 + dx);
+    const uint32_t lanebit = lane < NQ ? (1u << lane) : 0u;
+    const uint32_t ltm = lane < 32u ? ((1u << lane) - 1u) : 0xFFFFFFFFu;
+    const uint32_t trmax = nprow > 64u ? nprow - 64u : 0u;
+    // (readfirstlane: the walker's window address comes from threadIdx.x / 64, uniform but not provably so)
+    const uint32_t sw_addr = UNI((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)sw);
+    // the tile (registers) and where it sits
+    uint32_t tlo = 0, thi = 0, tr0 = 0, twc32 = 0;
+#define DFSW_TILE_LOAD(PR, PC)                                                                      \
+    do {                                                                                            \
+        int t_ = (int)(PR) - 32;                                                                    \
+        t_ = t_ < 0 ? 0 : t_;                                                                       \
+        tr0 = UNI((uint32_t)t_ > trmax ? trmax : (uint32_t)t_);                                     \
+        int w_ = ((int)(PC) - 16) >> 5;                                                             \
+        w_ = w_ < 0 ? 0 : w_;                                                                       \
+        const uint32_t twc_ = (uint32_t)w_ > wpr - 2u ? wpr - 2u : (uint32_t)w_;                    \
+        twc32 = UNI(twc_ << 5);                                                                     \
+        const uint32_t r_ = tr0 + lane;                                                             \
+        const bool ok_ = r_ < nprow;                                                                \
+        const uint32_t a_ = r_ * wpr + twc_;                                                        \
+        tlo = ok_ ? bm[a_] : 0u;                                                                    \
+        thi = ok_ ? bm[a_ + 1u] : 0u;                                                               \
+    } while (0)
+#define DFSW_TILE_FLUSH()                                                                           \
+    do {                                                                                            \
+        const uint32_t r_ = tr0 + lane;                                                             \
+        if (r_ < nprow) {                                                                           \
+            const uint32_t a_ = r_ * wpr + (twc32 >> 5);                                            \
+            bm[a_] = tlo;                                                                           \
+            bm[a_ + 1u] = thi;                                                                      \
+        }                                                                                           \
+        __builtin_amdgcn_wave_barrier();                                                            \
+    } while (0)
+#define DFSW_ROW_GET(R) ((u64)(uint32_t)__builtin_amdgcn_readlane((int)tlo, (int)(R)) |             \
+                         ((u64)(uint32_t)__builtin_amdgcn_readlane((int)thi, (int)(R)) << 32))
+#define DFSW_ROW_PUT(R, V)                                                                          \
+    do {      /* (clang has no writelane builtin: a compare and two selects) */                     \
+        const bool me_ = lane == (R);                                                               \
+        tlo = me_ ? (uint32_t)(V) : tlo;                                                            \
+        thi = me_ ? (uint32_t)((V) >> 32) : thi;                                                    \
+    } while (0)
+    // the window rows that are valid go back into the tile (on the rim one of them lies outside)
+#define DFSW_WINDOW_PUT()                                                                           \
+    do {                                                                                            \
+        if (ry == 63u) { DFSW_ROW_PUT(62u, U); DFSW_ROW_PUT(63u, C); }                              \
+        else if (ry == 0u) { DFSW_ROW_PUT(0u, C); DFSW_ROW_PUT(1u, D); }                            \
+        else { DFSW_ROW_PUT(ry - 1u, U); DFSW_ROW_PUT(ry, C); DFSW_ROW_PUT(ry + 1u, D); }           \
+    } while (0)
+    uint32_t wcur = 0;                           // first word that can still hold a set bit
+    PF_LAP(pf_build);
+    for (;;) {
+        // ---- next seed = first set bit in raster order (the bitmap in LDS is current here) ----
+        uint32_t sword = 0xFFFFFFFFu, sbits = 0;
+        for (uint32_t w0 = wcur; w0 < nwords; w0 += 64u) {
+            const uint32_t wi = w0 + lane;
+            const uint32_t v = wi < nwords ? bm[wi] : 0u;
+            const u64 mm = __ballot(v != 0u);
+            if (mm) {
+                const int fl = __builtin_ctzll(mm);
+                sword = w0 + (uint32_t)fl;
+                sbits = (uint32_t)__builtin_amdgcn_readlane((int)v, fl);
+                break;
+            }
+        }
+        if (sword == 0xFFFFFFFFu) break;
+        wcur = sword;
+        const uint32_t sy = sword / wpr, sx = ((sword - sy * wpr) << 5) + (uint32_t)__builtin_ctz(sbits);
+        const uint32_t seed = gbase + sy * ncols + sx;
+        const uint32_t FL = seed | VIS_FLAG;
+        if (lane == 0) bm[sword] = sbits & (sbits - 1u);     // clear the seed's (lowest) bit
+        __builtin_amdgcn_wave_barrier();
+        uint32_t sp_l = 0, sp_g = 0;             // stack entries in the LDS window / spilled
+        uint32_t cnt = 0;
+        uint32_t cpk = UNI((sy << 16) | sx);     // current position, packed padded coordinates
+        uint32_t rmin = UNI(sy), rmax = rmin;    // rows the piece has stood on
+        DFSW_TILE_LOAD(sy, sx);
+        uint32_t ry = UNI(sy - tr0), b = UNI(sx - twc32);        // both in 1 .. 62
+        u64 U = DFSW_ROW_GET(ry - 1u), C = DFSW_ROW_GET(ry), D = DFSW_ROW_GET(ry + 1u);
+        PF_LAP(pf_seed); PF_CNT(pf_npiece);
+        for (;;) {
+            if (FOUR) {
+                // ---- the steps, in the assembly block (dfs_walk4_asm.h); it comes back for the events
+                //      below.  Slack offsets: a side of the tile that coincides with the bitmap's own
+                //      zero border cannot be crossed and never binds ----
+                const int big = 1 << 20;
+                int up_off = tr0 == 0u ? -big : 1, dn_off = tr0 + 64u >= nprow ? big : 62;
+                int lf_off = twc32 == 0u ? -big : 1, rt_off = (twc32 >> 5) + 2u >= wpr ? big : 62;
+                uint32_t rylo = UNI(ry + 1u), ryhi = rylo, why;
+                uint32_t ssp = UNI(sw_addr + (sp_l << 2)), sw_end = UNI(sw_addr + (DFS_SWN << 2)), sw_base = sw_addr;
+                uint32_t vcpk = cpk, vsp = ssp, vt, a_tr0 = UNI(tr0), a_twc = UNI(twc32);
+                // (every scalar operand through readfirstlane: the register constraints need values
+                //  the compiler can PROVE uniform)
+                U = UNI64(U); C = UNI64(C); D = UNI64(D); cnt = UNI(cnt);
+                up_off = (int)UNI(up_off); dn_off = (int)UNI(dn_off); lf_off = (int)UNI(lf_off); rt_off = (int)UNI(rt_off);
+                PF_LAP(pf_walk); PF_CNT(pf_nrun);
+                asm volatile(DFS_WALK4_ASM
+                             : "+{s[64:65]}"(U), "+{s[66:67]}"(C), "+{s[68:69]}"(D), "+{s73}"(rylo), "+{s74}"(ryhi), "={s75}"(why),
+                               "+{s88}"(cnt), "+{s89}"(ssp),
+                               [tlo] "+v"(tlo), [thi] "+v"(thi), [vcpk] "+v"(vcpk), [vsp] "+v"(vsp), [vt] "=&v"(vt)
+                             : "{s90}"(a_tr0), "{s91}"(a_twc), "{s92}"(up_off), "{s93}"(dn_off), "{s94}"(lf_off), "{s95}"(rt_off),
+                               "{s96}"(sw_end), "{s99}"(sw_base)
+                             : "s70", "s71", "s72", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86",
+                               "s87", "s97", "s98", "scc", "memory");
+                PF_LAP(pf_asm);
+                // (and back: the compiler takes every result of an asm block with vector outputs as divergent)
+                U = UNI64(U); C = UNI64(C); D = UNI64(D);
+                cnt = UNI(cnt); ssp = UNI(ssp); rylo = UNI(rylo); ryhi = UNI(ryhi); why = UNI(why);
+                cpk = UNI(vcpk);
+                sp_l = (ssp - sw_addr) >> 2;
+                ry = (cpk >> 16) - tr0; b = (cpk & 0xffffu) - twc32;
+                {
+                    const uint32_t a0 = tr0 + rylo - 1u, a1 = tr0 + ryhi - 1u;
+                    rmin = a0 < rmin ? a0 : rmin;
+                    rmax = a1 > rmax ? a1 : rmax;
+                }
+                if (why == 2u) {                 // the cap
+                    DFSW_WINDOW_PUT();
+                    DFSW_TILE_FLUSH();
+                    break;
+                }
+                if (why == 3u) {                 // the stack window is nearly full
+                    const u64 r = dfs_spill(sw, gstack, sp_l, sp_g);
+                    sp_l = UNI((uint32_t)r); sp_g = UNI((uint32_t)(r >> 32));
+                    continue;
+                }
+                if (why == 1u || why == 4u) {    // re-centre the tile / an entry outside it was popped
+                    PF_LAP(pf_walk); PF_CNT(pf_nrim);
+                    if (why == 1u) DFSW_WINDOW_PUT();           // (4: the block wrote the window back)
+                    DFSW_TILE_FLUSH();
+                    const uint32_t pr = cpk >> 16, pc = cpk & 0xffffu;
+                    rmin = pr < rmin ? pr : rmin;
+                    rmax = pr > rmax ? pr : rmax;
+                    DFSW_TILE_LOAD(pr, pc);
+                    ry = UNI(pr - tr0); b = UNI(pc - twc32);
+                    U = DFSW_ROW_GET(ry - 1u); C = DFSW_ROW_GET(ry); D = DFSW_ROW_GET(ry + 1u);
+                    PF_LAP(pf_rim);
+                    continue;
+                }
+            } else {
+                PF_CNT(pf_nstep);
+                const uint32_t sh = b - 1u;
+                const uint32_t u3 = (uint32_t)(U >> sh) & 7u, c3 = (uint32_t)(C >> sh) & 7u, d3 = (uint32_t)(D >> sh) & 7u;
+                // unvisited member neighbours, bit = push order
+                const uint32_t m = (u3 & 1u) | ((c3 & 1u) << 1) | ((d3 & 1u) << 2) | ((u3 & 2u) << 2) | ((d3 & 2u) << 3) |
+                                   ((u3 & 4u) << 3) | ((c3 & 4u) << 4) | ((d3 & 4u) << 5);
+                if (m != 0u) {
+                    // ---- mark this step's neighbours (clear their bits), stack all but the last, move there ----
+                    C &= ~(5ull << sh); U &= ~(7ull << sh); D &= ~(7ull << sh);
+                    const uint32_t np = (uint32_t)__builtin_popcount(m);
+                    // (the last one is stored too, one slot above the new top: never read)
+                    if (m & lanebit) sw[sp_l + (uint32_t)__builtin_popcount(m & ltm)] = cpk + dpk;
+                    sp_l += np - 1u;
+                    cnt += np;
+                    const int last = 31 - __builtin_clz(m);
+                    cpk += (uint32_t)__builtin_amdgcn_readlane((int)dpk, last);
+                    const uint32_t nry = (cpk >> 16) - tr0;
+                    const int vy = (int)nry - (int)ry;
+                    b = (cpk & 0xffffu) - twc32;
+                    if (vy > 0) {
+                        DFSW_ROW_PUT(ry - 1u, U);
+                        U = C; C = D; ry += 1u;
+                        const uint32_t pr = cpk >> 16;
+                        rmax = pr > rmax ? pr : rmax;
+                        if (ry < 63u) D = DFSW_ROW_GET(ry + 1u);
+                    } else if (vy < 0) {
+                        DFSW_ROW_PUT(ry + 1u, D);
+                        D = C; C = U; ry -= 1u;
+                        const uint32_t pr = cpk >> 16;
+                        rmin = pr < rmin ? pr : rmin;
+                        if (ry > 0u) U = DFSW_ROW_GET(ry - 1u);
+                    }
+                    if (!((ry - 1u) < 62u && (b - 1u) < 62u)) {
+                        // the position reached the tile's rim: write the window back, re-centre
+                        PF_LAP(pf_walk); PF_CNT(pf_nrim);
+                        DFSW_WINDOW_PUT();
+                        DFSW_TILE_FLUSH();
+                        const uint32_t pr = cpk >> 16, pc = cpk & 0xffffu;
+                        DFSW_TILE_LOAD(pr, pc);
+                        ry = UNI(pr - tr0); b = UNI(pc - twc32);
+                        U = DFSW_ROW_GET(ry - 1u); C = DFSW_ROW_GET(ry); D = DFSW_ROW_GET(ry + 1u);
+                        PF_LAP(pf_rim);
+                    }
+                    if (cnt >= MAX_CLUMP_SIZE) {
+                        DFSW_WINDOW_PUT();
+                        DFSW_TILE_FLUSH();
+                        break;
+                    }
+                    if (sp_l + 9u > DFS_SWN) {
+                        const u64 r = dfs_spill(sw, gstack, sp_l, sp_g);
+                        sp_l = UNI((uint32_t)r); sp_g = UNI((uint32_t)(r >> 32));
+                    }
+                    continue;
+                }
+            }
+            // ---- dead end: make the bitmap current, then find the topmost stack entry that still
+            //      has an unvisited neighbour (everything above it pops without effect) ----
+            PF_LAP(pf_walk); PF_CNT(pf_ndead);
+            DFSW_WINDOW_PUT();
+            DFSW_TILE_FLUSH();
+            uint32_t e = 0xFFFFFFFFu;
+            for (;;) {
+                PF_CNT(pf_nbulk);
+                if (sp_l == 0u) {
+                    if (sp_g == 0u) break;                       // stack empty: the piece is complete
+                    const u64 r = dfs_refill(sw, gstack, sp_g);
+                    sp_l = UNI((uint32_t)r); sp_g = UNI((uint32_t)(r >> 32));
+                }
+                const uint32_t k = sp_l < 64u ? sp_l : 64u;
+                const uint32_t base = sp_l - k;
+                bool alive = false;
+                uint32_t ent = 0;
+                if (lane < k) {
+                    ent = sw[base + lane];
+                    const uint32_t er = ent >> 16, ec = ent & 0xffffu;
+#pragma unroll
+                    for (uint32_t q = 0; q < NQ; q++) {
+                        int qy, qx;
+                        if (FOUR) { qy = (q == 1u) ? -1 : (q == 2u) ? 1 : 0; qx = (q == 0u) ? -1 : (q == 3u) ? 1 : 0; }
+                        else { qx = (q < 3u) ? -1 : (q < 5u) ? 0 : 1; qy = (q == 0u || q == 3u || q == 5u) ? -1 : (q == 1u || q == 6u) ? 0 : 1; }
+                        const uint32_t rr = (uint32_t)((int)er + qy), cc = (uint32_t)((int)ec + qx);
+                        alive = alive || (((bm[rr * wpr + (cc >> 5)] >> (cc & 31u)) & 1u) != 0u);
+                    }
+                }
+                const u64 am = __ballot(alive);
+                if (am) {
+                    const int top = 63 - __builtin_clzll(am);
+                    e = (uint32_t)__builtin_amdgcn_readlane((int)ent, top);
+                    sp_l = base + (uint32_t)top;
+                    break;
+                }
+                sp_l = base;
+            }
+            if (e == 0xFFFFFFFFu) { PF_LAP(pf_dead); break; }
+            cpk = e;
+            {
+                const uint32_t pr = e >> 16, pc = e & 0xffffu;
+                rmin = pr < rmin ? pr : rmin;
+                rmax = pr > rmax ? pr : rmax;
+                ry = pr - tr0; b = pc - twc32;
+                if (!((ry - 1u) < 62u && (b - 1u) < 62u)) {
+                    DFSW_TILE_LOAD(pr, pc);
+                    ry = UNI(pr - tr0); b = UNI(pc - twc32);
+                }
+            }
+            U = DFSW_ROW_GET(ry - 1u); C = DFSW_ROW_GET(ry); D = DFSW_ROW_GET(ry + 1u);
+            PF_LAP(pf_dead);
+        }
+        // ---- the piece is complete and the bitmap in LDS is current: label its pixels ----
+        PF_LAP(pf_walk);
+        if (FOUR) PF_ADD(pf_nstep, cnt);
+        if (cnt == 0u) {
+            if (lane == 0) {
+                lab[seed] = FL;
+                csize[seed] = 1u;
+                snap[sword] = sbits & (sbits - 1u);          // (the snapshot follows: only the seed's bit went)
+                if (singles) singles[atomicAdd(nsingles, 1u)] = seed;
+            }
+        } else {
+            // the piece's pixels = the bits that went since the snapshot (the bitmap at the last piece's
+            // end, in global memory), in the rows the piece stood on +- 1: a word per lane, four loads
+            // in flight; the snapshot moves on as it is compared
+            const uint32_t r0 = rmin > 1u ? rmin - 1u : 1u, r1 = rmax + 1u < H ? rmax + 1u : H;
+            const uint32_t iend = (r1 + 1u) * wpr;
+            for (uint32_t i0 = r0 * wpr; i0 < iend; i0 += 256u) {
+                uint32_t sv[4];
+#pragma unroll
+                for (uint32_t u = 0; u < 4u; u++) {
+                    const uint32_t i = i0 + u * 64u + lane;
+                    // (agent scope: past this CU's vector cache, which the stores below do not update)
+                    sv[u] = i < iend ? __hip_atomic_load(&snap[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < 4u; u++) {
+                    const uint32_t i = i0 + u * 64u + lane;
+                    const uint32_t cur = i < iend ? bm[i] : 0u;
+                    uint32_t d = sv[u] & ~cur;
+                    if (d) {
+                        snap[i] = cur;
+                        const uint32_t pr = __umulhi(i, wpr_inv);
+                        const uint32_t pbase = gbase + pr * ncols + ((i - pr * wpr) << 5);
+                        do {
+                            lab[pbase + (uint32_t)__builtin_ctz(d)] = FL;
+                            d &= d - 1u;
+                        } while (d);
+                    }
+                }
+            }
+            if (lane == 0) csize[seed] = cnt + 1u;
+        }
+        __builtin_amdgcn_wave_barrier();
+        PF_LAP(pf_label);
+    }
+#ifdef DFS_PROF
+    if (prof && lane == 0) {
+        prof[0] = pf_build; prof[1] = pf_walk; prof[2] = pf_dead; prof[3] = pf_label; prof[4] = pf_seed; prof[5] = pf_rim;
+        prof[6] = pf_nstep; prof[7] = pf_ndead; prof[8] = pf_nbulk; prof[9] = pf_nrim; prof[10] = pf_npiece; prof[11] = pf_asm; prof[12] = pf_nrun;
+    }
+#endif
+#undef PF_LAP
+#undef PF_CNT
+#undef PF_ADD
+#undef DFSW_TILE_LOAD
+#undef DFSW_TILE_FLUSH
+#undef DFSW_ROW_GET
+#undef DFSW_ROW_PUT
+#undef DFSW_WINDOW_PUT
+}
+
 // order[rank] = component index, largest first: the longest replays start first (LPT), which
 // shortens the makespan whenever there are more components than resident workgroups
 // counters[2] = how many of them do not fit the walker pool (bitmap above bmw_small words)
@@ -650,9 +1054,11 @@ __global__ __launch_bounds__(256) void k_big_order(const BigInfo *__restrict__ b
 // anything, so the wait is finite); after DFS_ALLOC_SPINS polls, or for a bitmap larger than the
 // whole pool, it walks in global memory instead.
 #define DFS_WAVES 8u
+#define DFS_DBG_WORDS 20u        // SHEPSEG_DFS_STATS: 6 words per component + 11 of the DFS_PROF build
 #define DFS_GRAN_WORDS 512u          // granule = 2 KiB
 #define DFS_POOL_GRANS_DEFAULT 34u   // 68 KiB pool (+ 16 KiB of stack windows + the mask = 84 KiB)
 #define DFS_ALLOC_SPINS 200000u
+#define DFS_MAX_BLOCKS 256u          // 2048 walkers: 8 per CU
 
 // start granule of `need` contiguous free granules, or -1; wave-uniform, lane 0 talks to the mask
 __device__ __forceinline__ int dfs_pool_alloc(unsigned long long *mask, uint32_t need, uint32_t ngrans,
@@ -688,11 +1094,13 @@ __global__ __launch_bounds__(DFS_WAVES * 64) void k_dfs_pool(        // blockDim
 
     uint32_t *lab, const BigInfo *__restrict__ big, uint32_t *counters, uint32_t *stackbuf, uint32_t nrows,
     uint32_t ncols, int four, uint32_t pool_grans, uint32_t *singles, uint32_t *nsingles,
-    const uint32_t *__restrict__ order, uint32_t *csize, unsigned long long *dbg)
+    const uint32_t *__restrict__ order, uint32_t *csize, unsigned long long *dbg, int oldwalk, uint32_t *snap)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t dfs_lds[];
     unsigned long long *mask = (unsigned long long *)dfs_lds;             // 4 words (2 used)
-    const unsigned w = threadIdx.x >> 6, lane = lane_id();
+    // (readfirstlane: the walker index is wave-uniform, and everything derived from it -- the
+    //  component record, the bitmap's geometry -- must be PROVABLY so to stay in scalar registers)
+    const unsigned w = UNI(threadIdx.x >> 6), lane = lane_id();
     const uint32_t nwalk = blockDim.x >> 6;
     uint32_t *sw = dfs_lds + 4u + w * DFS_SWN;
     uint32_t *pool = dfs_lds + 4u + nwalk * DFS_SWN;
@@ -737,7 +1145,11 @@ __global__ __launch_bounds__(DFS_WAVES * 64) void k_dfs_pool(        // blockDim
         first = false;
         const unsigned long long t1 = dbg ? wall_clock64() : 0ull;
         if (g0 >= 0) {
-            dfs_split_lds(lab, B, pool + (uint32_t)g0 * DFS_GRAN_WORDS, sw, stackbuf, ncols, four, singles, nsingles, csize);
+            uint32_t *bmw = pool + (uint32_t)g0 * DFS_GRAN_WORDS;
+            uint32_t *snapw = snap + (size_t)(blockIdx.x * nwalk + w) * ((size_t)pool_grans * DFS_GRAN_WORDS);
+            if (oldwalk) dfs_split_lds(lab, B, bmw, sw, stackbuf, ncols, four, singles, nsingles, csize);
+            else if (four) dfs_split_win<true>(lab, B, bmw, sw, stackbuf, ncols, singles, nsingles, csize, snapw, dbg ? dbg + (size_t)idx * DFS_DBG_WORDS + 6u : nullptr);
+            else dfs_split_win<false>(lab, B, bmw, sw, stackbuf, ncols, singles, nsingles, csize, snapw, dbg ? dbg + (size_t)idx * DFS_DBG_WORDS + 6u : nullptr);
             __builtin_amdgcn_wave_barrier();
             if (lane == 0) {
                 const unsigned long long ones = need >= 64u ? ~0ull : ((1ull << need) - 1ull);
@@ -747,7 +1159,7 @@ __global__ __launch_bounds__(DFS_WAVES * 64) void k_dfs_pool(        // blockDim
             dfs_split_global(lab, B, sw, stackbuf, nrows, ncols, four, singles, nsingles, csize);
         }
         if (dbg && lane == 0) {          // SHEPSEG_DFS_STATS: size, bitmap words, wait / walk ticks (100 MHz), start
-            unsigned long long *d = dbg + (size_t)idx * 6u;
+            unsigned long long *d = dbg + (size_t)idx * DFS_DBG_WORDS;
             d[0] = B.size; d[1] = words; d[2] = t1 - t0; d[3] = wall_clock64() - t1; d[4] = t0;
             d[5] = ((unsigned long long)blockIdx.x << 8) | w | (g0 < 0 ? 1ull << 40 : 0ull);
         }
@@ -891,12 +1303,14 @@ static int run_clump(shp_ctx *ctx, const uint16_t *d_clus, uint32_t nrows, uint3
     ps = prof_begin(ctx, PROF_DFS);              // events hug the kernel
     unsigned long long *dbg = nullptr;
     if (getenv("SHEPSEG_DFS_STATS") && nbig_h) {
-        CHK(buf_ensure(ctx, ctx->dbg, (size_t)nbig_h * 48u));
+        CHK(buf_ensure(ctx, ctx->dbg, (size_t)nbig_h * DFS_DBG_WORDS * 8u));
+        HIPCHK(ctx, hipMemsetAsync(ctx->dbg.p, 0, (size_t)nbig_h * DFS_DBG_WORDS * 8u, st));
         dbg = bp<unsigned long long>(ctx->dbg);
     }
     if (nbig_h) {
         static const uint32_t pool_grans = getenv("SHEPSEG_DFS_POOL") ? (uint32_t)atoi(getenv("SHEPSEG_DFS_POOL")) : DFS_POOL_GRANS_DEFAULT;
         static const uint32_t per_wg = getenv("SHEPSEG_DFS_PER_WG") ? (uint32_t)atoi(getenv("SHEPSEG_DFS_PER_WG")) : DFS_WAVES;
+        static const int oldwalk = getenv("SHEPSEG_DFS_OLDWALK") ? atoi(getenv("SHEPSEG_DFS_OLDWALK")) : 0;
         const uint32_t pg = pool_grans < 1u ? 1u : pool_grans > 64u ? 64u : pool_grans;
         const uint32_t pw = per_wg < 1u ? 1u : per_wg > DFS_WAVES ? DFS_WAVES : per_wg;
         const size_t lds = (4u + pw * DFS_SWN + (size_t)pg * DFS_GRAN_WORDS) * 4u;
@@ -905,29 +1319,49 @@ static int run_clump(shp_ctx *ctx, const uint16_t *d_clus, uint32_t nrows, uint3
             HIPCHK(ctx, hipFuncSetAttribute((const void *)k_dfs_pool, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 256));
             attr_set = true;
         }
-        hipLaunchKernelGGL(k_dfs_pool, dim3((nbig_h + pw - 1u) / pw), dim3(pw * 64u), lds, st, lab, big,
+        // at most DFS_MAX_BLOCKS workgroups (the rest of the components is pulled from the counter):
+        // every walker owns a slot of the snapshot buffer as large as the walker pool
+        uint32_t nblk = (nbig_h + pw - 1u) / pw;
+        nblk = nblk > DFS_MAX_BLOCKS ? DFS_MAX_BLOCKS : nblk;
+        CHK(buf_ensure(ctx, ctx->snap, (size_t)nblk * pw * pg * DFS_GRAN_WORDS * 4u));
+        hipLaunchKernelGGL(k_dfs_pool, dim3(nblk), dim3(pw * 64u), lds, st, lab, big,
                            counters, bp<uint32_t>(ctx->stack), nrows, ncols, four, pg, d_singles, d_nsingles,
-                           order, csize, dbg); KCHK(ctx);
+                           order, csize, dbg, oldwalk, bp<uint32_t>(ctx->snap)); KCHK(ctx);
     }
     prof_end(ctx, ps);
     if (dbg) {
-        std::vector<unsigned long long> h((size_t)nbig_h * 6u);
+        const size_t DW = DFS_DBG_WORDS;
+        std::vector<unsigned long long> h((size_t)nbig_h * DW);
         HIPCHK(ctx, hipMemcpyAsync(h.data(), dbg, h.size() * 8u, hipMemcpyDeviceToHost, st));
         HIPCHK(ctx, hipStreamSynchronize(st));
         unsigned long long tmin = ~0ull, tend = 0, swait = 0, swalk = 0, spx = 0;
         for (uint32_t i = 0; i < nbig_h; i++) {
-            tmin = h[i * 6 + 4] < tmin ? h[i * 6 + 4] : tmin;
-            const unsigned long long e = h[i * 6 + 4] + h[i * 6 + 2] + h[i * 6 + 3];
+            tmin = h[i * DW + 4] < tmin ? h[i * DW + 4] : tmin;
+            const unsigned long long e = h[i * DW + 4] + h[i * DW + 2] + h[i * DW + 3];
             tend = e > tend ? e : tend;
-            swait += h[i * 6 + 2]; swalk += h[i * 6 + 3]; spx += h[i * 6];
+            swait += h[i * DW + 2]; swalk += h[i * DW + 3]; spx += h[i * DW];
         }
         fprintf(stderr, "dfs: %u components, %llu px, span %.2f ms, sum wait %.2f ms, sum walk %.2f ms (%.1f ns/px)\n",
                 nbig_h, spx, (tend - tmin) / 1e5, swait / 1e5, swalk / 1e5, swalk * 10.0 / (double)(spx ? spx : 1));
         for (uint32_t i = 0; i < nbig_h && i < 12u; i++)
             fprintf(stderr, "  rank %u: %llu px, %llu words, start %.2f wait %.2f walk %.2f ms (%.1f ns/px) wg %llu wave %llu%s\n", i,
-                    h[i * 6], h[i * 6 + 1], (h[i * 6 + 4] - tmin) / 1e5, h[i * 6 + 2] / 1e5, h[i * 6 + 3] / 1e5,
-                    h[i * 6 + 3] * 10.0 / (double)h[i * 6], (h[i * 6 + 5] >> 8) & 0xffffffffull, h[i * 6 + 5] & 255ull,
-                    (h[i * 6 + 5] >> 40) ? " GLOBAL" : "");
+                    h[i * DW], h[i * DW + 1], (h[i * DW + 4] - tmin) / 1e5, h[i * DW + 2] / 1e5, h[i * DW + 3] / 1e5,
+                    h[i * DW + 3] * 10.0 / (double)h[i * DW], (h[i * DW + 5] >> 8) & 0xffffffffull, h[i * DW + 5] & 255ull,
+                    (h[i * DW + 5] >> 40) ? " GLOBAL" : "");
+    #ifdef DFS_PROF
+        {
+            unsigned long long a[13] = {0};
+            for (uint32_t i = 0; i < nbig_h; i++) for (int j = 0; j < 13; j++) a[j] += h[i * DW + 6 + j];
+            fprintf(stderr, "  prof (Mcycles): build %.1f walk %.1f dead %.1f label %.1f seed %.1f rim %.1f | steps %llu dead ends %llu bulk iters %llu rims %llu pieces %llu | %.1f cycles/step, %.0f cycles/dead end, %.0f cycles/piece label\n",
+                    a[0] / 1e6, a[1] / 1e6, a[2] / 1e6, a[3] / 1e6, a[4] / 1e6, a[5] / 1e6, a[6], a[7], a[8], a[9], a[10],
+                    (double)a[1] / (double)(a[6] ? a[6] : 1), (double)a[2] / (double)(a[7] ? a[7] : 1), (double)a[3] / (double)(a[10] ? a[10] : 1));
+            fprintf(stderr, "  asm runs %llu, %.1f Mcycles inside (%.1f per marked px), %.1f outside per run\n", a[12], a[11] / 1e6,
+                    (double)a[11] / (double)(a[6] ? a[6] : 1), (double)a[1] / (double)(a[12] ? a[12] : 1));
+            const unsigned long long *p0 = &h[6];
+            fprintf(stderr, "  rank 0 prof (Mcycles): build %.2f walk %.2f dead %.2f label %.2f seed %.2f rim %.2f | steps %llu dead %llu bulk %llu rims %llu pieces %llu\n",
+                    p0[0] / 1e6, p0[1] / 1e6, p0[2] / 1e6, p0[3] / 1e6, p0[4] / 1e6, p0[5] / 1e6, p0[6], p0[7], p0[8], p0[9], p0[10]);
+        }
+#endif
     }
     if (fill_gating(ctx) || stream_sharing(ctx)) {
         HIPCHK(ctx, hipStreamSynchronize(st));

@@ -46,7 +46,7 @@ struct shp_ctx {
     // named workspace buffers (grow-only)
     DevBuf img, clus, lab, seg, aux, aux2, stack, scan_tmp, sort_k0, sort_k1, sort_v1, sort_hist,
         pix, segsz, origsz, off, ssum, chnext, chtail, mergeto, tcount, toff, tfill, tlist, tsorted,
-        small, cen, fit_x, fit_lab, fit_part, fit_lb, big, srclist, tgtlist, bigbits, singles, dbg;
+        small, cen, fit_x, fit_lab, fit_part, fit_lb, big, srclist, tgtlist, bigbits, singles, dbg, snap;
     uint32_t *h_pinned = nullptr;   // SHP_PINNED_BYTES of pinned host staging (small transfers)
     int fit_path = 0;               // last k-means fit: 0 the fast (Lloyd) path, 1 the reference's Elkan path
     double *h_fit = nullptr;        // pinned, grow-only: the centred k-means sample
