@@ -154,8 +154,9 @@ def segment_tile(img, centres, min_seg_size, max_spectral_diff, null_val=None, f
 
 def kmeans_fit(xsample, init, max_iter=300, tol=1e-4, mstep='rows', algorithm='full'):
     """algorithm='full': Lloyd; 'elkan': what sklearn 0.24.2's KMeans(algorithm='auto') runs for k > 1.
-    mstep='rows': sklearn's one-thread summation order; 'device': the sums of the M-step
-    associated as the HIP fit does (chunks of min(256, 4096 // nBands) rows, groups of 64 chunks)"""
+    mstep='rows': sklearn's one-thread summation order (what the HIP fit uses on both of its paths);
+    'device': chunked sums (min(256, 4096 // nBands) rows, groups of 64 chunks) -- the association an
+    earlier HIP fit had, kept to show what a different order does to the centres"""
     x = np.ascontiguousarray(xsample, dtype=np.float64)
     init = np.ascontiguousarray(init, dtype=np.float64)
     n, nb = x.shape

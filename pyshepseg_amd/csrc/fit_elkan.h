@@ -12,11 +12,12 @@
 // fits, this one on none).
 //
 // run_kmeans_fit therefore has two paths with the same result where both apply:
-//  * the fast one (kmeans.h: Lloyd E-step in the dgemm order, chunked M-step sums, 8 iterations per
-//    host round trip) with a guard: an E-step that meets a sample whose two nearest centres are
+//  * the fast one (kmeans.h: Lloyd E-step in the dgemm order, the same row-order M-step sums as below,
+//    8 iterations per host round trip) with a guard: an E-step that meets a sample whose two nearest centres are
 //    within FIT_TIE_EPS (relative) raises FitCtl::near.  Without such a sample every label is decided
 //    by a margin far above the rounding of either evaluation, so both algorithms visit the same
-//    partitions and stop after the same iteration;
+//    partitions, compute the same centres from them (bit for bit: same sums in the same order) and
+//    stop after the same iteration;
 //  * this one, taken when the guard fires (SHEPSEG_FIT_ALGO=elkan: always): bounds kept per sample and
 //    centre (k x n float64, cluster-major), M-step sums in ROW order per cluster (sklearn with one
 //    OpenMP thread; row lists by one stable radix pass over the labels), the k x nb sized tail of an
@@ -742,9 +743,15 @@ static int run_fit_elkan(shp_ctx *ctx, const double *dX, XAt Xat, uint32_t n, in
         HIPCHK(ctx, hipMemcpyAsync(h_ctl, dctl, sizeof(ElkCtl), hipMemcpyDeviceToHost, st));
         HIPCHK(ctx, hipStreamSynchronize(st));
         const uint32_t stop = h_ctl->stop;
-        if (getenv("SHEPSEG_FIT_TRACE"))
-            fprintf(stderr, "elkan batch to %d: stop %u iters %u labels changed %u / %u shift %.17g\n", b_end, stop,
-                    h_ctl->iters, h_ctl->nd[0], h_ctl->nd[1], h_ctl->shift_tot);
+        if (getenv("SHEPSEG_FIT_TRACE")) {
+            std::vector<double> hs(k);
+            HIPCHK(ctx, hipMemcpyAsync(hs.data(), dcshift, (size_t)k * 8, hipMemcpyDeviceToHost, st));
+            HIPCHK(ctx, hipStreamSynchronize(st));
+            int nz = 0;
+            for (int j = 0; j < k; j++) nz += hs[j] == 0.0;
+            fprintf(stderr, "elkan batch to %d: stop %u iters %u labels changed %u / %u shift %.17g, %d of %d centres did not move\n",
+                    b_end, stop, h_ctl->iters, h_ctl->nd[0], h_ctl->nd[1], h_ctl->shift_tot, nz, k);
+        }
         if (stop == 0u) { it_done = b_end; continue; }
         if (stop == 1u || stop == 3u) {
             it_done = (int)h_ctl->iters;

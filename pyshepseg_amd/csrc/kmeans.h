@@ -227,16 +227,12 @@ static int launch_assign(shp_ctx *ctx, const void *d_img, int dtype, int nb, siz
 // shepseg.fitSpectralClusters (shepseg.py:305-312); algorithm restated in SURVEY Appendix D
 // and oracle/shepseg_oracle.c orc_kmeans_fit (sklearn 0.24.2 semantics: centred data,
 // tol = mean(var)*tol_rel, strict-convergence test, empty-cluster relocation, centres *= 1/w).
-// E-step: one thread per sample row, same fma chain as predict.  M-step: deterministic --
-// fixed 4096-row chunks produce per-chunk partial sums (one thread per (cluster, band), rows
-// in index order), then a second kernel adds the chunk partials in chunk order.  No float
-// atomics, so results are bitwise reproducible run to run.
+// E-step: one thread per sample row, same fma chain as predict.  M-step: the reference's sums --
+// one chain per (cluster, band) over the cluster's rows in row order (fit_elkan.h:
+// k_fit_sum_lists[_staged] on the row numbers sorted stably by label), so the centres are the
+// reference's bits (one OpenMP thread) whenever the partitions are.  No float atomics.
 // ---------------------------------------------------------------------------------------
-#define FIT_CHUNK 256u
-#define FIT_LDS_DOUBLES 4096u       // 32 KiB of staged sample rows: FIT_CHUNK rows x up to 16 bands
-#define FIT_GROUP 64u               // chunks per first-level reduction group
 #define FIT_BATCH 8                 // Lloyd iterations enqueued between two host synchronisations
-#define FIT_SORT_MAXK 256           // the in-LDS counting sort of k_fit_partial handles k up to this
 
 // loop control of the Lloyd iterations, owned by the device between host synchronisations
 struct FitCtl {
@@ -367,118 +363,20 @@ static void launch_fit_assign(shp_ctx *ctx, unsigned g, const double *dX, uint32
 #undef FA
 }
 
-// partial[c][j*nb+b] = sum over rows of chunk c with label j of X[row][b], rows in index order
-// (deterministic); pcount[c][j] = number of such rows.  The chunk (labels + rows) is staged in
-// LDS once.  SORTED: the chunk's rows are grouped by label with a stable counting sort in LDS
-// (rank inside a wavefront by ballot matching, across wavefronts by a small count table), so
-// the (cluster, band) threads only walk their own rows -- same additions in the same order as
-// the plain walk (every thread scans the whole chunk), which remains for k > FIT_SORT_MAXK.
-template <bool SORTED>
-__global__ __launch_bounds__(256) void k_fit_partial(const double *__restrict__ X, uint32_t n, int nb,
-                                                     const int32_t *__restrict__ lab, int k,
-                                                     double *__restrict__ partial,
-                                                     uint32_t *__restrict__ pcount, uint32_t chunk,
-                                                     const FitCtl *__restrict__ ctl)
+// The M-step's sums are the reference's: one chain per (cluster, band) in ROW order (sklearn with one
+// OpenMP thread; fit_elkan.h: the row numbers sorted stably by label, k_fit_sum_lists[_staged]), on
+// this path too -- an earlier version added per-256-row partial sums, whose association left the
+// centres 1e-9 away from the reference's bits.  pcount[j] = rows of cluster j from the list offsets.
+__global__ __launch_bounds__(256) void k_fit_counts(const uint32_t *__restrict__ off, int k,
+                                                    uint32_t *__restrict__ pcount, const uint32_t *stop)
 {
-    if (ctl->stop) return;
-    __shared__ int32_t sl[FIT_CHUNK];
-    extern __shared__ __attribute__((aligned(16))) double sx[];     // chunk * nb doubles (launch parameter):
-                                                                    // 12 KiB at 6 bands, so ten workgroups fit a CU
-    __shared__ uint16_t order[SORTED ? FIT_CHUNK : 1];
-    __shared__ uint16_t cntw[SORTED ? 4 * FIT_SORT_MAXK : 1];
-    __shared__ uint16_t start[SORTED ? FIT_SORT_MAXK + 1 : 1];
-    const uint32_t c = blockIdx.x;
-    const uint32_t r0 = c * chunk;
-    const uint32_t cnt = (n - r0 < chunk) ? (n - r0) : chunk;     // <= FIT_CHUNK = blockDim
-    const int kn = k * nb;
-    int32_t mylab = -1;
-    if (threadIdx.x < cnt) { mylab = lab[r0 + threadIdx.x]; sl[threadIdx.x] = mylab; }
-    const uint32_t tot = cnt * (uint32_t)nb;
-    for (uint32_t i = threadIdx.x; i < tot; i += 256u) sx[i] = X[(size_t)r0 * nb + i];
-    if (SORTED) {
-        for (int i = threadIdx.x; i < 4 * k; i += 256) cntw[i] = 0;
-        __syncthreads();
-        const unsigned lane = lane_id(), wv = threadIdx.x >> 6;
-        const bool valid = threadIdx.x < cnt;
-        unsigned long long same = __ballot(valid);
-        for (int bit = 0; (k - 1) >> bit; bit++) {
-            const bool one = (mylab >> bit) & 1;
-            const unsigned long long bal = __ballot(one);
-            same &= one ? bal : ~bal;
-        }
-        const uint32_t wrank = (uint32_t)__popcll(same & lanemask_lt());
-        if (valid && (same >> lane) >> 1 == 0ull) cntw[wv * k + mylab] = (uint16_t)__popcll(same);
-        __syncthreads();
-        for (int j = threadIdx.x; j <= k; j += 256) {         // start[j] = rows with a label < j
-            uint32_t a = 0;
-            for (int q = 0; q < j; q++) a += cntw[q] + cntw[k + q] + cntw[2 * k + q] + cntw[3 * k + q];
-            start[j] = (uint16_t)a;
-        }
-        __syncthreads();
-        if (valid) {
-            uint32_t pos = start[mylab] + wrank;
-            for (unsigned w2 = 0; w2 < wv; w2++) pos += cntw[w2 * k + mylab];
-            order[pos] = (uint16_t)threadIdx.x;
-        }
-        __syncthreads();
-        for (int t = threadIdx.x; t < kn; t += 256) {
-            const int j = t / nb, b = t - j * nb;
-            const uint32_t q0 = start[j], q1 = start[j + 1];
-            double acc = 0.0;
-            for (uint32_t q = q0; q < q1; q++) acc += sx[(uint32_t)order[q] * nb + b];
-            partial[(size_t)c * kn + t] = acc;
-            if (b == 0) pcount[(size_t)c * k + j] = q1 - q0;
-        }
-    } else {
-        __syncthreads();
-        for (int t = threadIdx.x; t < kn; t += 256) {
-            const int j = t / nb, b = t - j * nb;
-            double acc = 0.0;
-            uint32_t w = 0;
-            for (uint32_t i = 0; i < cnt; i++)
-                if (sl[i] == j) { acc += sx[i * nb + b]; w++; }
-            partial[(size_t)c * kn + t] = acc;
-            if (b == 0) pcount[(size_t)c * k + j] = w;
-        }
-    }
+    if (stop && *stop) return;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j < k) pcount[j] = off[j + 1] - off[j];
 }
 
-// level 1: partial2[g][t] = sum of partial[c][t] over the FIT_GROUP chunks of group g, chunk order
-__global__ __launch_bounds__(256) void k_fit_reduce1(const double *__restrict__ partial,
-                                                     const uint32_t *__restrict__ pcount,
-                                                     uint32_t nchunks, int k, int nb,
-                                                     double *__restrict__ partial2,
-                                                     uint32_t *__restrict__ pcount2,
-                                                     const FitCtl *__restrict__ ctl)
-{
-    if (ctl->stop) return;
-    const int kn = k * nb;
-    const uint32_t g = blockIdx.y;
-    const uint32_t c0 = g * FIT_GROUP;
-    const uint32_t c1 = (c0 + FIT_GROUP < nchunks) ? c0 + FIT_GROUP : nchunks;
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t < kn) {
-        double acc = 0.0;
-        uint32_t c = c0;
-        for (; c + 8u <= c1; c += 8u) {
-            double v[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) v[u] = partial[(size_t)(c + u) * kn + t];
-#pragma unroll
-            for (int u = 0; u < 8; u++) acc += v[u];
-        }
-        for (; c < c1; c++) acc += partial[(size_t)c * kn + t];
-        partial2[(size_t)g * kn + t] = acc;
-    }
-    if (t < k) {
-        uint32_t ww = 0;
-        for (uint32_t c = c0; c < c1; c++) ww += pcount[(size_t)c * k + t];
-        pcount2[(size_t)g * k + t] = ww;
-    }
-}
-
-// End of a Lloyd iteration in one workgroup: level-2 sums (S[t] = sum over groups in order,
-// w[j] likewise), then -- unless a cluster came out empty, which is left to the host --
+// End of a Lloyd iteration in one workgroup: S[t] = sum over `ngroups` partial sums in order (one
+// group = the row-order sums themselves: 0.0 + x is x), w[j] likewise, then -- unless a cluster came out empty, which is left to the host --
 // centres = S * (1 / w), the squared centre shift, the convergence tests of sklearn 0.24.2
 // (labels unchanged -> strict; shift <= tol) and the E-step operands of the next iteration
 // (m2c = -2c, cnorm = |c|^2 as kmeans_prepare_host).  Every float64 operation and its order are
@@ -763,26 +661,20 @@ static int run_kmeans_fit(shp_ctx *ctx, const void *xin_any, int xdtype, int64_t
     std::vector<double> C(kn);
     for (int t = 0; t < kn; t++) C[t] = init[t] - mu[t % nb];
 
-    uint32_t chunk = FIT_LDS_DOUBLES / (uint32_t)nb;
-    if (chunk > FIT_CHUNK) chunk = FIT_CHUNK;
-    if (chunk < 1) SHP_FAIL(ctx, SHP_ERR_ARG, "too many bands for the k-means fit (%d)", nb);
-    const uint32_t nchunks = (n + chunk - 1) / chunk;
-    const uint32_t ngroups = (nchunks + FIT_GROUP - 1) / FIT_GROUP;
     if ((size_t)(2 * kn + 2 * k + 8) * 8 > SHP_PINNED_BYTES)
         SHP_FAIL(ctx, SHP_ERR_ARG, "k * nbands too large for the k-means fit (%d x %d)", k, nb);
     CHK(buf_ensure(ctx, ctx->fit_x, (size_t)n * nb * 8 + (size_t)n * 8));
     CHK(buf_ensure(ctx, ctx->fit_lab, (size_t)n * 4 * 2 + 64));
-    CHK(buf_ensure(ctx, ctx->fit_part,
-                   ((size_t)nchunks + ngroups) * ((size_t)kn * 8 + (size_t)k * 4) + (size_t)(kn + k) * 8 * 2 + 512));
+    CHK(buf_ensure(ctx, ctx->fit_part, (size_t)(kn + k) * 8 * 3 + ((size_t)2 * k + 4) * 4 + 512));
     CHK(buf_ensure(ctx, ctx->cen, (size_t)(kn + k) * 8 * 2));
     double *dX = bp<double>(ctx->fit_x), *ddist = dX + (size_t)n * nb;
     int32_t *dlabA = bp<int32_t>(ctx->fit_lab), *dlabB = dlabA + n;
     FitCtl *dctl = (FitCtl *)(dlabB + n);
-    double *dpart = bp<double>(ctx->fit_part);
-    double *dpart2 = dpart + (size_t)nchunks * kn;
-    double *dS = dpart2 + (size_t)ngroups * kn, *dw = dS + kn;
-    uint32_t *dpc = (uint32_t *)(dw + k + 2);
-    uint32_t *dpc2 = dpc + (size_t)nchunks * k;
+    // row-order sums | their counts as float64 (unused here) | S | w | counts | list offsets (k + 1) + a spare word
+    double *dpart2 = bp<double>(ctx->fit_part), *dcntd = dpart2 + kn;
+    double *dS = dcntd + k, *dw = dS + kn;
+    uint32_t *dpc2 = (uint32_t *)(dw + k + 2);
+    uint32_t *doff = dpc2 + k;
     double *dm2c = bp<double>(ctx->cen), *dcn = dm2c + kn, *dC = dcn + k;
     hipStream_t st = ctx->stream;
     // pinned staging: [0..] FitCtl, then m2c|cnorm|C (2kn+k doubles)
@@ -815,7 +707,6 @@ static int run_kmeans_fit(shp_ctx *ctx, const void *xin_any, int xdtype, int64_t
     // iteration (k_fit_update) owns the convergence tests and, once it raises ctl->stop, the
     // kernels still queued behind it return at once.  Iteration `it` writes its labels to buffer
     // A when it is odd, B when even, and compares them with the other buffer (labels_old).
-    const bool sorted = k <= FIT_SORT_MAXK;
     const auto t_prep = std::chrono::steady_clock::now();
     bool strict = false, finished = false;
     int it_done = 0;
@@ -833,16 +724,22 @@ static int run_kmeans_fit(shp_ctx *ctx, const void *xin_any, int xdtype, int64_t
         for (int it = it_done + 1; it <= b_end; it++) {
             int32_t *dlab = (it & 1) ? dlabA : dlabB, *dlab_old = (it & 1) ? dlabB : dlabA;
             launch_fit_assign(ctx, g, dX, n, nb, dm2c, dcn, k, dlab, dlab_old, dctl); KCHK(ctx);
-            if (sorted)
-                hipLaunchKernelGGL(k_fit_partial<true>, dim3(nchunks), dim3(256), (size_t)chunk * nb * 8, st, dX, n, nb, dlab, k,
-                                   dpart, dpc, chunk, dctl);
-            else
-                hipLaunchKernelGGL(k_fit_partial<false>, dim3(nchunks), dim3(256), (size_t)chunk * nb * 8, st, dX, n, nb, dlab, k,
-                                   dpart, dpc, chunk, dctl);
-            KCHK(ctx);
-            hipLaunchKernelGGL(k_fit_reduce1, dim3(grid_for(kn, 256), ngroups), dim3(256), 0, st, dpart, dpc,
-                               nchunks, k, nb, dpart2, dpc2, dctl); KCHK(ctx);
-            hipLaunchKernelGGL(k_fit_update, dim3(1), dim3(256), 0, st, dpart2, dpc2, ngroups, k, nb, dS, dw,
+            {
+                uint32_t *ks = nullptr, *rows = nullptr;
+                CHK(sort_pairs(ctx, (const uint32_t *)dlab, nullptr, n, bits_for((uint32_t)(k - 1)), &ks, &rows));
+                hipLaunchKernelGGL(k_elk_offsets, dim3(grid_for((size_t)k + 1, 256)), dim3(256), 0, st, ks, n, k, doff,
+                                   doff + k + 1, &dctl->stop); KCHK(ctx);
+                if (nb <= 64)
+                    hipLaunchKernelGGL(k_fit_sum_lists_staged, dim3(k), dim3(256), 0, st, dX, nb, rows, doff, dpart2,
+                                       dcntd, &dctl->stop);
+                else
+                    hipLaunchKernelGGL(k_fit_sum_lists, dim3(k, (nb + 63) / 64), dim3(64), 0, st, dX, nb, rows, doff,
+                                       dpart2, dcntd, &dctl->stop);
+                KCHK(ctx);
+                hipLaunchKernelGGL(k_fit_counts, dim3(grid_for((size_t)k, 256)), dim3(256), 0, st, doff, k, dpc2,
+                                   &dctl->stop); KCHK(ctx);
+            }
+            hipLaunchKernelGGL(k_fit_update, dim3(1), dim3(256), 0, st, dpart2, dpc2, 1u, k, nb, dS, dw,
                                dC, dm2c, dcn, dctl, tol, (uint32_t)it); KCHK(ctx);
         }
         HIPCHK(ctx, hipMemcpyAsync(pin_ctl, dctl, sizeof(FitCtl), hipMemcpyDeviceToHost, st));
