@@ -383,6 +383,8 @@ struct SmallCtl {
     uint32_t xcd_cnt[16];           // per-XCD arrival counters of the two-level grid barrier
     unsigned long long tphase[4];   // SHEPSEG_SMALL_TIMING: wall_clock64 ticks spent in control+find / link / apply
     uint32_t plog[64][4];           // per pass: target, sources, find ticks, merge-phase ticks
+    uint32_t phops[64];             // per pass: chunk-chain hops of the find phase (diagnostic)
+    uint32_t hopcnt, hoppad;        // the running counter behind phops
 };
 
 struct SmallArgs {
@@ -398,6 +400,7 @@ struct SmallArgs {
     double thr2;
     int poll;           // s_sleep(8) repetitions between two polls of a grid barrier
     int bar2;           // two-level (per-XCD) grid barrier
+    uint32_t *hopstat;  // SHEPSEG_SMALL_TIMING: counts chunk-chain hops of the find phase (else null)
 };
 
 // (the software grid barriers live in gridbar.h)
@@ -463,6 +466,7 @@ __device__ __forceinline__ bool find_merge_wave(uint32_t s, uint32_t target, con
             if (ci >= cm) {
                 c = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.chnext[c]);
                 if (c == 0) break;
+                if (a.hopstat && lane == 0) atomicAdd(a.hopstat, 1u);
                 ci = 0;
                 co = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.off[c]);
                 cm = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.origsz[c]);
@@ -747,6 +751,7 @@ __global__ __launch_bounds__(256) void k_small_loop(SmallArgs a)
             const unsigned long long t = wall_clock64();
             const uint32_t pi = (uint32_t)ctl->tphase[3] & 63u;
             ctl->plog[pi][0] = target; ctl->plog[pi][1] = nsrc; ctl->plog[pi][2] = (uint32_t)(t - tmark); ctl->plog[pi][3] = 0;
+            if (a.hopstat) ctl->phops[pi] = atomicExch(a.hopstat, 0u);
             ctl->tphase[0] += t - tmark; tmark = t;
         }
         if (cnt->nmerge == 0u) {
@@ -922,6 +927,7 @@ static int run_eliminate_small(shp_ctx *ctx, const void *d_img, int dtype, int n
     static const int bar2_env = getenv("SHEPSEG_SMALL_BAR2") ? atoi(getenv("SHEPSEG_SMALL_BAR2")) : 1;
     args.bar2 = bar2_env;
     args.pin = (uint32_t *)pin;
+    args.hopstat = getenv("SHEPSEG_SMALL_TIMING") ? &ctl->hopcnt : nullptr;
     pin->done = 0; pin->fail = 0;       // (a loop that gives up at a barrier leaves them so)
     fill_release(ctx, true);            // the pass loop is a latency-bound phase
     {
@@ -956,8 +962,8 @@ static int run_eliminate_small(shp_ctx *ctx, const void *d_img, int dtype, int n
                 pin->tphase[3], pin->tphase[0] / 1e5, pin->tphase[1] / 1e5, S);
     if (getenv("SHEPSEG_SMALL_TIMING")) {
         for (unsigned i = 0; i < 64u && i < pin->tphase[3]; i++)
-            fprintf(stderr, "  pass %u: target %u, %u sources, find %.1f us, merge %.1f us\n", i, pin->plog[i][0],
-                    pin->plog[i][1], pin->plog[i][2] / 100.0, pin->plog[i][3] / 100.0);
+            fprintf(stderr, "  pass %u: target %u, %u sources, find %.1f us, merge %.1f us, %u chain hops\n", i, pin->plog[i][0],
+                    pin->plog[i][1], pin->plog[i][2] / 100.0, pin->plog[i][3] / 100.0, pin->phops[i]);
         fprintf(stderr, "  workgroups per XCD:");
         for (int i = 0; i < 16; i++) fprintf(stderr, " %u", pin->xcd_n[i]);
         fprintf(stderr, "\n");

@@ -180,6 +180,16 @@ def test_c4_fullsize_properties(oracle):
         assert hist[0] == 0 and N * N - 20000 <= int(hist.sum()) <= N * N
         assert r.numTileRows == 12 and r.numTileCols == 12
         assert r.kmeans.cluster_centers_.shape == (60, 10)
+        # the whole-image k-means model is the REFERENCE's, bit for bit: tests/golden/c4_fit_reference.npz holds
+        # shepseg.fitSpectralClusters' centres for this raster's sub-sample (sklearn 0.24.2, Elkan's algorithm,
+        # all 300 iterations, one OpenMP thread; oracle/refgen/gen_golden_c3_fit.py)
+        ref = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'c4_fit_reference.npz'))
+        import zlib
+        sample = tiling.readSubsampledImage(ras, list(range(1, 11)), np.sqrt(1e6 / (N * N)))
+        assert zlib.crc32(np.ascontiguousarray(sample).tobytes()) == int(ref['sample_crc32'])    # the fixture's input
+        assert r.kmeans.n_iter_ == int(ref['n_iter'])
+        assert np.array_equal(np.ascontiguousarray(r.kmeans.cluster_centers_, dtype=np.float64).view(np.uint64),
+                              ref['centres'].view(np.uint64))
         assert bool(r.hasEmptySegments) == bool((hist[1:] == 0).any())
         assert (hist[1:] == 0).sum() < 1e-3 * mx
         # one interior 10-band tile window at full tile size against the oracle
