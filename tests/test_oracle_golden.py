@@ -149,3 +149,26 @@ def test_subset_recode_vs_reference(golden, oracle):
         assert np.array_equal(out, g[name + '_out'])
         assert np.array_equal(orig, g[name + '_orig'])
         assert np.array_equal(hist, g[name + '_hist'])
+
+
+def test_ci_scenario_data_and_oracle(golden, oracle):
+    """the reference's CI scenario at 1000 x 1000 (tests/golden/ci_scenario_1000.npz, from the unmodified
+    reference): the test-data generator reproduces the raster the reference was given, and the oracle's
+    k-means (100 clusters on 100 colours, 8-connected) reproduces the reference's model bit for bit"""
+    import ci_scenario
+    g = golden('ci_scenario_1000')
+    trueseg = ci_scenario.true_segments(1000, 8)
+    assert np.array_equal(trueseg, g['trueseg'])
+    img = ci_scenario.multispectral(trueseg)
+    assert (img[0][trueseg == 0] == ci_scenario.NULLVAL).all() and trueseg[:10].max() == 0
+    xs = np.transpose(img, (1, 2, 0)).reshape(-1, 3)
+    xs = xs[(xs != ci_scenario.NULLVAL).all(axis=1)]
+    pal = ci_scenario.palette(100)
+    init = np.empty((100, 3))
+    for b in range(3):      # diagonalClusterCentres on a uint16 sample (shepseg.py:364-397)
+        (mn, mx) = (int(xs[:, b].min()), int(xs[:, b].max()))
+        init[:, b] = np.floor(mn + np.arange(1, 101) * ((mx - mn) / 101.0))
+    centres, labels, nit = oracle.kmeans_fit(xs.astype(np.float64), init, algorithm='elkan')
+    assert nit == int(g['n_iter'])
+    assert np.array_equal(centres.view(np.uint64), g['centres'].view(np.uint64))
+    assert len(pal) == 100
