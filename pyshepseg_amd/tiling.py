@@ -1430,6 +1430,8 @@ def _createGdalOutput(outfile, ys, xs, infile, outputDriver, creationOptions):
     drvr = gdal.GetDriverByName(outputDriver)
     if drvr is None:
         raise PyShepSegTilingError("This GDAL does not support driver '{}'".format(outputDriver))
+    if os.path.exists(outfile):                    # (tiling.py:960-962)
+        gdal.IdentifyDriver(outfile).Delete(outfile)
     ds = drvr.Create(outfile, xs, ys, 1, gdal.GDT_UInt32, creationOptions)
     if isinstance(infile, str):
         inDs = gdal.Open(infile)
@@ -1453,9 +1455,13 @@ def _finishGdalOutput(gdalOut, hist, writeHistogram, overviews, bandStatistics):
             band.GetOverview(j).WriteArray(overviews[lvl], 0, 0)
     for (k, v) in bandStatistics:
         band.SetMetadataItem(k, v)
-    if writeHistogram:
+    if writeHistogram:                              # writeHistogramToFile, tiling.py:1343-1358
         rat = band.GetDefaultRAT()
-        rat.SetRowCount(len(hist))
-        rat.CreateColumn('Histogram', gdal.GFT_Real, gdal.GFU_PixelCount)
-        rat.WriteArray(hist.astype(numpy.float64), rat.GetColumnCount() - 1)
+        if rat.GetRowCount() != len(hist):
+            rat.SetRowCount(len(hist))
+        colNum = rat.GetColOfUsage(gdal.GFU_PixelCount)
+        if colNum == -1:
+            rat.CreateColumn('Histogram', gdal.GFT_Real, gdal.GFU_PixelCount)
+            colNum = rat.GetColumnCount() - 1
+        rat.WriteArray(hist.astype(numpy.float64), colNum)
     ds.FlushCache()
