@@ -144,8 +144,31 @@ def spawn_ranks(args):
                    LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else None, text=True))
-    out0 = procs[0].communicate()[0]
-    rcs = [procs[0].returncode] + [p.wait() for p in procs[1:]]
+    # rank 0's stdout is drained by a thread; all ranks are polled: when one dies the others would sit in a
+    # receive for ever, so they are stopped (fresh children of this process), and there is a deadline
+    import threading
+    out0 = []
+    rd = threading.Thread(target=lambda: out0.append(procs[0].stdout.read()), daemon=True)
+    rd.start()
+    deadline = time.time() + float(os.environ.get('SHEPSEG_BENCH_DEADLINE', '3000'))
+    failed = None
+    while any(p.poll() is None for p in procs):
+        bad = [(r, p.returncode) for (r, p) in enumerate(procs) if p.poll() not in (None, 0)]
+        if bad or time.time() > deadline:
+            failed = bad[0] if bad else ('deadline', None)
+            sys.stderr.write('bench.py: rank %s ended with %s: stopping the other ranks\n' % failed)
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            time.sleep(5)
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            break
+        time.sleep(0.2)
+    rcs = [p.wait() for p in procs]
+    rd.join(timeout=10)
+    out0 = out0[0] if out0 else ''
     line = None
     for ln in (out0 or '').splitlines():
         if ln.startswith('{') and '"metric"' in ln:

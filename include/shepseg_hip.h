@@ -359,6 +359,21 @@ int  shp_comm_recv(shp_comm *comm, void *d_buf, size_t bytes, int src);
 int  shp_comm_bcast(shp_comm *comm, void *d_buf, size_t bytes, int root);
 int  shp_comm_allgather(shp_comm *comm, const void *d_send, void *d_recv, size_t bytes_per_rank);
 int  shp_comm_allreduce(shp_comm *comm, void *d_buf, size_t count, int op);
+/* ncclCommCount: how many ranks RCCL itself says the communicator spans (quoted by the bench line). */
+int  shp_comm_count(shp_comm *comm, int *nranks_out);
+/* The strips of the parallel stitch (distributed.py, replacing the whole-tile pickles of tiling.py:1799-1912)
+ * travel asynchronously: shp_comm_isend enqueues the send on the communicator's own stream behind an event
+ * recorded on `producer`'s stream (the chain step that writes the strip), shp_comm_irecv enqueues the
+ * receive there and makes `consumer`'s stream wait for it on the device; neither waits on the host, so a
+ * rank's chain never stalls for its neighbour.  Operations of one communicator complete in issue order; both
+ * ends issue them in the order of the boundary plan.  shp_comm_group(1) / (0) = ncclGroupStart / End (a rank
+ * that sends to itself must group the pair; inside a group pass consumer = NULL and call shp_comm_wait after
+ * the group's end: the receive is only enqueued then); shp_comm_drain waits on the host for everything issued. */
+int  shp_comm_isend(shp_comm *comm, const void *d_buf, size_t bytes, int dst, shp_ctx *producer);
+int  shp_comm_irecv(shp_comm *comm, void *d_buf, size_t bytes, int src, shp_ctx *consumer);
+int  shp_comm_group(shp_comm *comm, int begin);
+int  shp_comm_wait(shp_comm *comm, shp_ctx *consumer);
+int  shp_comm_drain(shp_comm *comm);
 
 #ifdef __cplusplus
 }

@@ -138,6 +138,12 @@ _SIGS = {
     'shp_comm_bcast': (_c.c_int, [_vp, _vp, _c.c_size_t, _c.c_int]),
     'shp_comm_allgather': (_c.c_int, [_vp, _vp, _vp, _c.c_size_t]),
     'shp_comm_allreduce': (_c.c_int, [_vp, _vp, _c.c_size_t, _c.c_int]),
+    'shp_comm_count': (_c.c_int, [_vp, _c.POINTER(_c.c_int)]),
+    'shp_comm_isend': (_c.c_int, [_vp, _vp, _c.c_size_t, _c.c_int, _vp]),
+    'shp_comm_irecv': (_c.c_int, [_vp, _vp, _c.c_size_t, _c.c_int, _vp]),
+    'shp_comm_group': (_c.c_int, [_vp, _c.c_int]),
+    'shp_comm_wait': (_c.c_int, [_vp, _vp]),
+    'shp_comm_drain': (_c.c_int, [_vp]),
     'shp_gather_flagged_dev': (_c.c_int, [_vp, _vp, _vp, _c.c_int, _c.c_int64, _c.c_uint32, _vp,
                                           _c.c_int64, _vp, _vp, _vp]),
 }

@@ -16,9 +16,13 @@ Ranks find each other through the environment the launcher sets (RANK, WORLD_SIZ
 MASTER_PORT: what ``bench.py --gpus N`` and ``python -m torch.distributed.run`` both provide).
 """
 import ctypes
+import hashlib
+import hmac
 import os
 import pickle
+import secrets
 import socket
+import stat
 import struct
 import threading
 import time
@@ -33,13 +37,35 @@ class CommError(RuntimeError):
 
 
 def rendezvousDir():
-    """A directory private to this launch: the ranks are children of one launcher process."""
+    """A directory private to this launch and to this user: the ranks are children of one launcher
+    process.  Created with mode 0700; an existing one must be a real directory owned by this user and
+    closed to everybody else -- on a shared host another user could otherwise plant the files the ranks
+    trust (ports, the RCCL unique id, the handshake key)."""
     d = os.environ.get('SHEPSEG_COMM_DIR')
     if not d:
-        d = os.path.join(os.environ.get('TMPDIR', '/tmp'), 'shepseg_comm_%s_%d' % (
-            os.environ.get('MASTER_PORT', '0'), os.getppid()))
-    os.makedirs(d, exist_ok=True)
+        # (TORCHELASTIC_RESTART_COUNT: a relaunch by the same agent must not find the last attempt's files)
+        d = os.path.join(os.environ.get('TMPDIR', '/tmp'), 'shepseg_comm_%s_%d_%s' % (
+            os.environ.get('MASTER_PORT', '0'), os.getppid(), os.environ.get('TORCHELASTIC_RESTART_COUNT', '0')))
+    try:
+        os.makedirs(d, mode=0o700)
+    except FileExistsError:
+        pass
+    st = os.lstat(d)
+    if not stat.S_ISDIR(st.st_mode) or st.st_uid != os.getuid() or (st.st_mode & 0o077):
+        raise CommError("rendezvous directory %s is not a private directory of this user "
+                        "(mode %o, uid %d)" % (d, st.st_mode & 0o7777, st.st_uid))
     return d
+
+
+def launchKey(d, rank):
+    """32 random bytes shared by the ranks of one launch (rank 0 makes them): the key of the socket
+    transport's connection handshake."""
+    path = os.path.join(d, 'key')
+    if rank == 0:
+        key = secrets.token_bytes(32)
+        _publish(path, key)
+        return key
+    return _await(path)
 
 
 def _publish(path, data):
@@ -63,6 +89,7 @@ class LocalComm(object):
     """World size 1: every collective is the identity."""
     rank = 0
     world = 1
+    transport = 'none (one rank)'
     onDevice = False
 
     def allgather_obj(self, obj):
@@ -125,6 +152,7 @@ class SocketComm(_ObjCollectives):
     """TCP between the ranks of one host.  Every rank listens on an ephemeral port and publishes it
     in the rendezvous directory; a directed connection per (sender, receiver) pair is opened on the
     first send.  Messages are length-prefixed."""
+    transport = 'socket: TCP on the loopback interface, strips staged through host memory'
     onDevice = False
 
     def __init__(self, rank=None, world=None):
@@ -134,6 +162,14 @@ class SocketComm(_ObjCollectives):
         self.out = {}
         self.inc = {}
         self.cond = threading.Condition()
+        if self.rank == 0:          # leftovers of an earlier launch that shared this directory
+            for f in os.listdir(self.dir):
+                if f.startswith('port') or f in ('key', 'rccl_unique_id'):
+                    try:
+                        os.remove(os.path.join(self.dir, f))
+                    except OSError:
+                        pass
+        self.key = launchKey(self.dir, self.rank)
         self.srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
         self.srv.bind(('127.0.0.1', 0))
         self.srv.listen(self.world + 4)
@@ -143,13 +179,31 @@ class SocketComm(_ObjCollectives):
         _publish(os.path.join(self.dir, 'port%d' % self.rank), str(self.srv.getsockname()[1]).encode())
 
     def _accept(self):
+        """Registers a peer only after it proved that it holds the launch key (HMAC over a fresh nonce
+        and the rank it claims): anything else that reaches the loopback port is dropped, and a
+        connection that dies half way does not stop the acceptor."""
         while not self.closing:
             try:
                 (conn, _addr) = self.srv.accept()
             except OSError:
                 return
-            conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-            src = struct.unpack('<i', self._read(conn, 4))[0]
+            try:
+                conn.settimeout(30.0)
+                conn.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
+                nonce = secrets.token_bytes(16)
+                conn.sendall(nonce)
+                hello = self._read(conn, 4 + 32)
+                src = struct.unpack('<i', hello[:4])[0]
+                want = hmac.new(self.key, nonce + hello[:4], hashlib.sha256).digest()
+                if not (0 <= src < self.world) or not hmac.compare_digest(want, hello[4:]):
+                    raise CommError("handshake failed")
+                conn.settimeout(None)
+            except (CommError, OSError, struct.error):
+                try:
+                    conn.close()
+                except OSError:
+                    pass
+                continue
             with self.cond:
                 self.inc[src] = conn
                 self.cond.notify_all()
@@ -173,7 +227,9 @@ class SocketComm(_ObjCollectives):
             c = socket.create_connection(('127.0.0.1', port), timeout=180)
             c.settimeout(None)
             c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-            c.sendall(struct.pack('<i', self.rank))
+            nonce = self._read(c, 16)
+            me = struct.pack('<i', self.rank)
+            c.sendall(me + hmac.new(self.key, nonce + me, hashlib.sha256).digest())
             self.out[dst] = c
         return c
 
@@ -215,8 +271,13 @@ class SocketComm(_ObjCollectives):
             self.srv.close()
         except OSError:
             pass
+        for f in ['port%d' % self.rank] + (['key'] if self.rank == 0 else []):
+            try:
+                os.remove(os.path.join(self.dir, f))
+            except OSError:
+                pass
         try:
-            os.remove(os.path.join(self.dir, 'port%d' % self.rank))
+            os.rmdir(self.dir)          # (the last rank out succeeds)
         except OSError:
             pass
 
@@ -237,6 +298,10 @@ class RcclComm(_ObjCollectives):
         self.dir = rendezvousDir()
         idpath = os.path.join(self.dir, 'rccl_unique_id')
         if self.rank == 0:
+            try:
+                os.remove(idpath)       # (an earlier launch's id must not be taken for this one's)
+            except OSError:
+                pass
             buf = (ctypes.c_uint8 * 128)()
             if self.L.shp_comm_unique_id(buf) != 0:
                 raise CommError("ncclGetUniqueId failed")
@@ -277,6 +342,31 @@ class RcclComm(_ObjCollectives):
 
     def recv_dev(self, dptr, nbytes, src):
         self.c.check(self.L.shp_comm_recv(self.h, ctypes.c_void_p(dptr), nbytes, src))
+
+    # ---- asynchronous strips: ordered on the device against the given context's stream, no host wait ----
+    def isend_dev(self, dptr, nbytes, dst, producer):
+        self.c.check(self.L.shp_comm_isend(self.h, ctypes.c_void_p(dptr), nbytes, dst, producer.handle))
+
+    def irecv_dev(self, dptr, nbytes, src, consumer):
+        self.c.check(self.L.shp_comm_irecv(self.h, ctypes.c_void_p(dptr), nbytes, src,
+                                           consumer.handle if consumer is not None else None))
+
+    def wait_dev(self, consumer):
+        self.c.check(self.L.shp_comm_wait(self.h, consumer.handle))
+
+    def group(self, begin):
+        self.c.check(self.L.shp_comm_group(self.h, 1 if begin else 0))
+
+    def drain(self):
+        self.c.check(self.L.shp_comm_drain(self.h))
+
+    def count(self):
+        """ncclCommCount: the number of ranks RCCL itself says this communicator spans"""
+        n = ctypes.c_int(0)
+        self.c.check(self.L.shp_comm_count(self.h, ctypes.byref(n)))
+        return n.value
+
+    transport = 'rccl: ncclSend / ncclRecv of device buffers (xGMI inside a node)'
 
     # ---- host data through the staging buffer ----
     def send_bytes(self, data, dst):

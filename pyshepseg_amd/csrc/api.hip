@@ -1228,6 +1228,11 @@ API int shp_comm_create(shp_ctx *ctx, int rank, int world, const void *unique_id
         delete cm;
         SHP_FAIL(ctx, SHP_ERR_HIP, "ncclCommInitRank(rank %d of %d): %s", rank, world, ncclGetErrorString(r));
     }
+    if (hipStreamCreateWithFlags(&cm->cstream, hipStreamNonBlocking) != hipSuccess) {
+        ncclCommDestroy(cm->nc);
+        delete cm;
+        SHP_FAIL(ctx, SHP_ERR_HIP, "hipStreamCreate for the communicator failed");
+    }
     *out = cm;
     return 0;
 }
@@ -1236,8 +1241,85 @@ API void shp_comm_destroy(shp_comm *cm)
 {
     if (!cm) return;
     if (cm->ctx) { hipSetDevice(cm->ctx->device); hipStreamSynchronize(cm->ctx->stream); }
+    if (cm->cstream) { hipStreamSynchronize(cm->cstream); hipStreamDestroy(cm->cstream); }
+    for (hipEvent_t e : cm->evpool) hipEventDestroy(e);
     if (cm->nc) ncclCommDestroy(cm->nc);
     delete cm;
+}
+
+// what RCCL itself says the communicator spans (ncclCommCount): bench lines quote it
+API int shp_comm_count(shp_comm *cm, int *nranks_out)
+{
+    if (!cm || !nranks_out) return SHP_ERR_ARG;
+    CHK(enter(cm->ctx));
+    NCCLCHK(cm->ctx, ncclCommCount(cm->nc, nranks_out));
+    return 0;
+}
+
+// ncclGroupStart / ncclGroupEnd around the asynchronous calls (a send and its matching receive of ONE
+// rank must be grouped; between different ranks the calls pair up by themselves)
+API int shp_comm_group(shp_comm *cm, int begin)
+{
+    if (!cm) return SHP_ERR_ARG;
+    CHK(enter(cm->ctx));
+    NCCLCHK(cm->ctx, begin ? ncclGroupStart() : ncclGroupEnd());
+    return 0;
+}
+
+// Asynchronous send of a device buffer that `producer`'s stream is still writing: enqueued on the
+// communicator's stream behind an event recorded on the producer's stream now.  Returns at once.
+API int shp_comm_isend(shp_comm *cm, const void *d_buf, size_t bytes, int dst, shp_ctx *producer)
+{
+    if (!cm) return SHP_ERR_ARG;
+    CHK(enter(cm->ctx));
+    if ((!d_buf && bytes) || dst < 0 || dst >= cm->world) SHP_FAIL(cm->ctx, SHP_ERR_ARG, "bad argument");
+    if (producer) {
+        hipEvent_t e = comm_event(cm);
+        if (!e) SHP_FAIL(cm->ctx, SHP_ERR_HIP, "hipEventCreate failed");
+        HIPCHK(cm->ctx, hipEventRecord(e, producer->stream));
+        HIPCHK(cm->ctx, hipStreamWaitEvent(cm->cstream, e, 0));
+    }
+    NCCLCHK(cm->ctx, ncclSend(d_buf, bytes, ncclUint8, dst, cm->nc, cm->cstream));
+    return 0;
+}
+
+// Asynchronous receive into a device buffer that `consumer`'s stream will read: enqueued on the
+// communicator's stream; the consumer's stream is made to wait (on the device) for its completion.
+API int shp_comm_irecv(shp_comm *cm, void *d_buf, size_t bytes, int src, shp_ctx *consumer)
+{
+    if (!cm) return SHP_ERR_ARG;
+    CHK(enter(cm->ctx));
+    if ((!d_buf && bytes) || src < 0 || src >= cm->world) SHP_FAIL(cm->ctx, SHP_ERR_ARG, "bad argument");
+    NCCLCHK(cm->ctx, ncclRecv(d_buf, bytes, ncclUint8, src, cm->nc, cm->cstream));
+    if (consumer) {
+        hipEvent_t e = comm_event(cm);
+        if (!e) SHP_FAIL(cm->ctx, SHP_ERR_HIP, "hipEventCreate failed");
+        HIPCHK(cm->ctx, hipEventRecord(e, cm->cstream));
+        HIPCHK(cm->ctx, hipStreamWaitEvent(consumer->stream, e, 0));
+    }
+    return 0;
+}
+
+// `consumer`'s stream waits (on the device) for everything enqueued on the communicator's stream so far:
+// for receives issued inside a group, whose ncclRecv is only enqueued by shp_comm_group(0)
+API int shp_comm_wait(shp_comm *cm, shp_ctx *consumer)
+{
+    if (!cm || !consumer) return SHP_ERR_ARG;
+    CHK(enter(cm->ctx));
+    hipEvent_t e = comm_event(cm);
+    if (!e) SHP_FAIL(cm->ctx, SHP_ERR_HIP, "hipEventCreate failed");
+    HIPCHK(cm->ctx, hipEventRecord(e, cm->cstream));
+    HIPCHK(cm->ctx, hipStreamWaitEvent(consumer->stream, e, 0));
+    return 0;
+}
+
+// host waits until every asynchronous operation issued so far has completed
+API int shp_comm_drain(shp_comm *cm)
+{
+    if (!cm) return SHP_ERR_ARG;
+    CHK(enter(cm->ctx));
+    HIPCHK(cm->ctx, hipStreamSynchronize(cm->cstream));
+    return 0;
 }
 
 API int shp_comm_send(shp_comm *cm, const void *d_buf, size_t bytes, int dst)

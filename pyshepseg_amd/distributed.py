@@ -176,8 +176,10 @@ def runDistributed(engine, comm, nRows, nCols, tileSize, overlapSize, minSegment
     DistResult with maxSegId, hist (global), kmeans, maxSpectralDiff, tileRange (row-major tile
     indices of this rank), rowRange (the tile rows they touch) and outRows (image rows of the
     output buffer this rank holds: its tiles' trimmed windows are written, the rest is 0) and
-    stitchMode ('sequential', 'parallel', or 'parallel->sequential' when the parallel form had to
-    be redone; argument / SHEPSEG_STITCH: None = parallel when comm.world > 1)."""
+    stitchMode ('sequential', 'parallel', or 'parallel->sequential' when part of the parallel form
+    had to be redone -- chainStepsRedone says how many tiles, from the first one whose ids the
+    provisional numbering cannot express; argument / SHEPSEG_STITCH: None = parallel when
+    comm.world > 1)."""
     if stitchMode is None:
         stitchMode = os.environ.get('SHEPSEG_STITCH') or ('parallel' if comm.world > 1 else 'sequential')
     if stitchMode not in ('sequential', 'parallel'):
@@ -327,28 +329,82 @@ def runDistributed(engine, comm, nRows, nCols, tileSize, overlapSize, minSegment
                     engine.sendStrip(comm, nextRank, it, j)
             while got[0] < len(planPrev):          # (every planned strip has a reader; be safe)
                 need((planPrev[got[0]][0], planPrev[got[0]][1], planPrev[got[0]][2]))
+            if hasattr(engine, 'drainStrips'):
+                engine.drainStrips()               # strips in flight must land before anything is renumbered
             counts = engine.tileCounts(len(jobs))
             mine = [(j.row * ncolsT + j.col, int(k), int(r), int(j.maxLocal))
                     for (j, (k, r)) in zip(jobs, counts)]
         everyone = [x for part in comm.allgather_obj(mine) for x in part]
         K = numpy.zeros(ntAll, dtype=numpy.int64)
-        safe = len(everyone) == ntAll
+        R = numpy.zeros(ntAll, dtype=numpy.int64)
+        hard = len(everyone) != ntAll
         for (t, k, r, mloc) in everyone:
             K[t] = k
-            if k != r or mloc >= stride or k >= stride:
-                safe = False
-        if not safe or int(K.sum()) > 0xFFFFFFFF:
+            R[t] = r
+            if mloc >= stride or k >= stride:
+                hard = True
+        if hard or int(K.sum()) > 0xFFFFFFFF:
             return None
         base = numpy.concatenate(([0], numpy.cumsum(K)[:-1])).astype(numpy.uint32)
-        if haveTiles:
-            engine.renumber(stride, base)
-        return int(K.sum())
+        off = numpy.nonzero(K != R)[0]
+        if len(off) == 0:
+            if haveTiles:
+                engine.renumber(stride, base)
+            return int(K.sum())
+        # Tile `bad` is the first (row-major) to hide ids it handed out from its trimmed window.  Up to
+        # and including it the sequential run has maxSegId = sum of the earlier tiles' K at every step
+        # (the induction of the safety test), so every decision taken so far -- bad's own recode
+        # included -- stands and the provisional ids of tiles <= bad renumber to the final ones.  What
+        # changes is where the NEXT tile starts: at base[bad] + R[bad], not + K[bad] (tiling.py:1029-1043:
+        # maxSegId follows trimmed.max()).  The chain is redone from there only.
+        bad = int(off[0])
+        return ('partial', bad, base, int(base[bad]) + int(R[bad]), stride, fromPrev if haveTiles else {})
 
+    def _resume(bad, base, mAfter, stride, fromPrevProv):
+        """The sequential chain from tile bad + 1 on, after the tiles up to `bad` were kept."""
+        maxSegId = 0
+        if haveTiles:
+            kept = [j for j in jobs if j.row * ncolsT + j.col <= bad]
+            redo = [j for j in jobs if j.row * ncolsT + j.col > bad]
+            ownsBad = t0 <= bad < t1
+            # final ids for what is kept: output rows, the kept tiles' strips, and (on the rank that owns
+            # `bad`) the previous rank's strips, which arrived with provisional ids
+            engine.renumberKept(stride, base, kept, list(fromPrevProv.values()) if (ownsBad and redo) else [])
+            if redo:
+                if ownsBad:
+                    (maxSegId, fromPrev) = (mAfter, fromPrevProv)
+                else:
+                    (maxSegId, fromPrev) = (0, {})
+                    if prevRank is not None:
+                        maxSegId, fromPrev = engine.recvBoundary(
+                            comm, prevRank, boundaryPlan(tileInfo, shards, prevRank, overlapSize))
+                engine.setMaxSegId(maxSegId)
+                for j in redo:
+                    engine.waitTile(j)
+                    (top, left) = _neighbours(j, fromPrev)
+                    engine.stitchTile(j, top, left, _winOf(j.col, j.row), simpleTileRecode)
+                maxSegId = engine.getMaxSegId()
+            elif ownsBad:
+                maxSegId = mAfter
+            if nextRank is not None and t1 - 1 >= bad:          # the next rank redoes all its tiles
+                plan = boundaryPlan(tileInfo, shards, comm.rank, overlapSize)
+                engine.sendBoundary(comm, nextRank, maxSegId,
+                                    [(kind, jobmap[(c, r)], h, w) for (kind, c, r, h, w) in plan])
+        vals = comm.allgather_obj(int(maxSegId))
+        return vals[nonEmpty[-1]] if nonEmpty else 0
+
+    chainRedone = 0
     if stitchMode == 'parallel':
         maxSegId = _parallel()
-        if maxSegId is None:
+        if maxSegId is None:               # (a tile outgrew the provisional id range: everything again)
             stitchMode = 'parallel->sequential'
+            chainRedone = ncolsT * tileInfo.nrows
             maxSegId = _sequential()
+        elif isinstance(maxSegId, tuple):
+            (_tag, bad, base, mAfter, stride, fromPrevProv) = maxSegId
+            stitchMode = 'parallel->sequential'
+            chainRedone = ncolsT * tileInfo.nrows - (bad + 1)
+            maxSegId = _resume(bad, base, mAfter, stride, fromPrevProv)
     else:
         maxSegId = _sequential()
     hist = engine.histogram(maxSegId) if haveTiles else numpy.zeros(maxSegId + 1, numpy.int64)
@@ -362,6 +418,7 @@ def runDistributed(engine, comm, nRows, nCols, tileSize, overlapSize, minSegment
     res.kmeans = kmeansObj
     res.maxSpectralDiff = msd
     res.stitchMode = stitchMode
+    res.chainStepsRedone = chainRedone      # parallel form: tiles whose chain step ran a second time
     res.subsamplePcnt = subsamplePcnt
     res.rowRange = (r0, r1)
     res.tileRange = (t0, t1)
@@ -558,14 +615,47 @@ class HipEngine(object):
         self.c.check(self.L.shp_renumber_dev(self.c.handle, self.d_out, (self.outHi - self.outLo) * self.nCols,
                                              int(stride), _lib.ptr(base), len(base)))
 
+    def renumberKept(self, stride, base, keptJobs, recvStrips):
+        """provisional -> final ids in the output rows, in the recoded strips of the tiles that are kept
+        and in strips received from the previous rank (the partial redo of the parallel stitch)"""
+        self.renumber(stride, base)
+        base = numpy.ascontiguousarray(base, dtype=numpy.uint32)
+        for j in keptJobs:
+            n = j.ysize * min(self.overlap, j.xsize) + min(self.overlap, j.ysize) * j.xsize      # right | bottom
+            self.c.check(self.L.shp_renumber_dev(self.c.handle, ctypes.c_void_p(self.d_strips.value + 4 * j.rightOff),
+                                                 n, int(stride), _lib.ptr(base), len(base)))
+        if recvStrips:
+            for (d, nbytes) in self.recvDev:
+                self.c.check(self.L.shp_renumber_dev(self.c.handle, d, nbytes // 4, int(stride), _lib.ptr(base), len(base)))
+
     def sendStrip(self, comm, dst, item, a):
         (kind, _c, _r, h, w) = item
+        if hasattr(comm, 'isend_dev'):
+            # asynchronous: the send waits ON THE DEVICE for the chain step that writes the strip, the chain
+            # (this thread and its stream) goes on with the next tile
+            (ptr, _pitch) = self.bottomStripOf(a) if kind == 'b' else self.rightStripOf(a)
+            comm.isend_dev(ptr, h * w * 4, dst, self.c)
+            self.asyncComm = comm
+            return
         self.c.check(self.L.shp_sync(self.c.handle))          # the chain step that wrote it is done
         self._sendOne(comm, dst, kind, a, h * w)
 
     def recvStrip(self, comm, src, item):
         (kind, _c, _r, h, w) = item
+        if hasattr(comm, 'irecv_dev'):
+            d = tiling._devAlloc(self.c, h * w * 4)
+            self.recvDev.append((d, h * w * 4))
+            comm.irecv_dev(d.value, h * w * 4, src, self.c)     # the chain's stream waits for the data, not the host
+            self.asyncComm = comm
+            return (d.value, w)
         return (self._recvOne(comm, src, h * w), w)
+
+    def drainStrips(self):
+        """every strip sent or received asynchronously so far has arrived (host wait)"""
+        c = getattr(self, 'asyncComm', None)
+        if c is not None:
+            c.drain()
+            self.asyncComm = None
 
     def _sendOne(self, comm, dst, kind, a, n):
         (ptr, _pitch) = self.bottomStripOf(a) if kind == 'b' else self.rightStripOf(a)
@@ -659,6 +749,7 @@ class HipEngine(object):
     def finish(self):
         for t in self.threads:
             t.join()
+        self.drainStrips()
         self.c.check(self.L.shp_sync(self.c.handle))
         self.recvBufs = []
         for (d, nbytes) in self.recvDev:
@@ -706,6 +797,8 @@ def bench_main(args, rank, world, local_rank):
     sync.check(sync._L.shp_sync(sync.handle))
     comm.barrier()
     dt = comm.max_f64((time.time() - t0) / max(args.steps, 1))
+    tilesPerRank = [int(x) for x in comm.allgather_obj(int(r.tileRange[1] - r.tileRange[0]))]
+    rcclRanks = comm.count() if hasattr(comm, 'count') else None      # what RCCL itself says (ncclCommCount)
     if rank == 0:
         npix = args.size * args.size
         value = npix / dt / 1e6
@@ -721,9 +814,15 @@ def bench_main(args, rank, world, local_rank):
                                       args.tile, args.overlap, world),
                        "tiles": r.numTileRows * r.numTileCols, "workers": args.workers,
                        "max_seg_id": int(r.maxSegId),
-                       "stitch": r.stitchMode,
-                       "parallelism": "tiles sharded by area; overlap strips over ncclSend/ncclRecv (%s)"
-                                      % type(comm).__name__},
+                       "stitch": r.stitchMode, "chain_steps_redone": int(r.chainStepsRedone),
+                       "tiles_per_rank": tilesPerRank,
+                       "transport": getattr(comm, 'transport', type(comm).__name__),
+                       "rccl_nranks": rcclRanks,
+                       "parallelism": "tiles sharded by area over %d ranks, one process per GPU; the k-means fit "
+                                      "on rank 0; overlap strips point to point, histogram all-reduced" % world},
+            # (cpu_baseline is a one-GPU figure: `python bench.py` prints it; BASELINE.md: the reference's numba
+            #  path does ~1.3 Mpixels/s per core)
+            "reference_numba_mpx_per_core": 1.3,
             "roofline": {"bound": "hbm", "kernel": "whole path", "achieved": round(
                 value * 1e6 * (2 * nb + 4) / 1e9, 3), "peak": 8000.0 * world, "unit": "GB/s",
                 "frac": round(value * 1e6 * (2 * nb + 4) / 1e9 / (8000.0 * world), 6),

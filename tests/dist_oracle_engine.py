@@ -93,6 +93,17 @@ class OracleEngine(object):
         t = (v // np.uint32(stride)).astype(np.int64)
         self.out = np.where(v == 0, 0, base[np.minimum(t, len(base) - 1)] + (v % np.uint32(stride))).astype(np.uint32)
 
+    def renumberKept(self, stride, base, keptJobs, recvStrips):
+        def fix(v):
+            t = (v // np.uint32(stride)).astype(np.int64)
+            return np.where(v == 0, 0, base[np.minimum(t, len(base) - 1)] + (v % np.uint32(stride))).astype(np.uint32)
+        self.renumber(stride, base)
+        for j in keptJobs:
+            self.recoded[(j.col, j.row)] = fix(self.recoded[(j.col, j.row)])
+        for a in recvStrips:
+            a[...] = fix(a)
+        self.chainRedone = len(self.jobs) - len(keptJobs)
+
     def sendStrip(self, comm, dst, item, a):
         (kind, _c, _r, h, w) = item
         s = self.bottomStripOf(a) if kind == 'b' else self.rightStripOf(a)

@@ -32,7 +32,8 @@ def main():
             imgNullVal=(int(g['null_val']) if int(g['has_null']) else None),
             fourConnected=bool(int(g['four'])), kmeansObj=shepseg.KMeansModel(g['centres']))
         np.savez(os.path.join(outdir, 'rank%d.npz' % comm.rank), out=eng.out, outLo=r.outRows[0],
-                 outHi=r.outRows[1], maxSegId=r.maxSegId, hist=r.hist, mode=r.stitchMode)
+                 outHi=r.outRows[1], maxSegId=r.maxSegId, hist=r.hist, mode=r.stitchMode,
+                 redone=r.chainStepsRedone, ntiles=r.numTileRows * r.numTileCols)
         comm.close()
         return
     img = np.load(os.path.join(outdir, 'img.npy'))

@@ -141,10 +141,16 @@ def test_parallel_stitch_equals_reference_mosaic(name, world, tmp_path):
         modes.add(str(q['mode']))
     assert np.array_equal(got, want)
     assert len(modes) == 1                       # every rank took the same decision
+    redone = {int(q['redone']) for q in parts}
+    ntiles = int(parts[0]['ntiles'])
+    assert len(redone) == 1
     if name == 'stitch_quirk_empties':
+        # the chain is redone only from the tile after the first one that hides an id it handed out: the
+        # tiles up to it keep their (renumbered) result
         assert modes == {'parallel->sequential'}
+        assert 0 < redone.pop() < ntiles
     elif name in ('stitch_2x2', 'stitch_3x3_null', 'stitch_3x4_8conn'):
-        assert modes == {'parallel'}
+        assert modes == {'parallel'} and redone == {0}
 
 
 @pytest.mark.parametrize('world,simple,NR,mode,shard,order', [
@@ -225,3 +231,28 @@ def test_parallel_stitch_fuzz_in_process(seed, oracle):
     assert np.array_equal(res['sequential'][0], res['parallel'][0])
     assert res['sequential'][1] == res['parallel'][1]
     assert np.array_equal(res['sequential'][2], res['parallel'][2])
+
+
+def test_socket_comm_handshake_and_private_rendezvous(tmp_path, monkeypatch):
+    """a connection that does not hold the launch key is dropped and the acceptor keeps accepting; the
+    rendezvous directory must be private to this user"""
+    import struct
+    from pyshepseg_amd import comm as C
+    d = tmp_path / 'rv'
+    monkeypatch.setenv('SHEPSEG_COMM_DIR', str(d))
+    c = C.SocketComm(rank=0, world=1)
+    assert (os.stat(d).st_mode & 0o777) == 0o700
+    port = c.srv.getsockname()[1]
+    for junk in (b'', b'\x00' * 3, struct.pack('<i', 0) + b'x' * 32):
+        s = socket.create_connection(('127.0.0.1', port), timeout=10)
+        s.recv(16)
+        s.sendall(junk)
+        s.close()
+    assert 0 not in c.inc                                      # nobody was registered as rank 0
+    c.send_bytes(np.arange(1000, dtype=np.uint32), 0)          # the real thing still gets through
+    assert np.array_equal(np.frombuffer(c.recv_bytes(0, timeout=20), dtype=np.uint32), np.arange(1000))
+    c.closing = True
+    c.srv.close()
+    os.chmod(d, 0o777)
+    with pytest.raises(C.CommError, match='not a private directory'):
+        C.rendezvousDir()

@@ -47,6 +47,19 @@ def test_rccl_comm_world_one(tmp_path):
         "b = np.zeros(16, dtype=np.int64)\n"
         "c.c.check(c.L.shp_dev_download(c.c.handle, _lib.ptr(b), out, 128))\n"
         "assert np.array_equal(a, b)\n"
+        "assert c.count() == 1\n"                                  # ncclCommCount
+        # the asynchronous strip exchange on the communicator's own stream, ordered against a context's
+        # stream on the device: this rank sends to itself (a send and its receive of ONE rank are grouped)
+        "src = ctypes.c_void_p(st.value); dst = ctypes.c_void_p(st.value + 1024)\n"
+        "w = _lib.Context()\n"
+        "x = (np.arange(32, dtype=np.int64) * 7 + 3)\n"
+        "w.check(w._L.shp_dev_upload(w.handle, src, _lib.ptr(x), x.nbytes))\n"      # producer: w's stream
+        "c.group(True); c.isend_dev(src.value, 256, 0, w); c.irecv_dev(dst.value, 256, 0, None); c.group(False)\n"
+        "c.wait_dev(w)\n"
+        "y = np.zeros(32, dtype=np.int64)\n"
+        "w.check(w._L.shp_dev_download(w.handle, _lib.ptr(y), dst, 256))\n"        # consumer: waits on the device
+        "assert np.array_equal(x, y)\n"
+        "c.drain(); w.close()\n"
         "c.close()\n" % ROOT)
     _run_ranks(1, ['-c', code], tmp_path, timeout=300)
 
