@@ -369,6 +369,7 @@ __global__ __launch_bounds__(256) void k_small_init(const uint32_t *src, uint32_
 // that all their workgroups are co-resident.
 // ---------------------------------------------------------------------------------------------
 #define SMALL_BLOCKS 64u
+#define SMALL_BALANCED_MAX 2048u      // passes with at most this many sources deal them round robin (three barriers)
 #define SMALL_SPIN_LIMIT GRID_SPIN_LIMIT
 
 struct SmallCnt { uint32_t nsrc, ntgt, nmerge, pad; };    // nmerge: sources that found a target
@@ -644,7 +645,7 @@ __device__ __forceinline__ uint32_t find_merge_packed(unsigned long long m, uint
 __global__ __launch_bounds__(256) void k_small_loop(SmallArgs a)
 {
     __shared__ uint32_t wpix[4][64];
-    __shared__ uint32_t s_target, s_done;
+    __shared__ uint32_t s_target, s_done, s_count;
     __shared__ uint32_t lhist[256];
     SmallCtl *ctl = a.ctl;
     __builtin_amdgcn_s_setprio(2);
@@ -690,7 +691,7 @@ __global__ __launch_bounds__(256) void k_small_loop(SmallArgs a)
                     target++; prev = -1; passes = 0;          // next targetSize, shepseg.py:970
                 }
             }
-            s_target = target; s_done = done;
+            s_target = target; s_done = done; s_count = done ? 0u : (uint32_t)prev;      // sources of this pass
             if (blockIdx.x == 0) {
                 ctl->st[par ^ 1u].target = target; ctl->st[par ^ 1u].prev = prev;
                 ctl->st[par ^ 1u].passes = passes;
@@ -712,7 +713,12 @@ __global__ __launch_bounds__(256) void k_small_loop(SmallArgs a)
         SmallCnt *cnt = &ctl->cnt[slot % 3u];
         // ---- find phase: sources = segments of the target size.  Every wavefront scans its own
         //      64-id slices of the size table (four slices in flight: the scan of ~2.5 M ids is
-        //      repeated every pass and is pure load latency) and handles the sources it finds. ----
+        //      repeated every pass and is pure load latency).  With many sources a wavefront handles
+        //      what it finds at once.  With few (the ~40 late passes of a tile: a few hundred sources of
+        //      30-50 pixels) the pass lasts as long as the wavefront that happened to find the most --
+        //      four or five dependent find chains where the average is one -- so the sources are only
+        //      LISTED by the scan, the grid meets once more, and the list is dealt round robin. ----
+        const bool balanced = s_count <= SMALL_BALANCED_MAX;
         {
             const uint32_t stride = gwaves * 64u;
             uint32_t wmerges = 0;
@@ -732,6 +738,7 @@ __global__ __launch_bounds__(256) void k_small_loop(SmallArgs a)
                     if (lane == 0) gbase = atomicAdd(&cnt->nsrc, (uint32_t)__popcll(m));
                     gbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)gbase);
                     if (sz[u] == target) a.srclist[gbase + (uint32_t)__popcll(m & lanemask_lt())] = b0 + lane + 1u;
+                    if (balanced) continue;
                     const uint32_t npairs = target * (a.four ? 4u : 8u);
                     if (npairs <= 8u) wmerges += find_merge_packed<8>(m, b0, target, a, cnt);
                     else if (npairs <= 16u) wmerges += find_merge_packed<16>(m, b0, target, a, cnt);
@@ -741,6 +748,14 @@ __global__ __launch_bounds__(256) void k_small_loop(SmallArgs a)
                         m &= m - 1ull;
                         wmerges += find_merge_wave(src, target, a, wpix[w], cnt) ? 1u : 0u;
                     }
+                }
+            }
+            if (balanced) {
+                if (!(a.bar2 ? small_grid_barrier2(ctl, bar) : small_grid_barrier(ctl, G, a.poll))) return;
+                const uint32_t nlisted = cnt->nsrc;
+                for (uint32_t i = gwave; i < nlisted; i += gwaves) {
+                    const uint32_t src = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.srclist[i]);
+                    wmerges += find_merge_wave(src, target, a, wpix[w], cnt) ? 1u : 0u;
                 }
             }
             if (wmerges && lane == 0) atomicAdd(&cnt->nmerge, wmerges);
