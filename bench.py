@@ -7,7 +7,7 @@
 
 Workloads (BASELINE.json configs):
   c3 (default, the config the metric is quoted on): a step = one complete tiled Shepherd
-      segmentation of the 40000^2 x 6 image (global k-means subsample + Lloyd fit, every tile
+      segmentation of the 40000^2 x 6 image (global k-means subsample + the reference's k-means fit, every tile
       through assign -> clump -> elimination, cross-tile stitch, histogram) with the image already
       resident in HBM (synthimg v1 generated on the device) and the stitched labels left in HBM;
       tile 4096 / overlap 1024, k = 60, minSegmentSize = 50, fixed k-means init.
@@ -187,7 +187,7 @@ def spawn_ranks(args):
 def pmc_traffic(kernel_name, scale=1.0):
     """HBM bytes per launch of a kernel from the committed PMC passes (rocprofv3 cannot run inside
     this process): FETCH_SIZE + WRITE_SIZE, see profiles/README.md."""
-    for fn in ('r02_pmc_summary.json', 'r01_n_pmc_summary.json'):
+    for fn in ('r03_pmc_summary.json', 'r02_pmc_summary.json', 'r01_n_pmc_summary.json'):
         try:
             pmc = json.load(open(os.path.join(ROOT, 'profiles', fn)))['kernels']
             k = pmc.get(kernel_name)
@@ -310,6 +310,7 @@ def bench_segmentation(args):
     if args.cpu_sample > 0 and args.source == 'hbm':
         out["cpu_baseline"] = cpu_baseline(ras, args, r.kmeans.cluster_centers_,
                                            float(r.maxSpectralDiff))
+        out["cpu_baseline"]["reference_numba_mpx_per_core"] = 1.3       # the reference's own path
     print(json.dumps(out))
     if args.source == 'hbm':
         ras.free()

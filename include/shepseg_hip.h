@@ -69,7 +69,7 @@ const char *shp_last_error(const shp_ctx *ctx);  /* valid until the next call on
  * [4]=h2d [5]=d2h [6]=total.  out must hold 8 doubles. */
 int shp_last_timings(const shp_ctx *ctx, double *out);
 /* accumulated device time (ms, HIP events on the ctx stream) and launch count of the
- * instrumented kernels: ids 0 assign, 1 ccl, 2 dfs_split, 3 radix sort, 4 spectra,
+ * instrumented kernels: ids 0 assign, 1 ccl, 2 dfs_pool (the replay), 3 radix sort, 4 spectra,
  * 5 small-segment pass loop, 7 seed scan + final labels.  reset != 0 clears the counters. */
 int shp_prof_get(shp_ctx *ctx, double *ms_out, uint64_t *count_out, int n, int reset);
 
