@@ -85,8 +85,8 @@ __global__ __launch_bounds__(256) void k_ccl_local(const uint16_t *__restrict__ 
                                                    uint32_t *zero_a, uint32_t *zero_b)
 {
     // the scalars of the later clump kernels are zeroed here instead of by memset launches
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 4u) {
-        zero4[threadIdx.x] = 0u;
+    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 8u) {
+        zero4[threadIdx.x] = 0u;          // (eight words: counters[0..4] of run_clump and spares)
         if (threadIdx.x == 0) { if (zero_a) *zero_a = 0u; if (zero_b) { zero_b[0] = 0u; zero_b[1] = 0u; } }
     }
     __shared__ uint32_t L[CCL_ROWS * 64u];
@@ -643,13 +643,18 @@ __device__ __forceinline__ void dfs_split_lds(uint32_t *lab, const BigInfo &B, u
 //     by the time they surface (mean run of 6-7 dead pops).
 // Bit-exact replay of shepseg.py:490-539 like the walk above.
 #include "dfs_walk4_asm.h"
-template <bool FOUR>
+// GLB: the bitmap does not fit the walker pool and lives in global memory (with its snapshot): the same
+// walk -- a step touches registers only, so the backing store's latency is paid at re-centrings, dead ends,
+// seeds and piece ends -- with the bitmap read past this CU's vector cache (agent scope: lanes read words
+// that other lanes of the wavefront stored).
+template <bool FOUR, bool GLB = false>
 __device__ __forceinline__ void dfs_split_win(uint32_t *lab, const BigInfo &B, uint32_t *bm,
                                               uint32_t *sw, uint32_t *stackbuf, uint32_t ncols,
                                               uint32_t *singles, uint32_t *nsingles, uint32_t *csize,
                                               uint32_t *snap, unsigned long long *prof)
 {
     typedef unsigned long long u64;
+#define BMLD(P) (GLB ? __hip_atomic_load((P), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *(P))
 #ifdef DFS_PROF     // diagnostic build (make PROF=1): cycles per phase and event counts per component
     u64 pf_t = __builtin_readcyclecounter(), pf_build = 0, pf_dead = 0, pf_label = 0, pf_seed = 0, pf_rim = 0, pf_walk = 0, pf_asm = 0;
     u64 pf_nstep = 0, pf_ndead = 0, pf_nbulk = 0, pf_nrim = 0, pf_npiece = 0, pf_nrun = 0;
@@ -694,6 +699,7 @@ __device__ __forceinline__ void dfs_split_win(uint32_t *lab, const BigInfo &B, u
             }
         }
     }
+    if (GLB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
     const uint32_t wpr_inv = 0xFFFFFFFFu / wpr + 1u;              // __umulhi(i, wpr_inv) == i / wpr for i < 2^32 / wpr
     // per-lane constants (8-connectivity and the dead-end test): lanes 0..nq-1 own the neighbours in
@@ -714,6 +720,34 @@ __device__ __forceinline__ void dfs_split_win(uint32_t *lab, const BigInfo &B, u
     const uint32_t trmax = nprow > 64u ? nprow - 64u : 0u;
     // (readfirstlane: the walker's window address comes from threadIdx.x / 64, uniform but not provably so)
     const uint32_t sw_addr = UNI((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)sw);
+    // GLB: which parts of the (large) bitmap a piece has touched, for the sweep at its end -- a bit per CELL of
+    // (64 << vsr) rows x (2 << vsc) words, at most 8192 cells in two 64-bit words per lane; every tile that is
+    // loaded marks the cells it overlaps.  (The rows a piece stood on, which bound the sweep of a bitmap in LDS,
+    // do not do here: a piece that runs down one column of a 4096-pixel-wide component would sweep 900 rows x
+    // 129 words for its 10000 pixels.)
+    uint32_t vsr = 0, vsc = 0, vCR = (nprow + 63u) >> 6, vCC = (wpr + 1u) >> 1;
+    if (GLB) {
+        while (vCR * vCC > 8192u) {
+            if (vCR >= vCC) { vsr++; vCR = (vCR + 1u) >> 1; } else { vsc++; vCC = (vCC + 1u) >> 1; }
+        }
+    }
+    u64 vis0 = 0, vis1 = 0;
+#define DFSW_MARK_ONE(IDX)                                                                          \
+    do {                                                                                            \
+        const uint32_t ix_ = (IDX);                                                                 \
+        if (lane == (ix_ >> 7)) { if (ix_ & 64u) vis1 |= 1ull << (ix_ & 63u); else vis0 |= 1ull << (ix_ & 63u); } \
+    } while (0)
+#define DFSW_MARK()                                                                                 \
+    do {                                                                                            \
+        if (GLB) {                                                                                  \
+            const uint32_t ra_ = tr0 >> (6u + vsr);                                                 \
+            uint32_t rb_ = (tr0 + 63u) >> (6u + vsr);                                               \
+            rb_ = rb_ < vCR ? rb_ : vCR - 1u;                                                       \
+            const uint32_t ca_ = (twc32 >> 5) >> (1u + vsc), cb_ = ((twc32 >> 5) + 1u) >> (1u + vsc); \
+            DFSW_MARK_ONE(ra_ * vCC + ca_); DFSW_MARK_ONE(ra_ * vCC + cb_);                         \
+            DFSW_MARK_ONE(rb_ * vCC + ca_); DFSW_MARK_ONE(rb_ * vCC + cb_);                         \
+        }                                                                                           \
+    } while (0)
     // the tile (registers) and where it sits
     uint32_t tlo = 0, thi = 0, tr0 = 0, twc32 = 0;
 #define DFSW_TILE_LOAD(PR, PC)                                                                      \
@@ -728,8 +762,9 @@ __device__ __forceinline__ void dfs_split_win(uint32_t *lab, const BigInfo &B, u
         const uint32_t r_ = tr0 + lane;                                                             \
         const bool ok_ = r_ < nprow;                                                                \
         const uint32_t a_ = r_ * wpr + twc_;                                                        \
-        tlo = ok_ ? bm[a_] : 0u;                                                                    \
-        thi = ok_ ? bm[a_ + 1u] : 0u;                                                               \
+        tlo = ok_ ? BMLD(&bm[a_]) : 0u;                                                             \
+        thi = ok_ ? BMLD(&bm[a_ + 1u]) : 0u;                                                        \
+        DFSW_MARK();                                                                                \
     } while (0)
 #define DFSW_TILE_FLUSH()                                                                           \
     do {                                                                                            \
@@ -739,6 +774,8 @@ __device__ __forceinline__ void dfs_split_win(uint32_t *lab, const BigInfo &B, u
             bm[a_] = tlo;                                                                           \
             bm[a_ + 1u] = thi;                                                                      \
         }                                                                                           \
+        /* (GLB: no wait -- the loads that follow come from this wavefront too, and a wavefront's       \
+            accesses to one address reach the L2 in program order) */                                \
         __builtin_amdgcn_wave_barrier();                                                            \
     } while (0)
 #define DFSW_ROW_GET(R) ((u64)(uint32_t)__builtin_amdgcn_readlane((int)tlo, (int)(R)) |             \
@@ -763,7 +800,7 @@ __device__ __forceinline__ void dfs_split_win(uint32_t *lab, const BigInfo &B, u
         uint32_t sword = 0xFFFFFFFFu, sbits = 0;
         for (uint32_t w0 = wcur; w0 < nwords; w0 += 64u) {
             const uint32_t wi = w0 + lane;
-            const uint32_t v = wi < nwords ? bm[wi] : 0u;
+            const uint32_t v = wi < nwords ? BMLD(&bm[wi]) : 0u;
             const u64 mm = __ballot(v != 0u);
             if (mm) {
                 const int fl = __builtin_ctzll(mm);
@@ -778,11 +815,13 @@ __device__ __forceinline__ void dfs_split_win(uint32_t *lab, const BigInfo &B, u
         const uint32_t seed = gbase + sy * ncols + sx;
         const uint32_t FL = seed | VIS_FLAG;
         if (lane == 0) bm[sword] = sbits & (sbits - 1u);     // clear the seed's (lowest) bit
+        if (GLB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the store has left before the tile is read)
         __builtin_amdgcn_wave_barrier();
         uint32_t sp_l = 0, sp_g = 0;             // stack entries in the LDS window / spilled
         uint32_t cnt = 0;
         uint32_t cpk = UNI((sy << 16) | sx);     // current position, packed padded coordinates
         uint32_t rmin = UNI(sy), rmax = rmin;    // rows the piece has stood on
+        vis0 = 0; vis1 = 0;
         DFSW_TILE_LOAD(sy, sx);
         uint32_t ry = UNI(sy - tr0), b = UNI(sx - twc32);        // both in 1 .. 62
         u64 U = DFSW_ROW_GET(ry - 1u), C = DFSW_ROW_GET(ry), D = DFSW_ROW_GET(ry + 1u);
@@ -928,7 +967,7 @@ __device__ __forceinline__ void dfs_split_win(uint32_t *lab, const BigInfo &B, u
                         if (FOUR) { qy = (q == 1u) ? -1 : (q == 2u) ? 1 : 0; qx = (q == 0u) ? -1 : (q == 3u) ? 1 : 0; }
                         else { qx = (q < 3u) ? -1 : (q < 5u) ? 0 : 1; qy = (q == 0u || q == 3u || q == 5u) ? -1 : (q == 1u || q == 6u) ? 0 : 1; }
                         const uint32_t rr = (uint32_t)((int)er + qy), cc = (uint32_t)((int)ec + qx);
-                        alive = alive || (((bm[rr * wpr + (cc >> 5)] >> (cc & 31u)) & 1u) != 0u);
+                        alive = alive || (((BMLD(&bm[rr * wpr + (cc >> 5)]) >> (cc & 31u)) & 1u) != 0u);
                     }
                 }
                 const u64 am = __ballot(alive);
@@ -965,6 +1004,46 @@ __device__ __forceinline__ void dfs_split_win(uint32_t *lab, const BigInfo &B, u
                 snap[sword] = sbits & (sbits - 1u);          // (the snapshot follows: only the seed's bit went)
                 if (singles) singles[atomicAdd(nsingles, 1u)] = seed;
             }
+        } else if (GLB) {
+            // the marked cells, one at a time: lane = row of the cell's block, two words per lane
+            for (int h = 0; h < 2; h++) {
+                u64 mine = h ? vis1 : vis0;
+                for (;;) {
+                    const u64 any = __ballot(mine != 0ull);
+                    if (!any) break;
+                    const int L = __builtin_ctzll(any);
+                    const uint32_t mlo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mine, L);
+                    const uint32_t mhi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mine >> 32), L);
+                    const uint32_t bpos = mlo ? (uint32_t)__builtin_ctz(mlo) : 32u + (uint32_t)__builtin_ctz(mhi);
+                    if ((int)lane == L) mine &= mine - 1ull;
+                    const uint32_t cell = ((uint32_t)L << 7) + ((uint32_t)h << 6) + bpos;
+                    const uint32_t cr = cell / vCC, cc = cell - cr * vCC;
+                    for (uint32_t rb = 0; rb < (1u << vsr); rb++) {
+                        const uint32_t row = (((cr << vsr) + rb) << 6) + lane;
+                        if ((((cr << vsr) + rb) << 6) >= nprow) break;                 // (uniform)
+                        for (uint32_t wp = 0; wp < (1u << vsc); wp++) {
+                            const uint32_t w = ((cc << vsc) + wp) << 1;
+                            if (w >= wpr) break;                                           // (uniform)
+                            const bool ok0 = row < nprow, ok1 = ok0 && w + 1u < wpr;
+                            const uint32_t i = row * wpr + w;
+                            const uint32_t s0 = ok0 ? __hip_atomic_load(&snap[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                            const uint32_t s1 = ok1 ? __hip_atomic_load(&snap[i + 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                            const uint32_t c0 = ok0 ? BMLD(&bm[i]) : 0u, c1 = ok1 ? BMLD(&bm[i + 1u]) : 0u;
+                            uint32_t d0 = s0 & ~c0, d1 = s1 & ~c1;
+                            const uint32_t pbase = gbase + row * ncols + (w << 5);
+                            if (d0) {
+                                snap[i] = c0;
+                                do { lab[pbase + (uint32_t)__builtin_ctz(d0)] = FL; d0 &= d0 - 1u; } while (d0);
+                            }
+                            if (d1) {
+                                snap[i + 1u] = c1;
+                                do { lab[pbase + 32u + (uint32_t)__builtin_ctz(d1)] = FL; d1 &= d1 - 1u; } while (d1);
+                            }
+                        }
+                    }
+                }
+            }
+            if (lane == 0) csize[seed] = cnt + 1u;
         } else {
             // the piece's pixels = the bits that went since the snapshot (the bitmap at the last piece's
             // end, in global memory), in the rows the piece stood on +- 1: a word per lane, four loads
@@ -982,7 +1061,7 @@ __device__ __forceinline__ void dfs_split_win(uint32_t *lab, const BigInfo &B, u
 #pragma unroll
                 for (uint32_t u = 0; u < 4u; u++) {
                     const uint32_t i = i0 + u * 64u + lane;
-                    const uint32_t cur = i < iend ? bm[i] : 0u;
+                    const uint32_t cur = i < iend ? BMLD(&bm[i]) : 0u;
                     uint32_t d = sv[u] & ~cur;
                     if (d) {
                         snap[i] = cur;
@@ -1009,7 +1088,10 @@ __device__ __forceinline__ void dfs_split_win(uint32_t *lab, const BigInfo &B, u
 #undef PF_LAP
 #undef PF_CNT
 #undef PF_ADD
+#undef BMLD
 #undef DFSW_TILE_LOAD
+#undef DFSW_MARK
+#undef DFSW_MARK_ONE
 #undef DFSW_TILE_FLUSH
 #undef DFSW_ROW_GET
 #undef DFSW_ROW_PUT
@@ -1094,7 +1176,8 @@ __global__ __launch_bounds__(DFS_WAVES * 64) void k_dfs_pool(        // blockDim
 
     uint32_t *lab, const BigInfo *__restrict__ big, uint32_t *counters, uint32_t *stackbuf, uint32_t nrows,
     uint32_t ncols, int four, uint32_t pool_grans, uint32_t *singles, uint32_t *nsingles,
-    const uint32_t *__restrict__ order, uint32_t *csize, unsigned long long *dbg, int oldwalk, uint32_t *snap)
+    const uint32_t *__restrict__ order, uint32_t *csize, unsigned long long *dbg, int oldwalk, uint32_t *snap,
+    uint32_t *gscratch, uint32_t gscratch_words)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t dfs_lds[];
     unsigned long long *mask = (unsigned long long *)dfs_lds;             // 4 words (2 used)
@@ -1156,7 +1239,24 @@ __global__ __launch_bounds__(DFS_WAVES * 64) void k_dfs_pool(        // blockDim
                 __hip_atomic_fetch_and(mask, ~(ones << g0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         } else {
-            dfs_split_global(lab, B, sw, stackbuf, nrows, ncols, four, singles, nsingles, csize);
+            // the bitmap does not fit the pool (or no room came free): bitmap and snapshot in global memory,
+            // carved from the scratch block (counters[4] = words taken); the plain global walk when that is full
+            uint32_t goff = 0xFFFFFFFFu;
+            if (!oldwalk && words <= 0x3FFFFFFFull && gscratch) {
+                if (lane == 0) {
+                    const uint32_t need2 = 2u * (uint32_t)words;
+                    const uint32_t o = atomicAdd(&counters[4], need2);
+                    goff = (o + need2 <= gscratch_words) ? o : 0xFFFFFFFFu;
+                }
+                goff = (uint32_t)__builtin_amdgcn_readfirstlane((int)goff);
+            }
+            if (goff != 0xFFFFFFFFu) {
+                uint32_t *gbm = gscratch + goff, *gsnap = gbm + (uint32_t)words;
+                if (four) dfs_split_win<true, true>(lab, B, gbm, sw, stackbuf, ncols, singles, nsingles, csize, gsnap, dbg ? dbg + (size_t)idx * DFS_DBG_WORDS + 6u : nullptr);
+                else dfs_split_win<false, true>(lab, B, gbm, sw, stackbuf, ncols, singles, nsingles, csize, gsnap, dbg ? dbg + (size_t)idx * DFS_DBG_WORDS + 6u : nullptr);
+            } else {
+                dfs_split_global(lab, B, sw, stackbuf, nrows, ncols, four, singles, nsingles, csize);
+            }
         }
         if (dbg && lane == 0) {          // SHEPSEG_DFS_STATS: size, bitmap words, wait / walk ticks (100 MHz), start
             unsigned long long *d = dbg + (size_t)idx * DFS_DBG_WORDS;
@@ -1326,7 +1426,8 @@ static int run_clump(shp_ctx *ctx, const uint16_t *d_clus, uint32_t nrows, uint3
         CHK(buf_ensure(ctx, ctx->snap, (size_t)nblk * pw * pg * DFS_GRAN_WORDS * 4u));
         hipLaunchKernelGGL(k_dfs_pool, dim3(nblk), dim3(pw * 64u), lds, st, lab, big,
                            counters, bp<uint32_t>(ctx->stack), nrows, ncols, four, pg, d_singles, d_nsingles,
-                           order, csize, dbg, oldwalk, bp<uint32_t>(ctx->snap)); KCHK(ctx);
+                           order, csize, dbg, oldwalk, bp<uint32_t>(ctx->snap), rank /* aux2: free until the seed scan */,
+                           n); KCHK(ctx);
     }
     prof_end(ctx, ps);
     if (dbg) {
