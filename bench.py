@@ -333,8 +333,8 @@ def bench_stats(args):
     fc = np.zeros((nf, S + 1), dtype=np.float32)
 
     def step():
-        c.check(c._L.shp_segstats_dev(c.handle, d_seg, ctypes.c_void_p(ras.ptr), 2, N * N, S, 0, 0,
-                                      _lib.ptr(fast), len(sel), -9999, _lib.ptr(ic), _lib.ptr(fc)))
+        c.check(c._L.shp_segstats2d_dev(c.handle, d_seg, ctypes.c_void_p(ras.ptr), 2, N, N, S, 0, 0,
+                                        _lib.ptr(fast), len(sel), -9999, _lib.ptr(ic), _lib.ptr(fc)))
 
     for _ in range(args.warmup):
         step()
@@ -361,8 +361,8 @@ def bench_stats(args):
                                "pageable host arrays inside the step" % (
                                    N, N, BH, BW, S, (ni * 8 + nf * 4) * (S + 1) / 1e9),
                    "segments": S, "segments_per_s": round(S / dt, 0)},
-        "roofline": {"bound": "hbm", "kernel": "segstats device pipeline (k_stats_keys + 6 radix passes "
-                                               "+ k_run_count + k_seg_stats)",
+        "roofline": {"bound": "hbm", "kernel": "segstats device pipeline (k_label_hist + k_stats_prefill + k_stats_patch; "
+                                               "the sorts only for segments that straddle 32 x 64-pixel patches)",
                      "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None,
                      "avg_launch_ms": round(ms / max(cnt, 1), 3), "launches": int(cnt),

@@ -288,6 +288,13 @@ int shp_segstats_dev(shp_ctx *ctx, const uint32_t *d_seg, const void *d_band, in
                      int64_t npix, uint32_t max_seg_id, int has_null, int64_t null_val,
                      const uint32_t *stats_sel, int nstats, int64_t missing,
                      int64_t *intcols_out, float *floatcols_out);
+/* The same for a raster whose shape is known (nrows x ncols pixels, row-major; one tile block of
+ * calcPerSegmentStatsTiled, tilingstats.py:183-206): where the average segment is at most 64 pixels the
+ * statistics are computed patch by patch in LDS and only the segments that straddle patches are sorted. */
+int shp_segstats2d_dev(shp_ctx *ctx, const uint32_t *d_seg, const void *d_band, int dtype,
+                       int64_t nrows, int64_t ncols, uint32_t max_seg_id, int has_null, int64_t null_val,
+                       const uint32_t *stats_sel, int nstats, int64_t missing,
+                       int64_t *intcols_out, float *floatcols_out);
 
 /* Multi-GPU split of the statistics: a segment that straddles two ranks' rows needs its
  * pixels from both.  Writes (segment id, band value) of every pixel whose segment id s has

@@ -115,6 +115,8 @@ _SIGS = {
                                 _c.c_int64, _vp, _c.c_int, _c.c_int64, _vp, _vp]),
     'shp_segstats_dev': (_c.c_int, [_vp, _vp, _vp, _c.c_int, _c.c_int64, _c.c_uint32, _c.c_int,
                                     _c.c_int64, _vp, _c.c_int, _c.c_int64, _vp, _vp]),
+    'shp_segstats2d_dev': (_c.c_int, [_vp, _vp, _vp, _c.c_int, _c.c_int64, _c.c_int64, _c.c_uint32, _c.c_int,
+                                      _c.c_int64, _vp, _c.c_int, _c.c_int64, _vp, _vp]),
     'shp_ctx_reserve': (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int64]),
     'shp_ctx_reserve_query': (_c.c_int, [_vp, _c.c_int, _c.c_int, _c.c_int64, _c.POINTER(_c.c_int64),
                                          _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int64)]),

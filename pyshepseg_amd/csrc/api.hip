@@ -995,6 +995,22 @@ API int shp_segstats_dev(shp_ctx *ctx, const uint32_t *d_seg, const void *d_band
                         stats_sel, nstats, missing, intcols_out, floatcols_out);
 }
 
+// the same for a raster whose shape is known (nrows x ncols pixels, row-major): lets the library take the
+// patch-by-patch path when the segments are small (segstats.h)
+API int shp_segstats2d_dev(shp_ctx *ctx, const uint32_t *d_seg, const void *d_band, int dtype,
+                           int64_t nrows, int64_t ncols, uint32_t max_seg_id, int has_null, int64_t null_val,
+                           const uint32_t *stats_sel, int nstats, int64_t missing,
+                           int64_t *intcols_out, float *floatcols_out)
+{
+    CHK(enter(ctx));
+    if (!d_seg || !d_band || !stats_sel || nstats < 1 || dtype_size(dtype) == 0 || nrows < 0 || ncols < 0)
+        SHP_FAIL(ctx, SHP_ERR_ARG, "bad argument");
+    if (nrows > 0xffffffffll || ncols > 0xffffffffll || nrows * ncols >= 0xffffffffll)
+        SHP_FAIL(ctx, SHP_ERR_ARG, "raster too large (%lld x %lld px)", (long long)nrows, (long long)ncols);
+    return run_segstats(ctx, d_seg, d_band, dtype, (uint32_t)(nrows * ncols), max_seg_id, has_null, null_val,
+                        stats_sel, nstats, missing, intcols_out, floatcols_out, (uint32_t)nrows, (uint32_t)ncols);
+}
+
 API int shp_segstats(shp_ctx *ctx, const uint32_t *seg, const void *band, int dtype, int64_t npix,
                      uint32_t max_seg_id, int has_null, int64_t null_val, const uint32_t *stats_sel,
                      int nstats, int64_t missing, int64_t *intcols_out, float *floatcols_out)

@@ -70,47 +70,11 @@ __device__ __forceinline__ void seg_stats_emit(uint32_t s, uint32_t n, const uin
     }
 }
 
-#define SEGSTATS_BIG 4096u       // segments above this many valid pixels go to k_seg_stats_big
-#define SEGSTATS_STAGE 3072u     // values a wavefront stages in LDS (12 KiB; 48 KiB per workgroup)
-// one thread per segment over its ascending value run
-__global__ __launch_bounds__(256) void k_seg_stats(const uint32_t *__restrict__ vals,
-                                                   const uint32_t *__restrict__ off,
-                                                   const uint32_t *__restrict__ cnt, uint32_t S,
-                                                   long long bias, const uint32_t *__restrict__ sel,
-                                                   int nstats, long long missing,
-                                                   long long *__restrict__ intcols,
-                                                   float *__restrict__ fltcols, uint32_t *biglist)
+// the statistics of one segment from its ascending value run (a[0..n), biased values), into their columns
+__device__ __forceinline__ void seg_stats_of_run(uint32_t s, uint32_t n, const uint32_t *a, long long bias,
+                                                 const uint32_t *__restrict__ sel, int nstats, long long missing,
+                                                 long long *__restrict__ intcols, float *__restrict__ fltcols, size_t ns)
 {
-    // The 64 segments of a wavefront hold one contiguous span of the value array.  When that span is
-    // short (many small segments: 50 M segments of 32 pixels in the C5 workload) the wavefront loads
-    // it into LDS with coalesced reads and every thread walks its own run there; a thread reading
-    // its 128 bytes straight from memory, twice, moved a cache line per load.
-    __shared__ uint32_t stage[4][SEGSTATS_STAGE];
-    const uint32_t s = blockIdx.x * 256u + threadIdx.x;
-    const unsigned lane = lane_id(), wv = threadIdx.x >> 6;
-    const uint32_t s_first = s - lane, s_last = s_first + 63u < S ? s_first + 63u : S;
-    const uint32_t span0 = s_first <= S ? off[s_first] : 0u;
-    const uint32_t span1 = s_first <= S ? off[s_last] + cnt[s_last] : 0u;
-    const bool staged = span1 - span0 <= SEGSTATS_STAGE;          // (uniform per wavefront)
-    if (staged) {
-        for (uint32_t i = lane; i < span1 - span0; i += 64u) stage[wv][i] = vals[span0 + i];
-        __builtin_amdgcn_wave_barrier();
-    }
-    if (s > S) return;
-    const size_t ns = (size_t)S + 1;
-    if (s == 0) {                       // null segment row: zeros (RatPage :1992-1996)
-        for (int i = 0; i < nstats; i++) {
-            if (sel[i * 5 + 2] == 0) intcols[(size_t)sel[i * 5 + 3] * ns] = 0;
-            else fltcols[(size_t)sel[i * 5 + 3] * ns] = 0.0f;
-        }
-        return;
-    }
-    const uint32_t n = cnt[s];
-    if (n > SEGSTATS_BIG) {             // a long run is a wavefront's work (k_seg_stats_big), not a thread's
-        biglist[1u + atomicAdd(&biglist[0], 1u)] = s;
-        return;
-    }
-    const uint32_t *a = staged ? &stage[wv][off[s] - span0] : vals + off[s];
     long long vmin = missing, vmax = missing, vmode = missing;
     float mean = (float)missing, stddev = (float)missing;
     if (n > 0) {
@@ -135,6 +99,53 @@ __global__ __launch_bounds__(256) void k_seg_stats(const uint32_t *__restrict__ 
         stddev = (float)sqrt((double)var / (double)n);
     }
     seg_stats_emit(s, n, a, bias, sel, nstats, missing, intcols, fltcols, ns, vmin, vmax, vmode, mean, stddev);
+}
+
+#define SEGSTATS_BIG 4096u       // segments above this many valid pixels go to k_seg_stats_big
+#define SEGSTATS_STAGE 3072u     // values a wavefront stages in LDS (12 KiB; 48 KiB per workgroup)
+// one thread per segment over its ascending value run
+__global__ __launch_bounds__(256) void k_seg_stats(const uint32_t *__restrict__ vals,
+                                                   const uint32_t *__restrict__ off,
+                                                   const uint32_t *__restrict__ cnt, uint32_t S,
+                                                   long long bias, const uint32_t *__restrict__ sel,
+                                                   int nstats, long long missing,
+                                                   long long *__restrict__ intcols,
+                                                   float *__restrict__ fltcols, uint32_t *biglist,
+                                                   const uint8_t *__restrict__ only)
+{
+    // (only != nullptr: the rows of unflagged segments belong to somebody else -- the patch path below)
+    // The 64 segments of a wavefront hold one contiguous span of the value array.  When that span is
+    // short (many small segments: 50 M segments of 32 pixels in the C5 workload) the wavefront loads
+    // it into LDS with coalesced reads and every thread walks its own run there; a thread reading
+    // its 128 bytes straight from memory, twice, moved a cache line per load.
+    __shared__ uint32_t stage[4][SEGSTATS_STAGE];
+    const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+    const unsigned lane = lane_id(), wv = threadIdx.x >> 6;
+    const uint32_t s_first = s - lane, s_last = s_first + 63u < S ? s_first + 63u : S;
+    const uint32_t span0 = s_first <= S ? off[s_first] : 0u;
+    const uint32_t span1 = s_first <= S ? off[s_last] + cnt[s_last] : 0u;
+    const bool staged = span1 - span0 <= SEGSTATS_STAGE;          // (uniform per wavefront)
+    if (staged) {
+        for (uint32_t i = lane; i < span1 - span0; i += 64u) stage[wv][i] = vals[span0 + i];
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (s > S) return;
+    const size_t ns = (size_t)S + 1;
+    if (only && s != 0u && !only[s]) return;
+    if (s == 0) {                       // null segment row: zeros (RatPage :1992-1996)
+        for (int i = 0; i < nstats; i++) {
+            if (sel[i * 5 + 2] == 0) intcols[(size_t)sel[i * 5 + 3] * ns] = 0;
+            else fltcols[(size_t)sel[i * 5 + 3] * ns] = 0.0f;
+        }
+        return;
+    }
+    const uint32_t n = cnt[s];
+    if (n > SEGSTATS_BIG) {             // a long run is a wavefront's work (k_seg_stats_big), not a thread's
+        biglist[1u + atomicAdd(&biglist[0], 1u)] = s;
+        return;
+    }
+    const uint32_t *a = staged ? &stage[wv][off[s] - span0] : vals + off[s];
+    seg_stats_of_run(s, n, a, bias, sel, nstats, missing, intcols, fltcols, ns);
 }
 
 // Segments with long value runs, one wavefront each (a persistent grid over biglist: [0] = count,
@@ -200,11 +211,210 @@ __global__ __launch_bounds__(256) void k_seg_stats_big(const uint32_t *__restric
     }
 }
 
+// ---- small segments: statistics patch by patch, without the global sorts -----------------------------
+// Where the average segment is a few dozen pixels (the C5 workload: 50 M segments of 4 x 8 pixels) nearly
+// every segment lies inside one 32 x 64-pixel patch, and six radix passes over (segment, value) pairs of the
+// WHOLE raster -- 16 B per pixel and pass -- sort what is already together.  Here a workgroup takes a patch:
+// its pixels stay in registers (eight per thread), the distinct labels get slots in an LDS hash table with
+// their pixel counts; a label whose count equals its count in the whole raster (tot[], one histogram pass
+// before) is COMPLETE here: its valid values (at most SPP_MAXRUN) are gathered into one LDS run, sorted by
+// rank, and reduced with the same code as k_seg_stats.  The pixels of every other label --
+// segments that straddle patches or are too long -- are appended to a (segment, value) list that goes through
+// the sorts as before; flagged[] tells the two paths' rows apart.  HBM traffic: the rasters twice (histogram,
+// patches) + the columns, instead of ~100 B per pixel.
+#define SPP_H 32u
+#define SPP_W 64u
+#define SPP_PPT 8u                  // pixels per thread: SPP_H * SPP_W / 256
+#define SPP_SLOTS 1024u
+#define SPP_MAXDIST 704u            // distinct labels a patch may hold before it gives up (load factor 0.69)
+#define SPP_MAXRUN 64u
+#define SPP_EMPTY 0xFFFFFFFFu
+
+// tot[label] = pixels carrying it (labels above S are nobody's), one atomic per run of equal labels per wavefront
+__global__ __launch_bounds__(256) void k_label_hist(const uint32_t *__restrict__ seg, uint32_t n, uint32_t S,
+                                                    uint32_t *tot)
+{
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    const bool inb = p < n;
+    const unsigned lane = lane_id();
+    const uint32_t v = inb ? seg[p] : 0u;
+    const uint32_t pv = __shfl_up(v, 1, 64);
+    const bool head = lane == 0 || pv != v || !inb;
+    const unsigned long long heads = __ballot(head);
+    if (head && inb && v != 0u && v <= S) {
+        const unsigned long long nxt = (lane == 63) ? 0ull : (heads & ~((2ull << lane) - 1ull));
+        const unsigned nl = nxt ? (unsigned)__builtin_ctzll(nxt) : 64u;
+        atomicAdd(&tot[v], nl - lane);
+    }
+}
+
+// every row as for a segment without valid pixels; the paths below overwrite what they compute
+__global__ __launch_bounds__(256) void k_stats_prefill(uint32_t S, long long bias, const uint32_t *__restrict__ sel,
+                                                       int nstats, long long missing, long long *__restrict__ intcols,
+                                                       float *__restrict__ fltcols)
+{
+    const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+    if (s > S) return;
+    const size_t ns = (size_t)S + 1;
+    if (s == 0) {
+        for (int i = 0; i < nstats; i++) {
+            if (sel[i * 5 + 2] == 0) intcols[(size_t)sel[i * 5 + 3] * ns] = 0;
+            else fltcols[(size_t)sel[i * 5 + 3] * ns] = 0.0f;
+        }
+        return;
+    }
+    seg_stats_of_run(s, 0u, nullptr, bias, sel, nstats, missing, intcols, fltcols, ns);
+}
+
+__global__ __launch_bounds__(256) void k_stats_patch(const uint32_t *__restrict__ seg, const void *__restrict__ band,
+                                                     int dtype, uint32_t nrows, uint32_t ncols, uint32_t S,
+                                                     int has_null, long long null_val, long long bias,
+                                                     const uint32_t *__restrict__ tot, const uint32_t *__restrict__ sel,
+                                                     int nstats, long long missing, long long *__restrict__ intcols,
+                                                     float *__restrict__ fltcols, uint8_t *__restrict__ flagged,
+                                                     uint32_t *__restrict__ left_seg, uint32_t *__restrict__ left_val,
+                                                     uint32_t *left_count)
+{
+    __shared__ uint32_t key[SPP_SLOTS], cnt[SPP_SLOTS], offs[SPP_SLOTS], fill[SPP_SLOTS];
+    __shared__ uint32_t runs[SPP_H * SPP_W];
+    __shared__ uint32_t s_ndist, s_left, s_leftbase, s_wsum[4], s_nc;
+    __shared__ uint16_t clist[SPP_SLOTS];       // the complete labels' slots, compacted: consecutive threads take them
+    for (uint32_t i = threadIdx.x; i < SPP_SLOTS; i += 256u) { key[i] = SPP_EMPTY; cnt[i] = 0u; fill[i] = 0u; }
+    if (threadIdx.x == 0) { s_ndist = 0u; s_left = 0u; s_nc = 0u; }
+    __syncthreads();
+    const uint32_t x0 = blockIdx.x * SPP_W, y0 = blockIdx.y * SPP_H;
+    // this thread's pixels: (segment, biased value, slot); the same thread keeps them through every phase
+    uint32_t ps[SPP_PPT], pv[SPP_PPT], pslot[SPP_PPT];
+    bool pvalid[SPP_PPT];
+#pragma unroll
+    for (uint32_t k = 0; k < SPP_PPT; k++) {
+        const uint32_t pl = k * 256u + threadIdx.x;
+        const uint32_t y = y0 + pl / SPP_W, x = x0 + (pl % SPP_W);
+        ps[k] = 0u; pv[k] = 0u; pvalid[k] = false;
+        if (y < nrows && x < ncols) {
+            const size_t p = (size_t)y * ncols + x;
+            const uint32_t sg = seg[p];
+            const long long v = ld_px(band, dtype, p);
+            if (sg != 0u && sg <= S) {
+                ps[k] = sg;
+                pv[k] = (uint32_t)(v - bias);
+                pvalid[k] = !(has_null && v == null_val);
+            }
+        }
+    }
+    // ---- slots and counts (all pixels in the low half, valid ones in the high half) ----
+#pragma unroll
+    for (uint32_t k = 0; k < SPP_PPT; k++) {
+        pslot[k] = SPP_SLOTS;
+        if (ps[k] == 0u) continue;
+        uint32_t h = (ps[k] * 2654435761u) >> 22;
+        for (uint32_t probe = 0; probe < SPP_SLOTS; probe++) {
+            const uint32_t kk = key[h];
+            if (kk == ps[k]) { pslot[k] = h; break; }
+            if (kk == SPP_EMPTY) {
+                const uint32_t old = atomicCAS(&key[h], SPP_EMPTY, ps[k]);
+                if (old == SPP_EMPTY) { atomicAdd(&s_ndist, 1u); pslot[k] = h; break; }
+                if (old == ps[k]) { pslot[k] = h; break; }
+            }
+            h = (h + 1u) & (SPP_SLOTS - 1u);
+        }
+        if (pslot[k] < SPP_SLOTS) atomicAdd(&cnt[pslot[k]], 1u + (pvalid[k] ? 65536u : 0u));
+    }
+    __syncthreads();
+    const bool crowded = s_ndist > SPP_MAXDIST;          // (a pixel may then have found no slot at all)
+    // ---- which labels are complete here; run offsets by a scan of their valid counts ----
+    uint32_t mine[4], msum = 0;
+#pragma unroll
+    for (uint32_t q = 0; q < 4u; q++) {
+        const uint32_t sl = threadIdx.x * 4u + q;
+        const uint32_t kk = key[sl], c = cnt[sl];
+        uint32_t nv = 0;
+        if (kk != SPP_EMPTY) {
+            const bool complete = !crowded && (c & 0xFFFFu) == tot[kk] && (c >> 16) <= SPP_MAXRUN;
+            if (complete) { nv = c >> 16; clist[atomicAdd(&s_nc, 1u)] = (uint16_t)sl; }
+            else flagged[kk] = 1;
+            cnt[sl] = complete ? (c | 0x80000000u) : (c & 0x7FFFFFFFu);      // bit 31: complete
+        }
+        mine[q] = nv;
+        msum += nv;
+    }
+    uint32_t incl = msum;                                  // inclusive scan over the workgroup's 256 threads
+    const unsigned lane = lane_id(), wv = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(incl, d, 64);
+        if ((int)lane >= d) incl += o;
+    }
+    if (lane == 63) s_wsum[wv] = incl;
+    __syncthreads();
+    uint32_t base = incl - msum;
+    for (unsigned w2 = 0; w2 < wv; w2++) base += s_wsum[w2];
+#pragma unroll
+    for (uint32_t q = 0; q < 4u; q++) { offs[threadIdx.x * 4u + q] = base; base += mine[q]; }
+    __syncthreads();
+    // ---- values of complete labels into their runs, the rest into the list ----
+    uint32_t lidx[SPP_PPT], rpos[SPP_PPT];
+#pragma unroll
+    for (uint32_t k = 0; k < SPP_PPT; k++) {
+        lidx[k] = 0xFFFFFFFFu; rpos[k] = 0xFFFFFFFFu;
+        if (ps[k] == 0u || !pvalid[k]) continue;           // (nodata pixels count for completeness only)
+        const uint32_t sl = pslot[k];
+        if (sl < SPP_SLOTS && (cnt[sl] & 0x80000000u)) {
+            rpos[k] = atomicAdd(&fill[sl], 1u);
+            runs[offs[sl] + rpos[k]] = pv[k];
+        } else lidx[k] = atomicAdd(&s_left, 1u);
+    }
+    if (crowded) {                                          // pixels without a slot: their labels are flagged here
+#pragma unroll
+        for (uint32_t k = 0; k < SPP_PPT; k++)
+            if (ps[k] != 0u && pslot[k] >= SPP_SLOTS) flagged[ps[k]] = 1;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && s_left) s_leftbase = atomicAdd(left_count, s_left);
+    __syncthreads();
+#pragma unroll
+    for (uint32_t k = 0; k < SPP_PPT; k++)
+        if (lidx[k] != 0xFFFFFFFFu) { left_seg[s_leftbase + lidx[k]] = ps[k]; left_val[s_leftbase + lidx[k]] = pv[k]; }
+    // ---- the runs sorted by RANK: every pixel counts the values of its run that come before it (smaller, or equal
+    //      and stored earlier) -- all threads busy on independent LDS reads, where a thread per run doing an
+    //      insertion sort was a chain of dependent LDS round trips on a quarter of the lanes ----
+    uint32_t rank[SPP_PPT];
+#pragma unroll
+    for (uint32_t k = 0; k < SPP_PPT; k++) {
+        rank[k] = 0u;
+        if (rpos[k] == 0xFFFFFFFFu) continue;
+        const uint32_t sl = pslot[k];
+        const uint32_t n = (cnt[sl] >> 16) & 0x7FFFu, o = offs[sl];
+        const uint32_t v = pv[k];
+        uint32_t r = 0;
+        for (uint32_t j = 0; j < n; j++) {
+            const uint32_t w = runs[o + j];
+            r += (w < v || (w == v && j < rpos[k])) ? 1u : 0u;
+        }
+        rank[k] = r;
+    }
+    __syncthreads();
+#pragma unroll
+    for (uint32_t k = 0; k < SPP_PPT; k++)
+        if (rpos[k] != 0xFFFFFFFFu) runs[offs[pslot[k]] + rank[k]] = pv[k];
+    __syncthreads();
+    // ---- a thread per complete label -- consecutive threads take consecutive entries of the compacted list, so
+    //      that a wavefront's lanes all work (a thread per SLOT left 4 lanes in 64 busy, four times over) ----
+    const size_t ns = (size_t)S + 1;
+    for (uint32_t ci = threadIdx.x; ci < s_nc; ci += 256u) {
+        const uint32_t sl = clist[ci];
+        const uint32_t n = (cnt[sl] >> 16) & 0x7FFFu;
+        seg_stats_of_run(key[sl], n, &runs[offs[sl]], bias, sel, nstats, missing, intcols, fltcols, ns);
+    }
+}
+
 // d_seg / d_band: device rasters of n pixels.  Outputs are HOST arrays.
+// nrows x ncols = n when the caller knows the raster's shape (0, 0 otherwise): with small segments the
+// statistics are then computed patch by patch (k_stats_patch) and only what is left over is sorted.
 static int run_segstats(shp_ctx *ctx, const uint32_t *d_seg, const void *d_band, int dtype,
                         uint32_t n, uint32_t S, int has_null, int64_t null_val,
                         const uint32_t *sel_host, int nstats, int64_t missing,
-                        int64_t *intcols_out, float *fltcols_out)
+                        int64_t *intcols_out, float *fltcols_out, uint32_t nrows = 0, uint32_t ncols = 0)
 {
     hipStream_t st = ctx->stream;
     const size_t ns = (size_t)S + 1;
@@ -240,10 +450,42 @@ static int run_segstats(shp_ctx *ctx, const uint32_t *d_seg, const void *d_band,
     memcpy(pin, sel_host, (size_t)nstats * 20);
     HIPCHK(ctx, hipMemcpyAsync(d_sel, pin, (size_t)nstats * 20, hipMemcpyHostToDevice, st));
     const int ps = prof_begin(ctx, PROF_SEGSTATS);      // device time of the kernels (keys .. statistics)
-    if (n) {
+    // (SHEPSEG_STATS_PATCH=0: never; =1: whenever the shape is known; default: when the average segment has
+    //  at most SPP_MAXRUN pixels)
+    const int patch_env = getenv("SHEPSEG_STATS_PATCH") ? atoi(getenv("SHEPSEG_STATS_PATCH")) : -1;
+    const bool patches = n && nrows && ncols && (uint64_t)nrows * ncols == n && patch_env != 0 &&
+                         (patch_env == 1 || (uint64_t)n <= (uint64_t)SPP_MAXRUN * ((uint64_t)S + 1));
+    const uint8_t *only = nullptr;
+    uint32_t nsort = n;                                   // pairs that go through the sorts
+    if (patches) {
+        CHK(buf_ensure(ctx, ctx->tcount, (ns + 1) * 4));
+        CHK(buf_ensure(ctx, ctx->mergeto, ns + 64));
+        uint32_t *tot = bp<uint32_t>(ctx->tcount);
+        uint8_t *flagged = bp<uint8_t>(ctx->mergeto);
+        uint32_t *d_left = bp<uint32_t>(ctx->small);      // (word 0; the selection sits behind word 256)
+        HIPCHK(ctx, hipMemsetAsync(tot, 0, ns * 4, st));
+        HIPCHK(ctx, hipMemsetAsync(flagged, 0, ns, st));
+        HIPCHK(ctx, hipMemsetAsync(d_left, 0, 4, st));
+        hipLaunchKernelGGL(k_label_hist, dim3(grid_for(n, 256)), dim3(256), 0, st, d_seg, n, S, tot); KCHK(ctx);
+        hipLaunchKernelGGL(k_stats_prefill, dim3(grid_for(ns, 256)), dim3(256), 0, st, S, bias, d_sel, nstats,
+                           (long long)missing, d_int, d_flt); KCHK(ctx);
+        hipLaunchKernelGGL(k_stats_patch, dim3(grid_for(ncols, SPP_W), grid_for(nrows, SPP_H)), dim3(256), 0, st,
+                           d_seg, d_band, dtype, nrows, ncols, S, has_null, (long long)null_val, bias, tot, d_sel,
+                           nstats, (long long)missing, d_int, d_flt, flagged, kseg, kval, d_left); KCHK(ctx);
+        CHK(read_u32(ctx, d_left, &nsort));
+        only = flagged;
+    } else if (n) {
         hipLaunchKernelGGL(k_stats_keys, dim3(grid_for(n, 256)), dim3(256), 0, st, d_seg, d_band, dtype, n,
                            S, has_null, (long long)null_val, bias, kseg, kval); KCHK(ctx);
     }
+    if (patches && nsort == 0) {                          // every segment was complete in its patch
+        prof_end(ctx, ps);
+        if (nint) HIPCHK(ctx, hipMemcpyAsync(intcols_out, d_int, (size_t)nint * ns * 8, hipMemcpyDeviceToHost, st));
+        if (nflt) HIPCHK(ctx, hipMemcpyAsync(fltcols_out, d_flt, (size_t)nflt * ns * 4, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        return 0;
+    }
+    n = nsort;
     // sort by value (payload: segment key), then stably by segment key (payload: value)
     uint32_t *k1 = nullptr, *v1 = nullptr, *k2 = nullptr, *v2 = nullptr;
     CHK(sort_pairs(ctx, kval, kseg, n, valbits, &k1, &v1, true));            // k1 = values, v1 = seg keys
@@ -272,9 +514,9 @@ static int run_segstats(shp_ctx *ctx, const uint32_t *d_seg, const void *d_band,
     uint32_t *biglist = kval;
     HIPCHK(ctx, hipMemsetAsync(biglist, 0, 4, st));
     hipLaunchKernelGGL(k_seg_stats, dim3(grid_for(ns, 256)), dim3(256), 0, st, v2, off, cnt, S, bias, d_sel,
-                       nstats, (long long)missing, d_int, d_flt, biglist); KCHK(ctx);
+                       nstats, (long long)missing, d_int, d_flt, biglist, only); KCHK(ctx);
     hipLaunchKernelGGL(k_seg_stats_big, dim3(512), dim3(256), 0, st, v2, off, cnt, S, bias, d_sel, nstats,
-                       (long long)missing, d_int, d_flt, biglist); KCHK(ctx);
+                       (long long)missing, d_int, d_flt, biglist); KCHK(ctx);      // (only flagged ones got onto the list)
     prof_end(ctx, ps);
     if (nint) HIPCHK(ctx, hipMemcpyAsync(intcols_out, d_int, (size_t)nint * ns * 8, hipMemcpyDeviceToHost, st));
     if (nflt) HIPCHK(ctx, hipMemcpyAsync(fltcols_out, d_flt, (size_t)nflt * ns * 4, hipMemcpyDeviceToHost, st));

@@ -336,8 +336,10 @@ def _streamStats(src, segSize, statsSelection_fast, numIntCols, numFloatCols, im
                 continue
             ic = numpy.zeros((max(numIntCols, 1), m + 1), dtype=numpy.int64)
             fc = numpy.zeros((max(numFloatCols, 1), m + 1), dtype=numpy.float32)
-            c.check(L.shp_segstats_dev(c.handle, drec, dband, dt, n, m, nullFlag, nullV, _lib.ptr(fast),
-                                       nstats, int(missingStatsValue), _lib.ptr(ic), _lib.ptr(fc)))
+            # (the block's shape goes along: with small segments the library works patch by patch)
+            c.check(L.shp_segstats2d_dev(c.handle, drec, dband, dt, y1 - y0, ncols, m, nullFlag, nullV,
+                                         _lib.ptr(fast), nstats, int(missingStatsValue), _lib.ptr(ic),
+                                         _lib.ptr(fc)))
         with timings.interval('statscompletion'):
             ids = orig[1:m + 1].astype(numpy.int64)
             done = lhist[1:m + 1] == segSize[ids]

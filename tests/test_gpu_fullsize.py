@@ -245,6 +245,13 @@ def test_c5_stats_fullsize(oracle):
         wi, wf = oracle.segstats((compact.reshape(lab.shape) + 1).astype(np.uint32), band, sel)
         assert np.array_equal(ic[:, ids], wi[:, 1:])
         assert np.array_equal(fc[:, ids].view(np.uint32), wf[:, 1:].view(np.uint32))
+        # the same raster with its shape given: segments of 32 pixels take the patch-by-patch path (no global
+        # sort at all on this raster); every column must come out the same, bit for bit
+        ic2 = np.zeros_like(ic)
+        fc2 = np.zeros_like(fc)
+        c.check(c._L.shp_segstats2d_dev(c.handle, d_seg, ctypes.c_void_p(ras.ptr), 2, N, N, S, 0, 0,
+                                        _lib.ptr(fast), len(sel), -9999, _lib.ptr(ic2), _lib.ptr(fc2)))
+        assert np.array_equal(ic2, ic) and np.array_equal(fc2.view(np.uint32), fc.view(np.uint32))
     finally:
         c.check(c._L.shp_dev_free(c.handle, d_seg))
         ras.free()

@@ -228,3 +228,36 @@ def test_stats_giant_segment_vs_oracle(oracle):
         wic, wfc = oracle.segstats(seg, band, sel, null, -9999, max_seg_id=S)
         assert np.array_equal(ic, wic)
         assert np.array_equal(fc.view(np.uint32), wfc.view(np.uint32))
+
+
+@pytest.mark.parametrize('mode', ['blocks', 'ragged', 'crowded'])
+def test_stats_patch_path_equals_sort_path(mode, oracle, monkeypatch):
+    """small segments: the patch-by-patch path (segstats.h k_stats_patch) against the sort path and the oracle --
+    aligned 4 x 8 blocks (every segment complete in its patch), ragged segments that straddle patches and hold
+    nodata pixels (the leftovers go through the sorts), and a patch with more distinct labels than its table takes"""
+    from pyshepseg_amd import tilingstats
+    rng = np.random.RandomState(5)
+    (nr, nc) = (203, 331)
+    if mode == 'blocks':
+        seg = ((np.arange(nr)[:, None] // 4) * ((nc + 7) // 8) + np.arange(nc)[None, :] // 8 + 1).astype(np.uint32)
+    elif mode == 'ragged':
+        seg = ((np.arange(nr)[:, None] // 5) * 100 + np.arange(nc)[None, :] // 7 + 1).astype(np.uint32)
+        seg[40:90, 100:260] = 7                     # a segment far too long for a thread's sort
+        seg[:3] = 0
+    else:
+        seg = (np.arange(nr * nc, dtype=np.uint32).reshape(nr, nc) // 2 + 1).astype(np.uint32)      # 2-pixel segments
+    band = oracle.synthimg(19, 1, nr, nc)[0].copy()
+    band[rng.rand(nr, nc) < 0.05] = 0
+    sel = [('mn', 'min'), ('mx', 'max'), ('mean', 'mean'), ('sd', 'stddev'), ('med', 'median'),
+           ('mode', 'mode'), ('p25', 'percentile', 25), ('n', 'pixcount')]
+    ic, fc = oracle.segstats(seg, band, sel, null_val=0)
+    got = {}
+    for flag in ('1', '0'):
+        monkeypatch.setenv('SHEPSEG_STATS_PATCH', flag)
+        r = tilingstats.calcPerSegmentStatsTiled(band, 1, seg, sel, imgNullVal=0)
+        got[flag] = r
+    for r in got.values():
+        for i, name in enumerate(['mn', 'mx', 'med', 'mode', 'p25', 'n']):
+            assert np.array_equal(r.columns[name], ic[i]), (mode, name)
+        assert np.array_equal(r.columns['mean'].view(np.uint32), fc[0].view(np.uint32)), mode
+        assert np.array_equal(r.columns['sd'].view(np.uint32), fc[1].view(np.uint32)), mode
