@@ -28,7 +28,7 @@ walk)       # the replay walker: clump parity tests, then per-component statisti
       [ "${spec#SHEPSEG_LIBPATH}" != "$spec" ] && [ ! -f "${spec#SHEPSEG_LIBPATH=}" ] && continue
       echo "== $spec"
       env $spec SHEPSEG_DFS_STATS=1 timeout -k 10 120 python tools/perf_tile.py ${1:-4096} > gpurun_out/walk.log 2>&1 || { tail -5 gpurun_out/walk.log; exit 1; }
-      grep -A12 "^dfs:" gpurun_out/walk.log | tail -13 | grep -v "^  rank [2-9]\|^  rank 1[0-9]"; grep "^rep 2" gpurun_out/walk.log
+      grep -A16 "^dfs:" gpurun_out/walk.log | tail -17 | grep -v "^  rank [2-9]\|^  rank 1[0-9]"; grep "^rep 2" gpurun_out/walk.log
     done ;;
 small)      # the pass loop: elimination parity tests, then its per-pass timing on one tile
     timeout -k 10 400 python -m pytest tests/test_gpu_tile.py tests/test_gpu_tiling.py -x -q -m gpu > gpurun_out/small_tests.log 2>&1 || { tail -30 gpurun_out/small_tests.log; exit 1; }
