@@ -500,69 +500,214 @@ __global__ __launch_bounds__(64) void k_fit_sum_lists(const double *__restrict__
     S[(size_t)j * nb + b] = acc;
 }
 
-// The same for nb <= 64 with the rows staged through LDS: a workgroup per cluster gathers the next
-// B = FIT_STAGE_DOUBLES / nb rows of its list with all 256 threads (row numbers first, then the values,
-// all loads unconditional and in flight together; the loads of block i + 1 are issued before block i is
-// summed), laid out band-major in LDS (band b's values of consecutive rows are adjacent), then one lane
-// per band adds them in order, two rows per 128-bit LDS read.  What remains is the chain of dependent
-// additions of the largest cluster.
-#define FIT_STAGE_DOUBLES 6144u       // 48 KiB
-#define FIT_STAGE_PER_THREAD (FIT_STAGE_DOUBLES / 256u)
-__global__ __launch_bounds__(256) void k_fit_sum_lists_staged(const double *__restrict__ X, int nb,
+// The row-order sums as a chain of v_mfma_f64_4x4x4_4b_f64.  With B = 1.0 in every lane the instruction
+// computes, for each of 16 (block, row) pairs m, D = (((C + A[m][0]) + A[m][1]) + A[m][2]) + A[m][3]: four
+// IEEE float64 additions one after the other in ascending k, bit for bit what four `acc += x` statements
+// give (tools/ubench/mfma_f64_order.hip checks exactly that on the hardware: one-hot inputs for the lane
+// map, 200 000 random trials x 64 lanes with 60 binades of spread and near-cancellations against every
+// permutation of the four; a x 1.0 is exact and a fused multiply-add of an exact product is an addition).
+// A[m][k] is lane m + 16 k; the result for m appears in lanes 16 (m & 3) + 4 (m >> 2) + {0..3}, which is
+// also where C is read, so the accumulator stays put.  A dependent chain of these takes 20.4 cycles per
+// instruction = 5.1 cycles per row for 16 chains at once; the VALU form costs 5.5 for the dependent
+// v_add_f64 PLUS 8.8 for the half ds_read_b128 that feeds it (a lone wavefront pays ~4.4 issue cycles per
+// dword an LDS read returns, whatever the number of active lanes): 14.3.  Here one ds_read_b64 feeds four
+// rows and issues in the shadow of the previous instruction.  Padding rows are -0.0: x + -0.0 == x for
+// every x, -0.0 and +0.0 included.
+__device__ __forceinline__ double fit_mfma4(double a, double acc)
+{
+    return __builtin_amdgcn_mfma_f64_4x4x4f64(a, 1.0, acc, 0, 0, 0);
+}
+// 32 n rows (n >= 1) of the 16 chains of one wavefront: lane m + 16 k reads p_m[4 i + k] at LDS byte address
+// `addr` + 32 i.  Two register sets of eight operands, v[64:79] and v[80:95]; the reads of one are issued
+// between the instructions that consume the other, eight instructions (~160 cycles) ahead of their use, and
+// LDS reads return in order, so "at most seven reads outstanding" is the wait of every instruction.  A
+// dependent v_mfma_f64_4x4x4 needs four wait states behind its producer (hipcc puts s_nop 3 there): the
+// read, the wait and an s_nop 1 stand in them.
+#define FCM_RD(r, off) "ds_read_b64 v[" #r ":" #r "+1], %[a] offset:" #off "\n"
+#define FCM_MF(r) "s_waitcnt lgkmcnt(7)\n v_mfma_f64_4x4x4_4b_f64 %[acc], v[" #r ":" #r "+1], %[one], %[acc]\n"
+#define FCM_MF_LAST(r) "v_mfma_f64_4x4x4_4b_f64 %[acc], v[" #r ":" #r "+1], %[one], %[acc]\n s_nop 3\n"
+#define FCM_STEP(x, y, o) FCM_MF(x) FCM_RD(y, o) "s_nop 1\n"
+#define FCM_HALF(x0, y0, o)                                                                                   \
+    FCM_STEP(x0, y0, o) FCM_STEP(x0 + 2, y0 + 2, o + 32) FCM_STEP(x0 + 4, y0 + 4, o + 64)                      \
+    FCM_STEP(x0 + 6, y0 + 6, o + 96) FCM_STEP(x0 + 8, y0 + 8, o + 128) FCM_STEP(x0 + 10, y0 + 10, o + 160)     \
+    FCM_STEP(x0 + 12, y0 + 12, o + 192) FCM_STEP(x0 + 14, y0 + 14, o + 224)
+#define FCM_TAIL(x0)                                                                                          \
+    FCM_MF_LAST(x0) FCM_MF_LAST(x0 + 2) FCM_MF_LAST(x0 + 4) FCM_MF_LAST(x0 + 6) FCM_MF_LAST(x0 + 8)              \
+    FCM_MF_LAST(x0 + 10) FCM_MF_LAST(x0 + 12) FCM_MF_LAST(x0 + 14)
+__device__ __forceinline__ double fit_chain_mfma32(double acc, uint32_t addr, uint32_t n)
+{
+    uint32_t left = (uint32_t)__builtin_amdgcn_readfirstlane((int)n);
+    const double one = 1.0;
+    asm volatile(
+        FCM_RD(64, 0) FCM_RD(66, 32) FCM_RD(68, 64) FCM_RD(70, 96) FCM_RD(72, 128) FCM_RD(74, 160) FCM_RD(76, 192)
+        FCM_RD(78, 224)
+        "s_sub_u32 %[n], %[n], 1\n"
+        "s_cmp_eq_u32 %[n], 0\n"
+        "s_cbranch_scc1 2f\n"
+        "1:\n"
+        FCM_HALF(64, 80, 256)
+        "s_sub_u32 %[n], %[n], 1\n"
+        "s_cmp_eq_u32 %[n], 0\n"
+        "s_cbranch_scc1 3f\n"
+        "v_add_u32 %[a], 0x200, %[a]\n"
+        FCM_HALF(80, 64, 0)
+        "s_sub_u32 %[n], %[n], 1\n"
+        "s_cmp_eq_u32 %[n], 0\n"
+        "s_cbranch_scc0 1b\n"
+        "2:\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        FCM_TAIL(64)
+        "s_branch 4f\n"
+        "3:\n"
+        "s_waitcnt lgkmcnt(0)\n"
+        FCM_TAIL(80)
+        "4:\n"
+        "s_nop 7\n"                                  // (the result is next read by code hipcc does not see behind)
+        : [acc] "+v"(acc), [a] "+v"(addr), [n] "+s"(left)
+        : [one] "v"(one)
+        : "scc", "memory", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76",
+          "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91",
+          "v92", "v93", "v94", "v95");
+    return acc;
+}
+
+// The same for nb <= 64 with the rows staged through LDS, a workgroup per cluster.  The time of this kernel
+// is the chain of dependent additions of the largest cluster, PROVIDED the adding wavefront never waits for
+// memory: wave 0 only adds (fit_chain_mfma32: 16 bands' chains per instruction, ceil(nb / 16) accumulators),
+// waves 1..7 only gather.  A block is B rows; while block s is summed from one LDS buffer, the gatherers
+// store block s + 1 (loaded a step ago) into the other, issue the value loads of block s + 2 and the
+// row-number loads of block s + 3, so every global load has a whole step to arrive.  On the benchmark sample
+// (1 032 256 rows, 60 clusters of ~17 200): 190 us in round 2 (all threads gathered AND wave 0 added, two
+// dependent round trips per block plus the chain), 129 us with the gatherers split off (the VALU chain:
+// 14.4 cycles per row measured), 81 us with the MFMA chain (6.6 cycles per row).
+#define FIT_STAGE_DOUBLES 6144u       // 48 KiB per buffer, two buffers
+#ifdef FIT_SUM_DIAG
+__device__ unsigned long long g_fit_diag[256 * 4];      // tools/ubench/sumlists.hip: cycles adding / at barriers
+#endif
+#define FIT_SUM_THREADS 512u
+#define FIT_GATHERERS (FIT_SUM_THREADS - 64u)
+#define FIT_STAGE_PER_THREAD ((FIT_STAGE_DOUBLES + FIT_GATHERERS - 1u) / FIT_GATHERERS)
+__global__ __launch_bounds__(FIT_SUM_THREADS) void k_fit_sum_lists_staged(const double *__restrict__ X, int nb,
                                                              const uint32_t *__restrict__ rows,
                                                              const uint32_t *__restrict__ off,
                                                              double *__restrict__ S, double *__restrict__ cnt,
                                                              const uint32_t *stop)
 {
     if (stop && *stop) return;
-    __shared__ __attribute__((aligned(16))) double sx[FIT_STAGE_DOUBLES + 2u * 64u];
+    constexpr uint32_t BUF = FIT_STAGE_DOUBLES + 4u * 64u;        // nb runs of B + 4 doubles, nb <= 64
+    __shared__ __attribute__((aligned(16))) double sx[2u * BUF];
     const int j = blockIdx.x;
     const uint32_t q0 = off[j], q1 = off[j + 1];
     const uint32_t unb = (uint32_t)nb;
-    const uint32_t B = (FIT_STAGE_DOUBLES / unb) & ~1u;          // rows per block (even: 16-byte reads)
-    const uint32_t pitch = B + 2u;                               // doubles between two bands' runs
+    const uint32_t B = (FIT_STAGE_DOUBLES / unb) & ~31u;         // rows per block (whole 32-row groups of the chain)
+    const uint32_t pitch = B + 4u;                               // doubles between two bands' runs: bands 8 banks apart
+    const uint32_t nblk = (q1 - q0 + B - 1u) / B;
     if (threadIdx.x == 0) cnt[j] = (double)(q1 - q0);
-    double v[FIT_STAGE_PER_THREAD];
-    // element e = threadIdx.x + 256 u of a block is band eb[u] of its row er[u] (the same in every block);
-    // rows past the end of the list are clamped to its last one
-    uint32_t er[FIT_STAGE_PER_THREAD], eb[FIT_STAGE_PER_THREAD];
-#pragma unroll
-    for (uint32_t u = 0; u < FIT_STAGE_PER_THREAD; u++) {
-        const uint32_t e = threadIdx.x + u * 256u;
-        er[u] = e / unb; eb[u] = e - er[u] * unb;
+    if (nblk == 0u) {
+        if (threadIdx.x < unb) S[(size_t)j * unb + threadIdx.x] = 0.0;
+        return;
     }
-    auto gather = [&](uint32_t q) {
-        const uint32_t last = ((q1 - q < B) ? (q1 - q) : B) - 1u;
-        uint32_t idx[FIT_STAGE_PER_THREAD];
-#pragma unroll
-        for (uint32_t u = 0; u < FIT_STAGE_PER_THREAD; u++) idx[u] = rows[q + (er[u] < last ? er[u] : last)];
-#pragma unroll
-        for (uint32_t u = 0; u < FIT_STAGE_PER_THREAD; u++) v[u] = X[(size_t)idx[u] * unb + eb[u]];
-    };
-    double acc = 0.0;
-    if (q0 < q1) gather(q0);
-    for (uint32_t q = q0; q < q1; q += B) {
-        const uint32_t nrows = (q1 - q < B) ? (q1 - q) : B;
-#pragma unroll
-        for (uint32_t u = 0; u < FIT_STAGE_PER_THREAD; u++)
-            if (er[u] < nrows) sx[eb[u] * pitch + er[u]] = v[u];
-        __syncthreads();
-        if (q + B < q1) gather(q + B);
-        if (threadIdx.x < unb) {
-            const double *p = sx + threadIdx.x * pitch;
-            uint32_t r = 0;
-            for (; r + 16u <= nrows; r += 16u) {
-                double2 t[8];
-#pragma unroll
-                for (int u = 0; u < 8; u++) t[u] = *(const double2 *)(p + r + 2u * (uint32_t)u);
-#pragma unroll
-                for (int u = 0; u < 8; u++) { acc += t[u].x; acc += t[u].y; }
-            }
-            for (; r < nrows; r++) acc += p[r];
+    static_assert(FIT_STAGE_DOUBLES / 64u >= 32u, "a block holds at least one 32-row group of 64 bands");
+    if (threadIdx.x >= 64u) {
+        // ---- gatherers.  Element e = g + FIT_GATHERERS u of a block is band eb[u] of its row er[u] (the same in
+        //      every block); rows past the end of the list are clamped to its last one ----
+        const uint32_t g = threadIdx.x - 64u;
+        uint32_t er[FIT_STAGE_PER_THREAD], eb[FIT_STAGE_PER_THREAD];
+        uint32_t ia[FIT_STAGE_PER_THREAD], ib[FIT_STAGE_PER_THREAD];      // row numbers: two register sets that
+        double va[FIT_STAGE_PER_THREAD], vb[FIT_STAGE_PER_THREAD];       // swap roles every step (no copies:
+#pragma unroll                                                           // a copy would wait for its loads)
+        for (uint32_t u = 0; u < FIT_STAGE_PER_THREAD; u++) {
+            uint32_t e = g + u * FIT_GATHERERS;
+            if (e >= B * unb) e = B * unb - 1u;              // (stored twice with the same value)
+            er[u] = e / unb; eb[u] = e - er[u] * unb;
         }
+        auto load_idx = [&](uint32_t blk, uint32_t *idx) {
+            if (blk >= nblk) return;
+            const uint32_t q = q0 + blk * B;
+            const uint32_t last = ((q1 - q < B) ? (q1 - q) : B) - 1u;
+#pragma unroll
+            for (uint32_t u = 0; u < FIT_STAGE_PER_THREAD; u++) idx[u] = rows[q + (er[u] < last ? er[u] : last)];
+        };
+        auto load_x = [&](uint32_t blk, const uint32_t *idx, double *v) {
+            if (blk >= nblk) return;
+#pragma unroll
+            for (uint32_t u = 0; u < FIT_STAGE_PER_THREAD; u++) v[u] = X[(size_t)idx[u] * unb + eb[u]];
+        };
+        auto store = [&](uint32_t blk, const double *v) {
+            if (blk >= nblk) return;
+            double *dst = sx + (blk & 1u) * BUF;
+#pragma unroll
+            for (uint32_t u = 0; u < FIT_STAGE_PER_THREAD; u++) dst[eb[u] * pitch + er[u]] = v[u];
+        };
+        // block b's row numbers live in (b even ? ia : ib), its values in (b even ? va : vb).  (Loading the
+        // values three blocks ahead instead of two changed nothing: once the E-step has swept the caches the
+        // gatherers are bound by how fast ONE compute unit pulls 1 300 scattered lines per block, ~4.5 us
+        // against 2.9 us of chain; the kernel takes 56 us with the sample in cache and 74 us behind a 1 GB write.)
+        load_idx(0, ia); load_idx(1, ib);
+        load_x(0, ia, va); load_x(1, ib, vb);
+        load_idx(2, ia);
+        store(0, va);
         __syncthreads();
+        for (uint32_t s = 0; s < nblk; s += 2u) {
+            load_x(s + 2u, ia, va);
+            load_idx(s + 3u, ib);
+            store(s + 1u, vb);
+            __syncthreads();
+            if (s + 1u >= nblk) break;
+            load_x(s + 3u, ib, vb);
+            load_idx(s + 4u, ia);
+            store(s + 2u, va);
+            __syncthreads();
+        }
+    } else {
+        // ---- the adding wavefront ----
+#ifdef FIT_SUM_DIAG
+        unsigned long long tc = 0, tb = 0, t0 = __builtin_readcyclecounter();
+#define FIT_DIAG_MARK(acc_t) { const unsigned long long t1 = __builtin_readcyclecounter(); acc_t += t1 - t0; t0 = t1; }
+#else
+#define FIT_DIAG_MARK(acc_t)
+#endif
+        // lane l feeds chain m = l & 15 (band m + 16 c of accumulator c) with row 4 i + (l >> 4) of step i
+        const uint32_t m = threadIdx.x & 15u, kk = threadIdx.x >> 4;
+        const uint32_t nch = (unb + 15u) / 16u;
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+        uint32_t boff[4];                                    // chains past nb shadow band 0 (results unused)
+#pragma unroll
+        for (uint32_t c = 0; c < 4u; c++) boff[c] = ((m + 16u * c < unb) ? (m + 16u * c) : 0u) * pitch + kk;
+        __syncthreads();
+        FIT_DIAG_MARK(tb)
+        for (uint32_t s = 0; s < nblk; s++) {
+            const uint32_t q = q0 + s * B;
+            const uint32_t nrows = (q1 - q < B) ? (q1 - q) : B;
+            const double *buf = sx + (s & 1u) * BUF;
+#pragma unroll
+            for (uint32_t c = 0; c < 4u; c++) {
+                if (c >= nch) break;
+                const double *p = buf + boff[c];
+                uint32_t r = 0;
+                if (nrows >= 32u) {
+                    acc[c] = fit_chain_mfma32(acc[c], (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const double *)p,
+                                              nrows / 32u);
+                    r = nrows & ~31u;
+                }
+                for (; r + 4u <= nrows; r += 4u) acc[c] = fit_mfma4(p[r], acc[c]);
+                if (r < nrows) acc[c] = fit_mfma4(r + kk < nrows ? p[r] : -0.0, acc[c]);
+            }
+            FIT_DIAG_MARK(tc)
+            __syncthreads();
+            FIT_DIAG_MARK(tb)
+        }
+#ifdef FIT_SUM_DIAG
+        if (threadIdx.x == 0) { g_fit_diag[j * 4] = tc; g_fit_diag[j * 4 + 1] = tb; g_fit_diag[j * 4 + 2] = nblk; g_fit_diag[j * 4 + 3] = q1 - q0; }
+#endif
+        // chain m's sum stands in lanes 16 (m & 3) + 4 (m >> 2) + {0..3}
+        if ((threadIdx.x & 3u) == 0u) {
+            const uint32_t mo = (threadIdx.x >> 4) + 4u * ((threadIdx.x >> 2) & 3u);
+#pragma unroll
+            for (uint32_t c = 0; c < 4u; c++)
+                if (mo + 16u * c < unb) S[(size_t)j * unb + mo + 16u * c] = acc[c];
+        }
     }
-    if (threadIdx.x < unb) S[(size_t)j * unb + threadIdx.x] = acc;
 }
 
 // loop control of the Elkan iterations, owned by the device between host synchronisations
@@ -732,7 +877,7 @@ static int run_fit_elkan(shp_ctx *ctx, const double *dX, XAt Xat, uint32_t n, in
             hipLaunchKernelGGL(k_elk_offsets, dim3(grid_for((size_t)k + 1, 256)), dim3(256), 0, st, ks, n, k, doff,
                                &dctl->nd[(it + 1) & 1], dstop); KCHK(ctx);
             if (nb <= 64)
-                hipLaunchKernelGGL(k_fit_sum_lists_staged, dim3(k), dim3(256), 0, st, dX, nb, rows, doff, dS, dcnt, dstop);
+                hipLaunchKernelGGL(k_fit_sum_lists_staged, dim3(k), dim3(FIT_SUM_THREADS), 0, st, dX, nb, rows, doff, dS, dcnt, dstop);
             else
                 hipLaunchKernelGGL(k_fit_sum_lists, dim3(k, (nb + 63) / 64), dim3(64), 0, st, dX, nb, rows, doff, dS, dcnt,
                                    dstop);

@@ -730,7 +730,7 @@ static int run_kmeans_fit(shp_ctx *ctx, const void *xin_any, int xdtype, int64_t
                 hipLaunchKernelGGL(k_elk_offsets, dim3(grid_for((size_t)k + 1, 256)), dim3(256), 0, st, ks, n, k, doff,
                                    doff + k + 1, &dctl->stop); KCHK(ctx);
                 if (nb <= 64)
-                    hipLaunchKernelGGL(k_fit_sum_lists_staged, dim3(k), dim3(256), 0, st, dX, nb, rows, doff, dpart2,
+                    hipLaunchKernelGGL(k_fit_sum_lists_staged, dim3(k), dim3(FIT_SUM_THREADS), 0, st, dX, nb, rows, doff, dpart2,
                                        dcntd, &dctl->stop);
                 else
                     hipLaunchKernelGGL(k_fit_sum_lists, dim3(k, (nb + 63) / 64), dim3(64), 0, st, dX, nb, rows, doff,

@@ -140,6 +140,8 @@ def more_case(rng, kind, tmpdir):
     dtype = DTYPES[int(rng.integers(0, len(DTYPES)))]
     if kind == 'fit':
         nb = int(rng.integers(1, 11))
+        if rng.random() < 0.15:                  # more than 16 bands: several accumulators in the M-step's chain
+            nb = int(rng.integers(11, 70))
         n = int(rng.integers(50, 40000))
         k = int(rng.integers(2, 61))
         img = make_image(rng, dtype, nb, 1, n).reshape(nb, n).T.astype(np.float64)

@@ -295,6 +295,24 @@ def test_kmeans_fit_vs_oracle_shapes(k, n, shepseg, oracle):
     assert np.array_equal(km.labels_, want_l)
 
 
+@pytest.mark.parametrize('nb,n', [(17, 4000), (33, 2500), (64, 3000), (70, 1500)])
+def test_kmeans_fit_many_bands(nb, n, shepseg, oracle):
+    """The M-step's row-order sums run as chains of v_mfma_f64_4x4x4 (16 bands per accumulator): more than
+    16 bands take two to four accumulators, 64 bands fill the LDS staging buffer to its last run, more than
+    64 take the unstaged kernel.  Real-valued rows (no exact ties), the reference's algorithm bit for bit."""
+    rng = np.random.RandomState(nb)
+    k = 9
+    cent = rng.randint(500, 60000, size=(k, nb))
+    xs = cent[rng.randint(0, k, size=n)] + rng.randint(-300, 300, size=(n, nb)) + rng.random_sample((n, nb))
+    xs = np.ascontiguousarray(xs, dtype=np.float64)
+    init = shepseg.diagonalClusterCentres(xs, k).astype(np.float64)
+    want_c, want_l, want_n = oracle.kmeans_fit(xs, init, algorithm='elkan')
+    km = shepseg._fit(xs, init)
+    assert km.n_iter_ == want_n
+    assert np.array_equal(km.cluster_centers_.view(np.uint64), want_c.view(np.uint64))
+    assert np.array_equal(km.labels_, want_l)
+
+
 @pytest.mark.parametrize('four', [True, False])
 def test_cut_components_both_connectivities(four, shepseg, oracle):
     """Components far above the 10001-pixel cap, 4- and 8-connected: a few large smooth blobs with

@@ -66,8 +66,11 @@ np.save('gpurun_out/%s_centres_device.npy' % name, km.cluster_centers_)
 PY
     ;;
 ubench)     # micro-benchmarks of instruction issue / branch cost / float64 chains for a lone wavefront
-    for b in issue branch f64chain; do
+    for b in ${@:-issue branch f64chain mfma_f64_order}; do
       /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -o /tmp/ub_$b tools/ubench/$b.hip 2>/dev/null && timeout -k 5 60 /tmp/ub_$b
     done ;;
-*) echo "tasks: tests bench sweep walk small fit tiletrace two-ranks dump-sample ubench (and tools/refresh_profiles.sh TAG)"; exit 2 ;;
+sumlists)   # the M-step's row-order sums alone, with the adding wavefront's cycle split (tools/ubench/sumlists.hip)
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math -w -I pyshepseg_amd/csrc -o /tmp/ub_sumlists tools/ubench/sumlists.hip &&
+    timeout -k 5 120 /tmp/ub_sumlists ;;
+*) echo "tasks: tests bench sweep walk small fit tiletrace two-ranks dump-sample ubench sumlists (and tools/refresh_profiles.sh TAG)"; exit 2 ;;
 esac
