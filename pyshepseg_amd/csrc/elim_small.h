@@ -386,6 +386,7 @@ struct SmallCtl {
     uint32_t plog[64][4];           // per pass: target, sources, find ticks, merge-phase ticks
     uint32_t phops[64];             // per pass: chunk-chain hops of the find phase (diagnostic)
     uint32_t hopcnt, hoppad;        // the running counter behind phops
+    unsigned long long prof[16];    // SMALL_PROF build (make PROF=1): cycles of workgroup 0's wave 0 per phase, passes >= 15
 };
 
 struct SmallArgs {
@@ -405,6 +406,13 @@ struct SmallArgs {
 };
 
 // (the software grid barriers live in gridbar.h)
+#ifdef SMALL_PROF
+#define SP_DECL unsigned long long sp_t0 = __builtin_readcyclecounter();
+#define SP_MARK(ctl_, slot, on) { const unsigned long long sp_t1 = __builtin_readcyclecounter(); if (on) (ctl_)->prof[slot] += sp_t1 - sp_t0; sp_t0 = sp_t1; }
+#else
+#define SP_DECL
+#define SP_MARK(ctl_, slot, on)
+#endif
 
 __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
 {
@@ -442,6 +450,43 @@ __device__ __forceinline__ void link_source(const SmallArgs &a, SmallCnt *cnt, u
     }
 }
 
+// distSqr between the mean spectra of source s (n pixels) and of U neighbour segments (shepseg.py:1041-1049: band
+// by band in ascending order, float32 throughout, means by division).  All loads of a chunk of eight bands --
+// the source's row and the U neighbours' rows -- are issued before the first use: written band by band the
+// loop waited for memory once per band and per neighbour, a dozen dependent round trips where one does.
+// Rows of neighbours that do not qualify are passed as s itself (a valid row; the result is ignored).
+template <int U>
+__device__ __forceinline__ void seg_dist_multi(const SmallArgs &a, uint32_t s, float nf, const uint32_t (&nbe)[U],
+                                               const float (&sf)[U], float (&d)[U])
+{
+#pragma unroll
+    for (int u = 0; u < U; u++) d[u] = 0.0f;
+    const float *srow = a.ssum + (size_t)s * a.nb;
+    for (int b0 = 0; b0 < a.nb; b0 += 8) {
+        float xs[8], es[U][8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int b = b0 + j < a.nb ? b0 + j : a.nb - 1;
+            xs[j] = srow[b];
+#pragma unroll
+            for (int u = 0; u < U; u++) es[u][j] = a.ssum[(size_t)nbe[u] * a.nb + b];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            if (b0 + j < a.nb) {
+                const float x = xs[j] / nf;
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const float e2 = es[u][j] / sf[u];
+                    const float t = x - e2;
+                    const float t2 = t * t;
+                    d[u] = d[u] + t2;
+                }
+            }
+        }
+    }
+}
+
 // findMergeSegment (shepseg.py:1003-1063) for one source by one wavefront.  The source's pixel
 // list (chunk chain = the reference's list order) is gathered 64 entries at a time into this
 // wave's LDS slice; lanes then own (pixel k, neighbour position) pairs.  The reference keeps
@@ -449,8 +494,9 @@ __device__ __forceinline__ void link_source(const SmallArgs &a, SmallCnt *cnt, u
 // of (distSqr, k, position): one 64-bit wave reduction (distSqr >= +0, so its float32 bit
 // pattern orders like the value).
 __device__ __forceinline__ bool find_merge_wave(uint32_t s, uint32_t target, const SmallArgs &a,
-                                                uint32_t *wpix, SmallCnt *cnt)
+                                                uint32_t *wpix, SmallCnt *cnt, bool prof = false)
 {
+    SP_DECL
     const unsigned lane = lane_id();
     const float nf = (float)target;
     const uint32_t nq = a.four ? 4u : 8u;
@@ -459,6 +505,7 @@ __device__ __forceinline__ bool find_merge_wave(uint32_t s, uint32_t target, con
     uint32_t c = s, ci = 0;                  // chain cursor: chunk id, index inside the chunk
     uint32_t co = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.off[c]);
     uint32_t cm = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.origsz[c]);
+    SP_MARK(a.ctl, 8, prof)
     for (uint32_t kbase = 0; kbase < target; kbase += 64u) {
         const uint32_t want = (target - kbase < 64u) ? (target - kbase) : 64u;
         // gather list entries kbase .. kbase+want-1
@@ -480,6 +527,7 @@ __device__ __forceinline__ bool find_merge_wave(uint32_t s, uint32_t target, con
             ci += take;
         }
         __builtin_amdgcn_wave_barrier();
+        SP_MARK(a.ctl, 9, prof)
         // the (pixel, neighbour) pairs of these <= 64 list entries, four 64-pair steps at a time and
         // stage by stage (neighbour id, its size, its sums), so that a round trip to memory is paid
         // per stage and not per step: the pass loop is a chain of such round trips
@@ -508,36 +556,46 @@ __device__ __forceinline__ bool find_merge_wave(uint32_t s, uint32_t target, con
                         nbid[u] = a.seg[(uint32_t)ii * a.ncols + (uint32_t)jj];
                 }
             }
+            SP_MARK(a.ctl, 10, prof && nbid[0] != 0xFFFFFFFFu)
 #pragma unroll
             for (uint32_t u = 0; u < 4u; u++) {
                 if (nbid[u] == s) nbid[u] = 0u;
                 szn[u] = nbid[u] ? a.segsz[nbid[u]] : 0u;
             }
+            SP_MARK(a.ctl, 11, prof && szn[0] != 0xFFFFFFFFu)
+            {
+                uint32_t nbe[4];
+                float sfv[4], dv[4];
+                bool any = false;
 #pragma unroll
-            for (uint32_t u = 0; u < 4u; u++) {
-                if (szn[u] > target) {
-                    const uint32_t q = q0 + u * 64u + lane;
-                    const uint32_t kk = q / nq, pos = q - kk * nq;
-                    const float sf = (float)szn[u];
-                    float d = 0.0f;
-                    for (int b = 0; b < a.nb; b++) {
-                        const float x = a.ssum[(size_t)s * a.nb + b] / nf;
-                        const float e2 = a.ssum[(size_t)nbid[u] * a.nb + b] / sf;
-                        const float t = x - e2;
-                        const float t2 = t * t;
-                        d = d + t2;
+                for (uint32_t u = 0; u < 4u; u++) {
+                    const bool elig = szn[u] > target;
+                    any |= elig;
+                    nbe[u] = elig ? nbid[u] : s;
+                    sfv[u] = elig ? (float)szn[u] : nf;
+                }
+                if (__any(any)) {
+                    seg_dist_multi<4>(a, s, nf, nbe, sfv, dv);
+#pragma unroll
+                    for (uint32_t u = 0; u < 4u; u++) {
+                        if (szn[u] > target) {
+                            const uint32_t q = q0 + u * 64u + lane;
+                            const uint32_t kk = q / nq, pos = q - kk * nq;
+                            const unsigned long long key =
+                                ((unsigned long long)__float_as_uint(dv[u]) << 32) |
+                                (unsigned long long)((kbase + kk) * 8u + pos);
+                            if (key < best) { best = key; bestnb = nbid[u]; }
+                        }
                     }
-                    const unsigned long long key =
-                        ((unsigned long long)__float_as_uint(d) << 32) |
-                        (unsigned long long)((kbase + kk) * 8u + pos);
-                    if (key < best) { best = key; bestnb = nbid[u]; }
                 }
             }
+            SP_MARK(a.ctl, 12, prof && best != 1ull)
         }
         __builtin_amdgcn_wave_barrier();
         if (c == 0) break;
     }
     const unsigned long long wmin = wave_min_u64(best);
+    SP_MARK(a.ctl, 13, prof)
     if (wmin == ~0ull) { if (lane == 0) a.mergeto[s] = 0; return false; }
     const float bd = __uint_as_float((uint32_t)(wmin >> 32));
     const bool merges = !((double)bd > a.thr2);
@@ -545,106 +603,201 @@ __device__ __forceinline__ bool find_merge_wave(uint32_t s, uint32_t target, con
         a.mergeto[s] = merges ? bestnb : 0u;
         if (merges) link_source(a, cnt, s, bestnb);
     }
+    SP_MARK(a.ctl, 14, prof)
     return merges;                           // wave-uniform: does s merge in this pass?
 }
 
-// The same for small sources, several per wavefront: a source of `target` pixels has target * nq
-// (pixel, neighbour) pairs, 8 for the two-pixel segments that make up most of the work -- one
-// wavefront per source left 56 of 64 lanes idle there.  Here the sources found in a 64-id slice
-// (bit mask m, ids b0 + bit + 1) are dealt to groups of G >= target * nq lanes; every lane walks
-// the chunk chain to its own pixel (short: these segments are mostly still one chunk), evaluates
-// its pair and the group reduces the same (distSqr, k, position) key over G lanes.
-// Returns how many of the sources merge in this pass.
-template <unsigned G>
-__device__ __forceinline__ uint32_t find_merge_packed(unsigned long long m, uint32_t b0, uint32_t target,
-                                                      const SmallArgs &a, SmallCnt *cnt)
+// The same for sources of at most 256 (pixel, neighbour) pairs, as many of them at once as fit 256 slots: a
+// wavefront owns four slots per lane, slot q belongs to pair q % npairs of source q / npairs of the batch (the
+// sources of a pass all have `target` pixels), and every stage -- chunk heads, chain hops, pixel, neighbour id,
+// its size, the spectra -- issues the loads of all four slots before it waits: one round trip to memory per
+// stage and BATCH, where a wavefront per source (or a group of lanes per source, one batch of groups after the
+// other) paid them per source; two-pixel sources go 32 to a batch.  Each source's minimum of (distSqr, k,
+// position) is a 64-bit ds_min in the wavefront's LDS slice; the slot that holds it records the target and
+// links the source.  ids: this wavefront's list of `count` sources in LDS.  Returns how many of them merge.
+#define SMALL_BATCH_IDS 256u
+#define SMALL_BATCH_SRC 32u
+template <int U>
+__device__ __forceinline__ void seg_dist_pairs(const SmallArgs &a, const uint32_t (&src)[U], float nf,
+                                               const uint32_t (&nbe)[U], const float (&sf)[U], float (&d)[U])
 {
-    const unsigned lane = lane_id(), grp = lane / G, gl = lane % G;
+#pragma unroll
+    for (int u = 0; u < U; u++) d[u] = 0.0f;
+    for (int b0 = 0; b0 < a.nb; b0 += 4) {           // four bands at a time: 8 U values in registers
+        float xs[U][4], es[U][4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int b = b0 + j < a.nb ? b0 + j : a.nb - 1;
+#pragma unroll
+            for (int u = 0; u < U; u++) {
+                xs[u][j] = a.ssum[(size_t)src[u] * a.nb + b];
+                es[u][j] = a.ssum[(size_t)nbe[u] * a.nb + b];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if (b0 + j < a.nb) {
+#pragma unroll
+                for (int u = 0; u < U; u++) {
+                    const float x = xs[u][j] / nf;
+                    const float e2 = es[u][j] / sf[u];
+                    const float t = x - e2;
+                    const float t2 = t * t;
+                    d[u] = d[u] + t2;
+                }
+            }
+        }
+    }
+}
+
+template <int U>
+__device__ __forceinline__ uint32_t find_merge_batch(const uint32_t *ids, uint32_t count, uint32_t target,
+                                                     const SmallArgs &a, SmallCnt *cnt, unsigned long long *wkey)
+{
+    const unsigned lane = lane_id();
     const uint32_t nq = a.four ? 4u : 8u;
     const float nf = (float)target;
-    const uint32_t npairs = target * nq;
+    const uint32_t npairs = target * nq;                       // <= 64 U
+    uint32_t nsb = (64u * (uint32_t)U) / npairs;
+    nsb = nsb > SMALL_BATCH_SRC ? SMALL_BATCH_SRC : nsb;
     uint32_t merges = 0;
-    while (m) {
-        uint32_t s = 0;                              // this group's source (0 = none in this round)
+    for (uint32_t i0 = 0; i0 < count; i0 += nsb) {
+        const uint32_t nsrc = count - i0 < nsb ? count - i0 : nsb;
+        const uint32_t nslots = nsrc * npairs;
+        if (lane < SMALL_BATCH_SRC) wkey[lane] = ~0ull;
+        uint32_t src[U], si[U], kidx[U], kk[U], pos[U], c[U], cm[U], co[U];
+        bool valid[U];
+        // ---- the slots' sources and the heads of their pixel lists ----
 #pragma unroll
-        for (unsigned j = 0; j < 64u / G; j++) {
-            if (m) {
-                const uint32_t sid = b0 + (uint32_t)__builtin_ctzll(m) + 1u;
-                m &= m - 1ull;
-                if (grp == j) s = sid;
-            }
+        for (int u = 0; u < U; u++) {
+            const uint32_t q = (uint32_t)u * 64u + lane;
+            valid[u] = q < nslots;
+            si[u] = q / npairs;
+            const uint32_t pr = q - si[u] * npairs;
+            kidx[u] = pr / nq;
+            pos[u] = pr - kidx[u] * nq;
+            kk[u] = kidx[u];
+            src[u] = valid[u] ? ids[i0 + si[u]] : ids[i0];
+            c[u] = src[u];
         }
-        unsigned long long best = ~0ull;
-        uint32_t bestnb = 0;
-        if (s != 0u && gl < npairs) {
-            const uint32_t kk = gl / nq, pos = gl - kk * nq;
-            uint32_t c = s, k = kk, cm = a.origsz[c];
-            while (k >= cm) {                        // chunk chain = the reference's list order
-                k -= cm;
-                c = a.chnext[c];
-                if (c == 0u) break;
-                cm = a.origsz[c];
-            }
-            if (c != 0u) {
-                const uint32_t p = a.pix[a.off[c] + k];
-                const uint32_t r = p / a.ncols, cc = p - r * a.ncols;
-                int di, dj;                          // neighbour `pos` in (ii outer, jj inner) order
-                if (a.four) {
-                    di = (pos == 0u) ? -1 : (pos == 3u) ? 1 : 0;
-                    dj = (pos == 1u) ? -1 : (pos == 2u) ? 1 : 0;
-                } else {
-                    const uint32_t e = pos < 4u ? pos : pos + 1u;      // skip the centre
-                    di = (int)(e / 3u) - 1;
-                    dj = (int)(e % 3u) - 1;
+#pragma unroll
+        for (int u = 0; u < U; u++) { cm[u] = a.origsz[c[u]]; co[u] = a.off[c[u]]; }
+        // ---- chain hops (the chunk chain = the reference's list order), all slots together ----
+        bool need[U], hopped = false;
+#pragma unroll
+        for (int u = 0; u < U; u++) need[u] = valid[u] && kk[u] >= cm[u];
+        bool anyneed = false;
+#pragma unroll
+        for (int u = 0; u < U; u++) anyneed |= need[u];
+        while (__any(anyneed)) {
+            uint32_t nx[U];
+#pragma unroll
+            for (int u = 0; u < U; u++) nx[u] = need[u] ? a.chnext[c[u]] : 0u;
+#pragma unroll
+            for (int u = 0; u < U; u++)
+                if (need[u]) {
+                    kk[u] -= cm[u];
+                    c[u] = nx[u];
+                    if (nx[u] == 0u) { valid[u] = false; need[u] = false; c[u] = src[u]; }
                 }
-                const int ii = (int)r + di, jj = (int)cc + dj;
-                if (ii >= 0 && jj >= 0 && ii < (int)a.nrows && jj < (int)a.ncols) {
-                    const uint32_t nbid = a.seg[(uint32_t)ii * a.ncols + (uint32_t)jj];
-                    if (nbid != s && nbid != 0u) {
-                        const uint32_t szn = a.segsz[nbid];
-                        if (szn > target) {
-                            const float sf = (float)szn;
-                            float d = 0.0f;
-                            for (int b = 0; b < a.nb; b++) {
-                                const float x = a.ssum[(size_t)s * a.nb + b] / nf;
-                                const float e2 = a.ssum[(size_t)nbid * a.nb + b] / sf;
-                                const float t = x - e2;
-                                const float t2 = t * t;
-                                d = d + t2;
-                            }
-                            best = ((unsigned long long)__float_as_uint(d) << 32) |
-                                   (unsigned long long)(kk * 8u + pos);
-                            bestnb = nbid;
-                        }
+#pragma unroll
+            for (int u = 0; u < U; u++) if (need[u]) cm[u] = a.origsz[c[u]];
+#pragma unroll
+            for (int u = 0; u < U; u++) need[u] = need[u] && kk[u] >= cm[u];
+            anyneed = false;
+#pragma unroll
+            for (int u = 0; u < U; u++) anyneed |= need[u];
+            hopped = true;
+        }
+        if (hopped) {
+#pragma unroll
+            for (int u = 0; u < U; u++) co[u] = a.off[c[u]];
+        }
+        // ---- pixel, neighbour id, neighbour size ----
+        uint32_t p[U], nbid[U], szn[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) p[u] = a.pix[co[u] + (valid[u] ? kk[u] : 0u)];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            nbid[u] = 0u;
+            const uint32_t r = p[u] / a.ncols, cc = p[u] - r * a.ncols;
+            int di, dj;                          // neighbour `pos` in (ii outer, jj inner) order
+            if (a.four) {
+                di = (pos[u] == 0u) ? -1 : (pos[u] == 3u) ? 1 : 0;
+                dj = (pos[u] == 1u) ? -1 : (pos[u] == 2u) ? 1 : 0;
+            } else {
+                const uint32_t e = pos[u] < 4u ? pos[u] : pos[u] + 1u;      // skip the centre
+                di = (int)(e / 3u) - 1;
+                dj = (int)(e % 3u) - 1;
+            }
+            const int ii = (int)r + di, jj = (int)cc + dj;
+            if (valid[u] && ii >= 0 && jj >= 0 && ii < (int)a.nrows && jj < (int)a.ncols)
+                nbid[u] = a.seg[(uint32_t)ii * a.ncols + (uint32_t)jj];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            if (nbid[u] == src[u]) nbid[u] = 0u;
+            szn[u] = nbid[u] ? a.segsz[nbid[u]] : 0u;
+        }
+        // ---- distances, each source's minimum ----
+        unsigned long long key[U];
+#pragma unroll
+        for (int u0 = 0; u0 < U; u0 += 4) {
+            uint32_t srcg[4], nbe[4];
+            float sfv[4], dv[4];
+            bool any = false;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const bool elig = szn[u0 + u] > target;
+                any |= elig;
+                srcg[u] = src[u0 + u];
+                nbe[u] = elig ? nbid[u0 + u] : src[u0 + u];
+                sfv[u] = elig ? (float)szn[u0 + u] : nf;
+                key[u0 + u] = ~0ull;
+            }
+            if (__any(any)) {
+                seg_dist_pairs<4>(a, srcg, nf, nbe, sfv, dv);
+#pragma unroll
+                for (int u = 0; u < 4; u++)
+                    if (szn[u0 + u] > target) {
+                        key[u0 + u] = ((unsigned long long)__float_as_uint(dv[u]) << 32) |
+                                      (unsigned long long)(kidx[u0 + u] * 8u + pos[u0 + u]);
+                        atomicMin(&wkey[si[u0 + u]], key[u0 + u]);
                     }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // ---- the slot that holds its source's minimum decides (unique: (k, position) differs between
+        //      slots); a source without any candidate is reset by its first slot ----
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            bool won = false;
+            if ((uint32_t)u * 64u + lane < nslots) {
+                const unsigned long long wm = wkey[si[u]];
+                if (wm == ~0ull) {
+                    if (kidx[u] == 0u && pos[u] == 0u) a.mergeto[src[u]] = 0u;
+                } else if (key[u] == wm) {
+                    const float bd = __uint_as_float((uint32_t)(wm >> 32));
+                    won = !((double)bd > a.thr2);
+                    a.mergeto[src[u]] = won ? nbid[u] : 0u;
+                    if (won) link_source(a, cnt, src[u], nbid[u]);
                 }
             }
+            merges += (uint32_t)__popcll(__ballot(won));
         }
-        unsigned long long gmin = best;
-#pragma unroll
-        for (unsigned d = G / 2u; d >= 1u; d >>= 1) {
-            const unsigned long long o = __shfl_xor(gmin, (int)d, 64);
-            gmin = o < gmin ? o : gmin;
-        }
-        bool merged = false;
-        if (s != 0u) {
-            if (gmin == ~0ull) {
-                if (gl == 0u) a.mergeto[s] = 0u;
-            } else if (best == gmin) {               // unique: (k, position) differs between lanes
-                const float bd = __uint_as_float((uint32_t)(gmin >> 32));
-                merged = !((double)bd > a.thr2);
-                a.mergeto[s] = merged ? bestnb : 0u;
-                if (merged) link_source(a, cnt, s, bestnb);
-            }
-        }
-        merges += (uint32_t)__popcll(__ballot(merged));
+        __builtin_amdgcn_wave_barrier();
     }
     return merges;
 }
 
-__global__ __launch_bounds__(256) void k_small_loop(SmallArgs a)
+#ifndef SMALL_MINWAVES
+#define SMALL_MINWAVES 4
+#endif
+__global__ __launch_bounds__(256, SMALL_MINWAVES) void k_small_loop(SmallArgs a)
 {
     __shared__ uint32_t wpix[4][64];
+    __shared__ uint32_t wids[4][SMALL_BATCH_IDS];
+    __shared__ unsigned long long wkeys[4][SMALL_BATCH_SRC];
     __shared__ uint32_t s_target, s_done, s_count;
     __shared__ uint32_t lhist[256];
     SmallCtl *ctl = a.ctl;
@@ -673,8 +826,13 @@ __global__ __launch_bounds__(256) void k_small_loop(SmallArgs a)
     __syncthreads();
     const SmallBar bar = s_bar;
     unsigned long long tmark = wall_clock64();
+    SP_DECL
     for (uint32_t slot = 0;; slot++) {
         const uint32_t par = slot & 1u;
+#ifdef SMALL_PROF
+        const bool sprof = gtid == 0u && (uint32_t)ctl->tphase[3] >= 15u;
+#endif
+        SP_MARK(ctl, 15, false)
         // ---- loop control (identical in every workgroup; shepseg.py:970-997) ----
         if (threadIdx.x == 0) {
             uint32_t target = ctl->st[par].target, passes = ctl->st[par].passes;
@@ -711,6 +869,7 @@ __global__ __launch_bounds__(256) void k_small_loop(SmallArgs a)
         }
         const uint32_t target = s_target;
         SmallCnt *cnt = &ctl->cnt[slot % 3u];
+        SP_MARK(ctl, 0, sprof)
         // ---- find phase: sources = segments of the target size.  Every wavefront scans its own
         //      64-id slices of the size table (four slices in flight: the scan of ~2.5 M ids is
         //      repeated every pass and is pure load latency).  With many sources a wavefront handles
@@ -729,6 +888,8 @@ __global__ __launch_bounds__(256) void k_small_loop(SmallArgs a)
                     const uint32_t sid = base + (uint32_t)u * stride + lane + 1u;
                     sz[u] = sid <= a.S ? a.segsz[sid] : 0xFFFFFFFFu;
                 }
+                const uint32_t npairs = target * (a.four ? 4u : 8u);
+                uint32_t nfound = 0;                 // sources of these four slices, gathered in wids[w]
 #pragma unroll
                 for (int u = 0; u < 4; u++) {
                     unsigned long long m = __ballot(sz[u] == target);
@@ -737,30 +898,60 @@ __global__ __launch_bounds__(256) void k_small_loop(SmallArgs a)
                     uint32_t gbase = 0;
                     if (lane == 0) gbase = atomicAdd(&cnt->nsrc, (uint32_t)__popcll(m));
                     gbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)gbase);
-                    if (sz[u] == target) a.srclist[gbase + (uint32_t)__popcll(m & lanemask_lt())] = b0 + lane + 1u;
+                    const uint32_t rank = (uint32_t)__popcll(m & lanemask_lt());
+                    if (sz[u] == target) a.srclist[gbase + rank] = b0 + lane + 1u;
                     if (balanced) continue;
-                    const uint32_t npairs = target * (a.four ? 4u : 8u);
-                    if (npairs <= 8u) wmerges += find_merge_packed<8>(m, b0, target, a, cnt);
-                    else if (npairs <= 16u) wmerges += find_merge_packed<16>(m, b0, target, a, cnt);
-                    else if (npairs <= 32u) wmerges += find_merge_packed<32>(m, b0, target, a, cnt);
-                    else while (m) {
+                    if (npairs <= 256u) {
+                        if (sz[u] == target) wids[w][nfound + rank] = b0 + lane + 1u;
+                        nfound += (uint32_t)__popcll(m);
+                    } else while (m) {
                         const uint32_t src = b0 + (uint32_t)__builtin_ctzll(m) + 1u;
                         m &= m - 1ull;
                         wmerges += find_merge_wave(src, target, a, wpix[w], cnt) ? 1u : 0u;
                     }
                 }
+                if (nfound) {
+                    __builtin_amdgcn_wave_barrier();
+                    wmerges += find_merge_batch<4>(wids[w], nfound, target, a, cnt, wkeys[w]);
+                }
             }
             if (balanced) {
+                SP_MARK(ctl, 1, sprof)
                 if (!(a.bar2 ? small_grid_barrier2(ctl, bar) : small_grid_barrier(ctl, G, a.poll))) return;
+                SP_MARK(ctl, 2, sprof)
                 const uint32_t nlisted = cnt->nsrc;
+                const uint32_t npairs = target * (a.four ? 4u : 8u);
+                if (npairs <= 128u) {
+                    // several sources fit a batch: deal chunks of them (no larger than an even share).  (Eight
+                    // slots per lane, i.e. two sources of 33..64 pixels at once, need 250 registers -- two such
+                    // loops per CU -- or spill at 128: the late passes came out 10 % slower than with a
+                    // wavefront per source.)
+                    uint32_t chunk = 256u / npairs;
+                    chunk = chunk > SMALL_BATCH_SRC ? SMALL_BATCH_SRC : chunk;
+                    const uint32_t share = (nlisted + gwaves - 1u) / gwaves;
+                    chunk = chunk > share ? (share ? share : 1u) : chunk;
+                    for (uint32_t i = gwave * chunk; i < nlisted; i += gwaves * chunk) {
+                        const uint32_t nn = nlisted - i < chunk ? nlisted - i : chunk;
+                        if (lane < nn) wids[w][lane] = a.srclist[i + lane];
+                        __builtin_amdgcn_wave_barrier();
+                        wmerges += find_merge_batch<4>(wids[w], nn, target, a, cnt, wkeys[w]);
+                    }
+                } else
                 for (uint32_t i = gwave; i < nlisted; i += gwaves) {
                     const uint32_t src = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.srclist[i]);
+#ifdef SMALL_PROF
+                    wmerges += find_merge_wave(src, target, a, wpix[w], cnt, sprof) ? 1u : 0u;
+                    if (sprof) ctl->prof[7] += 1;
+#else
                     wmerges += find_merge_wave(src, target, a, wpix[w], cnt) ? 1u : 0u;
+#endif
                 }
+                SP_MARK(ctl, 3, sprof)
             }
             if (wmerges && lane == 0) atomicAdd(&cnt->nmerge, wmerges);
         }
         if (!(a.bar2 ? small_grid_barrier2(ctl, bar) : small_grid_barrier(ctl, G, a.poll))) return;
+        SP_MARK(ctl, 4, sprof)
         const uint32_t nsrc = cnt->nsrc;
         if (gtid == 0) {
             const unsigned long long t = wall_clock64();
@@ -806,6 +997,7 @@ __global__ __launch_bounds__(256) void k_small_loop(SmallArgs a)
                 }
             }
         }
+        SP_MARK(ctl, 5, sprof)
         const uint32_t ntgt = cnt->ntgt;
         // ---- merge step 2: each target absorbs its sources in ascending id (doMerge :1112-1123)
         //      size-histogram updates go through LDS, numElim through a wave reduction ----
@@ -847,7 +1039,9 @@ __global__ __launch_bounds__(256) void k_small_loop(SmallArgs a)
         __syncthreads();
         if (threadIdx.x < a.min_seg && lhist[threadIdx.x] != 0u)
             atomicAdd(&a.hist[threadIdx.x], lhist[threadIdx.x]);          // wrapping add of the delta
+        SP_MARK(ctl, 6, sprof)
         if (!(a.bar2 ? small_grid_barrier2(ctl, bar) : small_grid_barrier(ctl, G, a.poll))) return;
+        SP_MARK(ctl, 15, sprof)
         if (gtid == 0) {
             const unsigned long long t = wall_clock64();
             ctl->plog[(uint32_t)ctl->tphase[3] & 63u][3] = (uint32_t)(t - tmark);
@@ -945,14 +1139,25 @@ static int run_eliminate_small(shp_ctx *ctx, const void *d_img, int dtype, int n
     args.hopstat = getenv("SHEPSEG_SMALL_TIMING") ? &ctl->hopcnt : nullptr;
     pin->done = 0; pin->fail = 0;       // (a loop that gives up at a barrier leaves them so)
     fill_release(ctx, true);            // the pass loop is a latency-bound phase
+    static const unsigned small_blocks = getenv("SHEPSEG_SMALL_BLOCKS") ? (unsigned)atoi(getenv("SHEPSEG_SMALL_BLOCKS")) : SMALL_BLOCKS;
+    // how many loops fit the device at once, from the kernel's own occupancy (its register count decides:
+    // 168 VGPRs = 3 workgroups per CU = 768 on the device = 12 loops of 64); never more than SHEPSEG_SMALL_MAX
+    static const int cap = [] {
+        int per_cu = 0, dev = 0, ncu = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_small_loop, 256, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu < 1) ncu = 64;
+        int c = (int)((unsigned)(per_cu * ncu) / (small_blocks ? small_blocks : 1u));
+        c = c < 1 ? 1 : c;
+        return c < g_small_max ? c : g_small_max;
+    }();
     {
         std::unique_lock<std::mutex> lk(g_small_mu);
-        g_small_cv.wait(lk, [] { return g_small_running < g_small_max; });
+        g_small_cv.wait(lk, [] { return g_small_running < cap; });
         g_small_running++;
     }
     static const int dbg_skip_loop = getenv("SHEPSEG_DBG_SKIP_SMALL") ? atoi(getenv("SHEPSEG_DBG_SKIP_SMALL")) : 0;
     if (dbg_skip_loop) args.min_seg = 1;      // diagnostic only: the loop ends at once (wrong labels)
-    static const unsigned small_blocks = getenv("SHEPSEG_SMALL_BLOCKS") ? (unsigned)atoi(getenv("SHEPSEG_SMALL_BLOCKS")) : SMALL_BLOCKS;
     walk_begin(ctx);
     st = ctx->stream;
     ps = prof_begin(ctx, PROF_SMALL_LOOP);           // events hug the kernel: no copies, no host waits
@@ -979,6 +1184,12 @@ static int run_eliminate_small(shp_ctx *ctx, const void *d_img, int dtype, int n
         for (unsigned i = 0; i < 64u && i < pin->tphase[3]; i++)
             fprintf(stderr, "  pass %u: target %u, %u sources, find %.1f us, merge %.1f us, %u chain hops\n", i, pin->plog[i][0],
                     pin->plog[i][1], pin->plog[i][2] / 100.0, pin->plog[i][3] / 100.0, pin->phops[i]);
+#ifdef SMALL_PROF
+        fprintf(stderr, "  wave 0, passes >= 15, cycles: control %llu, scan %llu, list barrier %llu, finds %llu (%llu sources), find barrier %llu, relabel %llu, apply %llu, merge barrier %llu\n",
+                pin->prof[0], pin->prof[1], pin->prof[2], pin->prof[3], pin->prof[7], pin->prof[4], pin->prof[5], pin->prof[6], pin->prof[15]);
+        fprintf(stderr, "    inside the finds: head %llu, gather %llu, neighbour ids %llu, sizes %llu, distances %llu, reduce %llu, link %llu\n",
+                pin->prof[8], pin->prof[9], pin->prof[10], pin->prof[11], pin->prof[12], pin->prof[13], pin->prof[14]);
+#endif
         fprintf(stderr, "  workgroups per XCD:");
         for (int i = 0; i < 16; i++) fprintf(stderr, " %u", pin->xcd_n[i]);
         fprintf(stderr, "\n");
