@@ -254,6 +254,11 @@ int shp_renumber_dev(shp_ctx *ctx, uint32_t *d_raster, int64_t npix, uint32_t st
  * clipped to the ov_w x ov_h layer.  Asynchronous, ordered behind the tile's output write. */
 int shp_overview_window_dev(shp_ctx *ctx, const uint32_t *d_raster, int64_t pitch, int xout, int yout,
                             int w, int h, int level, uint32_t *d_ov, int ov_w, int ov_h);
+/* the band statistics the reference derives from the segment histogram (utils.estimateStatsFromHisto,
+ * utils.py:47-95), evaluated as numpy evaluates them there (int64 sums, float64 pairwise sum for the
+ * variance, float64 comparison for the median): out[0..5] = minimum, maximum, mean, standard deviation,
+ * mode, median of hist[0..n).  Host only: no device work, no context. */
+int shp_hist_stats(const uint32_t *hist, int64_t n, double *out);
 /* histogram of a device label raster, hist_out_host[0..max_seg_id], entry 0 zeroed (the RAT
  * Histogram column, HistogramAccumulator tiling.py:1915-1963).  ncols = the raster's row length
  * (npix a multiple of it; lets a segment's pixels be combined per 2-D patch), or 0. */

@@ -571,7 +571,7 @@ static void lloyd_assign(const double *X, size_t n, int nb, const double *C, int
 
 /* DOUBLE_pairwise_sum (numpy/core/src/umath/loops_utils.h.src) of a contiguous run: what a float64
  * .sum() over the last axis evaluates.  Plain left-to-right below 8 elements. */
-static double np_pairwise_sum(const double *a, size_t n)
+static double np_pairwise_block(const double *a, size_t n)
 {
     if (n < 8) {
         double res = 0.0;
@@ -590,7 +590,15 @@ static double np_pairwise_sum(const double *a, size_t n)
     }
     size_t n2 = n / 2;
     n2 -= n2 % 8;
-    return np_pairwise_sum(a, n2) + np_pairwise_sum(a + n2, n - n2);
+    return np_pairwise_block(a, n2) + np_pairwise_block(a + n2, n - n2);
+}
+/* ... which a .sum() reaches one ufunc buffer (8192 elements) at a time, the blocks' sums added one after
+ * the other (checked against numpy 2.2.6 with runs of up to 2.5 M elements, tests/test_tiling_host.py) */
+static double np_pairwise_sum(const double *a, size_t n)
+{
+    double res = np_pairwise_block(a, n < 8192 ? n : 8192);
+    for (size_t o = 8192; o < n; o += 8192) res += np_pairwise_block(a + o, n - o < 8192 ? n - o : 8192);
+    return res;
 }
 
 /* np.argpartition(v, kth) for float64 without NaNs: numpy/core/src/npysort/selection.cpp

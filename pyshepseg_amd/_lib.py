@@ -111,6 +111,7 @@ _SIGS = {
     'shp_overview_window_dev': (_c.c_int, [_vp, _vp, _c.c_int64, _c.c_int, _c.c_int, _c.c_int, _c.c_int,
                                            _c.c_int, _vp, _c.c_int, _c.c_int]),
     'shp_histogram_dev': (_c.c_int, [_vp, _vp, _c.c_int64, _c.c_int64, _c.c_uint32, _vp]),
+    'shp_hist_stats': (_c.c_int, [_vp, _c.c_int64, _vp]),
     'shp_segstats': (_c.c_int, [_vp, _vp, _vp, _c.c_int, _c.c_int64, _c.c_uint32, _c.c_int,
                                 _c.c_int64, _vp, _c.c_int, _c.c_int64, _vp, _vp]),
     'shp_segstats_dev': (_c.c_int, [_vp, _vp, _vp, _c.c_int, _c.c_int64, _c.c_uint32, _c.c_int,

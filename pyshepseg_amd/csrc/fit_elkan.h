@@ -36,7 +36,7 @@
 // (the halving above 128 elements is numpy's recursion; here its depth is a template parameter, so that
 //  device code gets plain nested calls instead of a recursive function on a dynamic stack -- the
 //  recursive form made k_fit_update, the one kernel that called it out of line, read its loop control
-//  back wrongly.  LEVELS = 10 covers 131072 elements: k <= 65534 centres, nb <= 4096 bands.)
+//  back wrongly.  LEVELS = 6 covers the 8192 elements numpy hands the routine at a time, see below.)
 template <int LEVELS, class Get>
 __host__ __device__ inline double np_pairwise_sum_lv(Get get, size_t lo, size_t n)
 {
@@ -63,10 +63,20 @@ __host__ __device__ inline double np_pairwise_sum_lv(Get get, size_t lo, size_t 
         return __builtin_nan("");           // more than 128 * 2^10 elements: no caller gets here
     }
 }
+// A .sum() over a contiguous run longer than the ufunc buffer (8192 elements) reaches the routine above one
+// buffer at a time, the blocks' sums added one after the other.
+#define NP_REDUCE_BLOCK ((size_t)8192)
 template <class Get>
 __host__ __device__ inline double np_pairwise_sum_fn(Get get, size_t lo, size_t n)
 {
-    return np_pairwise_sum_lv<10>(get, lo, n);
+    double res = 0.0;
+    for (size_t o = 0; o < n || o == 0; o += NP_REDUCE_BLOCK) {
+        const size_t m = n - o < NP_REDUCE_BLOCK ? n - o : NP_REDUCE_BLOCK;
+        const double part = np_pairwise_sum_lv<6>(get, lo + o, m);
+        res = o ? res + part : part;
+        if (n == 0) break;
+    }
+    return res;
 }
 __host__ __device__ inline double np_pairwise_sum(const double *a, size_t n)
 {

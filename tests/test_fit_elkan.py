@@ -56,6 +56,11 @@ def test_oracle_numpy_pieces(ties, oracle):
         assert got == float(ties['ps%02d_sum' % t]), t
         t += 1
     assert t >= 10
+    # runs longer than the ufunc buffer: numpy adds the 8192-element blocks' pairwise sums one after the other
+    rng = np.random.RandomState(8192)
+    for n in (8193, 20000, 200000):
+        a = np.ascontiguousarray(rng.random_sample(n) * 1e12)
+        assert L.orc_np_pairwise_sum(a.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(n)) == float(a.sum()), n
 
 
 def test_oracle_elkan_equals_lloyd_without_ties(oracle):

@@ -80,6 +80,39 @@ def test_overview_levels_and_band_statistics(golden):
         assert got == g[case + '_stats'].tolist(), case
 
 
+def test_band_statistics_compiled_equals_numpy():
+    """estimateStatsFromHisto evaluates the reference's numpy expressions (utils.py:54-70) in one compiled pass
+    (shp_hist_stats, host only): same strings as numpy's own evaluation, also where a .sum() spans several
+    8192-element reduction blocks and for histograms of a few million bins (the C3 benchmark has 2.6 M)."""
+    from pyshepseg_amd import tiling
+
+    def ref(hist):
+        mask = hist > 0
+        nVals = hist.sum()
+        minVal = mask.argmax()
+        maxVal = hist.shape[0] - np.flip(mask).argmax() - 1
+        values = np.arange(hist.shape[0])
+        meanVal = (values * hist).sum() / nVals
+        sd = np.sqrt((hist * np.power(values - meanVal, 2)).sum() / nVals)
+        med = (hist.cumsum() >= hist.sum() / 2).nonzero()[0][0]
+        return [repr(int(minVal)), repr(int(maxVal)), repr(float(meanVal)), repr(float(sd)),
+                repr(int(np.argmax(hist))), repr(int(med))]
+
+    rng = np.random.default_rng(3)
+    for n in (1, 2, 7, 8, 9, 127, 128, 129, 1000, 8191, 8192, 8193, 16385, 20000, 131073, 700001):
+        for trial in range(4):
+            h = rng.integers(0, 5000, size=n).astype(np.uint32)
+            if trial == 1 and n > 4:
+                h[:n // 3] = 0
+                h[-(n // 4):] = 0
+            if trial == 3:
+                h = (h % 3 == 0).astype(np.uint32) * rng.integers(1, 2 ** 31, size=n).astype(np.uint32)
+            if h.sum() == 0:
+                h[0] = 1
+            got = [v for (_k, v) in tiling.estimateStatsFromHisto(h)][:6]
+            assert got == ref(h), (n, trial)
+
+
 def test_subsample_indices_restart_per_block():
     from pyshepseg_amd import tiling
     idx = tiling._subsample_indices(2500, 40)
