@@ -411,6 +411,32 @@ __global__ __launch_bounds__(256) void k_stats_patch(const uint32_t *__restrict_
 // d_seg / d_band: device rasters of n pixels.  Outputs are HOST arrays.
 // nrows x ncols = n when the caller knows the raster's shape (0, 0 otherwise): with small segments the
 // statistics are then computed patch by patch (k_stats_patch) and only what is left over is sorted.
+// The result columns go to pageable host arrays (the caller's numpy columns): the runtime stages such a copy
+// through its own pinned buffers, one pipeline per stream, so the integer and the float columns travel on two
+// streams at once (the second waits on an event for the kernels that wrote them).
+static int segstats_download(shp_ctx *ctx, void *intcols_out, const void *d_int, size_t int_bytes,
+                             void *fltcols_out, const void *d_flt, size_t flt_bytes)
+{
+    hipStream_t st = ctx->stream;
+    if (int_bytes && flt_bytes && int_bytes + flt_bytes > (size_t)(8u << 20)) {
+        CHK(ensure_stream2(ctx));
+        hipEvent_t ev = nullptr;
+        HIPCHK(ctx, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        HIPCHK(ctx, hipEventRecord(ev, st));
+        HIPCHK(ctx, hipStreamWaitEvent(ctx->stream2, ev, 0));
+        HIPCHK(ctx, hipMemcpyAsync(fltcols_out, d_flt, flt_bytes, hipMemcpyDeviceToHost, ctx->stream2));
+        HIPCHK(ctx, hipMemcpyAsync(intcols_out, d_int, int_bytes, hipMemcpyDeviceToHost, st));
+        HIPCHK(ctx, hipStreamSynchronize(st));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream2));
+        HIPCHK(ctx, hipEventDestroy(ev));
+        return 0;
+    }
+    if (int_bytes) HIPCHK(ctx, hipMemcpyAsync(intcols_out, d_int, int_bytes, hipMemcpyDeviceToHost, st));
+    if (flt_bytes) HIPCHK(ctx, hipMemcpyAsync(fltcols_out, d_flt, flt_bytes, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    return 0;
+}
+
 static int run_segstats(shp_ctx *ctx, const uint32_t *d_seg, const void *d_band, int dtype,
                         uint32_t n, uint32_t S, int has_null, int64_t null_val,
                         const uint32_t *sel_host, int nstats, int64_t missing,
@@ -480,10 +506,7 @@ static int run_segstats(shp_ctx *ctx, const uint32_t *d_seg, const void *d_band,
     }
     if (patches && nsort == 0) {                          // every segment was complete in its patch
         prof_end(ctx, ps);
-        if (nint) HIPCHK(ctx, hipMemcpyAsync(intcols_out, d_int, (size_t)nint * ns * 8, hipMemcpyDeviceToHost, st));
-        if (nflt) HIPCHK(ctx, hipMemcpyAsync(fltcols_out, d_flt, (size_t)nflt * ns * 4, hipMemcpyDeviceToHost, st));
-        HIPCHK(ctx, hipStreamSynchronize(st));
-        return 0;
+        return segstats_download(ctx, intcols_out, d_int, (size_t)nint * ns * 8, fltcols_out, d_flt, (size_t)nflt * ns * 4);
     }
     n = nsort;
     // sort by value (payload: segment key), then stably by segment key (payload: value)
@@ -518,10 +541,7 @@ static int run_segstats(shp_ctx *ctx, const uint32_t *d_seg, const void *d_band,
     hipLaunchKernelGGL(k_seg_stats_big, dim3(512), dim3(256), 0, st, v2, off, cnt, S, bias, d_sel, nstats,
                        (long long)missing, d_int, d_flt, biglist); KCHK(ctx);      // (only flagged ones got onto the list)
     prof_end(ctx, ps);
-    if (nint) HIPCHK(ctx, hipMemcpyAsync(intcols_out, d_int, (size_t)nint * ns * 8, hipMemcpyDeviceToHost, st));
-    if (nflt) HIPCHK(ctx, hipMemcpyAsync(fltcols_out, d_flt, (size_t)nflt * ns * 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(ctx, hipStreamSynchronize(st));
-    return 0;
+    return segstats_download(ctx, intcols_out, d_int, (size_t)nint * ns * 8, fltcols_out, d_flt, (size_t)nflt * ns * 4);
 }
 
 // ---- multi-GPU split: the pixels of segments that straddle a rank boundary ------------------

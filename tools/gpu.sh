@@ -41,6 +41,11 @@ fit)        # the whole-image k-means fit on the benchmark sample: Elkan trace, 
     SHEPSEG_FIT_TIMING=1 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/fitprof -- python3 tools/perf_fit.py 40000 6 > gpurun_out/fitprof.log 2>&1
     python3 tools/kstats.py --top 12 "$(find gpurun_out/fitprof -name '*kernel_stats.csv' | head -1)"
     grep "kmeans fit: n=" gpurun_out/fitprof.log | tail -1; rm -f gpurun_out/fitprof/*/*kernel_trace.csv ;;
+fit-shard)  # one rank's share of a row-sharded E-step: the same fit on 1/N of the sample's rows (N = $1, default 8)
+    rm -rf gpurun_out/fitprof
+    SHEPSEG_FIT_TIMING=1 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/fitprof -- python3 tools/perf_fit.py 40000 6 ${1:-8} > gpurun_out/fitprof.log 2>&1
+    python3 tools/kstats.py --top 6 "$(find gpurun_out/fitprof -name '*kernel_stats.csv' | head -1)"
+    grep "kmeans fit: n=" gpurun_out/fitprof.log | tail -1; rm -f gpurun_out/fitprof/*/*kernel_trace.csv ;;
 tiletrace)  # kernel sequence (durations, gaps) of ONE tile run alone -> gpurun_out/tiletrace.txt
     rm -rf gpurun_out/tt
     timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/tt -o run -- python tools/perf_tile.py ${1:-4096} > gpurun_out/tt.log 2>&1 &&
@@ -72,5 +77,5 @@ ubench)     # micro-benchmarks of instruction issue / branch cost / float64 chai
 sumlists)   # the M-step's row-order sums alone, with the adding wavefront's cycle split (tools/ubench/sumlists.hip)
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -fno-fast-math -w -I pyshepseg_amd/csrc -o /tmp/ub_sumlists tools/ubench/sumlists.hip &&
     timeout -k 5 120 /tmp/ub_sumlists ;;
-*) echo "tasks: tests bench sweep walk small fit tiletrace two-ranks dump-sample ubench sumlists (and tools/refresh_profiles.sh TAG)"; exit 2 ;;
+*) echo "tasks: tests bench sweep walk small fit fit-shard tiletrace two-ranks dump-sample ubench sumlists (and tools/refresh_profiles.sh TAG)"; exit 2 ;;
 esac
