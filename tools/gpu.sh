@@ -71,7 +71,7 @@ np.save('gpurun_out/%s_centres_device.npy' % name, km.cluster_centers_)
 PY
     ;;
 ubench)     # micro-benchmarks of instruction issue / branch cost / float64 chains for a lone wavefront
-    for b in ${@:-issue branch f64chain mfma_f64_order}; do
+    for b in ${@:-issue branch f64chain mfma_f64_order mfma_f32_order}; do
       /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -o /tmp/ub_$b tools/ubench/$b.hip 2>/dev/null && timeout -k 5 60 /tmp/ub_$b
     done ;;
 sumlists)   # the M-step's row-order sums alone, with the adding wavefront's cycle split (tools/ubench/sumlists.hip)
