@@ -29,16 +29,16 @@ __device__ __forceinline__ uint32_t hash64(unsigned long long k)
 // neither the segment above it nor to its left, and so on for the other extremes.  That leaves a
 // handful of candidates per segment; they are combined per 32 x 64 patch in LDS (AggTable) and
 // flushed with one pruned global atomic per (patch, segment, field).
-__global__ __launch_bounds__(256) void k_strip_minmax(const uint32_t *__restrict__ tile, uint32_t xs,
-                                                      uint32_t srows, uint32_t scols, int horizontal,
-                                                      uint32_t *mn, uint32_t *mx)
+__device__ __forceinline__ void strip_minmax_body(const uint32_t *__restrict__ tile, uint32_t xs,
+                                                  uint32_t srows, uint32_t scols, int horizontal,
+                                                  uint32_t *mn, uint32_t *mx, uint32_t bx, uint32_t by)
 {
     __shared__ AggTable tab;
     agg_init(tab, 0xFFFFFFFFu, 0u, 0u);
     __syncthreads();
     const unsigned lane = lane_id(), wv = threadIdx.x >> 6;
-    const uint32_t c = blockIdx.x * 64u + lane;
-    const uint32_t r0 = blockIdx.y * AGG_ROWS + wv * (AGG_ROWS / 4u);
+    const uint32_t c = bx * 64u + lane;
+    const uint32_t r0 = by * AGG_ROWS + wv * (AGG_ROWS / 4u);
     const bool cin = c < scols;
     uint32_t above = (cin && r0 > 0u && r0 <= srows) ? tile[(size_t)(r0 - 1u) * xs + c] : 0u;
     uint32_t cur = (cin && r0 < srows) ? tile[(size_t)r0 * xs + c] : 0u;
@@ -78,6 +78,24 @@ __global__ __launch_bounds__(256) void k_strip_minmax(const uint32_t *__restrict
         if (tab.v[0][i] < mn[s]) atomicMin(&mn[s], tab.v[0][i]);
         if (tab.v[1][i] > mx[s]) atomicMax(&mx[s], tab.v[1][i]);
     }
+}
+__global__ __launch_bounds__(256) void k_strip_minmax(const uint32_t *__restrict__ tile, uint32_t xs,
+                                                      uint32_t srows, uint32_t scols, int horizontal,
+                                                      uint32_t *mn, uint32_t *mx)
+{
+    strip_minmax_body(tile, xs, srows, scols, horizontal, mn, mx, blockIdx.x, blockIdx.y);
+}
+// both overlap strips of a tile in one launch: blockIdx.z = 0 the top strip (rows < g.rows0, horizontal),
+// 1 the left strip (columns < g.cols1); each has its own (mn, mx) pair behind mnmx: [z][mn | mx][nseg]
+struct StripPair { uint32_t rows0, cols0, rows1, cols1; };      // a strip that is absent has 0 rows
+__global__ __launch_bounds__(256) void k_strip_minmax2(const uint32_t *__restrict__ tile, uint32_t xs,
+                                                       StripPair g, uint32_t *mnmx, uint32_t nseg)
+{
+    const uint32_t z = blockIdx.z;
+    const uint32_t srows = z ? g.rows1 : g.rows0, scols = z ? g.cols1 : g.cols0;
+    if (blockIdx.x * 64u >= scols || blockIdx.y * AGG_ROWS >= srows) return;       // (uniform per workgroup)
+    uint32_t *mn = mnmx + (size_t)z * 2u * nseg;
+    strip_minmax_body(tile, xs, srows, scols, z == 0u, mn, mn + nseg, blockIdx.x, blockIdx.y);
 }
 
 __global__ __launch_bounds__(256) void k_pair_count(
@@ -325,6 +343,17 @@ __global__ __launch_bounds__(256) void k_meta_init(uint32_t nseg, uint32_t *__re
     flags[s] = 0u; segtop[s] = 0xFFFFFFFFu; segleft[s] = 0xFFFFFFFFu;
     if (mn) { mn[s] = 0xFFFFFFFFu; mx[s] = 0u; }
 }
+// the same with the (mn, mx) pairs of both strips: mnmx = [z][mn | mx][nseg]
+__global__ __launch_bounds__(256) void k_meta_init2(uint32_t nseg, uint32_t *__restrict__ flags,
+                                                    uint32_t *__restrict__ segtop,
+                                                    uint32_t *__restrict__ segleft, uint32_t *__restrict__ mnmx)
+{
+    const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+    if (s >= nseg) return;
+    flags[s] = 0u; segtop[s] = 0xFFFFFFFFu; segleft[s] = 0xFFFFFFFFu;
+    mnmx[s] = 0xFFFFFFFFu; mnmx[(size_t)nseg + s] = 0u;
+    mnmx[2 * (size_t)nseg + s] = 0xFFFFFFFFu; mnmx[3 * (size_t)nseg + s] = 0u;
+}
 
 // crossesMidline for every segment of the strip; leaves mn / mx reset for the next strip
 __global__ __launch_bounds__(256) void k_meta_cross(uint32_t *__restrict__ mn, uint32_t *__restrict__ mx,
@@ -335,6 +364,18 @@ __global__ __launch_bounds__(256) void k_meta_cross(uint32_t *__restrict__ mn, u
     if (s >= nseg) return;
     if (s != 0 && mn[s] < mid && mx[s] >= mid + 1u) flags[s] |= bit;
     mn[s] = 0xFFFFFFFFu; mx[s] = 0u;
+}
+// crossesMidline against both strips' midlines at once (mid0 / mid1; a strip that is absent has on = 0)
+__global__ __launch_bounds__(256) void k_meta_cross2(const uint32_t *__restrict__ mnmx, uint32_t nseg,
+                                                     uint32_t mid0, int on0, uint32_t mid1, int on1,
+                                                     uint32_t *flags)
+{
+    const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+    if (s >= nseg || s == 0u) return;
+    uint32_t f = 0u;
+    if (on0 && mnmx[s] < mid0 && mnmx[(size_t)nseg + s] >= mid0 + 1u) f |= META_CROSS_TOP;
+    if (on1 && mnmx[2 * (size_t)nseg + s] < mid1 && mnmx[3 * (size_t)nseg + s] >= mid1 + 1u) f |= META_CROSS_LEFT;
+    if (f) flags[s] |= f;
 }
 
 // hist[id] += pixels of id (id 0 is not counted) over a raster of `ncols` columns: run lengths per
@@ -452,6 +493,31 @@ __global__ __launch_bounds__(256) void k_cross_count(const uint32_t *__restrict_
     __syncthreads();
     if (threadIdx.x == 0 && s_cnt) atomicAdd(count, s_cnt);
 }
+// both strips in one launch: blockIdx.y = strip, count[0] the top strip's, count[1] the left strip's
+__global__ __launch_bounds__(256) void k_cross_count2(const uint32_t *__restrict__ tile, uint32_t xs, StripPair g,
+                                                      const uint32_t *__restrict__ flags, uint32_t *count)
+{
+    __shared__ uint32_t s_cnt;
+    const uint32_t z = blockIdx.y;
+    const uint32_t srows = z ? g.rows1 : g.rows0, scols = z ? g.cols1 : g.cols0;
+    const uint32_t bit = z ? META_CROSS_LEFT : META_CROSS_TOP;
+    if ((size_t)blockIdx.x * 1024u >= (size_t)srows * scols) return;             // (uniform per workgroup)
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    uint32_t mine = 0;
+    for (uint32_t i = blockIdx.x * 1024u + threadIdx.x, e = 0; e < 4u; e++, i += 256u) {
+        if (i < srows * scols) {
+            const uint32_t r = i / scols, c = i - r * scols;
+            const uint32_t s = tile[r * xs + c];
+            mine += (s != 0u && (flags[s] & bit)) ? 1u : 0u;
+        }
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d, 64);
+    if (lane_id() == 0 && mine) atomicAdd(&s_cnt, mine);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_cnt) atomicAdd(count + z, s_cnt);
+}
 
 static int run_stitch_prepare(shp_ctx *ctx, const uint32_t *d_tile, uint32_t ys, uint32_t xs,
                               uint32_t overlap, int has_top, int has_left, uint32_t max_local,
@@ -461,26 +527,27 @@ static int run_stitch_prepare(shp_ctx *ctx, const uint32_t *d_tile, uint32_t ys,
     hipStream_t st = ctx->stream;
     const uint32_t n = ys * xs, nseg = max_local + 1u;
     uint32_t *flags = d_meta, *segtop = d_meta + nseg, *segleft = d_meta + 2 * (size_t)nseg;
-    CHK(buf_ensure(ctx, ctx->aux, (size_t)nseg * 8 + 64));
-    uint32_t *mn = bp<uint32_t>(ctx->aux), *mx = mn + nseg;
-    hipLaunchKernelGGL(k_meta_init, dim3(grid_for(nseg, 256)), dim3(256), 0, st, nseg, flags, segtop, segleft,
-                       mn, mx); KCHK(ctx);
+    CHK(buf_ensure(ctx, ctx->aux, (size_t)nseg * 16 + 64));
+    uint32_t *mnmx = bp<uint32_t>(ctx->aux);
+    hipLaunchKernelGGL(k_meta_init2, dim3(grid_for(nseg, 256)), dim3(256), 0, st, nseg, flags, segtop, segleft,
+                       mnmx); KCHK(ctx);
     if (n == 0) return 0;
+    // both overlap strips per launch (three launches instead of six: a launch costs the fill phase 50-100 us
+    // of queueing under load, whatever it does)
     const uint32_t an_rows = overlap < ys ? overlap : ys, an_cols = overlap < xs ? overlap : xs;
-    for (int pass = 0; pass < 2; pass++) {
-        const int horizontal = pass == 0;
-        if (horizontal ? !has_top : !has_left) continue;
-        const uint32_t srows = horizontal ? an_rows : ys, scols = horizontal ? xs : an_cols;
-        if (srows * scols == 0) continue;
-        hipLaunchKernelGGL(k_strip_minmax, dim3(grid_for(scols, 64), grid_for(srows, AGG_ROWS)), dim3(256), 0, st,
-                           d_tile, xs, srows, scols, horizontal, mn, mx); KCHK(ctx);
-        hipLaunchKernelGGL(k_meta_cross, dim3(grid_for(nseg, 256)), dim3(256), 0, st, mn, mx,
-                           (horizontal ? srows : scols) / 2u, nseg,
-                           horizontal ? META_CROSS_TOP : META_CROSS_LEFT, flags); KCHK(ctx);
+    StripPair g{0u, 0u, 0u, 0u};
+    if (has_top && an_rows * xs != 0u) { g.rows0 = an_rows; g.cols0 = xs; }
+    if (has_left && ys * an_cols != 0u) { g.rows1 = ys; g.cols1 = an_cols; }
+    if (g.rows0 || g.rows1) {
+        const uint32_t mc = g.cols0 > g.cols1 ? g.cols0 : g.cols1, mr = g.rows0 > g.rows1 ? g.rows0 : g.rows1;
+        hipLaunchKernelGGL(k_strip_minmax2, dim3(grid_for(mc, 64), grid_for(mr, AGG_ROWS), 2), dim3(256), 0, st,
+                           d_tile, xs, g, mnmx, nseg); KCHK(ctx);
+        hipLaunchKernelGGL(k_meta_cross2, dim3(grid_for(nseg, 256)), dim3(256), 0, st, mnmx, nseg, g.rows0 / 2u,
+                           g.rows0 != 0u, g.cols1 / 2u, g.rows1 != 0u, flags); KCHK(ctx);
         if (d_cross) {
-            hipLaunchKernelGGL(k_cross_count, dim3(grid_for((size_t)srows * scols, 1024)), dim3(256), 0, st, d_tile,
-                               xs, srows, scols, flags, horizontal ? META_CROSS_TOP : META_CROSS_LEFT,
-                               d_cross + (horizontal ? 0 : 1)); KCHK(ctx);
+            const size_t m0 = (size_t)g.rows0 * g.cols0, m1 = (size_t)g.rows1 * g.cols1;
+            hipLaunchKernelGGL(k_cross_count2, dim3(grid_for(m0 > m1 ? m0 : m1, 1024), 2), dim3(256), 0, st, d_tile,
+                               xs, g, flags, d_cross); KCHK(ctx);
         }
     }
     hipLaunchKernelGGL(k_meta_pixels, dim3(grid_for(xs, 64), grid_for(ys, AGG_ROWS)), dim3(256), 0, st, d_tile,
