@@ -180,20 +180,29 @@ __global__ __launch_bounds__(256) void k_single_apply_list(uint32_t *__restrict_
 template <int DT>
 __global__ __launch_bounds__(1024) void k_single_tail(
     const void *__restrict__ img, int nb, uint32_t *seg, uint32_t *segsz, uint32_t *tgt_l, uint32_t n,
-    uint32_t nrows, uint32_t ncols, int four, const uint32_t *__restrict__ rest2,
-    const uint32_t *__restrict__ nrest2, const ImgGeom geom)
+    uint32_t nrows, uint32_t ncols, int four, uint32_t *rest2, const uint32_t *__restrict__ nrest2,
+    const ImgGeom geom)
 {
-    __shared__ uint32_t s_merged;
-    const uint32_t nr = *nrest2;
+    __shared__ uint32_t s_merged, s_next;
+    uint32_t nr = *nrest2;
+    // The list shrinks from pass to pass: what merged, or stopped being a single pixel because a neighbour
+    // merged INTO it, never comes back, so only the candidates that are still single and found no target yet
+    // are carried on (compacted into the other half of the list's buffer; their order is immaterial: a pass
+    // reads the state before any of its applies and the applies commute).  Without it every pass walked all
+    // nr entries, five rounds per thread for the one or two hundred that were still alive.
+    const bool compact = 2ull * nr <= (unsigned long long)n;
+    uint32_t *cur = rest2, *nxt = rest2 + nr;
     for (;;) {
-        if (threadIdx.x == 0) s_merged = 0u;
+        if (threadIdx.x == 0) { s_merged = 0u; s_next = 0u; }
         __syncthreads();
         for (uint32_t i = threadIdx.x; i < nr; i += 1024u) {
-            const uint32_t p = rest2[i];
+            const uint32_t p = cur[i];
             uint32_t out = NO_TARGET;
-            if (L2LOAD(&segsz[L2LOAD(&seg[p])]) == 1u)
+            bool single = L2LOAD(&segsz[L2LOAD(&seg[p])]) == 1u;
+            if (single)
                 out = single_target<DT, true>(img, nb, seg, segsz, p, n, nrows, ncols, four, geom);
             tgt_l[i] = out;                       // (read back by this thread only)
+            if (compact && single && out == NO_TARGET) nxt[atomicAdd(&s_next, 1u)] = p;
         }
         __threadfence();
         __syncthreads();
@@ -201,7 +210,7 @@ __global__ __launch_bounds__(1024) void k_single_tail(
         for (uint32_t i = threadIdx.x; i < nr; i += 1024u) {
             const uint32_t t = tgt_l[i];
             if (t == NO_TARGET) continue;
-            const uint32_t p = rest2[i];
+            const uint32_t p = cur[i];
             const uint32_t old = L2LOAD(&seg[p]);
             __hip_atomic_store(&seg[p], t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(&segsz[old], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -212,8 +221,14 @@ __global__ __launch_bounds__(1024) void k_single_tail(
         __threadfence();
         __syncthreads();
         const bool more = s_merged != 0u;
+        const uint32_t left = s_next;
         __syncthreads();
         if (!more) break;
+        if (compact) {
+            if (left == 0u) break;                // nobody left to look for a target
+            nr = left;
+            uint32_t *t = cur; cur = nxt; nxt = t;
+        }
     }
 }
 
