@@ -106,6 +106,50 @@ __global__ __launch_bounds__(256) void k_spectra_small(
     }
 }
 
+// The same for 8/16-bit pixel types, eight lanes per segment.  With |v| <= 65535 and at most 64 pixels every
+// partial sum of the reference's float32 accumulation is an integer below 2^24, hence exact, hence the order
+// of the additions is immaterial: the eight lanes of a group read consecutive list entries (one coalesced
+// load, and their image values lie in one or two cache lines per band, where a thread per segment had its
+// wavefront touch 64 unrelated lines per load and run as long as its longest segment), keep integer partial
+// sums and combine them with three shuffles.  The float32 conversion of the exact total is the reference's
+// value bit for bit.  (32-bit types keep the ordered kernel above.)
+template <int DT, int BG>
+__global__ __launch_bounds__(256) void k_spectra_small_grp(
+    const void *__restrict__ img, int nb, const uint32_t *__restrict__ pix,
+    const uint32_t *__restrict__ off, const uint32_t *__restrict__ segsz, float *__restrict__ ssum,
+    uint32_t S, const ImgGeom g, uint32_t first)
+{
+    static_assert(DT != SHP_I32 && DT != SHP_U32, "exact only while 64 values stay below 2^24");
+    const uint32_t gl = threadIdx.x & 7u;
+    const uint32_t s = (blockIdx.x * 256u + threadIdx.x) / 8u + first;
+    uint32_t m = 0, o = 0;
+    if (s <= S) { m = segsz[s]; o = off[s]; }
+    if (m > 64u) m = 0u;                                  // (the larger ones: k_spectra_big)
+    for (int b0 = 0; b0 < nb; b0 += BG) {
+        const int bg = nb - b0 < BG ? nb - b0 : BG;
+        const size_t base = (size_t)b0 * g.bstride;
+        int acc[BG];
+#pragma unroll
+        for (int j = 0; j < BG; j++) acc[j] = 0;
+        for (uint32_t i = gl; i < m; i += 8u) {
+            const size_t idx = geom_off(g, pix[o + i]);
+#pragma unroll
+            for (int j = 0; j < BG; j++) acc[j] += (int)ld_t<DT>(img, base + (size_t)(j < bg ? j : 0) * g.bstride + idx);
+        }
+#pragma unroll
+        for (int j = 0; j < BG; j++) {
+            acc[j] += __shfl_xor(acc[j], 4, 64);
+            acc[j] += __shfl_xor(acc[j], 2, 64);
+            acc[j] += __shfl_xor(acc[j], 1, 64);
+        }
+        if (gl == 0u && m != 0u) {
+#pragma unroll
+            for (int j = 0; j < BG; j++)
+                if (j < bg) ssum[(size_t)s * nb + b0 + j] = (float)acc[j];
+        }
+    }
+}
+
 // list[0] = number of segments with > 64 pixels (zeroed by k_small_init), ids from list[16]
 __global__ __launch_bounds__(256) void k_big_seg_list(const uint32_t *__restrict__ segsz, uint32_t S,
                                                       uint32_t *list, uint32_t first)
@@ -279,6 +323,19 @@ __global__ __launch_bounds__(256) void k_spectra_big(
     }
 }
 
+template <int DT, int BG>
+static void launch_spectra_small(hipStream_t st, unsigned gs, const void *d_img, int nb, uint32_t n, const uint32_t *pix,
+                                 const uint32_t *off, const uint32_t *segsz, float *ssum, uint32_t S,
+                                 const ImgGeom &geom, uint32_t first)
+{
+    if constexpr (DT == SHP_I32 || DT == SHP_U32)
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_spectra_small<DT, BG>), dim3(gs), dim3(256), 0, st, d_img, nb, n, pix, off,
+                           segsz, ssum, S, geom, first);
+    else
+        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_spectra_small_grp<DT, BG>), dim3(grid_for(((size_t)S + 1) * 8, 256)),
+                           dim3(256), 0, st, d_img, nb, pix, off, segsz, ssum, S, geom, first);
+}
+
 // float32 sums of segments first .. S (buildSegmentSpectra): the ids above 64 pixels are compacted into
 // biglist (its counter word biglist[0] must be zero), then the two kernels above
 static int launch_spectra(shp_ctx *ctx, const void *d_img, int dtype, int nb, uint32_t n, const uint32_t *pix,
@@ -291,8 +348,7 @@ static int launch_spectra(shp_ctx *ctx, const void *d_img, int dtype, int nb, ui
     KCHK(ctx);
 #define SPECTRA_LAUNCH(BGN)                                                                           \
     DISPATCH_DTYPE(dtype,                                                                             \
-        hipLaunchKernelGGL(HIP_KERNEL_NAME(k_spectra_small<DT, BGN>), dim3(gs), dim3(256), 0, st, d_img, \
-                           nb, n, pix, off, segsz, ssum, S, geom, first);                             \
+        launch_spectra_small<DT, BGN>(st, gs, d_img, nb, n, pix, off, segsz, ssum, S, geom, first);    \
         hipLaunchKernelGGL(HIP_KERNEL_NAME(k_spectra_big<DT, BGN>), dim3(SPECTRA_GRID), dim3(256), 0, st, \
                            d_img, nb, n, pix, off, segsz, ssum, biglist, geom))
     switch (nb >= SPECTRA_BG ? SPECTRA_BG : nb) {
