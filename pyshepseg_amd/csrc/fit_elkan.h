@@ -300,7 +300,7 @@ __global__ __launch_bounds__(256) void k_elk_init(const double *__restrict__ X, 
 // nearest other centre -- was tried: on the benchmark sample most samples fail that test in every
 // iteration, and the replay's dependent loads made the kernel three times slower.)
 // *ndiff += labels changed.
-#define ELK_AHEAD 8
+#define ELK_AHEAD 20          // bounds loads in flight per thread (8: 0.303 ms per pass on the benchmark sample, 20: 0.285)
 __global__ __launch_bounds__(256) void k_elk_estep(const double *__restrict__ X, uint32_t n, int nb,
                                                    const double *__restrict__ C, int k,
                                                    const double *__restrict__ half,
