@@ -300,6 +300,7 @@ __global__ __launch_bounds__(256) void k_elk_init(const double *__restrict__ X, 
 // nearest other centre -- was tried: on the benchmark sample most samples fail that test in every
 // iteration, and the replay's dependent loads made the kernel three times slower.)
 // *ndiff += labels changed.
+#define ELK_AHEAD_ANY 8        // the same for the one-pass kernel of k > 64
 #define ELK_AHEAD 20          // bounds loads in flight per thread (8: 0.303 ms per pass on the benchmark sample, 20: 0.285)
 __global__ __launch_bounds__(256) void k_elk_estep(const double *__restrict__ X, uint32_t n, int nb,
                                                    const double *__restrict__ C, int k,
@@ -324,15 +325,15 @@ __global__ __launch_bounds__(256) void k_elk_estep(const double *__restrict__ X,
         int fresh = -1;
         double fresh_val = 0.0;
         double *lbi = lb + i;
-        for (int j0 = 0; j0 < k; j0 += ELK_AHEAD) {
-            double pre[ELK_AHEAD];
+        for (int j0 = 0; j0 < k; j0 += ELK_AHEAD_ANY) {
+            double pre[ELK_AHEAD_ANY];
 #pragma unroll
-            for (int u = 0; u < ELK_AHEAD; u++) {
+            for (int u = 0; u < ELK_AHEAD_ANY; u++) {
                 const int jj = j0 + u < k ? j0 + u : k - 1;
                 pre[u] = lbi[(size_t)jj * n];
             }
 #pragma unroll
-            for (int u = 0; u < ELK_AHEAD; u++) {
+            for (int u = 0; u < ELK_AHEAD_ANY; u++) {
                 const int j = j0 + u;
                 if (j >= k) break;
                 double v;
