@@ -397,22 +397,26 @@ static int segment_device(shp_ctx *ctx, const void *d_img, uint32_t *d_seg, int 
                           uint32_t nrows, uint32_t ncols,
                           const double *centres, int k, int has_null, int64_t null_val, int four,
                           int min_seg_size, double msd, uint32_t *max_seg_id, int64_t *singles,
-                          int64_t *small, uint32_t *nclumps_out, bool have_clusters = false,
-                          const ImgGeom *geom = nullptr)
+                          int64_t *small, uint32_t *nclumps_out, const uint16_t *clus_window = nullptr,
+                          uint32_t clus_pitch = 0, const ImgGeom *geom = nullptr)
 {
     const uint32_t n = nrows * ncols;
-    CHK(buf_ensure(ctx, ctx->clus, (size_t)n * 2));
     CHK(buf_ensure(ctx, ctx->small, 4096));
     uint32_t *scal = bp<uint32_t>(ctx->small);
     hipEventRecord(ctx->ev[1], ctx->stream);
-    if (!have_clusters)         // (else ctx->clus already holds the tile's window of the cluster map)
+    const uint16_t *d_clus = clus_window;       // the tile's window of a raster-wide cluster map, read in place
+    if (!d_clus) {
+        CHK(buf_ensure(ctx, ctx->clus, (size_t)n * 2));
         CHK(launch_assign(ctx, d_img, dtype, nb, n, centres, k, has_null, null_val,
                           bp<uint16_t>(ctx->clus), nullptr));
+        d_clus = bp<uint16_t>(ctx->clus);
+        clus_pitch = ncols;
+    }
     hipEventRecord(ctx->ev[2], ctx->stream);
     CHK(buf_ensure(ctx, ctx->segsz, ((size_t)n + 2) * 4));
     CHK(buf_ensure(ctx, ctx->singles, ((size_t)n + 2) * 4));
-    CHK(run_clump(ctx, bp<uint16_t>(ctx->clus), nrows, ncols, four, d_seg, scal + 2, bp<uint32_t>(ctx->segsz),
-                  bp<uint32_t>(ctx->singles), scal + 3));
+    CHK(run_clump(ctx, d_clus, nrows, ncols, four, d_seg, scal + 2, bp<uint32_t>(ctx->segsz),
+                  bp<uint32_t>(ctx->singles), scal + 3, clus_pitch));
     // read back: number of clumps, number of one-pixel clumps, null-pixel count (scal[2..4])
     HIPCHK(ctx, hipMemcpyAsync(ctx->h_pinned, scal + 2, 12, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -709,12 +713,7 @@ API int shp_segment_window_dev(shp_ctx *ctx, const void *d_img, int dtype, int n
         geom.bstride = (size_t)img_rows * (size_t)img_cols;
         geom.origin = (size_t)y * (size_t)img_cols + (size_t)x;
         geom.pitch = (uint32_t)img_cols;
-        CHK(buf_ensure(ctx, ctx->clus, (size_t)n * 2));
-        const size_t rowbytes = (size_t)xs * 2;        // the window of the raster-wide cluster map
-        hipLaunchKernelGGL(k_window, dim3((unsigned)ys, grid_for((rowbytes + 15) / 16, 256)), dim3(256), 0,
-                           ctx->stream, (const uint8_t *)d_clusmap, 2u, (uint32_t)img_rows, (uint32_t)img_cols,
-                           (uint32_t)x, (uint32_t)y, (uint32_t)xs, (uint32_t)ys, (uint8_t *)ctx->clus.p);
-        KCHK(ctx);
+        // (the connected-component kernels read the window of the raster-wide cluster map in place too)
     } else if (!(x == 0 && y == 0 && xs == img_cols && ys == img_rows)) {
         const size_t total = (size_t)nbands * n;
         CHK(buf_ensure(ctx, ctx->img, total * dtype_size(dtype)));
@@ -726,9 +725,10 @@ API int shp_segment_window_dev(shp_ctx *ctx, const void *d_img, int dtype, int n
         KCHK(ctx);
         tile_img = ctx->img.p;
     }
+    const uint16_t *clus_window = d_clusmap ? (const uint16_t *)d_clusmap + (size_t)y * (size_t)img_cols + (size_t)x : nullptr;
     CHK(segment_device(ctx, tile_img, d_seg_out, dtype, nbands, ys, xs, centres, k, has_null, null_val,
                        four_connected, min_seg_size, max_spectral_diff, max_seg_id_out,
-                       singles_elim_out, small_elim_out, num_clumps_out, d_clusmap != nullptr, &geom));
+                       singles_elim_out, small_elim_out, num_clumps_out, clus_window, (uint32_t)img_cols, &geom));
     hipEventRecord(ctx->ev[6], ctx->stream);
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     collect_timings(ctx);

@@ -82,7 +82,7 @@ __global__ __launch_bounds__(256) void k_ccl_local(const uint16_t *__restrict__ 
                                                    uint32_t *__restrict__ lab,
                                                    uint32_t *__restrict__ csize, uint32_t nrows,
                                                    uint32_t ncols, int four, uint32_t *zero4,
-                                                   uint32_t *zero_a, uint32_t *zero_b)
+                                                   uint32_t *zero_a, uint32_t *zero_b, uint32_t cpitch)
 {
     // the scalars of the later clump kernels are zeroed here instead of by memset launches
     if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 8u) {
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void k_ccl_local(const uint16_t *__restrict__ 
 #pragma unroll
     for (uint32_t i = 0; i < CCL_ROWS / 4u; i++) {
         const uint32_t lr = wv * (CCL_ROWS / 4u) + i, r = prow0 + lr;
-        const uint32_t v = (cin && r < nrows) ? clus[(size_t)r * ncols + c] : 0u;
+        const uint32_t v = (cin && r < nrows) ? clus[(size_t)r * cpitch + c] : 0u;
         cv[i] = v;
         cl[lr * 64u + lane] = (uint16_t)v;
         sz[lr * 64u + lane] = 0u;
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(256) void k_ccl_local(const uint16_t *__restrict__ 
 // patch for the remaining rows.
 __global__ __launch_bounds__(256) void k_ccl_border(const uint16_t *__restrict__ clus, uint32_t *lab,
                                                     uint32_t nrows, uint32_t ncols, int four,
-                                                    uint32_t ntop, uint32_t npc)
+                                                    uint32_t ntop, uint32_t npc, uint32_t cpitch)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     uint32_t row, col;
@@ -178,17 +178,18 @@ __global__ __launch_bounds__(256) void k_ccl_border(const uint16_t *__restrict__
     }
     const uint32_t p = row * ncols + col;
     const bool topb = (row % CCL_ROWS) == 0u, leftb = (col & 63u) == 0u, rightb = (col & 63u) == 63u;
-    const uint32_t v = clus[p];
+    const size_t cp = (size_t)row * cpitch + col;          // (the cluster ids may be a window of a wider map)
+    const uint32_t v = clus[cp];
     if (v == 0u) return;
-    const bool L = col > 0 && clus[p - 1] == v;
-    const bool U = row > 0 && clus[p - ncols] == v;
-    const bool UL = row > 0 && col > 0 && clus[p - ncols - 1] == v;
+    const bool L = col > 0 && clus[cp - 1] == v;
+    const bool U = row > 0 && clus[cp - cpitch] == v;
+    const bool UL = row > 0 && col > 0 && clus[cp - cpitch - 1] == v;
     if (L && leftb) uf_merge(lab, p, p - 1);                       // row runs cut at a patch column
     if (U) {
         if (topb && !(L && UL)) uf_merge(lab, p, p - ncols);
     } else if (!four) {
         if (UL && !L && (topb || leftb)) uf_merge(lab, p, p - ncols - 1);
-        const bool UR = row > 0 && col + 1 < ncols && clus[p - ncols + 1] == v;
+        const bool UR = row > 0 && col + 1 < ncols && clus[cp - cpitch + 1] == v;
         if (UR && (topb || rightb)) uf_merge(lab, p, p - ncols + 1);
     }
 }
@@ -1346,8 +1347,9 @@ __global__ __launch_bounds__(256) void k_clump_final(const uint32_t *__restrict_
 // d_segsz (optional): receives the clump sizes, must hold n + 2 entries.
 static int run_clump(shp_ctx *ctx, const uint16_t *d_clus, uint32_t nrows, uint32_t ncols, int four,
                      uint32_t *d_seg, uint32_t *nclumps_dev, uint32_t *d_segsz = nullptr,
-                     uint32_t *d_singles = nullptr, uint32_t *d_nsingles = nullptr)
+                     uint32_t *d_singles = nullptr, uint32_t *d_nsingles = nullptr, uint32_t cpitch = 0)
 {
+    if (cpitch == 0u) cpitch = ncols;            // d_clus: nrows rows of ncols ids, cpitch ids apart
     const uint64_t n64 = (uint64_t)nrows * ncols;
     if (n64 >= 0x7fffffffull) SHP_FAIL(ctx, SHP_ERR_ARG, "tile too large (%llu px)", (unsigned long long)n64);
     if (nrows > 65535u || ncols > 65535u)
@@ -1373,12 +1375,12 @@ static int run_clump(shp_ctx *ctx, const uint16_t *d_clus, uint32_t nrows, uint3
     hipStream_t st = ctx->stream;
     int ps = prof_begin(ctx, PROF_CCL);
     hipLaunchKernelGGL(k_ccl_local, dim3(grid_for(ncols, 64), grid_for(nrows, CCL_ROWS)), dim3(256), 0, st, d_clus,
-                       lab, csize, nrows, ncols, four, counters, d_segsz, d_nsingles); KCHK(ctx);
+                       lab, csize, nrows, ncols, four, counters, d_segsz, d_nsingles, cpitch); KCHK(ctx);
     {
         const uint32_t ntop = (nrows + CCL_ROWS - 1u) / CCL_ROWS, npc = (ncols + 63u) / 64u;
         const size_t nborder = (size_t)ntop * ncols + (size_t)nrows * 2u * npc;
         hipLaunchKernelGGL(k_ccl_border, dim3(grid_for(nborder, 256)), dim3(256), 0, st, d_clus, lab, nrows, ncols,
-                           four, ntop, npc); KCHK(ctx);
+                           four, ntop, npc, cpitch); KCHK(ctx);
     }
     uint32_t *bigbits = bp<uint32_t>(ctx->bigbits), *rank = bp<uint32_t>(ctx->aux2);
     hipLaunchKernelGGL(k_ccl_flatten, dim3(g), dim3(256), 0, st, lab, n, csize, bigbits); KCHK(ctx);
