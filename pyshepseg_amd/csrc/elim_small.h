@@ -428,7 +428,8 @@ __global__ __launch_bounds__(256) void k_small_init(const uint32_t *src, uint32_
 #define SMALL_BALANCED_MAX 2048u      // passes with at most this many sources deal them round robin (three barriers)
 #define SMALL_SPIN_LIMIT GRID_SPIN_LIMIT
 
-struct SmallCnt { uint32_t nsrc, ntgt, nmerge, pad; };    // nmerge: sources that found a target
+struct SmallCnt { uint32_t nsrc, ntgt, nmerge, work; };   // nmerge: sources that found a target; work: the
+                                                          // next candidate of the size's lists nobody took yet
 struct SmallState { uint32_t target; int32_t prev; uint32_t passes; uint32_t pad; };
 struct SmallCtl {
     SmallState st[2];        // double-buffered loop state (slot parity)
@@ -458,6 +459,7 @@ struct SmallArgs {
     double thr2;
     int poll;           // s_sleep(8) repetitions between two polls of a grid barrier
     int bar2;           // two-level (per-XCD) grid barrier
+    int lists;          // per-size source lists instead of a scan of the size table per pass
     uint32_t *hopstat;  // SHEPSEG_SMALL_TIMING: counts chunk-chain hops of the find phase (else null)
 };
 
@@ -881,6 +883,52 @@ __global__ __launch_bounds__(256, SMALL_MINWAVES) void k_small_loop(SmallArgs a)
     }
     __syncthreads();
     const SmallBar bar = s_bar;
+    // ---- per-size source lists.  A pass needs the segments of exactly `target` pixels.  Sizes only grow, so
+    //      they are: the segments that HAD that size at entry (bysize: the ids below min_seg counting-sorted by
+    //      size, built here) plus the targets that GREW to it in an earlier pass (grown[size]: appended by the
+    //      merge phase, at most `cap` per size; a size that overflows is scanned for as before).  Either kind
+    //      may have grown on since: a candidate counts if its size is still the target's. ----
+    uint32_t *bstart = a.tcount, *gcount = a.tcount + (a.min_seg + 1u), *gover = gcount + a.min_seg,
+             *cursor = gover + a.min_seg;
+    uint32_t *bysize = a.tsorted, *grown = a.toff;
+    const uint32_t cap = (a.S + 1u) / (a.min_seg ? a.min_seg : 1u);
+    const bool lists = a.lists && a.min_seg >= 2u && a.min_seg <= 256u && 4u * a.min_seg + 1u <= a.S + 1u && cap >= 64u;
+    if (lists) {
+        if (blockIdx.x == 0) {
+            for (uint32_t u = threadIdx.x; u < a.min_seg; u += 256u) { gcount[u] = 0u; gover[u] = 0u; cursor[u] = 0u; }
+            if (threadIdx.x == 0) {
+                uint32_t acc = 0;
+                bstart[0] = 0u;
+                for (uint32_t u = 1; u <= a.min_seg; u++) { bstart[u] = acc; if (u < a.min_seg) acc += a.hist[u]; }
+            }
+        }
+        if (!(a.bar2 ? small_grid_barrier2(ctl, bar) : small_grid_barrier(ctl, G, a.poll))) return;
+        // counting sort, a contiguous range of ids per workgroup: sizes counted in LDS, one global atomic per
+        // (workgroup, size) to reserve the run (a global atomic per id put 77 000 of them on ONE address for the
+        // two-pixel segments of a tile -- a millisecond, and far more with twelve loops at it)
+        __shared__ uint32_t lbase[256];
+        const uint32_t per = (a.S + G - 1u) / G, lo = blockIdx.x * per + 1u;
+        const uint32_t hi = lo + per - 1u < a.S ? lo + per - 1u : a.S;
+        lhist[threadIdx.x] = 0u;
+        __syncthreads();
+        for (uint32_t sid = lo + threadIdx.x; sid <= hi; sid += 256u) {
+            const uint32_t m = a.segsz[sid];
+            if (m >= 1u && m < a.min_seg) atomicAdd(&lhist[m], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x < a.min_seg) {
+            const uint32_t c = lhist[threadIdx.x];
+            lbase[threadIdx.x] = c ? atomicAdd(&cursor[threadIdx.x], c) : 0u;
+            lhist[threadIdx.x] = 0u;
+        }
+        __syncthreads();
+        for (uint32_t sid = lo + threadIdx.x; sid <= hi; sid += 256u) {
+            const uint32_t m = a.segsz[sid];
+            if (m >= 1u && m < a.min_seg) bysize[bstart[m] + lbase[m] + atomicAdd(&lhist[m], 1u)] = sid;
+        }
+        __syncthreads();
+        if (!(a.bar2 ? small_grid_barrier2(ctl, bar) : small_grid_barrier(ctl, G, a.poll))) return;
+    }
     unsigned long long tmark = wall_clock64();
     SP_DECL
     for (uint32_t slot = 0;; slot++) {
@@ -910,7 +958,7 @@ __global__ __launch_bounds__(256, SMALL_MINWAVES) void k_small_loop(SmallArgs a)
                 ctl->st[par ^ 1u].target = target; ctl->st[par ^ 1u].prev = prev;
                 ctl->st[par ^ 1u].passes = passes;
                 SmallCnt *nx = &ctl->cnt[(slot + 1u) % 3u];
-                nx->nsrc = 0; nx->ntgt = 0; nx->nmerge = 0;
+                nx->nsrc = 0; nx->ntgt = 0; nx->nmerge = 0; nx->work = 0;
                 if (done) { ctl->done = 1; ctl->slots = slot; }
             }
         }
@@ -934,7 +982,56 @@ __global__ __launch_bounds__(256, SMALL_MINWAVES) void k_small_loop(SmallArgs a)
         //      four or five dependent find chains where the average is one -- so the sources are only
         //      LISTED by the scan, the grid meets once more, and the list is dealt round robin. ----
         const bool balanced = s_count <= SMALL_BALANCED_MAX;
-        {
+        const bool from_lists = lists && gover[target] == 0u;
+        if (from_lists) {
+            // the candidates of this size, dealt in even chunks of at most 256; no scan, no listing barrier
+            const uint32_t b0 = bstart[target], nb0 = bstart[target + 1u] - b0;
+            const uint32_t nc = nb0 + gcount[target];            // (no overflow: gcount <= cap)
+            const uint32_t npairs = target * (a.four ? 4u : 8u);
+            // (a third to a half of the candidates are stale, unevenly: a static deal left some wavefront with
+            //  three or four sources of 45 pixels where the average is one; so the wavefronts TAKE chunks from
+            //  a counter, about two per wavefront)
+            uint32_t chunk = (nc + 2u * gwaves - 1u) / (2u * gwaves);
+            chunk = chunk < 1u ? 1u : chunk > SMALL_BATCH_IDS ? SMALL_BATCH_IDS : chunk;
+            uint32_t wmerges = 0;
+            for (;;) {
+                uint32_t c0 = 0;
+                if (lane == 0) c0 = atomicAdd(&cnt->work, chunk);
+                c0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)c0);
+                if (c0 >= nc) break;
+                const uint32_t nn = nc - c0 < chunk ? nc - c0 : chunk;
+                uint32_t id[4];
+#pragma unroll
+                for (uint32_t u = 0; u < 4u; u++) {
+                    const uint32_t o = u * 64u + lane, ci = c0 + o;
+                    id[u] = 0u;
+                    if (o < nn) id[u] = ci < nb0 ? bysize[b0 + ci] : grown[(size_t)target * cap + (ci - nb0)];
+                }
+                uint32_t szv[4];
+#pragma unroll
+                for (uint32_t u = 0; u < 4u; u++) szv[u] = id[u] ? a.segsz[id[u]] : 0xFFFFFFFFu;
+                uint32_t nfound = 0;
+#pragma unroll
+                for (uint32_t u = 0; u < 4u; u++) {
+                    const bool ok = id[u] != 0u && szv[u] == target;
+                    const unsigned long long m = __ballot(ok);
+                    if (ok) wids[w][nfound + (uint32_t)__popcll(m & lanemask_lt())] = id[u];
+                    nfound += (uint32_t)__popcll(m);
+                }
+                if (nfound == 0u) continue;
+                __builtin_amdgcn_wave_barrier();
+                uint32_t gbase = 0;
+                if (lane == 0) gbase = atomicAdd(&cnt->nsrc, nfound);
+                gbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)gbase);
+                for (uint32_t q = lane; q < nfound; q += 64u) a.srclist[gbase + q] = wids[w][q];
+                if (npairs <= 256u) wmerges += find_merge_batch<4>(wids[w], nfound, target, a, cnt, wkeys[w]);
+                else for (uint32_t q = 0; q < nfound; q++)
+                    wmerges += find_merge_wave((uint32_t)__builtin_amdgcn_readfirstlane((int)wids[w][q]), target, a, wpix[w],
+                                               cnt) ? 1u : 0u;
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (wmerges && lane == 0) atomicAdd(&cnt->nmerge, wmerges);
+        } else {
             const uint32_t stride = gwaves * 64u;
             uint32_t wmerges = 0;
             for (uint32_t base = gwave * 64u; base < a.S; base += 4u * stride) {
@@ -1082,6 +1179,10 @@ __global__ __launch_bounds__(256, SMALL_MINWAVES) void k_small_loop(SmallArgs a)
             a.chtail[t] = tail;
             a.tfill[t] = 0;
             my_elim += n;
+            if (lists && sz < a.min_seg) {        // a source of a later pass: onto its size's list
+                const uint32_t gi = atomicAdd(&gcount[sz], 1u);
+                if (gi < cap) grown[(size_t)sz * cap + gi] = t; else gover[sz] = 1u;
+            }
             // histogram of sizes < min_seg: bins < 256 via LDS (signed deltas as uint32 wrap)
             if (a0 < a.min_seg) { if (a0 < 256u) atomicSub(&lhist[a0], 1u); else atomicSub(&a.hist[a0], 1u); }
             if (sz < a.min_seg) { if (sz < 256u) atomicAdd(&lhist[sz], 1u); else atomicAdd(&a.hist[sz], 1u); }
@@ -1191,6 +1292,8 @@ static int run_eliminate_small(shp_ctx *ctx, const void *d_img, int dtype, int n
     args.poll = poll_env < 1 ? 1 : poll_env;
     static const int bar2_env = getenv("SHEPSEG_SMALL_BAR2") ? atoi(getenv("SHEPSEG_SMALL_BAR2")) : 1;
     args.bar2 = bar2_env;
+    static const int lists_env = getenv("SHEPSEG_SMALL_LISTS") ? atoi(getenv("SHEPSEG_SMALL_LISTS")) : 1;
+    args.lists = lists_env;
     args.pin = (uint32_t *)pin;
     args.hopstat = getenv("SHEPSEG_SMALL_TIMING") ? &ctl->hopcnt : nullptr;
     pin->done = 0; pin->fail = 0;       // (a loop that gives up at a barrier leaves them so)
