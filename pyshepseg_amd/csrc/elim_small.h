@@ -990,8 +990,8 @@ __global__ __launch_bounds__(256, SMALL_MINWAVES) void k_small_loop(SmallArgs a)
             const uint32_t npairs = target * (a.four ? 4u : 8u);
             // (a third to a half of the candidates are stale, unevenly: a static deal left some wavefront with
             //  three or four sources of 45 pixels where the average is one; so the wavefronts TAKE chunks from
-            //  a counter, about two per wavefront)
-            uint32_t chunk = (nc + 2u * gwaves - 1u) / (2u * gwaves);
+            //  a counter, about four per wavefront)
+            uint32_t chunk = (nc + 4u * gwaves - 1u) / (4u * gwaves);
             chunk = chunk < 1u ? 1u : chunk > SMALL_BATCH_IDS ? SMALL_BATCH_IDS : chunk;
             uint32_t wmerges = 0;
             for (;;) {
@@ -1018,18 +1018,29 @@ __global__ __launch_bounds__(256, SMALL_MINWAVES) void k_small_loop(SmallArgs a)
                     if (ok) wids[w][nfound + (uint32_t)__popcll(m & lanemask_lt())] = id[u];
                     nfound += (uint32_t)__popcll(m);
                 }
+                SP_MARK(ctl, 1, sprof)
                 if (nfound == 0u) continue;
                 __builtin_amdgcn_wave_barrier();
                 uint32_t gbase = 0;
                 if (lane == 0) gbase = atomicAdd(&cnt->nsrc, nfound);
                 gbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)gbase);
                 for (uint32_t q = lane; q < nfound; q += 64u) a.srclist[gbase + q] = wids[w][q];
+                SP_MARK(ctl, 2, sprof)
                 if (npairs <= 256u) wmerges += find_merge_batch<4>(wids[w], nfound, target, a, cnt, wkeys[w]);
-                else for (uint32_t q = 0; q < nfound; q++)
+                else for (uint32_t q = 0; q < nfound; q++) {
+#ifdef SMALL_PROF
+                    wmerges += find_merge_wave((uint32_t)__builtin_amdgcn_readfirstlane((int)wids[w][q]), target, a, wpix[w],
+                                               cnt, sprof) ? 1u : 0u;
+                    if (sprof) ctl->prof[7] += 1;
+#else
                     wmerges += find_merge_wave((uint32_t)__builtin_amdgcn_readfirstlane((int)wids[w][q]), target, a, wpix[w],
                                                cnt) ? 1u : 0u;
+#endif
+                }
                 __builtin_amdgcn_wave_barrier();
+                SP_MARK(ctl, 3, sprof)
             }
+            SP_MARK(ctl, 1, sprof)
             if (wmerges && lane == 0) atomicAdd(&cnt->nmerge, wmerges);
         } else {
             const uint32_t stride = gwaves * 64u;
@@ -1344,7 +1355,7 @@ static int run_eliminate_small(shp_ctx *ctx, const void *d_img, int dtype, int n
             fprintf(stderr, "  pass %u: target %u, %u sources, find %.1f us, merge %.1f us, %u chain hops\n", i, pin->plog[i][0],
                     pin->plog[i][1], pin->plog[i][2] / 100.0, pin->plog[i][3] / 100.0, pin->phops[i]);
 #ifdef SMALL_PROF
-        fprintf(stderr, "  wave 0, passes >= 15, cycles: control %llu, scan %llu, list barrier %llu, finds %llu (%llu sources), find barrier %llu, relabel %llu, apply %llu, merge barrier %llu\n",
+        fprintf(stderr, "  wave 0, passes >= 15, cycles: control %llu, scan | take + validate %llu, list barrier | record %llu, finds %llu (%llu sources), find barrier %llu, relabel %llu, apply %llu, merge barrier %llu\n",
                 pin->prof[0], pin->prof[1], pin->prof[2], pin->prof[3], pin->prof[7], pin->prof[4], pin->prof[5], pin->prof[6], pin->prof[15]);
         fprintf(stderr, "    inside the finds: head %llu, gather %llu, neighbour ids %llu, sizes %llu, distances %llu, reduce %llu, link %llu\n",
                 pin->prof[8], pin->prof[9], pin->prof[10], pin->prof[11], pin->prof[12], pin->prof[13], pin->prof[14]);
