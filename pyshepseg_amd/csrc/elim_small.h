@@ -1153,11 +1153,20 @@ __global__ __launch_bounds__(256, SMALL_MINWAVES) void k_small_loop(SmallArgs a)
                 const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.mergeto[s]);
                 if (t == 0) continue;
                 const uint32_t last = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.chtail[s]);
-                for (uint32_t c = s;; c = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.chnext[c])) {
-                    const uint32_t o = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.off[c]);
-                    const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.origsz[c]);
+                // (a chunk's offset, length and successor are fetched together, the successor's while this
+                //  chunk's pixels are on their way)
+                uint32_t c = s;
+                uint32_t o = a.off[c], m = a.origsz[c], nx = a.chnext[c];
+                for (;;) {
+                    o = (uint32_t)__builtin_amdgcn_readfirstlane((int)o);
+                    m = (uint32_t)__builtin_amdgcn_readfirstlane((int)m);
+                    nx = (uint32_t)__builtin_amdgcn_readfirstlane((int)nx);
+                    const bool more = c != last && nx != 0u;
+                    uint32_t o2 = 0, m2 = 0, nx2 = 0;
+                    if (more) { o2 = a.off[nx]; m2 = a.origsz[nx]; nx2 = a.chnext[nx]; }
                     for (uint32_t j = lane; j < m; j += 64u) a.seg[a.pix[o + j]] = t;
-                    if (c == last) break;
+                    if (!more) break;
+                    c = nx; o = o2; m = m2; nx = nx2;
                 }
             }
         }
@@ -1172,19 +1181,34 @@ __global__ __launch_bounds__(256, SMALL_MINWAVES) void k_small_loop(SmallArgs a)
             const uint32_t t = a.tgtlist[i0];
             const uint32_t a0 = a.segsz[t];
             uint32_t sz = a0, tail = a.chtail[t], n = 0;
-            for (uint32_t s = a.tfill[t]; s != 0;) {
-                const uint32_t nxt = a.tlist[s];
-                for (int b = 0; b < a.nb; b++) {
-                    a.ssum[(size_t)t * a.nb + b] = a.ssum[(size_t)t * a.nb + b] + a.ssum[(size_t)s * a.nb + b];
-                    a.ssum[(size_t)s * a.nb + b] = 0.0f;
-                }
-                sz += a.segsz[s];
-                a.segsz[s] = 0;
-                a.chnext[tail] = s;
-                tail = a.chtail[s];
-                n++;                                 // (mergeto[s] stays: the relabel beside us reads it,
+            // the target's sums stay in registers (eight bands at a time) while its sources are added in
+            // ascending id; everything a source contributes -- its link, size, chain tail and sums -- is loaded
+            // together (band by band, with stores in between, every band was a round trip of its own)
+            for (int b0 = 0; b0 < a.nb; b0 += 8) {
+                float acc[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) acc[j] = b0 + j < a.nb ? a.ssum[(size_t)t * a.nb + b0 + j] : 0.0f;
+                for (uint32_t s = a.tfill[t]; s != 0;) {
+                    const uint32_t nxt = a.tlist[s];
+                    float add[8];
+#pragma unroll
+                    for (int j = 0; j < 8; j++) add[j] = b0 + j < a.nb ? a.ssum[(size_t)s * a.nb + b0 + j] : 0.0f;
+                    if (b0 == 0) {
+                        const uint32_t ssz = a.segsz[s], stail = a.chtail[s];
+                        sz += ssz;
+                        a.segsz[s] = 0;
+                        a.chnext[tail] = s;
+                        tail = stail;
+                        n++;                         // (mergeto[s] stays: the relabel beside us reads it,
                                                      //  and every pass rewrites it for its own sources)
-                s = nxt;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; j++)
+                        if (b0 + j < a.nb) { acc[j] = acc[j] + add[j]; a.ssum[(size_t)s * a.nb + b0 + j] = 0.0f; }
+                    s = nxt;
+                }
+#pragma unroll
+                for (int j = 0; j < 8; j++) if (b0 + j < a.nb) a.ssum[(size_t)t * a.nb + b0 + j] = acc[j];
             }
             a.segsz[t] = sz;
             a.chtail[t] = tail;
