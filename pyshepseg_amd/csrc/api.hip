@@ -1243,7 +1243,8 @@ static ReservePlan reserve_plan(int dtype, int nbands, size_t n)
     }
     pl.push_back({&shp_ctx::sort_hist, 2 * nh * 4});
     pl.push_back({&shp_ctx::scan_tmp, scan_tmp_bytes(n > nh ? n : nh)});
-    DevBuf shp_ctx::*perseg[] = {&shp_ctx::origsz, &shp_ctx::chnext, &shp_ctx::chtail, &shp_ctx::mergeto,
+    pl.push_back({&shp_ctx::chnext, ns * 16});       // the pass loop's chunk records (uint4 per segment)
+    DevBuf shp_ctx::*perseg[] = {&shp_ctx::origsz, &shp_ctx::mergeto,
                                  &shp_ctx::tcount, &shp_ctx::tfill, &shp_ctx::tsorted, &shp_ctx::srclist,
                                  &shp_ctx::tgtlist};
     for (auto m : perseg) pl.push_back({m, ns * 4});

@@ -7,7 +7,7 @@
 //   pix[]      pixel indices grouped by segment id, raster order inside a segment (a CSR built
 //              with one stable radix sort; == the reference's segLoc at entry, shepseg.py:880).
 //   off[s]     start of segment s in pix[]; origsz[s] its length at entry.
-//   chnext/chtail  a merged segment's pixel list is the chain of the ORIGINAL segments it
+//   ch[] (records {next, pixels, offset, tail})  a merged segment's pixel list is the chain of the ORIGINAL segments it
 //              absorbed, in merge order (doMerge appends the source's list to the target's,
 //              shepseg.py:1102-1110); iteration order == the reference's list order (N7).
 //   ssum[s][b] float32 spectral sums.  Built by an ordered float32 accumulation over the
@@ -371,8 +371,7 @@ static int launch_spectra(shp_ctx *ctx, const void *d_img, int dtype, int nb, ui
 // control block -- neither needs a copy launch of its own
 __global__ __launch_bounds__(256) void k_small_init(const uint32_t *src, uint32_t *segsz,
                                                     uint32_t *origsz,
-                                                    uint32_t *__restrict__ chnext,
-                                                    uint32_t *__restrict__ chtail,
+                                                    uint4 *__restrict__ ch,
                                                     uint32_t *__restrict__ mergeto,
                                                     uint32_t *__restrict__ tcount,
                                                     uint32_t *__restrict__ tfill, uint32_t *hist,
@@ -392,13 +391,14 @@ __global__ __launch_bounds__(256) void k_small_init(const uint32_t *src, uint32_
         const uint32_t m = src[s];
         segsz[s] = m;
         origsz[s] = m;
-        chnext[s] = 0;
-        chtail[s] = s;
         mergeto[s] = 0;
         tcount[s] = 0;
         tfill[s] = 0;
         if (s == 0u) tlist[0] = 0u;             // counter of k_big_seg_list
-        if (off_boff) off[s] += off_boff[s / SCAN_ITEMS];     // second level of the offset scan
+        uint32_t o = off[s];
+        if (off_boff) { o += off_boff[s / SCAN_ITEMS]; off[s] = o; }     // second level of the offset scan
+        // the segment's pixel list as ONE chunk: {next chunk, pixels, offset in pix[], last chunk of the chain}
+        ch[s] = make_uint4(0u, m, o, s);
         if (s >= 1u && m < min_seg) {
             if (m < 256u) atomicAdd(&lh[m], 1u);
             else atomicAdd(&hist[m], 1u);
@@ -453,7 +453,9 @@ struct SmallArgs {
     uint32_t *seg, *segsz;
     float *ssum;
     const uint32_t *pix, *off, *origsz;
-    uint32_t *chnext, *chtail, *mergeto, *tcount, *toff, *tfill, *tlist, *tsorted, *srclist, *tgtlist;
+    uint4 *ch;          // chunk records {next, pixels, offset, tail}: a merged segment's pixel list is the chain of
+                        // the original segments' runs in pix[] (one 16-byte load per hop)
+    uint32_t *mergeto, *tcount, *toff, *tfill, *tlist, *tsorted, *srclist, *tgtlist;
     uint32_t S, min_seg, nrows, ncols;
     int nb, four;
     double thr2;
@@ -561,8 +563,10 @@ __device__ __forceinline__ bool find_merge_wave(uint32_t s, uint32_t target, con
     unsigned long long best = ~0ull;         // (float bits of distSqr << 32) | order
     uint32_t bestnb = 0;
     uint32_t c = s, ci = 0;                  // chain cursor: chunk id, index inside the chunk
-    uint32_t co = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.off[c]);
-    uint32_t cm = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.origsz[c]);
+    uint4 rec = a.ch[c];
+    uint32_t co = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec.z);
+    uint32_t cm = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec.y);
+    uint32_t cn = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec.x);
     SP_MARK(a.ctl, 8, prof)
     for (uint32_t kbase = 0; kbase < target; kbase += 64u) {
         const uint32_t want = (target - kbase < 64u) ? (target - kbase) : 64u;
@@ -570,12 +574,14 @@ __device__ __forceinline__ bool find_merge_wave(uint32_t s, uint32_t target, con
         uint32_t got = 0;
         while (got < want) {
             if (ci >= cm) {
-                c = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.chnext[c]);
+                c = cn;
                 if (c == 0) break;
                 if (a.hopstat && lane == 0) atomicAdd(a.hopstat, 1u);
                 ci = 0;
-                co = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.off[c]);
-                cm = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.origsz[c]);
+                rec = a.ch[c];
+                co = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec.z);
+                cm = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec.y);
+                cn = (uint32_t)__builtin_amdgcn_readfirstlane((int)rec.x);
                 continue;
             }
             uint32_t take = cm - ci;
@@ -738,8 +744,9 @@ __device__ __forceinline__ uint32_t find_merge_batch(const uint32_t *ids, uint32
             src[u] = valid[u] ? ids[i0 + si[u]] : ids[i0];
             c[u] = src[u];
         }
+        uint32_t cx[U];                              // the chunks' successors
 #pragma unroll
-        for (int u = 0; u < U; u++) { cm[u] = a.origsz[c[u]]; co[u] = a.off[c[u]]; }
+        for (int u = 0; u < U; u++) { const uint4 r = a.ch[c[u]]; cx[u] = r.x; cm[u] = r.y; co[u] = r.z; }
         // ---- chain hops (the chunk chain = the reference's list order), all slots together ----
         bool need[U], hopped = false;
 #pragma unroll
@@ -748,18 +755,16 @@ __device__ __forceinline__ uint32_t find_merge_batch(const uint32_t *ids, uint32
 #pragma unroll
         for (int u = 0; u < U; u++) anyneed |= need[u];
         while (__any(anyneed)) {
-            uint32_t nx[U];
-#pragma unroll
-            for (int u = 0; u < U; u++) nx[u] = need[u] ? a.chnext[c[u]] : 0u;
 #pragma unroll
             for (int u = 0; u < U; u++)
                 if (need[u]) {
                     kk[u] -= cm[u];
-                    c[u] = nx[u];
-                    if (nx[u] == 0u) { valid[u] = false; need[u] = false; c[u] = src[u]; }
+                    c[u] = cx[u];
+                    if (cx[u] == 0u) { valid[u] = false; need[u] = false; c[u] = src[u]; }
                 }
 #pragma unroll
-            for (int u = 0; u < U; u++) if (need[u]) cm[u] = a.origsz[c[u]];
+            for (int u = 0; u < U; u++)
+                if (need[u]) { const uint4 r = a.ch[c[u]]; cx[u] = r.x; cm[u] = r.y; co[u] = r.z; }
 #pragma unroll
             for (int u = 0; u < U; u++) need[u] = need[u] && kk[u] >= cm[u];
             anyneed = false;
@@ -767,10 +772,7 @@ __device__ __forceinline__ uint32_t find_merge_batch(const uint32_t *ids, uint32
             for (int u = 0; u < U; u++) anyneed |= need[u];
             hopped = true;
         }
-        if (hopped) {
-#pragma unroll
-            for (int u = 0; u < U; u++) co[u] = a.off[c[u]];
-        }
+        (void)hopped;
         // ---- pixel, neighbour id, neighbour size ----
         uint32_t p[U], nbid[U], szn[U];
 #pragma unroll
@@ -1140,11 +1142,13 @@ __global__ __launch_bounds__(256, SMALL_MINWAVES) void k_small_loop(SmallArgs a)
                 const uint32_t s = a.srclist[i];
                 const uint32_t t = a.mergeto[s];
                 if (t == 0) continue;
-                const uint32_t last = a.chtail[s];
-                for (uint32_t c = s;; c = a.chnext[c]) {
-                    const uint32_t o = a.off[c], m = a.origsz[c];
-                    for (uint32_t j = 0; j < m; j++) a.seg[a.pix[o + j]] = t;
-                    if (c == last) break;
+                uint4 r = a.ch[s];
+                const uint32_t last = r.w;
+                for (uint32_t c = s;;) {
+                    for (uint32_t j = 0; j < r.y; j++) a.seg[a.pix[r.z + j]] = t;
+                    if (c == last || r.x == 0u) break;
+                    c = r.x;
+                    r = a.ch[c];
                 }
             }
         } else {
@@ -1152,21 +1156,21 @@ __global__ __launch_bounds__(256, SMALL_MINWAVES) void k_small_loop(SmallArgs a)
                 const uint32_t s = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.srclist[i]);
                 const uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.mergeto[s]);
                 if (t == 0) continue;
-                const uint32_t last = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.chtail[s]);
-                // (a chunk's offset, length and successor are fetched together, the successor's while this
-                //  chunk's pixels are on their way)
+                // (a chunk's record is one load; the successor's is fetched while this chunk's pixels are on
+                //  their way)
                 uint32_t c = s;
-                uint32_t o = a.off[c], m = a.origsz[c], nx = a.chnext[c];
+                uint4 r = a.ch[c];
+                const uint32_t last = (uint32_t)__builtin_amdgcn_readfirstlane((int)r.w);
                 for (;;) {
-                    o = (uint32_t)__builtin_amdgcn_readfirstlane((int)o);
-                    m = (uint32_t)__builtin_amdgcn_readfirstlane((int)m);
-                    nx = (uint32_t)__builtin_amdgcn_readfirstlane((int)nx);
+                    const uint32_t o = (uint32_t)__builtin_amdgcn_readfirstlane((int)r.z);
+                    const uint32_t m = (uint32_t)__builtin_amdgcn_readfirstlane((int)r.y);
+                    const uint32_t nx = (uint32_t)__builtin_amdgcn_readfirstlane((int)r.x);
                     const bool more = c != last && nx != 0u;
-                    uint32_t o2 = 0, m2 = 0, nx2 = 0;
-                    if (more) { o2 = a.off[nx]; m2 = a.origsz[nx]; nx2 = a.chnext[nx]; }
+                    uint4 r2 = r;
+                    if (more) r2 = a.ch[nx];
                     for (uint32_t j = lane; j < m; j += 64u) a.seg[a.pix[o + j]] = t;
                     if (!more) break;
-                    c = nx; o = o2; m = m2; nx = nx2;
+                    c = nx; r = r2;
                 }
             }
         }
@@ -1180,7 +1184,8 @@ __global__ __launch_bounds__(256, SMALL_MINWAVES) void k_small_loop(SmallArgs a)
         for (uint32_t i0 = gtid; i0 < ntgt; i0 += gthreads) {
             const uint32_t t = a.tgtlist[i0];
             const uint32_t a0 = a.segsz[t];
-            uint32_t sz = a0, tail = a.chtail[t], n = 0;
+            uint32_t *chw = (uint32_t *)a.ch;        // the records' words: [4 c] next, [4 c + 3] tail
+            uint32_t sz = a0, tail = chw[4u * (size_t)t + 3u], n = 0;
             // the target's sums stay in registers (eight bands at a time) while its sources are added in
             // ascending id; everything a source contributes -- its link, size, chain tail and sums -- is loaded
             // together (band by band, with stores in between, every band was a round trip of its own)
@@ -1194,10 +1199,10 @@ __global__ __launch_bounds__(256, SMALL_MINWAVES) void k_small_loop(SmallArgs a)
 #pragma unroll
                     for (int j = 0; j < 8; j++) add[j] = b0 + j < a.nb ? a.ssum[(size_t)s * a.nb + b0 + j] : 0.0f;
                     if (b0 == 0) {
-                        const uint32_t ssz = a.segsz[s], stail = a.chtail[s];
+                        const uint32_t ssz = a.segsz[s], stail = chw[4u * (size_t)s + 3u];
                         sz += ssz;
                         a.segsz[s] = 0;
-                        a.chnext[tail] = s;
+                        chw[4u * (size_t)tail] = s;
                         tail = stail;
                         n++;                         // (mergeto[s] stays: the relabel beside us reads it,
                                                      //  and every pass rewrites it for its own sources)
@@ -1211,7 +1216,7 @@ __global__ __launch_bounds__(256, SMALL_MINWAVES) void k_small_loop(SmallArgs a)
                 for (int j = 0; j < 8; j++) if (b0 + j < a.nb) a.ssum[(size_t)t * a.nb + b0 + j] = acc[j];
             }
             a.segsz[t] = sz;
-            a.chtail[t] = tail;
+            chw[4u * (size_t)t + 3u] = tail;
             a.tfill[t] = 0;
             my_elim += n;
             if (lists && sz < a.min_seg) {        // a source of a later pass: onto its size's list
@@ -1268,8 +1273,7 @@ static int run_eliminate_small(shp_ctx *ctx, const void *d_img, int dtype, int n
     CHK(buf_ensure(ctx, ctx->origsz, ns * 4));
     CHK(buf_ensure(ctx, ctx->off, ns * 4 + 16));
     CHK(buf_ensure(ctx, ctx->ssum, ns * nb * 4));
-    CHK(buf_ensure(ctx, ctx->chnext, ns * 4));
-    CHK(buf_ensure(ctx, ctx->chtail, ns * 4));
+    CHK(buf_ensure(ctx, ctx->chnext, ns * 16));           // the chunk records (uint4)
     CHK(buf_ensure(ctx, ctx->mergeto, ns * 4));
     CHK(buf_ensure(ctx, ctx->tcount, ns * 4));
     CHK(buf_ensure(ctx, ctx->toff, ns * 4 + 16));
@@ -1281,8 +1285,9 @@ static int run_eliminate_small(shp_ctx *ctx, const void *d_img, int dtype, int n
     CHK(buf_ensure(ctx, ctx->small, ((size_t)min_seg + 160) * 4));
     CHK(buf_ensure(ctx, ctx->scan_tmp, scan_tmp_bytes(ns > n ? ns : n)));
     uint32_t *segsz = bp<uint32_t>(ctx->segsz), *origsz = bp<uint32_t>(ctx->origsz);
-    uint32_t *off = bp<uint32_t>(ctx->off), *chnext = bp<uint32_t>(ctx->chnext);
-    uint32_t *chtail = bp<uint32_t>(ctx->chtail), *mergeto = bp<uint32_t>(ctx->mergeto);
+    uint32_t *off = bp<uint32_t>(ctx->off);
+    uint4 *ch = (uint4 *)ctx->chnext.p;
+    uint32_t *mergeto = bp<uint32_t>(ctx->mergeto);
     uint32_t *tcount = bp<uint32_t>(ctx->tcount), *toff = bp<uint32_t>(ctx->toff);
     uint32_t *tfill = bp<uint32_t>(ctx->tfill), *tlist = bp<uint32_t>(ctx->tlist);
     uint32_t *tsorted = bp<uint32_t>(ctx->tsorted);
@@ -1306,7 +1311,7 @@ static int run_eliminate_small(shp_ctx *ctx, const void *d_img, int dtype, int n
     CHK(scan_exclusive(ctx, szf, S + 1u, off, nullptr, stmp, &off_boff));
     const unsigned gs = grid_for((size_t)S + 1, 256);
     static_assert(sizeof(SmallCtl) % 4 == 0 && offsetof(SmallCtl, st) == 0, "SmallCtl layout");
-    hipLaunchKernelGGL(k_small_init, dim3(gs), dim3(256), 0, st, sizes, segsz, origsz, chnext, chtail,
+    hipLaunchKernelGGL(k_small_init, dim3(gs), dim3(256), 0, st, sizes, segsz, origsz, ch,
                        mergeto, tcount, tfill, hist, S, min_seg, tlist, (uint32_t *)ctl,
                        (uint32_t)(sizeof(SmallCtl) / 4), off, off_boff); KCHK(ctx);
     ps = prof_begin(ctx, PROF_SPECTRA);
@@ -1318,7 +1323,7 @@ static int run_eliminate_small(shp_ctx *ctx, const void *d_img, int dtype, int n
     SmallCtl *pin = (SmallCtl *)(ctx->h_pinned + 16);            // (the kernel above initialised ctl)
     SmallArgs args;
     args.ctl = ctl; args.hist = hist; args.seg = d_seg; args.segsz = segsz; args.ssum = ssum;
-    args.pix = pix; args.off = off; args.origsz = origsz; args.chnext = chnext; args.chtail = chtail;
+    args.pix = pix; args.off = off; args.origsz = origsz; args.ch = ch;
     args.mergeto = mergeto; args.tcount = tcount; args.toff = toff; args.tfill = tfill;
     args.tlist = tlist; args.tsorted = tsorted; args.srclist = srclist; args.tgtlist = tgtlist;
     args.S = S; args.min_seg = min_seg; args.nrows = nrows; args.ncols = ncols;
