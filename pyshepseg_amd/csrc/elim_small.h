@@ -488,8 +488,12 @@ __device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long v)
 // these lists): the list is kept in ascending source id by a lock-free sorted insert (head in
 // tfill[t], links in tlist[s]; inserts only, so a failed CAS simply retries), the first source to
 // arrive registers the target.
-__device__ __forceinline__ void link_source(const SmallArgs &a, SmallCnt *cnt, uint32_t s, uint32_t t)
+// Returns true if s is the first source of t in this pass: the caller registers the target (register_targets:
+// one atomic per wavefront, not per target -- tens of thousands of returning atomics on the one counter were a
+// large part of the early passes).
+__device__ __forceinline__ bool link_source(const SmallArgs &a, SmallCnt *cnt, uint32_t s, uint32_t t)
 {
+    bool first = false;
     for (uint32_t tries = 0;; tries++) {
         uint32_t prev = 0, cur = L2LOAD(&a.tfill[t]);
         while (cur != 0 && cur < s) { prev = cur; cur = L2LOAD(&a.tlist[cur]); }
@@ -500,7 +504,7 @@ __device__ __forceinline__ void link_source(const SmallArgs &a, SmallCnt *cnt, u
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         uint32_t *slot = prev ? &a.tlist[prev] : &a.tfill[t];
         if (atomicCAS(slot, cur, s) == cur) {
-            if (prev == 0 && cur == 0) a.tgtlist[atomicAdd(&cnt->ntgt, 1u)] = t;   // list was empty
+            first = prev == 0 && cur == 0;                                          // list was empty
             break;
         }
         if (tries > SMALL_SPIN_LIMIT) {
@@ -508,6 +512,17 @@ __device__ __forceinline__ void link_source(const SmallArgs &a, SmallCnt *cnt, u
             break;
         }
     }
+    return first;
+}
+// the lanes whose source opened its target's list append the targets to the pass's list (called by the whole wave)
+__device__ __forceinline__ void register_targets(const SmallArgs &a, SmallCnt *cnt, bool first, uint32_t t)
+{
+    const unsigned long long m = __ballot(first);
+    if (m == 0ull) return;
+    uint32_t base = 0;
+    if (lane_id() == (unsigned)__builtin_ctzll(m)) base = atomicAdd(&cnt->ntgt, (uint32_t)__popcll(m));
+    base = (uint32_t)__shfl((int)base, __builtin_ctzll(m), 64);
+    if (first) a.tgtlist[base + (uint32_t)__popcll(m & lanemask_lt())] = t;
 }
 
 // distSqr between the mean spectra of source s (n pixels) and of U neighbour segments (shepseg.py:1041-1049: band
@@ -663,10 +678,12 @@ __device__ __forceinline__ bool find_merge_wave(uint32_t s, uint32_t target, con
     if (wmin == ~0ull) { if (lane == 0) a.mergeto[s] = 0; return false; }
     const float bd = __uint_as_float((uint32_t)(wmin >> 32));
     const bool merges = !((double)bd > a.thr2);
+    bool first = false;
     if (best == wmin) {                      // unique: (k, position) differs between lanes
         a.mergeto[s] = merges ? bestnb : 0u;
-        if (merges) link_source(a, cnt, s, bestnb);
+        if (merges) first = link_source(a, cnt, s, bestnb);
     }
+    register_targets(a, cnt, first, bestnb);
     SP_MARK(a.ctl, 14, prof)
     return merges;                           // wave-uniform: does s merge in this pass?
 }
@@ -716,8 +733,10 @@ __device__ __forceinline__ void seg_dist_pairs(const SmallArgs &a, const uint32_
 
 template <int U>
 __device__ __forceinline__ uint32_t find_merge_batch(const uint32_t *ids, uint32_t count, uint32_t target,
-                                                     const SmallArgs &a, SmallCnt *cnt, unsigned long long *wkey)
+                                                     const SmallArgs &a, SmallCnt *cnt, unsigned long long *wkey,
+                                                     bool prof = false)
 {
+    SP_DECL
     const unsigned lane = lane_id();
     const uint32_t nq = a.four ? 4u : 8u;
     const float nf = (float)target;
@@ -744,6 +763,7 @@ __device__ __forceinline__ uint32_t find_merge_batch(const uint32_t *ids, uint32
             src[u] = valid[u] ? ids[i0 + si[u]] : ids[i0];
             c[u] = src[u];
         }
+        SP_MARK(a.ctl, 8, prof)
         uint32_t cx[U];                              // the chunks' successors
 #pragma unroll
         for (int u = 0; u < U; u++) { const uint4 r = a.ch[c[u]]; cx[u] = r.x; cm[u] = r.y; co[u] = r.z; }
@@ -774,6 +794,7 @@ __device__ __forceinline__ uint32_t find_merge_batch(const uint32_t *ids, uint32
         }
         (void)hopped;
         // ---- pixel, neighbour id, neighbour size ----
+        SP_MARK(a.ctl, 9, prof && cm[0] != 0xFFFFFFFFu)
         uint32_t p[U], nbid[U], szn[U];
 #pragma unroll
         for (int u = 0; u < U; u++) p[u] = a.pix[co[u] + (valid[u] ? kk[u] : 0u)];
@@ -794,11 +815,13 @@ __device__ __forceinline__ uint32_t find_merge_batch(const uint32_t *ids, uint32
             if (valid[u] && ii >= 0 && jj >= 0 && ii < (int)a.nrows && jj < (int)a.ncols)
                 nbid[u] = a.seg[(uint32_t)ii * a.ncols + (uint32_t)jj];
         }
+        SP_MARK(a.ctl, 10, prof && nbid[0] != 0xFFFFFFFFu)
 #pragma unroll
         for (int u = 0; u < U; u++) {
             if (nbid[u] == src[u]) nbid[u] = 0u;
             szn[u] = nbid[u] ? a.segsz[nbid[u]] : 0u;
         }
+        SP_MARK(a.ctl, 11, prof && szn[0] != 0xFFFFFFFFu)
         // ---- distances, each source's minimum ----
         unsigned long long key[U];
 #pragma unroll
@@ -827,24 +850,33 @@ __device__ __forceinline__ uint32_t find_merge_batch(const uint32_t *ids, uint32
             }
         }
         __builtin_amdgcn_wave_barrier();
-        // ---- the slot that holds its source's minimum decides (unique: (k, position) differs between
-        //      slots); a source without any candidate is reset by its first slot ----
+        SP_MARK(a.ctl, 12, prof)
+        // ---- the slot that holds its source's minimum (unique: (k, position) differs between slots) hands the
+        //      neighbour over; then a LANE PER SOURCE records the decision and links: all sources of the batch
+        //      in one round of the sorted insert's round trips (slot by slot it was up to U rounds) ----
+        uint32_t *wtgt = (uint32_t *)(wkey + SMALL_BATCH_SRC);
 #pragma unroll
-        for (int u = 0; u < U; u++) {
-            bool won = false;
-            if ((uint32_t)u * 64u + lane < nslots) {
-                const unsigned long long wm = wkey[si[u]];
-                if (wm == ~0ull) {
-                    if (kidx[u] == 0u && pos[u] == 0u) a.mergeto[src[u]] = 0u;
-                } else if (key[u] == wm) {
+        for (int u = 0; u < U; u++)
+            if ((uint32_t)u * 64u + lane < nslots && key[u] != ~0ull && key[u] == wkey[si[u]]) wtgt[si[u]] = nbid[u];
+        __builtin_amdgcn_wave_barrier();
+        {
+            bool won = false, first = false;
+            uint32_t t = 0u;
+            if (lane < nsrc) {
+                const uint32_t s = ids[i0 + lane];
+                const unsigned long long wm = wkey[lane];
+                if (wm != ~0ull) {
                     const float bd = __uint_as_float((uint32_t)(wm >> 32));
                     won = !((double)bd > a.thr2);
-                    a.mergeto[src[u]] = won ? nbid[u] : 0u;
-                    if (won) link_source(a, cnt, src[u], nbid[u]);
+                    t = wtgt[lane];
                 }
+                a.mergeto[s] = won ? t : 0u;
+                if (won) first = link_source(a, cnt, s, t);
             }
+            register_targets(a, cnt, first, t);
             merges += (uint32_t)__popcll(__ballot(won));
         }
+        SP_MARK(a.ctl, 14, prof)
         __builtin_amdgcn_wave_barrier();
     }
     return merges;
@@ -857,7 +889,7 @@ __global__ __launch_bounds__(256, SMALL_MINWAVES) void k_small_loop(SmallArgs a)
 {
     __shared__ uint32_t wpix[4][64];
     __shared__ uint32_t wids[4][SMALL_BATCH_IDS];
-    __shared__ unsigned long long wkeys[4][SMALL_BATCH_SRC];
+    __shared__ unsigned long long wkeys[4][SMALL_BATCH_SRC + SMALL_BATCH_SRC / 2u];     // keys, then the winners' targets
     __shared__ uint32_t s_target, s_done, s_count;
     __shared__ uint32_t lhist[256];
     SmallCtl *ctl = a.ctl;
@@ -936,7 +968,11 @@ __global__ __launch_bounds__(256, SMALL_MINWAVES) void k_small_loop(SmallArgs a)
     for (uint32_t slot = 0;; slot++) {
         const uint32_t par = slot & 1u;
 #ifdef SMALL_PROF
+#ifdef SMALL_PROF_EARLY
+        const bool sprof = gtid == 0u && (uint32_t)ctl->tphase[3] < 8u;
+#else
         const bool sprof = gtid == 0u && (uint32_t)ctl->tphase[3] >= 15u;
+#endif
 #endif
         SP_MARK(ctl, 15, false)
         // ---- loop control (identical in every workgroup; shepseg.py:970-997) ----
@@ -1028,7 +1064,11 @@ __global__ __launch_bounds__(256, SMALL_MINWAVES) void k_small_loop(SmallArgs a)
                 gbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)gbase);
                 for (uint32_t q = lane; q < nfound; q += 64u) a.srclist[gbase + q] = wids[w][q];
                 SP_MARK(ctl, 2, sprof)
+#ifdef SMALL_PROF
+                if (npairs <= 256u) wmerges += find_merge_batch<4>(wids[w], nfound, target, a, cnt, wkeys[w], sprof);
+#else
                 if (npairs <= 256u) wmerges += find_merge_batch<4>(wids[w], nfound, target, a, cnt, wkeys[w]);
+#endif
                 else for (uint32_t q = 0; q < nfound; q++) {
 #ifdef SMALL_PROF
                     wmerges += find_merge_wave((uint32_t)__builtin_amdgcn_readfirstlane((int)wids[w][q]), target, a, wpix[w],
@@ -1386,7 +1426,7 @@ static int run_eliminate_small(shp_ctx *ctx, const void *d_img, int dtype, int n
 #ifdef SMALL_PROF
         fprintf(stderr, "  wave 0, passes >= 15, cycles: control %llu, scan | take + validate %llu, list barrier | record %llu, finds %llu (%llu sources), find barrier %llu, relabel %llu, apply %llu, merge barrier %llu\n",
                 pin->prof[0], pin->prof[1], pin->prof[2], pin->prof[3], pin->prof[7], pin->prof[4], pin->prof[5], pin->prof[6], pin->prof[15]);
-        fprintf(stderr, "    inside the finds: head %llu, gather %llu, neighbour ids %llu, sizes %llu, distances %llu, reduce %llu, link %llu\n",
+        fprintf(stderr, "    inside the finds (a wavefront per source: head, gather, ...; batches: slots, chunk records + hops, pixels + neighbour ids, sizes, distances + minima, -, decide + link): %llu, %llu, %llu, %llu, %llu, %llu, %llu\n",
                 pin->prof[8], pin->prof[9], pin->prof[10], pin->prof[11], pin->prof[12], pin->prof[13], pin->prof[14]);
 #endif
         fprintf(stderr, "  workgroups per XCD:");
