@@ -485,15 +485,26 @@ __global__ __launch_bounds__(256) void k_elk_offsets(const uint32_t *__restrict_
 // numbers by label), one chain per (cluster, band): a lane per band, FIT_ROWS_AHEAD independent loads in
 // flight, the additions one after the other.  grid (k, ceil(nb / 64)).
 #define FIT_ROWS_AHEAD 32
+// (the clusters' ranges of the row list: off[j] .. off[j + 1], or -- dg.hscan given -- read off the scanned digit
+//  histogram of the one-pass radix sort that made the list)
+struct FitDigits { const uint32_t *hscan, *boff; uint32_t nblk, n; };
+__device__ __forceinline__ void fit_range(const uint32_t *off, const FitDigits &dg, int j, uint32_t *q0, uint32_t *q1)
+{
+    if (dg.hscan) {
+        *q0 = sort_digit_start(dg.hscan, dg.boff, dg.nblk, (uint32_t)j, dg.n);
+        *q1 = sort_digit_start(dg.hscan, dg.boff, dg.nblk, (uint32_t)j + 1u, dg.n);
+    } else { *q0 = off[j]; *q1 = off[j + 1]; }
+}
 __global__ __launch_bounds__(64) void k_fit_sum_lists(const double *__restrict__ X, int nb,
                                                       const uint32_t *__restrict__ rows,
                                                       const uint32_t *__restrict__ off,
                                                       double *__restrict__ S, double *__restrict__ cnt,
-                                                      const uint32_t *stop)
+                                                      const uint32_t *stop, FitDigits dg)
 {
     if (stop && *stop) return;
     const int j = blockIdx.x, b = blockIdx.y * 64 + threadIdx.x;
-    const uint32_t q0 = off[j], q1 = off[j + 1];
+    uint32_t q0, q1;
+    fit_range(off, dg, j, &q0, &q1);
     if (b == 0) cnt[j] = (double)(q1 - q0);
     if (b >= nb) return;
     double acc = 0.0;
@@ -602,13 +613,14 @@ __global__ __launch_bounds__(FIT_SUM_THREADS) void k_fit_sum_lists_staged(const 
                                                              const uint32_t *__restrict__ rows,
                                                              const uint32_t *__restrict__ off,
                                                              double *__restrict__ S, double *__restrict__ cnt,
-                                                             const uint32_t *stop)
+                                                             const uint32_t *stop, FitDigits dg)
 {
     if (stop && *stop) return;
     constexpr uint32_t BUF = FIT_STAGE_DOUBLES + 4u * 64u;        // nb runs of B + 4 doubles, nb <= 64
     __shared__ __attribute__((aligned(16))) double sx[2u * BUF];
     const int j = blockIdx.x;
-    const uint32_t q0 = off[j], q1 = off[j + 1];
+    uint32_t q0, q1;
+    fit_range(off, dg, j, &q0, &q1);
     const uint32_t unb = (uint32_t)nb;
     const uint32_t B = (FIT_STAGE_DOUBLES / unb) & ~31u;         // rows per block (whole 32-row groups of the chain)
     const uint32_t pitch = B + 4u;                               // doubles between two bands' runs: bands 8 banks apart
@@ -742,6 +754,7 @@ __global__ __launch_bounds__(1024) void k_elk_update(double *__restrict__ S, con
                                                     ElkCtl *ctl, double tol, uint32_t it)
 {
     if (ctl->stop) return;
+    if (threadIdx.x == 0) ctl->nd[(it + 1u) & 1u] = 0u;          // the next E-step's change counter
     __shared__ int s_empty;
     const int kn = k * nb;
     if (threadIdx.x == 0) s_empty = 0;
@@ -884,14 +897,21 @@ static int run_fit_elkan(shp_ctx *ctx, const double *dX, XAt Xat, uint32_t n, in
             CHK(estep(&dctl->nd[it & 1], dstop));
             // row lists: the row numbers sorted stably by label
             uint32_t *ks = nullptr, *rows = nullptr;
-            CHK(sort_pairs(ctx, (const uint32_t *)dlab, nullptr, n, bits_for((uint32_t)(k - 1)), &ks, &rows));
-            hipLaunchKernelGGL(k_elk_offsets, dim3(grid_for((size_t)k + 1, 256)), dim3(256), 0, st, ks, n, k, doff,
-                               &dctl->nd[(it + 1) & 1], dstop); KCHK(ctx);
+            SortDigits sd;
+            CHK(sort_pairs(ctx, (const uint32_t *)dlab, nullptr, n, bits_for((uint32_t)(k - 1)), &ks, &rows, false, &sd));
+            // with one radix pass (k <= 256) the clusters' ranges are in the sort's own scanned histogram:
+            // no search kernel (k_elk_update zeroes the next E-step's counter)
+            FitDigits dg{nullptr, nullptr, 0u, n};
+            if (sd.passes == 1) { dg.hscan = sd.hscan; dg.boff = sd.boff; dg.nblk = sd.nblk; }
+            else {
+                hipLaunchKernelGGL(k_elk_offsets, dim3(grid_for((size_t)k + 1, 256)), dim3(256), 0, st, ks, n, k, doff,
+                                   &dctl->nd[(it + 1) & 1], dstop); KCHK(ctx);
+            }
             if (nb <= 64)
-                hipLaunchKernelGGL(k_fit_sum_lists_staged, dim3(k), dim3(FIT_SUM_THREADS), 0, st, dX, nb, rows, doff, dS, dcnt, dstop);
+                hipLaunchKernelGGL(k_fit_sum_lists_staged, dim3(k), dim3(FIT_SUM_THREADS), 0, st, dX, nb, rows, doff, dS, dcnt, dstop, dg);
             else
                 hipLaunchKernelGGL(k_fit_sum_lists, dim3(k, (nb + 63) / 64), dim3(64), 0, st, dX, nb, rows, doff, dS, dcnt,
-                                   dstop);
+                                   dstop, dg);
             KCHK(ctx);
             hipLaunchKernelGGL(k_elk_update, dim3(1), dim3(1024), 0, st, dS, dcnt, k, nb, dC, dcshift, dhalf, dnext, dscr,
                                dctl, tol, (uint32_t)it); KCHK(ctx);

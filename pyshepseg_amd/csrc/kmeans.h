@@ -731,10 +731,10 @@ static int run_kmeans_fit(shp_ctx *ctx, const void *xin_any, int xdtype, int64_t
                                    doff + k + 1, &dctl->stop); KCHK(ctx);
                 if (nb <= 64)
                     hipLaunchKernelGGL(k_fit_sum_lists_staged, dim3(k), dim3(FIT_SUM_THREADS), 0, st, dX, nb, rows, doff, dpart2,
-                                       dcntd, &dctl->stop);
+                                       dcntd, &dctl->stop, FitDigits{nullptr, nullptr, 0u, n});
                 else
                     hipLaunchKernelGGL(k_fit_sum_lists, dim3(k, (nb + 63) / 64), dim3(64), 0, st, dX, nb, rows, doff,
-                                       dpart2, dcntd, &dctl->stop);
+                                       dpart2, dcntd, &dctl->stop, FitDigits{nullptr, nullptr, 0u, n});
                 KCHK(ctx);
                 hipLaunchKernelGGL(k_fit_counts, dim3(grid_for((size_t)k, 256)), dim3(256), 0, st, doff, k, dpc2,
                                    &dctl->stop); KCHK(ctx);

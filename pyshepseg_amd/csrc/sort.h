@@ -221,8 +221,19 @@ static inline int bits_for(uint32_t maxval)      // significant bits of the larg
 // scratch.  On return *keys_sorted / *vals_sorted point at the buffers holding the result
 // (vals always end up in ctx->pix or ctx->sort_v1).  keys_sorted == nullptr: the caller only wants
 // the values, the last pass does not write the keys.
+// digits_out (optional): where the LAST pass's scanned digit histogram lies -- with a single pass (bits <= 8)
+// entry d * nblk of it (+ the scan's block offset) is the position of the first key equal to d.
+struct SortDigits { const uint32_t *hscan = nullptr, *boff = nullptr; uint32_t nblk = 0; int passes = 0; };
+__device__ __forceinline__ uint32_t sort_digit_start(const uint32_t *hscan, const uint32_t *boff, uint32_t nblk,
+                                                     uint32_t d, uint32_t n)
+{
+    if (d >= 256u) return n;
+    const uint32_t hi = d * nblk;
+    return hscan[hi] + (boff ? boff[hi / SCAN_ITEMS] : 0u);
+}
 static int sort_pairs(shp_ctx *ctx, const uint32_t *keys_in, const uint32_t *vals_in, uint32_t n,
-                      int bits, uint32_t **keys_sorted, uint32_t **vals_sorted, bool staged = false)
+                      int bits, uint32_t **keys_sorted, uint32_t **vals_sorted, bool staged = false,
+                      SortDigits *digits_out = nullptr)
 {
     // SHEPSEG_SORT_WIDE=1: the staged form with 4096 items per workgroup (half the block histograms, 64-byte
     // runs per digit).  Measured on C5: histogram passes 3.8 -> 3.2 ms, scatter passes 9.2 -> 11.2 ms (116
@@ -268,6 +279,7 @@ static int sort_pairs(shp_ctx *ctx, const uint32_t *keys_in, const uint32_t *val
                                vout, n, p * 8, hscan, nblk, boff);
         KCHK(ctx);
         kin = kout; vin = vout;
+        if (digits_out) { digits_out->hscan = hscan; digits_out->boff = boff; digits_out->nblk = nblk; digits_out->passes = passes; }
     }
     if (keys_sorted) *keys_sorted = (uint32_t *)kin;
     *vals_sorted = (uint32_t *)vin;
