@@ -1026,6 +1026,7 @@ API int shp_histogram_dev(shp_ctx *ctx, const uint32_t *d_raster, int64_t npix, 
         ctx->h_fit_cap = hbytes + hbytes / 4;
     }
     lap("launched");
+    if (io_timing) { HIPCHK(ctx, hipStreamSynchronize(ctx->stream)); lap("kernel done"); }
     HIPCHK(ctx, hipMemcpyAsync(ctx->h_fit, h, hbytes, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     lap("on the host");
