@@ -119,14 +119,39 @@ def cpu_baseline(ras, args, centres, msd):
     order = sorted(tiles, key=lambda k: -(tiles[k][2] * tiles[k][3]))
     with ThreadPoolExecutor(nthreads) as ex:
         local = dict(ex.map(one, order))
-    oracle.stitch_tiles(local, tiles, ntc, ntr, w, w, args.overlap)
+    (mosaic, mosaicMax, mosaicHist) = oracle.stitch_tiles(local, tiles, ntc, ntr, w, w, args.overlap)
     dt = time.time() - t0
-    return {"value": round(w * w / dt / 1e6, 3), "unit": "Mpixels/s", "cores": nthreads, "kind": "port",
+    check = gpu_window_check(args, w, centres, mosaic, mosaicMax, mosaicHist)
+    return {"gpu_equals_oracle_on_sample": check, "value": round(w * w / dt / 1e6, 3), "unit": "Mpixels/s", "cores": nthreads, "kind": "port",
             "single_thread_value": round(xs0 * ys0 / t_one / 1e6 / 1.64, 3),
             "sample": "top-left %dx%d window of the same synthetic image, %d tiles (tile %d / overlap %d) "
                       "one per thread on %d threads + stitch: %.1f s of C oracle; single_thread_value = one "
                       "%dx%d tile alone (%.1f s) per output pixel (tiled runs process 1.64 x the image)"
                       % (w, w, len(tiles), args.tile, args.overlap, nthreads, dt, xs0, ys0, t_one)}
+
+
+def gpu_window_check(args, w, centres, mosaic, mosaicMax, mosaicHist):
+    """The checker's other use: the SAME window through the device path (untimed, the model handed in),
+    compared bit for bit with the oracle's stitched mosaic of the cpu_baseline leg."""
+    from pyshepseg_amd import tiling, shepseg, _lib
+    ras = tiling.DeviceRaster.synth(args.seed, args.bands, w, w)
+    try:
+        r = tiling.doTiledShepherdSegmentation(
+            ras, tiling._KEEP_ON_DEVICE, tileSize=args.tile, overlapSize=args.overlap, minSegmentSize=50,
+            numClusters=60, kmeansObj=shepseg.KMeansModel(np.ascontiguousarray(centres, dtype=np.float64)),
+            concurrencyCfg=tiling.SegmentationConcurrencyConfig(concurrencyType=tiling.CONC_THREADS,
+                                                                numWorkers=min(args.workers, 16)))
+        got = np.empty((w, w), dtype=np.uint32)
+        c = _lib.ctx()
+        c.check(c._L.shp_dev_download(c.handle, _lib.ptr(got), ctypes.c_void_p(r.outDev[0]), got.nbytes))
+        tiling.freeDeviceOutput(r)
+    finally:
+        ras.free()
+    ok = (int(r.maxSegId) == int(mosaicMax) and np.array_equal(got, mosaic) and
+          np.array_equal(np.asarray(r.hist).astype(np.int64), mosaicHist.astype(np.int64)))
+    if not ok:
+        sys.stderr.write('bench.py: the device mosaic of the %d x %d cpu_baseline window DIFFERS from the oracle\n' % (w, w))
+    return bool(ok)
 
 
 def spawn_ranks(args):
