@@ -9,7 +9,7 @@ reference's own k-means model of the full raster (tests/golden/c3_fit_reference.
 c4_fit_reference.npz).  Compared bit for bit: the mosaic, maxSegId, the histogram.
 
   C3: top-left 14336^2 of synthimg(11, 6, ...): 4 x 4 tiles, the last row / column grown to 5120.
-  C4: top-left 22528 x 13312 of synthimg(13, 10, ...): 7 x 4 tiles of 4096^2; it holds tile (5, 2)
+  C4: top-left 23552 x 14336 of synthimg(13, 10, ...): 7 x 4 tiles (last row / column 5120); it holds tile (5, 2)
       of the full job with both its neighbours, whose 10 716-pixel segment the reference's stitch
       recodes to 0 (the mode of the neighbour strip is 0: tests/diag_c4_zeros.py,
       tests/golden/stitch_quirk_zeros) -- labelled pixels that end up unlabelled, a stitch outcome
@@ -95,7 +95,7 @@ def test_c4_window_mosaic_vs_oracle(oracle):
     """28 ten-band tiles of the C4 raster around the full job's tile (5, 2): the window keeps that
     tile and its upper / left neighbours exactly as the full job has them (same pixels, same
     trimmed windows), so the segment the reference's stitch recodes to 0 is in the comparison."""
-    (got, tiles, r) = _run(oracle, 13, 10, 13312, 22528, 'c4_fit_reference.npz')
+    (got, tiles, r) = _run(oracle, 13, 10, 14336, 23552, 'c4_fit_reference.npz')
     assert len(tiles) == 28 and r.numTileRows == 4 and r.numTileCols == 7
     assert tiles[(5, 2)] == (15360, 6144, 4096, 4096)
     # the quirk itself: labelled pixels recoded to 0 inside tile (5, 2)'s trimmed window
