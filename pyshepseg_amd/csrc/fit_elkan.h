@@ -267,6 +267,8 @@ static void elk_half_distances(const double *C, int k, int nb, double *half, dou
     }
 }
 
+#include "fit_bounds.h"        // k <= 64: the E-step without a table of exact bounds
+
 // init_bounds_dense: lb is cluster-major (lb[j * n + i]), zero-filled by the caller
 __global__ __launch_bounds__(256) void k_elk_init(const double *__restrict__ X, uint32_t n, int nb,
                                                   const double *__restrict__ C, int k,
@@ -751,7 +753,7 @@ __global__ __launch_bounds__(1024) void k_elk_update(double *__restrict__ S, con
                                                     int k, int nb, double *__restrict__ C,
                                                     double *__restrict__ cshift, double *__restrict__ half,
                                                     double *__restrict__ next, double *__restrict__ scratch,
-                                                    ElkCtl *ctl, double tol, uint32_t it)
+                                                    ElkCtl *ctl, double tol, uint32_t it, ElkHist hist)
 {
     if (ctl->stop) return;
     if (threadIdx.x == 0) ctl->nd[(it + 1u) & 1u] = 0u;          // the next E-step's change counter
@@ -797,6 +799,14 @@ __global__ __launch_bounds__(1024) void k_elk_update(double *__restrict__ S, con
         half[e] = __builtin_sqrt(v) / 2.0;
     }
     for (int t = threadIdx.x; t < kn; t += 1024) C[t] = S[t];
+    if (hist.cs) {              // fit_bounds.h: this iteration's shifts, their running sums, the next E-step's centres
+        for (int j = threadIdx.x; j < k; j += 1024) {
+            hist.cs[(size_t)it * k + j] = cshift[j];
+            hist.csT[(size_t)j * hist.rows + it] = cshift[j];
+            hist.cum[((size_t)it + 1u) * k + j] = hist.cum[(size_t)it * k + j] + cshift[j];
+        }
+        for (int t = threadIdx.x; t < kn; t += 1024) hist.cen[((size_t)it + 1u) * kn + t] = S[t];
+    }
     __syncthreads();
     for (int l = threadIdx.x; l < k; l += 1024) {
         double m0 = half[l], m1 = -1.0;
@@ -837,11 +847,38 @@ static int run_fit_elkan(shp_ctx *ctx, const double *dX, XAt Xat, uint32_t n, in
 {
     const int kn = k * nb;
     hipStream_t st = ctx->stream;
-    CHK(buf_ensure(ctx, ctx->fit_lb, ((size_t)k * n + n) * 8));
+    // k <= 64: no table of exact bounds (fit_bounds.h): n x k float32 brackets + n x k 2-byte stamps + the upper
+    // bounds, and the history of shifts / their running sums / centres per iteration.  SHEPSEG_ELK_TABLE=1: the
+    // round-3 form (the exact table, cluster-major), which k > 64 always takes.
+    const bool lazy = k <= 64 && nb <= 64 && max_iter < 65000 &&
+                      !(getenv("SHEPSEG_ELK_TABLE") && atoi(getenv("SHEPSEG_ELK_TABLE")) != 0);
+    const size_t hist_rows = (size_t)max_iter + 3;
+    const size_t hist_doubles = lazy ? hist_rows * ((size_t)3 * k + kn) : 0;
+    if (lazy) CHK(buf_ensure(ctx, ctx->fit_lb, (size_t)n * k * 6 + 512 + (size_t)n * 8 * 3 + hist_doubles * 8 + 64));
+    else CHK(buf_ensure(ctx, ctx->fit_lb, ((size_t)k * n + n) * 8));
     // small device block: C | cshift | half | next | S | cnt | scratch (2k) | ctl | off (k + 1)
     const size_t small_doubles = (size_t)kn + k + (size_t)k * k + k + kn + k + 2 * (size_t)k;
     CHK(buf_ensure(ctx, ctx->fit_part, small_doubles * 8 + sizeof(ElkCtl) + ((size_t)k + 2) * 4 + 64));
     double *dlb = bp<double>(ctx->fit_lb), *dub = dlb + (size_t)k * n;
+    float *dA = nullptr;
+    uint16_t *dstamps = nullptr;
+    ElkHist hist{nullptr, nullptr, nullptr, nullptr, 0u};
+    unsigned long long *ddiag = nullptr, *dcmask = nullptr, *dmmask = nullptr;
+    if (lazy) {
+        // ub | cmask | mmask | hist (cs, cum, cen) | diag | A | stamps
+        dub = bp<double>(ctx->fit_lb);
+        dcmask = (unsigned long long *)(dub + n);
+        dmmask = dcmask + n;
+        hist.cs = (double *)(dmmask + n);
+        hist.cum = hist.cs + hist_rows * k;
+        hist.cen = hist.cum + hist_rows * k;
+        hist.csT = hist.cen + hist_rows * kn;
+        hist.rows = (uint32_t)hist_rows;
+        ddiag = (unsigned long long *)(hist.csT + hist_rows * k);
+        dA = (float *)(((uintptr_t)(ddiag + 8) + 255u) & ~(uintptr_t)255u);
+        dstamps = (uint16_t *)(dA + (size_t)n * k);
+        dlb = nullptr;
+    }
     double *dC = bp<double>(ctx->fit_part), *dcshift = dC + kn, *dhalf = dcshift + k, *dnext = dhalf + (size_t)k * k;
     double *dS = dnext + k, *dcnt = dS + kn, *dscr = dcnt + k;
     ElkCtl *dctl = (ElkCtl *)(dscr + 2 * (size_t)k);
@@ -876,11 +913,59 @@ static int run_fit_elkan(shp_ctx *ctx, const double *dX, XAt Xat, uint32_t n, in
     elk_half_distances(C.data(), k, nb, half.data(), next.data());
     CHK(upload());                                  // (cshift = 0: the first E-step's bounds update changes nothing)
     CHK(upload_ctl(0, 0, 0));
-    HIPCHK(ctx, hipMemsetAsync(dlb, 0, (size_t)k * n * 8, st));
     const unsigned g = grid_for(n, 256);
-    hipLaunchKernelGGL(k_elk_init, dim3(g), dim3(256), 0, st, dX, n, nb, dC, k, dhalf, dlab, dub, dlb); KCHK(ctx);
-    auto estep = [&](uint32_t *nd, const uint32_t *stop) -> int {
-        if (k <= 64)
+    const bool want_diag = lazy && getenv("SHEPSEG_FIT_TRACE");
+    // k_elk2_filter: shifts, nearest-centre distances (float64) and the half distances (float32) in LDS;
+    // k_elk2_visit: the half distances and the centres (float64), the shifts' running sums, the list of a chunk's visits
+    const size_t lds_f = (size_t)2 * k * 8 + (size_t)k * k * 4, lds2 = ((size_t)k * k + kn + k) * 8 + ELK2_VCHUNK * 4;
+    // the pixel-band count as a template parameter where it is small (the sample row then lives in registers)
+    auto visit2 = nb == 1 ? k_elk2_visit<1> : nb == 2 ? k_elk2_visit<2> : nb == 3 ? k_elk2_visit<3> : nb == 4 ? k_elk2_visit<4> :
+                  nb == 5 ? k_elk2_visit<5> : nb == 6 ? k_elk2_visit<6> : nb == 7 ? k_elk2_visit<7> : nb == 8 ? k_elk2_visit<8> :
+                  nb == 10 ? k_elk2_visit<10> : nb == 12 ? k_elk2_visit<12> : k_elk2_visit<0>;
+    unsigned g2 = g, gf = g, gv = (unsigned)grid_for(n, ELK2_VCHUNK);
+    if (lazy) {
+        // workgroups stride over chunks of samples: as many as stay resident
+        int dev = 0, ncu = 256;
+        (void)hipGetDevice(&dev);
+        (void)hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+        auto resident = [&](const void *fn, size_t lds) -> unsigned {
+            int per_cu = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, lds) != hipSuccess || per_cu < 1) {
+                (void)hipGetLastError();
+                per_cu = 2;
+            }
+            return (unsigned)(ncu * per_cu);
+        };
+        const unsigned cap_f = resident((const void *)k_elk2_filter<0>, lds_f), cap_v = resident((const void *)visit2, lds2);
+        const unsigned cap_i = resident((const void *)k_elk2_init, ((size_t)k * k + kn) * 8);
+        if (gf > cap_f) gf = cap_f;
+        if (gv > cap_v) gv = cap_v;
+        if (g2 > cap_i) g2 = cap_i;
+        // cum[1] = 0; cen[1] = the initial centres (dC, uploaded above)
+        HIPCHK(ctx, hipMemsetAsync(hist.cum, 0, (size_t)2 * k * 8, st));
+        HIPCHK(ctx, hipMemsetAsync(ddiag, 0, 64, st));
+        HIPCHK(ctx, hipMemcpyAsync(hist.cen + kn, dC, (size_t)kn * 8, hipMemcpyDeviceToDevice, st));
+        hipLaunchKernelGGL(k_elk2_init, dim3(g2), dim3(256), ((size_t)k * k + kn) * 8, st, dX, n, nb, dC, k, dhalf, dlab, dub, dA, dstamps); KCHK(ctx);
+    } else {
+        HIPCHK(ctx, hipMemsetAsync(dlb, 0, (size_t)k * n * 8, st));
+        hipLaunchKernelGGL(k_elk_init, dim3(g), dim3(256), 0, st, dX, n, nb, dC, k, dhalf, dlab, dub, dlb); KCHK(ctx);
+    }
+    auto estep = [&](uint32_t *nd, const uint32_t *stop, int it) -> int {
+        if (lazy) {
+            const double *csp = it > 1 ? hist.cs + (size_t)(it - 1) * k : (const double *)nullptr;
+            if (stop && getenv("SHEPSEG_ELK2_PROBE")) {        // timing experiments (fit_bounds.h)
+                hipLaunchKernelGGL(k_elk2_filter<1>, dim3(gf), dim3(256), lds_f, st, n, k, dhalf, dnext, csp, hist.cum + (size_t)it * k,
+                                   dlab, dub, dA, dcmask, dmmask, stop);
+                hipLaunchKernelGGL(k_elk2_filter<2>, dim3(gf), dim3(256), lds_f, st, n, k, dhalf, dnext, csp, hist.cum + (size_t)it * k,
+                                   dlab, dub, dA, dcmask, dmmask, stop);
+            }
+            hipLaunchKernelGGL(k_elk2_filter<0>, dim3(gf), dim3(256), lds_f, st, n, k, dhalf, dnext, csp, hist.cum + (size_t)it * k,
+                               dlab, dub, dA, dcmask, dmmask, stop); KCHK(ctx);
+            hipLaunchKernelGGL(visit2, dim3(gv), dim3(256), lds2, st, dX, n, nb, hist.cen + (size_t)it * kn, k, dhalf,
+                               hist.cum + (size_t)it * k, dlab, dub, dA, dstamps, dcmask, dmmask, hist, (uint32_t)it, nd, stop,
+                               want_diag ? ddiag : (unsigned long long *)nullptr);
+        }
+        else if (k <= 64)
             hipLaunchKernelGGL(k_elk_estep64, dim3(g), dim3(256), 0, st, dX, n, nb, dC, k, dhalf, dnext, dcshift, dlab,
                                dub, dlb, nd, stop);
         else
@@ -894,7 +979,7 @@ static int run_fit_elkan(shp_ctx *ctx, const double *dX, XAt Xat, uint32_t n, in
     while (it_done < max_iter && !finished) {
         const int b_end = it_done + ELK_BATCH < max_iter ? it_done + ELK_BATCH : max_iter;
         for (int it = it_done + 1; it <= b_end; it++) {
-            CHK(estep(&dctl->nd[it & 1], dstop));
+            CHK(estep(&dctl->nd[it & 1], dstop, it));
             // row lists: the row numbers sorted stably by label
             uint32_t *ks = nullptr, *rows = nullptr;
             SortDigits sd;
@@ -914,7 +999,7 @@ static int run_fit_elkan(shp_ctx *ctx, const double *dX, XAt Xat, uint32_t n, in
                                    dstop, dg);
             KCHK(ctx);
             hipLaunchKernelGGL(k_elk_update, dim3(1), dim3(1024), 0, st, dS, dcnt, k, nb, dC, dcshift, dhalf, dnext, dscr,
-                               dctl, tol, (uint32_t)it); KCHK(ctx);
+                               dctl, tol, (uint32_t)it, hist); KCHK(ctx);
         }
         HIPCHK(ctx, hipMemcpyAsync(h_ctl, dctl, sizeof(ElkCtl), hipMemcpyDeviceToHost, st));
         HIPCHK(ctx, hipStreamSynchronize(st));
@@ -927,6 +1012,13 @@ static int run_fit_elkan(shp_ctx *ctx, const double *dX, XAt Xat, uint32_t n, in
             for (int j = 0; j < k; j++) nz += hs[j] == 0.0;
             fprintf(stderr, "elkan batch to %d: stop %u iters %u labels changed %u / %u shift %.17g, %d of %d centres did not move\n",
                     b_end, stop, h_ctl->iters, h_ctl->nd[0], h_ctl->nd[1], h_ctl->shift_tot, nz, k);
+            if (want_diag) {
+                unsigned long long hd[3];
+                HIPCHK(ctx, hipMemcpyAsync(hd, ddiag, sizeof(hd), hipMemcpyDeviceToHost, st));
+                HIPCHK(ctx, hipStreamSynchronize(st));
+                fprintf(stderr, "   since the start: %llu rows read, %llu samples visited, %llu comparisons recomputed exactly (n = %u)\n",
+                        hd[0], hd[1], hd[2], n);
+            }
         }
         if (stop == 0u) { it_done = b_end; continue; }
         if (stop == 1u || stop == 3u) {
@@ -957,13 +1049,24 @@ static int run_fit_elkan(shp_ctx *ctx, const double *dX, XAt Xat, uint32_t n, in
         elk_half_distances(Cn.data(), k, nb, half.data(), next.data());
         C = Cn;
         CHK(upload());
+        if (lazy) {             // this iteration's shifts, their running sums and the next E-step's centres (k_elk_update's part)
+            std::vector<double> row(k);
+            HIPCHK(ctx, hipMemcpyAsync(row.data(), hist.cum + (size_t)it * k, (size_t)k * 8, hipMemcpyDeviceToHost, st));
+            HIPCHK(ctx, hipStreamSynchronize(st));
+            for (int j = 0; j < k; j++) row[j] = row[j] + cshift[j];
+            HIPCHK(ctx, hipMemcpyAsync(hist.cum + ((size_t)it + 1) * k, row.data(), (size_t)k * 8, hipMemcpyHostToDevice, st));
+            HIPCHK(ctx, hipMemcpyAsync(hist.cs + (size_t)it * k, cshift.data(), (size_t)k * 8, hipMemcpyHostToDevice, st));
+            HIPCHK(ctx, hipMemcpy2DAsync(hist.csT + it, hist_rows * 8, cshift.data(), 8, 8, (size_t)k, hipMemcpyHostToDevice, st));
+            HIPCHK(ctx, hipMemcpyAsync(hist.cen + ((size_t)it + 1) * kn, C.data(), (size_t)kn * 8, hipMemcpyHostToDevice, st));
+            HIPCHK(ctx, hipStreamSynchronize(st));
+        }
         // (the counter the next E-step adds to was zeroed by this iteration's k_elk_offsets)
         CHK(upload_ctl((uint32_t)it, (it & 1) ? nd_other : nd, (it & 1) ? nd : nd_other));
         it_done = it;
         if (it >= 2 && nd == 0u) { strict = true; finished = true; }
         else if (shift_tot <= tol) finished = true;
     }
-    if (!strict) CHK(estep(&dctl->nd[0], nullptr));
+    if (!strict) CHK(estep(&dctl->nd[0], nullptr, it_done + 1));
     // the final centres
     HIPCHK(ctx, hipMemcpyAsync(h_up, dC, (size_t)kn * 8, hipMemcpyDeviceToHost, st));
     HIPCHK(ctx, hipStreamSynchronize(st));

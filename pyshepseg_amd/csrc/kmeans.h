@@ -720,7 +720,10 @@ static int run_kmeans_fit(shp_ctx *ctx, const void *xin_any, int xdtype, int64_t
     CHK(upload_centres(C));
     CHK(upload_ctl(0));
     while (it_done < max_iter && !finished && !elkan) {
-        const int b_end = it_done + FIT_BATCH < max_iter ? it_done + FIT_BATCH : max_iter;
+        // (the first batch is ONE iteration: where the tie guard fires at all -- integer-valued initial centres on
+        //  integer imagery -- it fires in the very first E-step, and seven more iterations would be thrown away)
+        const int batch = it_done == 0 ? 1 : FIT_BATCH;
+        const int b_end = it_done + batch < max_iter ? it_done + batch : max_iter;
         for (int it = it_done + 1; it <= b_end; it++) {
             int32_t *dlab = (it & 1) ? dlabA : dlabB, *dlab_old = (it & 1) ? dlabB : dlabA;
             launch_fit_assign(ctx, g, dX, n, nb, dm2c, dcn, k, dlab, dlab_old, dctl); KCHK(ctx);

@@ -40,7 +40,11 @@ fit)        # the whole-image k-means fit on the benchmark sample: Elkan trace, 
     rm -rf gpurun_out/fitprof
     SHEPSEG_FIT_TIMING=1 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/fitprof -- python3 tools/perf_fit.py 40000 6 > gpurun_out/fitprof.log 2>&1
     python3 tools/kstats.py --top 12 "$(find gpurun_out/fitprof -name '*kernel_stats.csv' | head -1)"
-    grep "kmeans fit: n=" gpurun_out/fitprof.log | tail -1; rm -f gpurun_out/fitprof/*/*kernel_trace.csv ;;
+    grep "kmeans fit: n=" gpurun_out/fitprof.log | tail -1
+    for kn in "k_elk2_filter<0>" k_elk2_visit; do
+      python3 tools/kstats.py --calls "$kn" "$(find gpurun_out/fitprof -name '*kernel_trace.csv' | head -1)" 10 | cut -c1-700
+    done
+    rm -f gpurun_out/fitprof/*/*kernel_trace.csv ;;
 fit-shard)  # one rank's share of a row-sharded E-step: the same fit on 1/N of the sample's rows (N = $1, default 8)
     rm -rf gpurun_out/fitprof
     SHEPSEG_FIT_TIMING=1 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/fitprof -- python3 tools/perf_fit.py 40000 6 ${1:-8} > gpurun_out/fitprof.log 2>&1

@@ -2,7 +2,8 @@
     python tools/kstats.py DIR NTILES [TOP]        per-tile kernel time table from DIR/**/kernel_stats.csv
     python tools/kstats.py --top N FILE            the N largest rows of a kernel_stats.csv
     python tools/kstats.py --sequence TRACE.csv    kernel sequence (start, duration, gap) of the LAST tile call in a
-                                                   kernel trace of tools/perf_tile.py (one tile run alone)"""
+                                                   kernel trace of tools/perf_tile.py (one tile run alone)
+    python tools/kstats.py --calls NAME TRACE.csv [EVERY]   durations (us) of a kernel's calls in launch order, EVERY-th printed"""
 import csv
 import glob
 import sys
@@ -19,6 +20,16 @@ def main():
         for r in rows[:int(sys.argv[2])]:
             print('%-48s calls %6s  avg %9.1f us  total %8.1f ms' % (short(r['Name'])[:48], r['Calls'],
                   float(r['AverageNs']) / 1e3, float(r['TotalDurationNs']) / 1e6))
+        return
+    if sys.argv[1] == '--calls':
+        rows = []
+        for r in csv.DictReader(open(sys.argv[3])):
+            if short(r['Kernel_Name']).startswith(sys.argv[2]):
+                rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp'])))
+        rows.sort()
+        every = int(sys.argv[4]) if len(sys.argv) > 4 else 10
+        print('%d calls of %s; every %d-th (index: us): ' % (len(rows), sys.argv[2], every) +
+              ' '.join('%d:%.0f' % (i, (e - s) / 1e3) for i, (s, e) in enumerate(rows) if i % every == 0))
         return
     if sys.argv[1] == '--sequence':
         rows = []
