@@ -611,11 +611,33 @@ __device__ unsigned long long g_fit_diag[256 * 4];      // tools/ubench/sumlists
 #define FIT_SUM_THREADS 512u
 #define FIT_GATHERERS (FIT_SUM_THREADS - 64u)
 #define FIT_STAGE_PER_THREAD ((FIT_STAGE_DOUBLES + FIT_GATHERERS - 1u) / FIT_GATHERERS)
+// loop control of the Elkan iterations, owned by the device between host synchronisations
+struct ElkCtl {
+    uint32_t stop;      // 0 running; 1 labels unchanged (strict convergence); 2 an empty cluster: the host
+                        // finishes this iteration; 3 centre shift <= tol
+    uint32_t iters;     // completed iterations
+    uint32_t nd[2];     // labels changed by the E-step of iteration it: nd[it & 1]
+    double shift_tot;
+};
+
+struct ElkEpilogue {
+    ElkCtl *ctl;                    // nullptr: no epilogue
+    uint32_t *done;                 // zero-initialised device word: workgroups finished
+    double *C, *cshift, *half, *next;
+    double *scratch;                // 3 k doubles of device memory (the tail's small vectors when its tables are not in LDS)
+    double tol;
+    uint32_t it;
+    ElkHist hist;
+};
+// ep.ctl != nullptr: the workgroup that finishes LAST also runs the end of the iteration (elk_update_body, the
+// whole of k_elk_update) -- one launch and its gap less per iteration, and the tail's tables live in this
+// kernel's LDS instead of crossing global memory between its phases.
+__device__ void elk_update_body(double *lds, uint32_t nthreads, const ElkEpilogue &ep, double *S, const double *cnt, int k, int nb);
 __global__ __launch_bounds__(FIT_SUM_THREADS) void k_fit_sum_lists_staged(const double *__restrict__ X, int nb,
                                                              const uint32_t *__restrict__ rows,
                                                              const uint32_t *__restrict__ off,
                                                              double *__restrict__ S, double *__restrict__ cnt,
-                                                             const uint32_t *stop, FitDigits dg)
+                                                             const uint32_t *stop, FitDigits dg, ElkEpilogue ep)
 {
     if (stop && *stop) return;
     constexpr uint32_t BUF = FIT_STAGE_DOUBLES + 4u * 64u;        // nb runs of B + 4 doubles, nb <= 64
@@ -628,12 +650,10 @@ __global__ __launch_bounds__(FIT_SUM_THREADS) void k_fit_sum_lists_staged(const 
     const uint32_t pitch = B + 4u;                               // doubles between two bands' runs: bands 8 banks apart
     const uint32_t nblk = (q1 - q0 + B - 1u) / B;
     if (threadIdx.x == 0) cnt[j] = (double)(q1 - q0);
+    static_assert(FIT_STAGE_DOUBLES / 64u >= 32u, "a block holds at least one 32-row group of 64 bands");
     if (nblk == 0u) {
         if (threadIdx.x < unb) S[(size_t)j * unb + threadIdx.x] = 0.0;
-        return;
-    }
-    static_assert(FIT_STAGE_DOUBLES / 64u >= 32u, "a block holds at least one 32-row group of 64 bands");
-    if (threadIdx.x >= 64u) {
+    } else if (threadIdx.x >= 64u) {
         // ---- gatherers.  Element e = g + FIT_GATHERERS u of a block is band eb[u] of its row er[u] (the same in
         //      every block); rows past the end of the list are clamped to its last one ----
         const uint32_t g = threadIdx.x - 64u;
@@ -733,48 +753,58 @@ __global__ __launch_bounds__(FIT_SUM_THREADS) void k_fit_sum_lists_staged(const 
                 if (mo + 16u * c < unb) S[(size_t)j * unb + mo + 16u * c] = acc[c];
         }
     }
+    if (ep.ctl) {
+        // the last workgroup to finish ends the iteration (release / acquire at agent scope: gridbar.h)
+        __shared__ uint32_t s_last;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const uint32_t arrived = __hip_atomic_fetch_add(ep.done, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+            const uint32_t last = arrived == gridDim.x;
+            if (last) __hip_atomic_store(ep.done, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            s_last = last;
+        }
+        __syncthreads();
+        if (s_last) elk_update_body(sx, FIT_SUM_THREADS, ep, S, cnt, (int)gridDim.x, nb);
+    }
 }
-
-// loop control of the Elkan iterations, owned by the device between host synchronisations
-struct ElkCtl {
-    uint32_t stop;      // 0 running; 1 labels unchanged (strict convergence); 2 an empty cluster: the host
-                        // finishes this iteration; 3 centre shift <= tol
-    uint32_t iters;     // completed iterations
-    uint32_t nd[2];     // labels changed by the E-step of iteration it: nd[it & 1]
-    double shift_tot;
-};
 
 // The end of an iteration in one workgroup, unless a cluster came out empty (left to the host:
 // fit_mstep_tail): centres = sums * (1 / weight), the centres' shifts and their squared sum, the new
 // centres' half distances and nearest-centre distances, sklearn's two convergence tests.  Every float64
-// operation and its order are those of fit_mstep_tail / elk_half_distances.  C: the old centres in, the
-// new ones out.
-__global__ __launch_bounds__(1024) void k_elk_update(double *__restrict__ S, const double *__restrict__ cnt,
-                                                    int k, int nb, double *__restrict__ C,
-                                                    double *__restrict__ cshift, double *__restrict__ half,
-                                                    double *__restrict__ next, double *__restrict__ scratch,
-                                                    ElkCtl *ctl, double tol, uint32_t it, ElkHist hist)
+// operation and its order are those of fit_mstep_tail / elk_half_distances.  ep.C: the old centres in, the
+// new ones out.  lds: 2 k nb + k k + 3 k doubles of LDS (the tables of the tail never touch global memory
+// between its phases), or nullptr: S, ep.C, ep.half and ep.scratch stand in (k, nb beyond the LDS form).
+__device__ void elk_update_body(double *lds, uint32_t nthreads, const ElkEpilogue &ep, double *S, const double *cnt, int k, int nb)
 {
+    ElkCtl *ctl = ep.ctl;
+    const uint32_t it = ep.it;
     if (ctl->stop) return;
     if (threadIdx.x == 0) ctl->nd[(it + 1u) & 1u] = 0u;          // the next E-step's change counter
     __shared__ int s_empty;
     const int kn = k * nb;
     if (threadIdx.x == 0) s_empty = 0;
     __syncthreads();
-    for (int j = threadIdx.x; j < k; j += 1024) if (cnt[j] == 0.0) s_empty = 1;
+    for (int j = threadIdx.x; j < k; j += nthreads) if (cnt[j] == 0.0) s_empty = 1;
     __syncthreads();
     if (s_empty) {
         if (threadIdx.x == 0) ctl->stop = 2u;
         return;
     }
-    for (int t = threadIdx.x; t < kn; t += 1024) {
+    double *Sn = lds, *Co = lds + kn, *hf = Co + kn, *sq = hf + (size_t)k * k, *xx = sq + k, *cs = xx + k;
+    if (!lds) { Sn = S; Co = ep.C; hf = ep.half; sq = ep.scratch; xx = sq + k; cs = xx + k; }
+    for (int t = threadIdx.x; t < kn; t += nthreads) {
         const double alpha = 1.0 / cnt[t / nb];
-        S[t] = S[t] * alpha;                                 // the new centres
+        Sn[t] = S[t] * alpha;                                // the new centres
+        if (lds) Co[t] = ep.C[t];
     }
     __syncthreads();
-    double *sq = scratch, *xx = scratch + k;
-    for (int j = threadIdx.x; j < k; j += 1024) {
-        const double *a = &S[j * nb], *c = &C[j * nb];
+    for (int j = threadIdx.x; j < k; j += nthreads) {
+        const double *a = &Sn[j * nb], *c = &Co[j * nb];
         double r = 0.0;
         int b = 0;
         for (; b + 4 <= nb; b += 4)
@@ -782,46 +812,44 @@ __global__ __launch_bounds__(1024) void k_elk_update(double *__restrict__ S, con
                   (a[b + 2] - c[b + 2]) * (a[b + 2] - c[b + 2]) + (a[b + 3] - c[b + 3]) * (a[b + 3] - c[b + 3]));
         for (; b < nb; b++) r += (a[b] - c[b]) * (a[b] - c[b]);
         const double sh = __builtin_sqrt(r);
-        cshift[j] = sh;
+        cs[j] = sh;
         sq[j] = sh * sh;
         xx[j] = kmeans_sqnorm(a, nb);
     }
     __syncthreads();
-    for (int e = threadIdx.x; e < k * k; e += 1024) {
+    for (int e = threadIdx.x; e < k * k; e += nthreads) {
         const int a = e / k, b = e - a * k;
         double d = 0.0;
-        for (int t = 0; t < nb; t++) d = d + S[(size_t)a * nb + t] * S[(size_t)b * nb + t];
+        for (int t = 0; t < nb; t++) d = d + Sn[(size_t)a * nb + t] * Sn[(size_t)b * nb + t];
         double v = -2.0 * d;
         v = v + xx[a];
         v = v + xx[b];
         if (!(v > 0.0)) v = 0.0;
         if (a == b) v = 0.0;
-        half[e] = __builtin_sqrt(v) / 2.0;
+        const double h = __builtin_sqrt(v) / 2.0;
+        hf[e] = h;
+        if (lds) ep.half[e] = h;
     }
-    for (int t = threadIdx.x; t < kn; t += 1024) C[t] = S[t];
-    if (hist.cs) {              // fit_bounds.h: this iteration's shifts, their running sums, the next E-step's centres
-        for (int j = threadIdx.x; j < k; j += 1024) {
-            hist.cs[(size_t)it * k + j] = cshift[j];
-            hist.csT[(size_t)j * hist.rows + it] = cshift[j];
-            hist.cum[((size_t)it + 1u) * k + j] = hist.cum[(size_t)it * k + j] + cshift[j];
+    __syncthreads();                                         // (without LDS Co IS ep.C: every shift has been taken)
+    for (int t = threadIdx.x; t < kn; t += nthreads) { if (lds) S[t] = Sn[t]; ep.C[t] = Sn[t]; }
+    for (int j = threadIdx.x; j < k; j += nthreads) ep.cshift[j] = cs[j];
+    if (ep.hist.cs) {           // fit_bounds.h: this iteration's shifts, their running sums, the next E-step's centres
+        for (int j = threadIdx.x; j < k; j += nthreads) {
+            ep.hist.cs[(size_t)it * k + j] = cs[j];
+            ep.hist.csT[(size_t)j * ep.hist.rows + it] = cs[j];
+            ep.hist.cum[((size_t)it + 1u) * k + j] = ep.hist.cum[(size_t)it * k + j] + cs[j];
         }
-        for (int t = threadIdx.x; t < kn; t += 1024) hist.cen[((size_t)it + 1u) * kn + t] = S[t];
+        for (int t = threadIdx.x; t < kn; t += nthreads) ep.hist.cen[((size_t)it + 1u) * kn + t] = Sn[t];
     }
     __syncthreads();
-    for (int l = threadIdx.x; l < k; l += 1024) {
-        double m0 = half[l], m1 = -1.0;
-        for (int a0 = 1; a0 < k; a0 += 8) {          // eight loads in flight, the comparisons in order
-            double v[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) v[u] = half[(size_t)(a0 + u < k ? a0 + u : k - 1) * k + l];
-#pragma unroll
-            for (int u = 0; u < 8; u++)
-                if (a0 + u < k) {
-                    if (v[u] < m0) { m1 = m0; m0 = v[u]; }
-                    else if (m1 < 0.0 || v[u] < m1) m1 = v[u];
-                }
+    for (int l = threadIdx.x; l < k; l += nthreads) {
+        double m0 = hf[l], m1 = -1.0;
+        for (int a = 1; a < k; a++) {
+            const double v = hf[(size_t)a * k + l];
+            if (v < m0) { m1 = m0; m0 = v; }
+            else if (m1 < 0.0 || v < m1) m1 = v;
         }
-        next[l] = k > 1 ? m1 : m0;
+        ep.next[l] = k > 1 ? m1 : m0;
     }
     if (threadIdx.x == 0) {
         const double shift_tot = np_pairwise_sum(sq, (size_t)k);
@@ -829,8 +857,16 @@ __global__ __launch_bounds__(1024) void k_elk_update(double *__restrict__ S, con
         ctl->shift_tot = shift_tot;
         ctl->iters = it;
         if (it >= 2u && nd == 0u) ctl->stop = 1u;
-        else if (shift_tot <= tol) ctl->stop = 3u;
+        else if (shift_tot <= ep.tol) ctl->stop = 3u;
     }
+}
+#define ELK_UPDATE_LDS_DOUBLES(k, nb) ((size_t)2 * (k) * (nb) + (size_t)(k) * (k) + 3 * (size_t)(k))
+// the same as a kernel of its own (k, nb beyond k_fit_sum_lists_staged; tables in dynamic LDS)
+__global__ __launch_bounds__(1024) void k_elk_update(double *__restrict__ S, const double *__restrict__ cnt,
+                                                    int k, int nb, ElkEpilogue ep)
+{
+    extern __shared__ double sh_upd[];
+    elk_update_body(ep.scratch ? (double *)nullptr : sh_upd, 1024u, ep, S, cnt, k, nb);
 }
 
 #define ELK_BATCH 8                 // iterations enqueued between two host synchronisations
@@ -857,8 +893,8 @@ static int run_fit_elkan(shp_ctx *ctx, const double *dX, XAt Xat, uint32_t n, in
     if (lazy) CHK(buf_ensure(ctx, ctx->fit_lb, (size_t)n * k * 6 + 512 + (size_t)n * 8 * 3 + hist_doubles * 8 + 64));
     else CHK(buf_ensure(ctx, ctx->fit_lb, ((size_t)k * n + n) * 8));
     // small device block: C | cshift | half | next | S | cnt | scratch (2k) | ctl | off (k + 1)
-    const size_t small_doubles = (size_t)kn + k + (size_t)k * k + k + kn + k + 2 * (size_t)k;
-    CHK(buf_ensure(ctx, ctx->fit_part, small_doubles * 8 + sizeof(ElkCtl) + ((size_t)k + 2) * 4 + 64));
+    const size_t small_doubles = (size_t)kn + k + (size_t)k * k + k + kn + k + 3 * (size_t)k;
+    CHK(buf_ensure(ctx, ctx->fit_part, small_doubles * 8 + sizeof(ElkCtl) + ((size_t)k + 4) * 4 + 64));
     double *dlb = bp<double>(ctx->fit_lb), *dub = dlb + (size_t)k * n;
     float *dA = nullptr;
     uint16_t *dstamps = nullptr;
@@ -881,7 +917,7 @@ static int run_fit_elkan(shp_ctx *ctx, const double *dX, XAt Xat, uint32_t n, in
     }
     double *dC = bp<double>(ctx->fit_part), *dcshift = dC + kn, *dhalf = dcshift + k, *dnext = dhalf + (size_t)k * k;
     double *dS = dnext + k, *dcnt = dS + kn, *dscr = dcnt + k;
-    ElkCtl *dctl = (ElkCtl *)(dscr + 2 * (size_t)k);
+    ElkCtl *dctl = (ElkCtl *)(dscr + 3 * (size_t)k);
     uint32_t *doff = (uint32_t *)(dctl + 1);
     uint32_t *dstop = &dctl->stop;
     // host staging (pinned when it fits the context's block): C | cshift | half | next up, S | cnt down, ctl
@@ -974,6 +1010,18 @@ static int run_fit_elkan(shp_ctx *ctx, const double *dX, XAt Xat, uint32_t n, in
         KCHK(ctx);
         return 0;
     };
+    // the end of an iteration: the last workgroup of the staged sums (nb <= 64, tables in its LDS), else k_elk_update
+    const bool upd_lds = ELK_UPDATE_LDS_DOUBLES(k, nb) * 8 <= 64 * 1024;
+    const bool fused = nb <= 64 && ELK_UPDATE_LDS_DOUBLES(k, nb) <= 2u * (FIT_STAGE_DOUBLES + 4u * 64u) &&
+                       !(getenv("SHEPSEG_ELK_UNFUSED") && atoi(getenv("SHEPSEG_ELK_UNFUSED")) != 0);
+    uint32_t *ddone = doff + (size_t)k + 1;
+    HIPCHK(ctx, hipMemsetAsync(ddone, 0, 4, st));
+    auto ep_of = [&](int it, bool on) -> ElkEpilogue {
+        ElkEpilogue ep;
+        ep.ctl = on ? dctl : nullptr; ep.done = ddone; ep.C = dC; ep.cshift = dcshift; ep.half = dhalf; ep.next = dnext;
+        ep.scratch = (fused || upd_lds) ? nullptr : dscr; ep.tol = tol; ep.it = (uint32_t)it; ep.hist = hist;
+        return ep;
+    };
     bool strict = false, finished = false;
     int it_done = 0;
     while (it_done < max_iter && !finished) {
@@ -993,13 +1041,16 @@ static int run_fit_elkan(shp_ctx *ctx, const double *dX, XAt Xat, uint32_t n, in
                                    &dctl->nd[(it + 1) & 1], dstop); KCHK(ctx);
             }
             if (nb <= 64)
-                hipLaunchKernelGGL(k_fit_sum_lists_staged, dim3(k), dim3(FIT_SUM_THREADS), 0, st, dX, nb, rows, doff, dS, dcnt, dstop, dg);
+                hipLaunchKernelGGL(k_fit_sum_lists_staged, dim3(k), dim3(FIT_SUM_THREADS), 0, st, dX, nb, rows, doff, dS, dcnt, dstop, dg,
+                                   ep_of(it, fused));
             else
                 hipLaunchKernelGGL(k_fit_sum_lists, dim3(k, (nb + 63) / 64), dim3(64), 0, st, dX, nb, rows, doff, dS, dcnt,
                                    dstop, dg);
             KCHK(ctx);
-            hipLaunchKernelGGL(k_elk_update, dim3(1), dim3(1024), 0, st, dS, dcnt, k, nb, dC, dcshift, dhalf, dnext, dscr,
-                               dctl, tol, (uint32_t)it, hist); KCHK(ctx);
+            if (!fused) {
+                hipLaunchKernelGGL(k_elk_update, dim3(1), dim3(1024), upd_lds ? ELK_UPDATE_LDS_DOUBLES(k, nb) * 8 : 0, st, dS, dcnt, k, nb,
+                                   ep_of(it, true)); KCHK(ctx);
+            }
         }
         HIPCHK(ctx, hipMemcpyAsync(h_ctl, dctl, sizeof(ElkCtl), hipMemcpyDeviceToHost, st));
         HIPCHK(ctx, hipStreamSynchronize(st));

@@ -734,7 +734,7 @@ static int run_kmeans_fit(shp_ctx *ctx, const void *xin_any, int xdtype, int64_t
                                    doff + k + 1, &dctl->stop); KCHK(ctx);
                 if (nb <= 64)
                     hipLaunchKernelGGL(k_fit_sum_lists_staged, dim3(k), dim3(FIT_SUM_THREADS), 0, st, dX, nb, rows, doff, dpart2,
-                                       dcntd, &dctl->stop, FitDigits{nullptr, nullptr, 0u, n});
+                                       dcntd, &dctl->stop, FitDigits{nullptr, nullptr, 0u, n}, ElkEpilogue{});
                 else
                     hipLaunchKernelGGL(k_fit_sum_lists, dim3(k, (nb + 63) / 64), dim3(64), 0, st, dX, nb, rows, doff,
                                        dpart2, dcntd, &dctl->stop, FitDigits{nullptr, nullptr, 0u, n});

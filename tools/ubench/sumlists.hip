@@ -32,7 +32,7 @@ int main()
     for (int rep = 0; rep < 3; rep++) {
         hipEventRecord(e0);
         for (int i = 0; i < 20; i++)
-            hipLaunchKernelGGL(k_fit_sum_lists_staged, dim3(k), dim3(FIT_SUM_THREADS), 0, 0, dX, nb, drows, doff, dS, dcnt, nullptr, FitDigits{nullptr, nullptr, 0u, n});
+            hipLaunchKernelGGL(k_fit_sum_lists_staged, dim3(k), dim3(FIT_SUM_THREADS), 0, 0, dX, nb, drows, doff, dS, dcnt, nullptr, FitDigits{nullptr, nullptr, 0u, n}, ElkEpilogue{});
         hipEventRecord(e1); hipEventSynchronize(e1);
         float ms; hipEventElapsedTime(&ms, e0, e1);
         printf("k_fit_sum_lists_staged: %.1f us per launch\n", ms * 1000.f / 20.f);
@@ -43,7 +43,7 @@ int main()
         for (int i = 0; i < 10; i++) {
             hipMemsetAsync(big, i, 1u << 30, 0);
             hipEventRecord(e0);
-            hipLaunchKernelGGL(k_fit_sum_lists_staged, dim3(k), dim3(FIT_SUM_THREADS), 0, 0, dX, nb, drows, doff, dS, dcnt, nullptr, FitDigits{nullptr, nullptr, 0u, n});
+            hipLaunchKernelGGL(k_fit_sum_lists_staged, dim3(k), dim3(FIT_SUM_THREADS), 0, 0, dX, nb, drows, doff, dS, dcnt, nullptr, FitDigits{nullptr, nullptr, 0u, n}, ElkEpilogue{});
             hipEventRecord(e1); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1); tot += ms;
         }
