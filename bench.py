@@ -425,11 +425,9 @@ def main():
     os.environ.setdefault('SHEPSEG_DEVICE', str(local_rank))
     force_dist = os.environ.get('SHEPSEG_FORCE_DIST', '0') == '1' and 'RANK' in os.environ
     if world > 1 or force_dist:
-        if args.workload == 'c5':
-            sys.stderr.write('bench.py: --workload c5 runs on one GPU (the sharded statistics are '
-                             'covered by tests/test_distributed_cpu.py)\n')
-            sys.exit(2)
         from pyshepseg_amd import distributed
+        if args.workload == 'c5':
+            return distributed.bench_stats_main(args, rank, world, local_rank)
         return distributed.bench_main(args, rank, world, local_rank)
     if args.workload == 'c5':
         return bench_stats(args)

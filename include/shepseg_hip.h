@@ -311,6 +311,32 @@ int shp_gather_flagged_dev(shp_ctx *ctx, const uint32_t *d_seg, const void *d_ba
                            int64_t npix, uint32_t max_seg_id, const uint8_t *flags, int64_t cap,
                            uint32_t *seg_out, int64_t *val_out, int64_t *count_out);
 
+/* The same split with everything left in device memory (the data path of calcPerSegmentStatsDistributed
+ * under RCCL; the reference has no counterpart: its per-segment dictionaries live in one process,
+ * tilingstats.py:466-553).
+ *  shp_dstats_local_dev: the statistics of this rank's nrows x ncols rows, then every id judged against the
+ *    GLOBAL histogram d_hist (max_seg_id + 1 uint32 in device memory: the reference's segSize, :165): rows of
+ *    segments complete on this rank stay, rows of straddlers (fewer pixels here than the histogram says) are
+ *    cleared and their pixels packed as (id, value) pairs, rows of ids nobody holds keep the "missing" values
+ *    on the one rank that passes keep_unheld != 0 -- so the ranks' columns ADD UP to the one-GPU columns.
+ *    d_cols (caller's device memory): (#int stats) int64 columns then (#float stats) float32 columns of
+ *    max_seg_id + 1 rows.  *d_pair_seg_out / *d_pair_val_out: the pairs (uint32 ids, int64 values) in the
+ *    context's workspace, valid until its next call; *n_pairs_out of them, *n_straddlers_out segments.
+ *  shp_dstats_merge_dev: after the all-gather -- `world` slots of `slot` pairs, counts[r] valid in slot r --
+ *    the pairs with id_lo <= id < id_hi (*n_merged_out of them, of *n_ids_out segments) are reduced with the
+ *    same code and their rows written into d_cols.
+ *  Summing d_cols over the ranks (one integer all-reduce over the whole block read as int64 words: every
+ *  32-bit half has at most one non-zero contributor) gives the columns shp_segstats2d_dev returns. */
+int shp_dstats_local_dev(shp_ctx *ctx, const uint32_t *d_seg, const void *d_band, int dtype, int64_t nrows,
+                         int64_t ncols, uint32_t max_seg_id, int has_null, int64_t null_val,
+                         const uint32_t *stats_sel, int nstats, int64_t missing, const uint32_t *d_hist,
+                         int keep_unheld, void *d_cols, void **d_pair_seg_out, void **d_pair_val_out,
+                         int64_t *n_pairs_out, int64_t *n_straddlers_out);
+int shp_dstats_merge_dev(shp_ctx *ctx, const uint32_t *d_pair_seg, const int64_t *d_pair_val, int64_t slot, int world,
+                         const uint32_t *counts, int dtype, uint32_t max_seg_id, int has_null, int64_t null_val,
+                         const uint32_t *stats_sel, int nstats, int64_t missing, uint32_t id_lo, uint32_t id_hi,
+                         void *d_cols, int64_t *n_merged_out, int64_t *n_ids_out);
+
 /* ---- subset --------------------------------------------------------------------------
  * replaces the tile loop of subset.subsetImage (subset.py:124-166) and its njit kernel
  * processSubsetTile (subset.py:366-425): the window (tlx, tly, xs, ys) of a label raster is

@@ -149,6 +149,13 @@ _SIGS = {
     'shp_comm_drain': (_c.c_int, [_vp]),
     'shp_gather_flagged_dev': (_c.c_int, [_vp, _vp, _vp, _c.c_int, _c.c_int64, _c.c_uint32, _vp,
                                           _c.c_int64, _vp, _vp, _vp]),
+    'shp_dstats_local_dev': (_c.c_int, [_vp, _vp, _vp, _c.c_int, _c.c_int64, _c.c_int64, _c.c_uint32, _c.c_int,
+                                        _c.c_int64, _vp, _c.c_int, _c.c_int64, _vp, _c.c_int, _vp,
+                                        _c.POINTER(_vp), _c.POINTER(_vp), _c.POINTER(_c.c_int64),
+                                        _c.POINTER(_c.c_int64)]),
+    'shp_dstats_merge_dev': (_c.c_int, [_vp, _vp, _vp, _c.c_int64, _c.c_int, _vp, _c.c_int, _c.c_uint32, _c.c_int,
+                                        _c.c_int64, _vp, _c.c_int, _c.c_int64, _c.c_uint32, _c.c_uint32, _vp,
+                                        _c.POINTER(_c.c_int64), _c.POINTER(_c.c_int64)]),
 }
 
 _lib = None

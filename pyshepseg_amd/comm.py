@@ -86,6 +86,9 @@ def _await(path, timeout=180.0):
 
 
 class LocalComm(object):
+    def allgather_arrays(self, arrays):
+        return [[numpy.ascontiguousarray(a).copy() for a in arrays]]
+
     """World size 1: every collective is the identity."""
     rank = 0
     world = 1
@@ -111,7 +114,53 @@ class LocalComm(object):
         pass
 
 
+def _packArrays(arrays):
+    """Several numpy arrays as ONE byte string with a fixed-size header per array (dtype char code, length):
+    the data path of the statistics exchange travels as raw bytes, not as pickled objects."""
+    parts = [numpy.array([len(arrays)], dtype=numpy.int64).tobytes()]
+    for a in arrays:
+        a = numpy.ascontiguousarray(a)
+        parts.append(numpy.array([ord(a.dtype.char), a.size], dtype=numpy.int64).tobytes())
+        parts.append(a.tobytes())
+    return b''.join(parts)
+
+
+def _unpackArrays(data):
+    data = memoryview(data)
+    n = int(numpy.frombuffer(data[:8], dtype=numpy.int64)[0])
+    off = 8
+    out = []
+    for _ in range(n):
+        (code, size) = numpy.frombuffer(data[off:off + 16], dtype=numpy.int64)
+        dt = numpy.dtype(chr(int(code)))
+        off += 16
+        nbytes = int(size) * dt.itemsize
+        out.append(numpy.frombuffer(data[off:off + nbytes], dtype=dt).copy())
+        off += nbytes
+    return out
+
+
 class _ObjCollectives(object):
+    def allgather_arrays(self, arrays):
+        """Every rank's list of numpy arrays on every rank: [rank][i].  Raw bytes point to point (rank r sends to
+        every other rank); built on send_bytes / recv_bytes of the transport."""
+        mine = _packArrays(arrays)
+        out = [None] * self.world
+        out[self.rank] = [numpy.ascontiguousarray(a).copy() for a in arrays]
+        # a fixed schedule without deadlock: in round d rank r sends to r + d and receives from r - d
+        for d in range(1, self.world):
+            dst = (self.rank + d) % self.world
+            src = (self.rank - d) % self.world
+            if (self.rank // d) % 2 == 0:
+                self.send_bytes(mine, dst)
+                out[src] = _unpackArrays(self.recv_bytes(src))
+            else:
+                got = self.recv_bytes(src)
+                self.send_bytes(mine, dst)
+                out[src] = _unpackArrays(got)
+        return out
+
+
     """Collectives on Python objects built from send_obj / recv_obj (gather to rank 0, fan out)."""
     def allgather_obj(self, obj):
         if self.world == 1:
@@ -368,6 +417,13 @@ class RcclComm(_ObjCollectives):
 
     transport = 'rccl: ncclSend / ncclRecv of device buffers (xGMI inside a node)'
 
+    # ---- collectives on device buffers (the statistics exchange: nothing crosses the host) ----
+    def allgather_dev(self, d_send, d_recv, bytesPerRank):
+        self.c.check(self.L.shp_comm_allgather(self.h, ctypes.c_void_p(d_send), ctypes.c_void_p(d_recv), bytesPerRank))
+
+    def allreduce_dev_i64(self, d_buf, count):
+        self.c.check(self.L.shp_comm_allreduce(self.h, ctypes.c_void_p(d_buf), count, 0))
+
     # ---- host data through the staging buffer ----
     def send_bytes(self, data, dst):
         a = numpy.frombuffer(memoryview(data).cast('B'), dtype=numpy.uint8)
@@ -475,6 +531,40 @@ class RcclComm(_ObjCollectives):
                 except OSError:
                     pass
             self.c.close()
+
+
+class HostStagedDev(object):
+    """The device collectives of the statistics exchange on top of a transport that is not on the device
+    (SocketComm: ranks that share one GPU, the rehearsal runs and tests of a one-GPU box): buffers are
+    downloaded, travel as raw arrays and are uploaded again.  Same interface as RcclComm's."""
+    onDevice = True
+
+    def __init__(self, comm, ctx):
+        (self.comm, self.c) = (comm, ctx)
+        (self.rank, self.world) = (comm.rank, comm.world)
+        self.transport = getattr(comm, 'transport', type(comm).__name__) + ' (device buffers staged through the host)'
+
+    def allgather_obj(self, obj):
+        return self.comm.allgather_obj(obj)
+
+    def allgather_dev(self, d_send, d_recv, bytesPerRank):
+        mine = numpy.empty(bytesPerRank, dtype=numpy.uint8)
+        self.c.check(self.c._L.shp_dev_download(self.c.handle, _lib.ptr(mine), ctypes.c_void_p(d_send), bytesPerRank))
+        parts = self.comm.allgather_arrays([mine])
+        allb = numpy.concatenate([p[0] for p in parts])
+        self.c.check(self.c._L.shp_dev_upload(self.c.handle, ctypes.c_void_p(d_recv), _lib.ptr(allb), allb.nbytes))
+
+    def allreduce_dev_i64(self, d_buf, count):
+        mine = numpy.empty(count, dtype=numpy.int64)
+        self.c.check(self.c._L.shp_dev_download(self.c.handle, _lib.ptr(mine), ctypes.c_void_p(d_buf), mine.nbytes))
+        tot = self.comm.allreduce_sum_i64(mine)
+        self.c.check(self.c._L.shp_dev_upload(self.c.handle, ctypes.c_void_p(d_buf), _lib.ptr(tot), tot.nbytes))
+
+    def barrier(self):
+        self.comm.barrier()
+
+    def max_f64(self, v):
+        return self.comm.max_f64(v)
 
 
 def fromEnvironment(transport=None):

@@ -1111,6 +1111,46 @@ API int shp_gather_flagged_dev(shp_ctx *ctx, const uint32_t *d_seg, const void *
                               seg_out, val_out, count_out);
 }
 
+// the multi-GPU split with everything left in device memory (segstats.h: run_dstats_local / run_dstats_merge)
+API int shp_dstats_local_dev(shp_ctx *ctx, const uint32_t *d_seg, const void *d_band, int dtype, int64_t nrows,
+                             int64_t ncols, uint32_t max_seg_id, int has_null, int64_t null_val,
+                             const uint32_t *stats_sel, int nstats, int64_t missing, const uint32_t *d_hist,
+                             int keep_unheld, void *d_cols, void **d_pair_seg_out, void **d_pair_val_out,
+                             int64_t *n_pairs_out, int64_t *n_straddlers_out)
+{
+    CHK(enter(ctx));
+    if (!d_seg || !d_band || !stats_sel || !d_hist || !d_cols || !d_pair_seg_out || !d_pair_val_out || !n_pairs_out ||
+        !n_straddlers_out || nstats < 1 || dtype_size(dtype) == 0 || nrows < 0 || ncols < 0)
+        SHP_FAIL(ctx, SHP_ERR_ARG, "bad argument");
+    if (nrows > 0xffffffffll || ncols > 0xffffffffll || nrows * ncols >= 0xffffffffll)
+        SHP_FAIL(ctx, SHP_ERR_ARG, "raster too large (%lld x %lld px)", (long long)nrows, (long long)ncols);
+    for (int i = 0; i < nstats; i++)
+        if (stats_sel[i * 5 + 1] > 7u || stats_sel[i * 5 + 2] > 1u) SHP_FAIL(ctx, SHP_ERR_ARG, "bad statsSelection entry %d", i);
+    uint32_t *ps = nullptr;
+    long long *pv = nullptr;
+    CHK(run_dstats_local(ctx, d_seg, d_band, dtype, (uint32_t)nrows, (uint32_t)ncols, max_seg_id, has_null, null_val,
+                         stats_sel, nstats, missing, d_hist, keep_unheld, d_cols, &ps, &pv, n_pairs_out, n_straddlers_out));
+    *d_pair_seg_out = ps;
+    *d_pair_val_out = pv;
+    return 0;
+}
+
+API int shp_dstats_merge_dev(shp_ctx *ctx, const uint32_t *d_pair_seg, const int64_t *d_pair_val, int64_t slot, int world,
+                             const uint32_t *counts, int dtype, uint32_t max_seg_id, int has_null, int64_t null_val,
+                             const uint32_t *stats_sel, int nstats, int64_t missing, uint32_t id_lo, uint32_t id_hi,
+                             void *d_cols, int64_t *n_merged_out, int64_t *n_ids_out)
+{
+    CHK(enter(ctx));
+    if (!stats_sel || !counts || !d_cols || !n_merged_out || !n_ids_out || nstats < 1 || dtype_size(dtype) == 0 || slot < 0 || world < 1 ||
+        slot >= 0xffffffffll || (slot > 0 && (!d_pair_seg || !d_pair_val)))
+        SHP_FAIL(ctx, SHP_ERR_ARG, "bad argument");
+    for (int i = 0; i < nstats; i++)
+        if (stats_sel[i * 5 + 1] > 7u || stats_sel[i * 5 + 2] > 1u) SHP_FAIL(ctx, SHP_ERR_ARG, "bad statsSelection entry %d", i);
+    for (int r = 0; r < world; r++) if ((int64_t)counts[r] > slot) SHP_FAIL(ctx, SHP_ERR_ARG, "counts[%d] exceeds the slot", r);
+    return run_dstats_merge(ctx, d_pair_seg, (const long long *)d_pair_val, (uint32_t)slot, (uint32_t)world, counts, dtype,
+                            max_seg_id, has_null, null_val, stats_sel, nstats, missing, id_lo, id_hi, d_cols, n_merged_out, n_ids_out);
+}
+
 // ---- subset ---------------------------------------------------------------------
 static int subset_check(shp_ctx *ctx, int64_t img_rows, int64_t img_cols, int64_t tlx, int64_t tly,
                         int64_t xs, int64_t ys, int tile_size)

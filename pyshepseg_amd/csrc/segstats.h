@@ -440,8 +440,10 @@ static int segstats_download(shp_ctx *ctx, void *intcols_out, const void *d_int,
 static int run_segstats(shp_ctx *ctx, const uint32_t *d_seg, const void *d_band, int dtype,
                         uint32_t n, uint32_t S, int has_null, int64_t null_val,
                         const uint32_t *sel_host, int nstats, int64_t missing,
-                        int64_t *intcols_out, float *fltcols_out, uint32_t nrows = 0, uint32_t ncols = 0)
+                        int64_t *intcols_out, float *fltcols_out, uint32_t nrows = 0, uint32_t ncols = 0,
+                        long long **dev_int = nullptr, float **dev_flt = nullptr)
 {
+    // (dev_int / dev_flt given: the columns stay in the context's workspace, nothing is copied to the host)
     hipStream_t st = ctx->stream;
     const size_t ns = (size_t)S + 1;
     int nint = 0, nflt = 0;
@@ -506,6 +508,7 @@ static int run_segstats(shp_ctx *ctx, const uint32_t *d_seg, const void *d_band,
     }
     if (patches && nsort == 0) {                          // every segment was complete in its patch
         prof_end(ctx, ps);
+        if (dev_int) { *dev_int = d_int; *dev_flt = d_flt; return 0; }
         return segstats_download(ctx, intcols_out, d_int, (size_t)nint * ns * 8, fltcols_out, d_flt, (size_t)nflt * ns * 4);
     }
     n = nsort;
@@ -541,6 +544,7 @@ static int run_segstats(shp_ctx *ctx, const uint32_t *d_seg, const void *d_band,
     hipLaunchKernelGGL(k_seg_stats_big, dim3(512), dim3(256), 0, st, v2, off, cnt, S, bias, d_sel, nstats,
                        (long long)missing, d_int, d_flt, biglist); KCHK(ctx);      // (only flagged ones got onto the list)
     prof_end(ctx, ps);
+    if (dev_int) { *dev_int = d_int; *dev_flt = d_flt; return 0; }
     return segstats_download(ctx, intcols_out, d_int, (size_t)nint * ns * 8, fltcols_out, d_flt, (size_t)nflt * ns * 4);
 }
 
@@ -615,5 +619,188 @@ static int run_gather_flagged(shp_ctx *ctx, const uint32_t *d_seg, const void *d
         HIPCHK(ctx, hipStreamSynchronize(st));
     }
     *count_out = (int64_t)cnt;
+    return 0;
+}
+
+// ---- multi-GPU split, device-resident (pyshepseg_amd/distributed.py) ---------------------------
+// Rank-local part.  The statistics of this rank's rows are computed as on one GPU; then every id is
+// classified against the global histogram (the reference's segSize, tilingstats.py:165): a segment whose
+// local pixel count equals it is complete here and its row is final (checkSegComplete, :518-553); a segment
+// with fewer is a straddler -- its row is cleared and its pixels are packed as (id, value) pairs for the
+// exchange; ids nobody holds (global count 0, row 0 among them) keep their "missing" row on the rank that is
+// told to (keep_unheld), so that the columns of all ranks ADD UP to the single-GPU columns.
+// cols: nint int64 columns then nflt float columns of S + 1 rows, in device memory of the caller.
+__global__ __launch_bounds__(256) void k_dstats_classify(const uint32_t *__restrict__ lh,
+                                                         const uint32_t *__restrict__ gh, uint32_t S,
+                                                         int keep_unheld, int nint, int nflt,
+                                                         const long long *__restrict__ src_int,
+                                                         const float *__restrict__ src_flt,
+                                                         long long *__restrict__ dst_int,
+                                                         float *__restrict__ dst_flt,
+                                                         uint8_t *__restrict__ flags,
+                                                         unsigned long long *counters)
+{
+    const size_t ns = (size_t)S + 1;
+    const size_t id = (size_t)blockIdx.x * 256u + threadIdx.x;
+    bool strad = false;
+    uint32_t l = 0;
+    if (id < ns) {
+        l = id == 0 ? 0u : lh[id];
+        const uint32_t g = id == 0 ? 0u : gh[id];
+        strad = l > 0u && l < g;
+        const bool keep = (l > 0u && l == g) || (keep_unheld && g == 0u);
+        flags[id] = strad ? 1 : 0;
+        for (int c = 0; c < nint; c++) dst_int[(size_t)c * ns + id] = keep ? src_int[(size_t)c * ns + id] : 0ll;
+        for (int c = 0; c < nflt; c++) dst_flt[(size_t)c * ns + id] = keep ? src_flt[(size_t)c * ns + id] : 0.0f;
+    }
+    // counters[0] += pixels of straddlers, counters[1] += straddling segments (one atomic pair per wavefront)
+    const unsigned long long m = __ballot(strad);
+    if (m != 0ull) {
+        unsigned long long px = strad ? (unsigned long long)l : 0ull;
+        for (int o = 32; o > 0; o >>= 1) px += __shfl_xor(px, o);
+        if (lane_id() == 0) { atomicAdd(&counters[0], px); atomicAdd(&counters[1], (unsigned long long)__popcll(m)); }
+    }
+}
+
+static int run_dstats_local(shp_ctx *ctx, const uint32_t *d_seg, const void *d_band, int dtype, uint32_t nrows,
+                            uint32_t ncols, uint32_t S, int has_null, int64_t null_val, const uint32_t *sel_host,
+                            int nstats, int64_t missing, const uint32_t *d_hist, int keep_unheld, void *d_cols,
+                            uint32_t **d_pair_seg, long long **d_pair_val, int64_t *n_pairs, int64_t *n_strad)
+{
+    hipStream_t st = ctx->stream;
+    const size_t ns = (size_t)S + 1;
+    const uint32_t n = nrows * ncols;
+    int nint = 0, nflt = 0;
+    for (int i = 0; i < nstats; i++) { if (sel_host[i * 5 + 2] == 0) nint++; else nflt++; }
+    long long *di = nullptr;
+    float *df = nullptr;
+    CHK(run_segstats(ctx, d_seg, d_band, dtype, n, S, has_null, null_val, sel_host, nstats, missing, nullptr, nullptr,
+                     nrows, ncols, &di, &df));
+    // the local label histogram (all pixels of a label, valid or not) | flags | two counters
+    CHK(buf_ensure(ctx, ctx->chnext, ns * 4 + 64));
+    CHK(buf_ensure(ctx, ctx->chtail, ns + 64));
+    uint32_t *lh = bp<uint32_t>(ctx->chnext);
+    unsigned long long *ctr = (unsigned long long *)bp<uint8_t>(ctx->chtail);
+    uint8_t *flags = bp<uint8_t>(ctx->chtail) + 64;
+    HIPCHK(ctx, hipMemsetAsync(lh, 0, ns * 4, st));
+    HIPCHK(ctx, hipMemsetAsync(ctr, 0, 16, st));
+    if (n) { hipLaunchKernelGGL(k_label_hist, dim3(grid_for(n, 256)), dim3(256), 0, st, d_seg, n, S, lh); KCHK(ctx); }
+    hipLaunchKernelGGL(k_dstats_classify, dim3(grid_for(ns, 256)), dim3(256), 0, st, lh, d_hist, S, keep_unheld, nint, nflt,
+                       di, df, (long long *)d_cols, (float *)((long long *)d_cols + (size_t)nint * ns), flags, ctr); KCHK(ctx);
+    unsigned long long h[2] = {0, 0};
+    HIPCHK(ctx, hipMemcpyAsync(h, ctr, 16, hipMemcpyDeviceToHost, st));
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    if (h[0] >= 0xffffffffull) SHP_FAIL(ctx, SHP_ERR_ARG, "too many straddling pixels (%llu)", h[0]);
+    const uint32_t cap = (uint32_t)h[0];
+    // the straddlers' pixels, packed (the sorts of run_segstats are done with aux / aux2)
+    CHK(buf_ensure(ctx, ctx->aux, (size_t)cap * 4 + 64));
+    CHK(buf_ensure(ctx, ctx->aux2, (size_t)cap * 8 + 64));
+    uint32_t *d_count = (uint32_t *)(ctr + 4);
+    HIPCHK(ctx, hipMemsetAsync(d_count, 0, 4, st));
+    if (n && cap) {
+        hipLaunchKernelGGL(k_gather_flagged, dim3(grid_for(n, 4096)), dim3(256), 0, st, d_seg, d_band, dtype, n, S, flags,
+                           bp<uint32_t>(ctx->aux), (long long *)ctx->aux2.p, cap, d_count); KCHK(ctx);
+        uint32_t got = 0;
+        CHK(read_u32(ctx, d_count, &got));
+        if (got != cap) SHP_FAIL(ctx, SHP_ERR_STATE, "straddler gather found %u pixels, the histogram says %u", got, cap);
+    }
+    *d_pair_seg = bp<uint32_t>(ctx->aux);
+    *d_pair_val = (long long *)ctx->aux2.p;
+    *n_pairs = (int64_t)cap;
+    *n_strad = (int64_t)h[1];
+    return 0;
+}
+
+// Merge part.  pairs: `world` slots of `slot` (id, value) pairs as the all-gather left them, counts[r] valid
+// in slot r.  The pairs whose id lies in [id_lo, id_hi) -- this rank's share of the id space -- are compacted
+// into a 1 x m raster, reduced by the same statistics code, and the rows of the ids that occur are written
+// into cols (they were cleared by every rank's classify step).
+__global__ __launch_bounds__(256) void k_dstats_pick(const uint32_t *__restrict__ pseg, const long long *__restrict__ pval,
+                                                     uint32_t slot, uint32_t world, const uint32_t *__restrict__ counts,
+                                                     uint32_t id_lo, uint32_t id_hi, int dtype,
+                                                     uint32_t *__restrict__ out_seg, void *__restrict__ out_band,
+                                                     uint32_t *count)
+{
+    const size_t q = (size_t)blockIdx.x * 256u + threadIdx.x;
+    bool take = false;
+    uint32_t sg = 0;
+    long long v = 0;
+    if (q < (size_t)slot * world) {
+        const uint32_t r = (uint32_t)(q / slot), e = (uint32_t)(q - (size_t)r * slot);
+        if (e < counts[r]) { sg = pseg[q]; v = pval[q]; take = sg >= id_lo && sg < id_hi; }
+    }
+    const unsigned long long m = __ballot(take);
+    if (m == 0ull) return;
+    uint32_t base = 0;
+    if (lane_id() == 0) base = atomicAdd(count, (uint32_t)__popcll(m));
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    if (take) {
+        const uint32_t o = base + (uint32_t)__popcll(m & lanemask_lt());
+        out_seg[o] = sg;
+        switch (dtype) {
+        case SHP_U8: ((uint8_t *)out_band)[o] = (uint8_t)v; break;
+        case SHP_I16: ((int16_t *)out_band)[o] = (int16_t)v; break;
+        case SHP_U16: ((uint16_t *)out_band)[o] = (uint16_t)v; break;
+        case SHP_I32: ((int32_t *)out_band)[o] = (int32_t)v; break;
+        default: ((uint32_t *)out_band)[o] = (uint32_t)v; break;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void k_dstats_take(const uint32_t *__restrict__ present, uint32_t S, int nint, int nflt,
+                                                     const long long *__restrict__ src_int, const float *__restrict__ src_flt,
+                                                     long long *__restrict__ dst_int, float *__restrict__ dst_flt,
+                                                     uint32_t *n_ids)
+{
+    const size_t ns = (size_t)S + 1;
+    const size_t id = (size_t)blockIdx.x * 256u + threadIdx.x;
+    const bool here = id != 0 && id < ns && present[id] != 0u;
+    const unsigned long long m = __ballot(here);
+    if (m != 0ull && lane_id() == 0) atomicAdd(n_ids, (uint32_t)__popcll(m));
+    if (!here) return;
+    for (int c = 0; c < nint; c++) dst_int[(size_t)c * ns + id] = src_int[(size_t)c * ns + id];
+    for (int c = 0; c < nflt; c++) dst_flt[(size_t)c * ns + id] = src_flt[(size_t)c * ns + id];
+}
+
+static int run_dstats_merge(shp_ctx *ctx, const uint32_t *d_pseg, const long long *d_pval, uint32_t slot, uint32_t world,
+                            const uint32_t *counts_host, int dtype, uint32_t S, int has_null, int64_t null_val,
+                            const uint32_t *sel_host, int nstats, int64_t missing, uint32_t id_lo, uint32_t id_hi,
+                            void *d_cols, int64_t *n_merged, int64_t *n_ids)
+{
+    hipStream_t st = ctx->stream;
+    const size_t ns = (size_t)S + 1;
+    int nint = 0, nflt = 0;
+    for (int i = 0; i < nstats; i++) { if (sel_host[i * 5 + 2] == 0) nint++; else nflt++; }
+    *n_merged = 0;
+    *n_ids = 0;
+    const size_t total = (size_t)slot * world;
+    if (total == 0 || id_lo >= id_hi) return 0;
+    if (total >= 0xffffffffull) SHP_FAIL(ctx, SHP_ERR_ARG, "too many gathered pairs");
+    CHK(buf_ensure(ctx, ctx->lab, total * 4 + 64));
+    CHK(buf_ensure(ctx, ctx->img, total * dtype_size(dtype) + 64));
+    CHK(buf_ensure(ctx, ctx->chtail, (size_t)world * 4 + 128));
+    uint32_t *d_counts = bp<uint32_t>(ctx->chtail) + 16, *d_n = bp<uint32_t>(ctx->chtail);
+    HIPCHK(ctx, hipStreamSynchronize(st));
+    HIPCHK(ctx, hipMemcpyAsync(d_counts, counts_host, (size_t)world * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(ctx, hipMemsetAsync(d_n, 0, 4, st));
+    hipLaunchKernelGGL(k_dstats_pick, dim3(grid_for(total, 256)), dim3(256), 0, st, d_pseg, d_pval, slot, world, d_counts,
+                       id_lo, id_hi, dtype, bp<uint32_t>(ctx->lab), ctx->img.p, d_n); KCHK(ctx);
+    uint32_t m = 0;
+    CHK(read_u32(ctx, d_n, &m));
+    *n_merged = (int64_t)m;
+    if (m == 0) return 0;
+    long long *di = nullptr;
+    float *df = nullptr;
+    CHK(run_segstats(ctx, bp<uint32_t>(ctx->lab), ctx->img.p, dtype, m, S, has_null, null_val, sel_host, nstats, missing,
+                     nullptr, nullptr, 0, 0, &di, &df));
+    CHK(buf_ensure(ctx, ctx->chnext, ns * 4 + 64));
+    uint32_t *present = bp<uint32_t>(ctx->chnext);
+    HIPCHK(ctx, hipMemsetAsync(present, 0, ns * 4, st));
+    hipLaunchKernelGGL(k_label_hist, dim3(grid_for(m, 256)), dim3(256), 0, st, bp<uint32_t>(ctx->lab), m, S, present); KCHK(ctx);
+    HIPCHK(ctx, hipMemsetAsync(d_n, 0, 4, st));
+    hipLaunchKernelGGL(k_dstats_take, dim3(grid_for(ns, 256)), dim3(256), 0, st, present, S, nint, nflt, di, df,
+                       (long long *)d_cols, (float *)((long long *)d_cols + (size_t)nint * ns), d_n); KCHK(ctx);
+    uint32_t ids = 0;
+    CHK(read_u32(ctx, d_n, &ids));
+    *n_ids = (int64_t)ids;
     return 0;
 }

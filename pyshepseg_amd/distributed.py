@@ -428,23 +428,41 @@ def runDistributed(engine, comm, nRows, nCols, tileSize, overlapSize, minSegment
     return res
 
 
+def idRange(rank, world, maxSegId):
+    """This rank's share [lo, hi) of the id space 0..maxSegId for the reduction of straddling segments
+    ('GPU g owns ids in [g S / N, (g + 1) S / N)')."""
+    ns = int(maxSegId) + 1
+    return (rank * ns) // world, ((rank + 1) * ns) // world
+
+
 def calcPerSegmentStatsDistributed(engine, comm, hist, imgbandnum, statsSelection,
-                                   missingStatsValue=-9999, imgNullVal=None):
+                                   missingStatsValue=-9999, imgNullVal=None, info=None):
     """Per-segment statistics of one image band against the stitched label raster that
     runDistributed left sharded by rows over the ranks (reference tilingstats.py:85-216; SURVEY
     8e).  ``hist`` is the global histogram of the labels (DistResult.hist), which plays the part
     of the reference's segSize: a segment whose local pixel count equals hist[id] is complete on
     this rank and its statistics are final (checkSegComplete, tilingstats.py:518-553).  The
-    pixels of the few segments that straddle a rank boundary are gathered as (id, value) pairs,
-    all-gathered, and their statistics computed once (rank 0) with the same kernel.  Finished
-    rows are disjoint between ranks, so one integer all-reduce assembles the columns.
+    pixels of the segments that straddle a rank boundary are packed as (id, value) pairs and
+    all-gathered; every rank then reduces the straddlers whose id lies in ITS share of the id space
+    (idRange) with the same kernel.  Finished rows are disjoint between ranks, so one integer
+    all-reduce assembles the columns.
+      With a device engine under RCCL nothing of this crosses the host (shp_dstats_local_dev ->
+    ncclAllGather of the pairs -> shp_dstats_merge_dev -> ncclAllReduce of the column block); other
+    transports carry the same arrays as raw bytes.  ``info`` (a dict, optional) receives 'straddlers'
+    (segments) and 'straddler_pixels' of the whole job and 'path'.
     Returns (intcols int64 (nInt, maxSegId+1), floatcols float32 (nFloat, maxSegId+1),
     statsSelection_fast) on every rank -- bit-identical to the single-GPU result."""
     from . import tilingstats
-    hist = numpy.asarray(hist).astype(numpy.int64)
-    S = len(hist) - 1
     (fast, nInt, nFloat) = tilingstats.makeFastStatsSelection(
         list(range(len(statsSelection))), statsSelection)
+    if getattr(comm, 'onDevice', False) and hasattr(engine, 'statsOnDevice'):
+        (ic, fc, nStrad, nPix) = engine.statsOnDevice(comm, hist, imgbandnum, fast, nInt, nFloat,
+                                                      missingStatsValue, imgNullVal)
+        if info is not None:
+            info.update(straddlers=nStrad, straddler_pixels=nPix, path='device')
+        return ic, fc, fast
+    hist = numpy.asarray(hist).astype(numpy.int64)
+    S = len(hist) - 1
     lh = numpy.asarray(engine.histogram(S)).astype(numpy.int64)
     lh[0] = 0
     complete = (lh == hist) & (lh > 0)
@@ -456,21 +474,96 @@ def calcPerSegmentStatsDistributed(engine, comm, hist, imgbandnum, statsSelectio
     ic[:, ~keep] = 0
     fc[:, ~keep] = 0
     pairs = engine.gatherFlagged(imgbandnum, S, strad.astype(numpy.uint8), int(lh[strad].sum()))
-    allPairs = comm.allgather_obj(pairs)
-    if comm.rank == 0:
-        segs = numpy.concatenate([p[0] for p in allPairs])
-        vals = numpy.concatenate([p[1] for p in allPairs])
-        if len(segs):
-            (ids, compact) = numpy.unique(segs, return_inverse=True)
-            (ic2, fc2) = engine.statsOfPairs((compact + 1).astype(numpy.uint32), vals, len(ids), fast,
-                                             nInt, nFloat, missingStatsValue, imgNullVal)
-            ic[:, ids] = ic2[:, 1:]
-            fc[:, ids] = fc2[:, 1:]
+    allPairs = comm.allgather_arrays([pairs[0], pairs[1]])
+    (lo, hi) = idRange(comm.rank, comm.world, S)
+    segs = numpy.concatenate([p[0] for p in allPairs])
+    vals = numpy.concatenate([p[1] for p in allPairs])
+    mine = (segs >= lo) & (segs < hi)
+    if mine.any():
+        (ids, compact) = numpy.unique(segs[mine], return_inverse=True)
+        (ic2, fc2) = engine.statsOfPairs((compact + 1).astype(numpy.uint32), vals[mine], len(ids), fast,
+                                         nInt, nFloat, missingStatsValue, imgNullVal)
+        ic[:, ids] = ic2[:, 1:]
+        fc[:, ids] = fc2[:, 1:]
+    if info is not None:
+        # (a straddler is counted by every rank that holds a part of it: count the ids, once each)
+        info.update(straddlers=int(len(numpy.unique(segs))), straddler_pixels=int(len(segs)), path='host')
     if comm.world > 1:
         ic = comm.allreduce_sum_i64(ic.reshape(-1)).reshape(nInt, S + 1)
         fbits = comm.allreduce_sum_i64(fc.view(numpy.int32).reshape(-1).astype(numpy.int64))
         fc = fbits.astype(numpy.int32).view(numpy.float32).reshape(nFloat, S + 1)
     return ic, fc, fast
+
+
+def deviceStats(c, comm, d_seg, d_band, dtypeCode, nRows, nCols, hist, fast, nInt, nFloat, missing, imgNullVal,
+                fetch=True):
+    """The device-resident data path of calcPerSegmentStatsDistributed for ONE rank: label rows d_seg
+    (nRows x nCols uint32) and band rows d_band in the HBM of context ``c``; comm: allgather_obj (control
+    data only), allgather_dev, allreduce_dev_i64.  ``hist``: the global histogram, a numpy array or
+    ('dev', address, length) when it is in device memory already.  fetch=False: the assembled columns are not
+    copied to the host (ic = fc = None).  Returns (ic, fc, straddling segments, their pixels)."""
+    L = c._L
+    if isinstance(hist, tuple):
+        (d_hist, ns, ownHist) = (ctypes.c_void_p(hist[1]), int(hist[2]), False)
+    else:
+        h32 = numpy.ascontiguousarray(hist, dtype=numpy.uint32)
+        ns = len(h32)
+        d_hist = ctypes.c_void_p()
+        c.check(L.shp_dev_alloc(c.handle, ns * 4, ctypes.byref(d_hist)))
+        c.check(L.shp_dev_upload(c.handle, d_hist, _lib.ptr(h32), ns * 4))
+        ownHist = True
+    S = ns - 1
+    colWords = ((nInt * 8 + nFloat * 4) * ns + 7) // 8
+    d_cols = ctypes.c_void_p()
+    c.check(L.shp_dev_alloc(c.handle, colWords * 8, ctypes.byref(d_cols)))
+    toFree = [d_cols] + ([d_hist] if ownHist else [])
+    try:
+        c.check(L.shp_dev_memset(c.handle, ctypes.c_void_p(d_cols.value + (colWords - 1) * 8), 0, 8))
+        (pSeg, pVal) = (ctypes.c_void_p(), ctypes.c_void_p())
+        (nPairs, nStrad) = (ctypes.c_int64(0), ctypes.c_int64(0))
+        hasNull = int(imgNullVal is not None)
+        nullVal = 0 if imgNullVal is None else int(imgNullVal)
+        c.check(L.shp_dstats_local_dev(c.handle, ctypes.c_void_p(d_seg), ctypes.c_void_p(d_band), dtypeCode, nRows, nCols,
+                                       S, hasNull, nullVal, _lib.ptr(fast), fast.shape[0], int(missing), d_hist,
+                                       int(comm.rank == 0), d_cols, ctypes.byref(pSeg), ctypes.byref(pVal),
+                                       ctypes.byref(nPairs), ctypes.byref(nStrad)))
+        counts = [int(x) for x in comm.allgather_obj(int(nPairs.value))]          # control data
+        slot = max(counts)
+        (merged, nIds) = (ctypes.c_int64(0), ctypes.c_int64(0))
+        if slot > 0:
+            bufs = []
+            for sz in (slot * 4, slot * 8, comm.world * slot * 4, comm.world * slot * 8):
+                p = ctypes.c_void_p()
+                c.check(L.shp_dev_alloc(c.handle, sz, ctypes.byref(p)))
+                bufs.append(p)
+                toFree.append(p)
+            (d_sendS, d_sendV, d_allS, d_allV) = bufs
+            if nPairs.value:
+                c.check(L.shp_dev_copy(c.handle, d_sendS, pSeg, nPairs.value * 4))
+                c.check(L.shp_dev_copy(c.handle, d_sendV, pVal, nPairs.value * 8))
+            comm.allgather_dev(d_sendS.value, d_allS.value, slot * 4)
+            comm.allgather_dev(d_sendV.value, d_allV.value, slot * 8)
+            (lo, hi) = idRange(comm.rank, comm.world, S)
+            cnts = numpy.array(counts, dtype=numpy.uint32)
+            c.check(L.shp_dstats_merge_dev(c.handle, d_allS, d_allV, slot, comm.world, _lib.ptr(cnts), dtypeCode, S,
+                                           hasNull, nullVal, _lib.ptr(fast), fast.shape[0], int(missing), lo, hi, d_cols,
+                                           ctypes.byref(merged), ctypes.byref(nIds)))
+        if comm.world > 1:
+            comm.allreduce_dev_i64(d_cols.value, colWords)
+        (ic, fc) = (None, None)
+        if fetch:
+            ic = numpy.empty((nInt, ns), dtype=numpy.int64)
+            fc = numpy.empty((nFloat, ns), dtype=numpy.float32)
+        if fetch and nInt:
+            c.check(L.shp_dev_download(c.handle, _lib.ptr(ic), d_cols, ic.nbytes))
+        if fetch and nFloat:
+            c.check(L.shp_dev_download(c.handle, _lib.ptr(fc), ctypes.c_void_p(d_cols.value + nInt * 8 * ns), fc.nbytes))
+    finally:
+        for p in toFree:
+            c.check(L.shp_dev_free(c.handle, p))
+    # the job's figures: the ranks' id shares partition the straddlers, the ranks' rows their pixels
+    tot = comm.allgather_obj((int(nIds.value), int(nPairs.value)))
+    return ic, fc, int(sum(t[0] for t in tot)), int(sum(t[1] for t in tot))
 
 
 # ------------------------------------------------------------------------------------------
@@ -741,6 +834,12 @@ class HipEngine(object):
             _lib.ptr(fast), fast.shape[0], int(missing), _lib.ptr(ic), _lib.ptr(fc)))
         return ic, fc
 
+    def statsOnDevice(self, comm, hist, imgbandnum, fast, nInt, nFloat, missing, imgNullVal):
+        """calcPerSegmentStatsDistributed's device path for this rank's output rows (deviceStats)."""
+        return deviceStats(self.c, comm, self._lastOut.value if hasattr(self._lastOut, 'value') else int(self._lastOut),
+                           self._bandPtr(imgbandnum), _lib.SHP_DTYPES[self.ras.dtype], self.outHi - self.outLo,
+                           self.nCols, hist, fast, nInt, nFloat, missing, imgNullVal)
+
     def localOutput(self):
         out = numpy.empty((self.outHi - self.outLo, self.nCols), dtype=numpy.uint32)
         self.c.check(self.L.shp_dev_download(self.c.handle, _lib.ptr(out), self._lastOut, out.nbytes))
@@ -771,6 +870,81 @@ class HipEngine(object):
 # ------------------------------------------------------------------------------------------
 # bench.py entry for --gpus N > 1
 # ------------------------------------------------------------------------------------------
+def bench_stats_main(args, rank, world, local_rank):
+    """One rank of `bench.py --workload c5 --gpus N`: the label raster of 4 x 8-pixel blocks (50 M segments at
+    40000^2) and one uint16 band, sharded by rows at boundaries that CUT blocks (every shard boundary makes
+    nCols / 8 straddling segments); a step = calcPerSegmentStatsDistributed's device path (deviceStats), the
+    assembled columns copied to the host on rank 0."""
+    from . import comm as _comm
+    from . import tilingstats
+    comm = _comm.fromEnvironment()
+    c = _lib.ctx()
+    L = c._L
+    dcomm = comm if getattr(comm, 'onDevice', False) else _comm.HostStagedDev(comm, c)
+    (N, BH, BW) = (args.size, 4, 8)
+    # shard boundaries two rows into a block row
+    cuts = [0] + [min(N, ((N * (r + 1)) // world) // BH * BH + 2) for r in range(world - 1)] + [N]
+    (y0, y1) = (cuts[rank], cuts[rank + 1])
+    ras = tiling.DeviceRaster.synth(getattr(args, 'seed', 11), 1, y1 - y0, N, y0=y0, x0=0)
+    d_full = ctypes.c_void_p()
+    c.check(L.shp_dev_alloc(c.handle, N * N * 4, ctypes.byref(d_full)))
+    S = ctypes.c_uint32(0)
+    c.check(L.shp_dev_block_labels(c.handle, N, N, BH, BW, d_full, ctypes.byref(S)))
+    S = S.value
+    d_seg = d_full.value + y0 * N * 4                       # this rank's rows of the label raster
+    h = numpy.full(S + 1, BH * BW, dtype=numpy.uint32)      # every block whole: the RAT's Histogram column
+    h[0] = 0
+    d_hist = ctypes.c_void_p()
+    c.check(L.shp_dev_alloc(c.handle, h.nbytes, ctypes.byref(d_hist)))
+    c.check(L.shp_dev_upload(c.handle, d_hist, _lib.ptr(h), h.nbytes))
+    sel = [('mean', 'mean'), ('sd', 'stddev'), ('med', 'median'), ('n', 'pixcount')]
+    (fast, nInt, nFloat) = tilingstats.makeFastStatsSelection(list(range(len(sel))), sel)
+
+    def step():
+        return deviceStats(c, dcomm, d_seg, ras.ptr, 2, y1 - y0, N, ('dev', d_hist.value, S + 1), fast, nInt, nFloat,
+                           -9999, None, fetch=(rank == 0))
+
+    for _ in range(args.warmup):
+        res = step()
+    c.check(L.shp_sync(c.handle))
+    comm.barrier()
+    t0 = time.time()
+    for _ in range(args.steps):
+        res = step()
+    c.check(L.shp_sync(c.handle))
+    comm.barrier()
+    dt = comm.max_f64((time.time() - t0) / max(args.steps, 1))
+    rcclRanks = comm.count() if hasattr(comm, 'count') else None
+    if rank == 0:
+        (ic, fc, nStrad, nPix) = res
+        assert int(ic[fast[3, 3]].sum()) == N * N and (ic[fast[3, 3]][1:] == BH * BW).all()
+        npix = N * N
+        alg = 6 * npix + 4 * len(sel) * (S + 1)            # SURVEY 8(d): 6 B/px + 4 * nCols B/segment
+        out = {
+            "metric": "Mpixels/sec, tilingstats per-segment mean/stddev/median/pixcount",
+            "value": round(npix / dt / 1e6, 3), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt * 1e3, 2), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "u16", "data": "synthetic",
+            "config": {"workload": "C5: %dx%d label raster of %d x %d-pixel blocks (%d segments) + one uint16 synthimg v1 "
+                                   "band, rows sharded over %d GPUs at boundaries that cut blocks; 4 result columns "
+                                   "assembled by one all-reduce and copied to the host on rank 0" % (N, N, BH, BW, S, world),
+                       "segments": S, "straddlers": int(nStrad), "straddler_pixels": int(nPix),
+                       "rows_per_rank": [cuts[r + 1] - cuts[r] for r in range(world)],
+                       "transport": getattr(dcomm, 'transport', type(dcomm).__name__), "rccl_nranks": rcclRanks,
+                       "parallelism": "label rows sharded over %d ranks, one process per GPU; straddling segments' pixels "
+                                      "all-gathered as packed device buffers and reduced by id share; columns all-reduced" % world},
+            "roofline": {"bound": "hbm", "kernel": "whole call (local statistics + exchange + all-reduce + download)",
+                         "achieved": round(alg / dt / 1e9, 3), "peak": 8000.0 * world, "unit": "GB/s",
+                         "frac": round(alg / dt / 1e9 / (8000.0 * world), 6), "traffic": None},
+        }
+        print(json.dumps(out), flush=True)
+    comm.barrier()
+    c.check(L.shp_dev_free(c.handle, d_hist))
+    c.check(L.shp_dev_free(c.handle, d_full))
+    ras.free()
+    comm.close()
+
+
 def bench_main(args, rank, world, local_rank):
     """One rank of the multi-GPU benchmark: this rank's rows of the synthetic image are generated
     in its own HBM (synthimg is position-deterministic); a step = runDistributed."""

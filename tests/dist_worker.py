@@ -43,9 +43,11 @@ def main():
                                    simpleTileRecode=bool(simple))
     sel = [('a', 'min'), ('b', 'max'), ('c', 'mean'), ('d', 'stddev'), ('e', 'median'),
            ('f', 'mode'), ('g', 'percentile', 25), ('h', 'pixcount')]
+    info = {}
     ic, fc, _fast = distributed.calcPerSegmentStatsDistributed(eng, comm, r.hist, 2, sel,
-                                                               imgNullVal=65535)
-    np.savez(os.path.join(outdir, 'stats%d.npz' % comm.rank), ic=ic, fc=fc)
+                                                               imgNullVal=65535, info=info)
+    np.savez(os.path.join(outdir, 'stats%d.npz' % comm.rank), ic=ic, fc=fc, straddlers=info['straddlers'],
+             straddler_pixels=info['straddler_pixels'])
     np.savez(os.path.join(outdir, 'rank%d.npz' % comm.rank), out=eng.out, outLo=r.outRows[0],
              outHi=r.outRows[1], maxSegId=r.maxSegId, hist=r.hist,
              centres=r.kmeans.cluster_centers_, msd=r.maxSpectralDiff, rows=np.array(r.rowRange),

@@ -199,6 +199,15 @@ def test_two_rank_chain_matches_single_process(world, simple, NR, mode, shard, o
         st = np.load(tmp_path / ('stats%d.npz' % r))
         assert np.array_equal(st['ic'], wic)
         assert np.array_equal(st['fc'].view(np.uint32), wfc.view(np.uint32))
+        # segments DO straddle the rank boundaries (their pixels travelled as raw arrays and were reduced by the
+        # rank whose share of the id space holds them): the ids present in more than one rank's rows
+        if world > 1:
+            held = [set(np.unique(q['out'])) - {0} for q in parts]
+            strad = set()
+            for a in range(world):
+                for b in range(a + 1, world):
+                    strad |= held[a] & held[b]
+            assert int(st['straddlers']) == len(strad) and (simple or NR < 330 or len(strad) > 0)
 
 
 @pytest.mark.parametrize('seed', range(8))

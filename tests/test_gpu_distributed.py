@@ -101,3 +101,116 @@ def test_hip_engine_chain_matches_single_process(world, mode, tmp_path):
         st = np.load(tmp_path / ('stats%d.npz' % r))
         assert np.array_equal(st['ic'], wic)
         assert np.array_equal(st['fc'].view(np.uint32), wfc.view(np.uint32))
+
+
+class _ThreadDevComm(object):
+    """An in-process stand-in for RcclComm's device collectives: `world` threads of one process, one GPU.
+    allgather_dev copies device to device, allreduce_dev_i64 adds through the host (test data is small)."""
+    onDevice = True
+
+    def __init__(self, rank, world, shared):
+        import threading
+        (self.rank, self.world, self.sh) = (rank, world, shared)
+        if rank == 0:
+            shared['bar'] = threading.Barrier(world)
+            shared['slots'] = [None] * world
+        self.c = None
+
+    def _xchg(self, v):
+        self.sh['bar'].wait()
+        self.sh['slots'][self.rank] = v
+        self.sh['bar'].wait()
+        out = list(self.sh['slots'])
+        self.sh['bar'].wait()
+        return out
+
+    def allgather_obj(self, obj):
+        return self._xchg(obj)
+
+    def allgather_dev(self, d_send, d_recv, nbytes):
+        import ctypes
+        ptrs = self._xchg(d_send)
+        for (r, p) in enumerate(ptrs):
+            self.c.check(self.c._L.shp_dev_copy(self.c.handle, ctypes.c_void_p(d_recv + r * nbytes), ctypes.c_void_p(p), nbytes))
+        self.sh['bar'].wait()                  # nobody frees a send buffer another rank still reads
+
+    def allreduce_dev_i64(self, d_buf, count):
+        import ctypes
+        from pyshepseg_amd import _lib
+        mine = np.empty(count, dtype=np.int64)
+        self.c.check(self.c._L.shp_dev_download(self.c.handle, _lib.ptr(mine), ctypes.c_void_p(d_buf), mine.nbytes))
+        tot = np.sum(self._xchg(mine), axis=0, dtype=np.int64)
+        self.c.check(self.c._L.shp_dev_upload(self.c.handle, ctypes.c_void_p(d_buf), _lib.ptr(tot), tot.nbytes))
+
+
+@pytest.mark.parametrize('world,dtype,nullv', [(2, np.uint16, None), (3, np.uint16, 7), (3, np.uint8, None), (2, np.int16, -5)])
+def test_device_stats_split_with_straddlers(world, dtype, nullv, oracle):
+    """The device-resident data path of calcPerSegmentStatsDistributed (shp_dstats_local_dev -> all-gather of
+    the packed pairs -> shp_dstats_merge_dev by id share -> all-reduce of the column block) with `world`
+    row shards of one raster on this one GPU, segments crossing every shard boundary, against the oracle on
+    the whole raster: every column bit for bit on every rank."""
+    import ctypes
+    import threading
+    from pyshepseg_amd import distributed, tilingstats, _lib
+    rng = np.random.default_rng(world * 10 + np.dtype(dtype).itemsize)
+    (nr, nc) = (203, 190)
+    # segments: blobs of a coarse random field -> long vertical streaks cross the shard boundaries
+    base = rng.integers(1, 40, size=(nr // 7 + 2, nc // 5 + 1))
+    seg = np.kron(base, np.ones((7, 5), dtype=np.int64))[:nr, :nc]
+    seg = (seg + (np.arange(nc)[None, :] // 37) * 40).astype(np.uint32)
+    seg[rng.random((nr, nc)) < 0.03] = 0
+    S = int(seg.max()) + 3                                             # ids nobody holds at the top
+    info = np.iinfo(dtype)
+    band = rng.integers(max(info.min, -300), min(info.max, 300) + 1, size=(nr, nc)).astype(dtype)
+    if nullv is not None:
+        band[rng.random((nr, nc)) < 0.1] = nullv
+        band[seg == 5] = nullv                                         # an all-nodata segment
+    sel = [('a', 'min'), ('b', 'max'), ('c', 'mean'), ('d', 'stddev'), ('e', 'median'), ('f', 'mode'),
+           ('g', 'percentile', 30), ('h', 'pixcount')]
+    (fast, nInt, nFloat) = tilingstats.makeFastStatsSelection(list(range(len(sel))), sel)
+    (wic, wfc) = oracle.segstats(seg, band, sel, nullv, -9999, max_seg_id=S)
+    hist = np.bincount(seg.ravel(), minlength=S + 1).astype(np.uint32)
+    hist[0] = 0
+    cuts = [0] + [int(round(nr * (r + 1) / world)) for r in range(world)]
+    shared, results, errors = {}, [None] * world, []
+
+    def rank(r):
+        try:
+            c = _lib.Context()
+            comm = _ThreadDevComm(r, world, shared)
+            comm.c = c
+            (lo, hi) = (cuts[r], cuts[r + 1])
+            (ds, db) = (ctypes.c_void_p(), ctypes.c_void_p())
+            ss, bb = np.ascontiguousarray(seg[lo:hi]), np.ascontiguousarray(band[lo:hi])
+            c.check(c._L.shp_dev_alloc(c.handle, ss.nbytes, ctypes.byref(ds)))
+            c.check(c._L.shp_dev_alloc(c.handle, bb.nbytes, ctypes.byref(db)))
+            c.check(c._L.shp_dev_upload(c.handle, ds, _lib.ptr(ss), ss.nbytes))
+            c.check(c._L.shp_dev_upload(c.handle, db, _lib.ptr(bb), bb.nbytes))
+            results[r] = distributed.deviceStats(c, comm, ds.value, db.value, _lib.SHP_DTYPES[np.dtype(dtype)], hi - lo, nc,
+                                                 hist, fast, nInt, nFloat, -9999, nullv)
+            c.check(c._L.shp_dev_free(c.handle, ds))
+            c.check(c._L.shp_dev_free(c.handle, db))
+            c.close()
+        except BaseException as e:      # noqa: B902  (a dead rank must not leave the others at a barrier)
+            errors.append(e)
+            try:
+                shared['bar'].abort()
+            except Exception:
+                pass
+    _ThreadDevComm(0, world, shared)          # the barrier exists before any thread runs
+    th = [threading.Thread(target=rank, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(300)
+    assert not errors, errors
+    held = [set(np.unique(seg[cuts[r]:cuts[r + 1]])) - {0} for r in range(world)]
+    strad = set()
+    for a in range(world):
+        for b in range(a + 1, world):
+            strad |= held[a] & held[b]
+    assert len(strad) > 10
+    for (ic, fc, nStrad, nPix) in results:
+        assert np.array_equal(ic, wic)
+        assert np.array_equal(fc.view(np.uint32), wfc.view(np.uint32))
+        assert nStrad == len(strad) and nPix == int(np.isin(seg, list(strad)).sum())

@@ -59,7 +59,13 @@ two-ranks)  # rehearsal of `bench.py --gpus 2`: two ranks share the one GPU, str
     for m in parallel sequential; do
       SHEPSEG_COMM=socket SHEPSEG_DEVICE=0 SHEPSEG_STITCH=$m timeout -k 10 500 python bench.py --gpus 2 --workers 12 --steps 2 --cpu-sample 0 > gpurun_out/two_$m.log 2>&1 || { tail -20 gpurun_out/two_$m.log; exit 1; }
       grep "^{" gpurun_out/two_$m.log | tail -1 | cut -c1-1400
-    done ;;
+    done
+    # the same for the sharded statistics (C5): two ranks over sockets (device buffers staged through the host),
+    # then one rank under RCCL itself (ncclAllGather / ncclAllReduce of the device buffers at world size 1)
+    SHEPSEG_COMM=socket SHEPSEG_DEVICE=0 timeout -k 10 500 python bench.py --gpus 2 --workload c5 --steps 2 --cpu-sample 0 > gpurun_out/two_c5.log 2>&1 || { tail -20 gpurun_out/two_c5.log; exit 1; }
+    grep "^{" gpurun_out/two_c5.log | tail -1 | cut -c1-1400
+    SHEPSEG_FORCE_DIST=1 RANK=0 LOCAL_RANK=0 WORLD_SIZE=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29517 timeout -k 10 300 python bench.py --gpus 1 --workload c5 --steps 3 --cpu-sample 0 > gpurun_out/one_c5.log 2>&1 || { tail -20 gpurun_out/one_c5.log; exit 1; }
+    grep "^{" gpurun_out/one_c5.log | tail -1 | cut -c1-1400 ;;
 dump-sample) # the k-means sub-sample of a benchmark raster for oracle/refgen/gen_golden_c3_fit.py: dump-sample SEED BANDS NAME
     timeout -k 10 300 python - "$@" <<'PY'
 import sys, numpy as np
