@@ -54,6 +54,9 @@ def parse():
     ap.add_argument('--overlap', type=int, default=1024)
     ap.add_argument('--workers', type=int, default=int(os.environ.get('SHEPSEG_WORKERS', '36')))
     ap.add_argument('--simple-recode', type=int, default=0, help='diagnostic: simpleTileRecode')
+    ap.add_argument('--also', type=int, default=1,
+                    help='default c3 run on one GPU: append "also": {"c5": ..., "c3_npy": ...} from two short extra '
+                         'runs after the headline timing (0 = skip)')
     ap.add_argument('--cpu-sample', type=int, default=14336,
                     help='window edge of the cpu_baseline sample (0 = skip)')
     args = ap.parse_args()
@@ -336,9 +339,39 @@ def bench_segmentation(args):
         out["cpu_baseline"] = cpu_baseline(ras, args, r.kmeans.cluster_centers_,
                                            float(r.maxSpectralDiff))
         out["cpu_baseline"]["reference_numba_mpx_per_core"] = 1.3       # the reference's own path
-    print(json.dumps(out))
     if args.source == 'hbm':
         ras.free()
+    return out
+
+
+def also_runs(args):
+    """Two short extra runs behind the headline (never part of `value`): BASELINE config 5 (tilingstats, C5) and
+    config 3's I/O variant (the image read from / the labels written to .npy files through the pipeline: PCIe and
+    the file system inclusive).  Each is its own line of this benchmark in miniature."""
+    import copy
+    from pyshepseg_amd import tiling
+    res = {}
+    for (name, over) in (('c5', dict(workload='c5', bands=1, seed=11, steps=2, warmup=1, cpu_sample=0, source='hbm')),
+                         ('c3_npy', dict(workload='c3', bands=6, seed=11, steps=2, warmup=1, cpu_sample=0, source='npy'))):
+        a = copy.copy(args)
+        for (k, v) in over.items():
+            setattr(a, k, v)
+        try:
+            o = bench_stats(a) if name == 'c5' else bench_segmentation(a)
+            keep = {k: o[k] for k in ('metric', 'value', 'unit', 'steps', 'warmup', 'ms_per_step', 'roofline') if k in o}
+            keep['workload'] = o['config']['workload']
+            if name == 'c3_npy':
+                keep['pcie_gb_per_s_both_directions'] = round(
+                    (a.bands * 2 + 4) * a.size * a.size / 1e9 / (o['ms_per_step'] / 1e3), 2)
+                keep['roofline'] = {k: o['roofline'][k] for k in ('bound', 'kernel', 'achieved', 'peak', 'unit', 'frac')}
+            res[name] = keep
+        except Exception as e:           # an extra must never cost the headline line
+            res[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+        try:
+            tiling.clearDeviceCache()
+        except Exception:
+            pass
+    return res
 
 
 def bench_stats(args):
@@ -407,9 +440,9 @@ def bench_stats(args):
                                "kind": "port",
                                "sample": "top-left %dx%d window (%d segments), %.1f s of single-thread C "
                                          "oracle (orc_segstats)" % (w, w, int(lab.max()), t)}
-    print(json.dumps(out))
     c.check(c._L.shp_dev_free(c.handle, d_seg))
     ras.free()
+    return out
 
 
 def main():
@@ -430,8 +463,12 @@ def main():
             return distributed.bench_stats_main(args, rank, world, local_rank)
         return distributed.bench_main(args, rank, world, local_rank)
     if args.workload == 'c5':
-        return bench_stats(args)
-    return bench_segmentation(args)
+        out = bench_stats(args)
+    else:
+        out = bench_segmentation(args)
+        if args.also and args.workload == 'c3' and args.source == 'hbm' and args.size == 40000:
+            out["also"] = also_runs(args)
+    print(json.dumps(out))
 
 
 if __name__ == '__main__':

@@ -508,15 +508,14 @@ def deviceStats(c, comm, d_seg, d_band, dtypeCode, nRows, nCols, hist, fast, nIn
     else:
         h32 = numpy.ascontiguousarray(hist, dtype=numpy.uint32)
         ns = len(h32)
-        d_hist = ctypes.c_void_p()
-        c.check(L.shp_dev_alloc(c.handle, ns * 4, ctypes.byref(d_hist)))
+        d_hist = tiling._devAlloc(c, ns * 4)
         c.check(L.shp_dev_upload(c.handle, d_hist, _lib.ptr(h32), ns * 4))
         ownHist = True
     S = ns - 1
     colWords = ((nInt * 8 + nFloat * 4) * ns + 7) // 8
-    d_cols = ctypes.c_void_p()
-    c.check(L.shp_dev_alloc(c.handle, colWords * 8, ctypes.byref(d_cols)))
-    toFree = [d_cols] + ([d_hist] if ownHist else [])
+    # (blocks from / back to the driver's cache of device scratch blocks: a 1.2-GB hipMalloc per call otherwise)
+    d_cols = tiling._devAlloc(c, colWords * 8)
+    toFree = [(d_cols, colWords * 8)] + ([(d_hist, ns * 4)] if ownHist else [])
     try:
         c.check(L.shp_dev_memset(c.handle, ctypes.c_void_p(d_cols.value + (colWords - 1) * 8), 0, 8))
         (pSeg, pVal) = (ctypes.c_void_p(), ctypes.c_void_p())
@@ -533,10 +532,9 @@ def deviceStats(c, comm, d_seg, d_band, dtypeCode, nRows, nCols, hist, fast, nIn
         if slot > 0:
             bufs = []
             for sz in (slot * 4, slot * 8, comm.world * slot * 4, comm.world * slot * 8):
-                p = ctypes.c_void_p()
-                c.check(L.shp_dev_alloc(c.handle, sz, ctypes.byref(p)))
+                p = tiling._devAlloc(c, sz)
                 bufs.append(p)
-                toFree.append(p)
+                toFree.append((p, sz))
             (d_sendS, d_sendV, d_allS, d_allV) = bufs
             if nPairs.value:
                 c.check(L.shp_dev_copy(c.handle, d_sendS, pSeg, nPairs.value * 4))
@@ -559,8 +557,8 @@ def deviceStats(c, comm, d_seg, d_band, dtypeCode, nRows, nCols, hist, fast, nIn
         if fetch and nFloat:
             c.check(L.shp_dev_download(c.handle, _lib.ptr(fc), ctypes.c_void_p(d_cols.value + nInt * 8 * ns), fc.nbytes))
     finally:
-        for p in toFree:
-            c.check(L.shp_dev_free(c.handle, p))
+        for (p, sz) in toFree:
+            tiling._devRelease(c, p, sz)
     # the job's figures: the ranks' id shares partition the straddlers, the ranks' rows their pixels
     tot = comm.allgather_obj((int(nIds.value), int(nPairs.value)))
     return ic, fc, int(sum(t[0] for t in tot)), int(sum(t[1] for t in tot))
