@@ -319,7 +319,7 @@ def bench_segmentation(args):
                                        "streamed to a .npy file: %.1f GB in + %.1f GB out over PCIe per step"
                                        % (args.bands * npix * 2 / 1e9, npix * 4 / 1e9)),
                    "source": args.source,
-                   "tiles": len(ti.tiles), "workers": cfg.numWorkers, "fill_streams": int(os.environ.get('SHEPSEG_FILL_MAX', '4')), "walker_streams": int(os.environ.get('SHEPSEG_WALK_STREAMS', '12')),
+                   "tiles": len(ti.tiles), "workers": cfg.numWorkers, "fill_streams": int(os.environ.get('SHEPSEG_FILL_MAX', '6')), "walker_streams": int(os.environ.get('SHEPSEG_WALK_STREAMS', '10')),
                    "max_seg_id": int(r.maxSegId)},
         "roofline": {"bound": "hbm", "kernel": names[dom], "achieved": round(achieved, 3),
                      "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -74,7 +74,8 @@ struct shp_ctx {
 // idles a quarter of the time.  The gate lets only a few tiles be in a filling phase at any time
 // (the others queue on the host), which staggers them: while some fill, the rest are in their
 // chains.  Phases nearer the end of a tile go first.  SHEPSEG_FILL_MAX = 0 switches it off.
-#define FILL_MAX_DEFAULT 4
+#define FILL_MAX_DEFAULT 6          // (round 4, with the shorter fit: 4 -> 6 fill and 12 -> 10 walker streams = -15 ms per step;
+                                    //  fill + walker + 3 must stay <= 21 hardware queues: 7 + 12 costs 60 ms)
 #define FILL_PRIOS 4
 struct FillGate {
     std::mutex mu;
@@ -94,7 +95,7 @@ static const int g_fill_max = getenv("SHEPSEG_FILL_MAX") ? atoi(getenv("SHEPSEG_
 // phase ends in a host synchronisation, so the next phase may run on any other stream).  More tiles
 // than streams can then be in flight.  Outside worker calls a shared context uses the pool's idle
 // stream, which all of them share.
-#define WALK_STREAMS_DEFAULT 12
+#define WALK_STREAMS_DEFAULT 10
 struct StreamPool {
     std::mutex mu;
     std::condition_variable cv;
