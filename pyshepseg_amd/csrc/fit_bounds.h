@@ -142,6 +142,27 @@ __global__ __launch_bounds__(256) void k_elk2_init(const double *__restrict__ X,
     }
 }
 
+// `count` doubles of a small global table into registers first, then wherever `put` takes them: the loads of a
+// thread are independent and all in flight (a load -> LDS store loop pays a memory round trip per 256 entries,
+// 15 of them for the half distances -- a third of a late iteration's visit kernel)
+template <class Put>
+__device__ __forceinline__ void elk2_stage(const double *__restrict__ src, int count, Put put)
+{
+    for (int q0 = 0; q0 < count; q0 += 256 * 16) {
+        double v[16];
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+            const int q = q0 + u * 256 + (int)threadIdx.x;
+            v[u] = src[q < count ? q : count - 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+            const int q = q0 + u * 256 + (int)threadIdx.x;
+            if (q < count) put(q, v[u]);
+        }
+    }
+}
+
 #define ELK2_ROWS 8                     // bounds rows per group
 #define ELK2_WIN 4                      // groups in flight per wavefront (8 groups = the 64 samples of a chunk)
 
@@ -186,12 +207,11 @@ __global__ __launch_bounds__(256) void k_elk2_filter(uint32_t n, int k, const do
     float *sh_hf = (float *)(sh_next + k);
     for (int q = threadIdx.x; q < k; q += 256) { sh_csp[q] = csprev ? csprev[q] : 0.0; sh_next[q] = next[q]; }
     // half distances rounded down; +inf on the diagonal (`upper > half[label][j]` then fails for j == label by itself)
-    for (int q = threadIdx.x; q < k * k; q += 256) {
-        const double h = half[q];
+    elk2_stage(half, k * k, [&](int q, double h) {
         float f = (float)h;
         if ((double)f > h) f = __uint_as_float(__float_as_uint(f) - 1u);       // (h >= 0: f > 0 here)
         sh_hf[q] = (q / k == q % k) ? __builtin_inff() : f;
-    }
+    });
     __syncthreads();
     const int lane = (int)lane_id();
     const int cl = lane < k ? lane : k - 1;
@@ -298,8 +318,8 @@ __global__ __launch_bounds__(256) void k_elk2_visit(const double *__restrict__ X
     double *sh_half = sh2, *sh_ct = sh2 + k * k, *sh_cum = sh_ct + k * nb;
     uint32_t *sh_list = (uint32_t *)(sh_cum + k);
     __shared__ uint32_t sh_cnt, sh_changed, sh_exact;
-    for (int q = threadIdx.x; q < k * k; q += 256) sh_half[q] = half[q];
-    for (int q = threadIdx.x; q < k * nb; q += 256) { const int j = q / nb, b = q - j * nb; sh_ct[b * k + j] = cen[q]; }
+    elk2_stage(half, k * k, [&](int q, double h) { sh_half[q] = h; });
+    elk2_stage(cen, k * nb, [&](int q, double c) { const int j = q / nb, b = q - j * nb; sh_ct[b * k + j] = c; });
     for (int q = threadIdx.x; q < k; q += 256) sh_cum[q] = cumt[q];
     if (threadIdx.x == 0) { sh_cnt = 0u; sh_changed = 0u; sh_exact = 0u; }
     __syncthreads();
