@@ -167,8 +167,10 @@ def spawn_ranks(args):
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
     procs = []
+    import secrets
+    nonce = secrets.token_hex(8)            # names this launch's rendezvous files (pyshepseg_amd/comm.py launchTag)
     for r in range(args.gpus):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
+        env = dict(os.environ, SHEPSEG_LAUNCH_NONCE=nonce, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus),
                    LOCAL_WORLD_SIZE=str(args.gpus), MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else None, text=True))

@@ -57,10 +57,20 @@ def rendezvousDir():
     return d
 
 
+def launchTag():
+    """Distinguishes the rendezvous files of THIS launch from what an earlier, crashed launch left in the same
+    directory: a nonce the launcher put into every rank's environment (bench.py's spawn_ranks and the test
+    helpers set SHEPSEG_LAUNCH_NONCE; torchrun sets TORCHELASTIC_RUN_ID).  Without one the names are plain and
+    rank 0's clean-up at start is all there is."""
+    t = os.environ.get('SHEPSEG_LAUNCH_NONCE') or os.environ.get('TORCHELASTIC_RUN_ID') or ''
+    t = ''.join(ch for ch in t if ch.isalnum() or ch in '-_')[:48]
+    return ('.' + t) if t and t != 'none' else ''
+
+
 def launchKey(d, rank):
     """32 random bytes shared by the ranks of one launch (rank 0 makes them): the key of the socket
     transport's connection handshake."""
-    path = os.path.join(d, 'key')
+    path = os.path.join(d, 'key' + launchTag())
     if rank == 0:
         key = secrets.token_bytes(32)
         _publish(path, key)
@@ -211,9 +221,11 @@ class SocketComm(_ObjCollectives):
         self.out = {}
         self.inc = {}
         self.cond = threading.Condition()
-        if self.rank == 0:          # leftovers of an earlier launch that shared this directory
+        self.tag = launchTag()
+        if self.rank == 0:          # leftovers of an earlier launch that shared this directory (any tag but ours)
             for f in os.listdir(self.dir):
-                if f.startswith('port') or f in ('key', 'rccl_unique_id'):
+                if (f.startswith('port') or f.startswith('key') or f.startswith('rccl_unique_id')) and \
+                        (not self.tag or not f.endswith(self.tag)):
                     try:
                         os.remove(os.path.join(self.dir, f))
                     except OSError:
@@ -225,7 +237,7 @@ class SocketComm(_ObjCollectives):
         self.closing = False
         self.acceptor = threading.Thread(target=self._accept, daemon=True)
         self.acceptor.start()
-        _publish(os.path.join(self.dir, 'port%d' % self.rank), str(self.srv.getsockname()[1]).encode())
+        _publish(os.path.join(self.dir, 'port%d%s' % (self.rank, self.tag)), str(self.srv.getsockname()[1]).encode())
 
     def _accept(self):
         """Registers a peer only after it proved that it holds the launch key (HMAC over a fresh nonce
@@ -246,6 +258,7 @@ class SocketComm(_ObjCollectives):
                 want = hmac.new(self.key, nonce + hello[:4], hashlib.sha256).digest()
                 if not (0 <= src < self.world) or not hmac.compare_digest(want, hello[4:]):
                     raise CommError("handshake failed")
+                conn.sendall(b'\x01')                   # accepted: the connecting side waits for this
                 conn.settimeout(None)
             except (CommError, OSError, struct.error):
                 try:
@@ -272,13 +285,23 @@ class SocketComm(_ObjCollectives):
     def _conn_to(self, dst):
         c = self.out.get(dst)
         if c is None:
-            port = int(_await(os.path.join(self.dir, 'port%d' % dst)).decode())
+            port = int(_await(os.path.join(self.dir, 'port%d%s' % (dst, self.tag))).decode())
             c = socket.create_connection(('127.0.0.1', port), timeout=180)
-            c.settimeout(None)
+            c.settimeout(60.0)
             c.setsockopt(socket.IPPROTO_TCP, socket.TCP_NODELAY, 1)
-            nonce = self._read(c, 16)
-            me = struct.pack('<i', self.rank)
-            c.sendall(me + hmac.new(self.key, nonce + me, hashlib.sha256).digest())
+            try:
+                nonce = self._read(c, 16)
+                me = struct.pack('<i', self.rank)
+                c.sendall(me + hmac.new(self.key, nonce + me, hashlib.sha256).digest())
+                if self._read(c, 1) != b'\x01':
+                    raise CommError("bad acknowledgement")
+            except (CommError, OSError) as e:
+                # fail HERE, not in a receive that never returns: the peer dropped us (a stale key or port file of
+                # an earlier launch in a shared rendezvous directory, or something else on that port)
+                c.close()
+                raise CommError("rank %d: rank %d refused the connection handshake (%s): stale rendezvous files in %s?"
+                                % (self.rank, dst, e, self.dir))
+            c.settimeout(None)
             self.out[dst] = c
         return c
 
@@ -320,7 +343,7 @@ class SocketComm(_ObjCollectives):
             self.srv.close()
         except OSError:
             pass
-        for f in ['port%d' % self.rank] + (['key'] if self.rank == 0 else []):
+        for f in ['port%d%s' % (self.rank, self.tag)] + (['key' + self.tag] if self.rank == 0 else []):
             try:
                 os.remove(os.path.join(self.dir, f))
             except OSError:
@@ -345,7 +368,7 @@ class RcclComm(_ObjCollectives):
         self.c = _lib.Context(device=device)
         self.L = self.c._L
         self.dir = rendezvousDir()
-        idpath = os.path.join(self.dir, 'rccl_unique_id')
+        idpath = os.path.join(self.dir, 'rccl_unique_id' + launchTag())
         if self.rank == 0:
             try:
                 os.remove(idpath)       # (an earlier launch's id must not be taken for this one's)
@@ -527,7 +550,7 @@ class RcclComm(_ObjCollectives):
             self.h = None
             if self.rank == 0:
                 try:
-                    os.remove(os.path.join(self.dir, 'rccl_unique_id'))
+                    os.remove(os.path.join(self.dir, 'rccl_unique_id' + launchTag()))
                 except OSError:
                     pass
             self.c.close()

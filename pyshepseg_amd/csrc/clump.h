@@ -1245,9 +1245,16 @@ __global__ __launch_bounds__(DFS_WAVES * 64) void k_dfs_pool(        // blockDim
             uint32_t goff = 0xFFFFFFFFu;
             if (!oldwalk && words <= 0x3FFFFFFFull && gscratch) {
                 if (lane == 0) {
+                    // a CAS loop that only advances on success: a counter that kept adding after the block was
+                    // full could wrap in 32 bits and hand a later component an offset inside live bitmaps
                     const uint32_t need2 = 2u * (uint32_t)words;
-                    const uint32_t o = atomicAdd(&counters[4], need2);
-                    goff = (o + need2 <= gscratch_words) ? o : 0xFFFFFFFFu;
+                    uint32_t cur = __hip_atomic_load(&counters[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    for (;;) {
+                        if ((unsigned long long)cur + need2 > (unsigned long long)gscratch_words) break;
+                        const uint32_t seen = atomicCAS(&counters[4], cur, cur + need2);
+                        if (seen == cur) { goff = cur; break; }
+                        cur = seen;
+                    }
                 }
                 goff = (uint32_t)__builtin_amdgcn_readfirstlane((int)goff);
             }

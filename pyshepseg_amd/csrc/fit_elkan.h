@@ -497,6 +497,11 @@ __device__ __forceinline__ void fit_range(const uint32_t *off, const FitDigits &
         *q1 = sort_digit_start(dg.hscan, dg.boff, dg.nblk, (uint32_t)j + 1u, dg.n);
     } else { *q0 = off[j]; *q1 = off[j + 1]; }
 }
+// SHEPSEG_FIT_CHECK_DIGITS=1: the clusters' ranges as the sums kernels read them, for a comparison on the host
+__global__ __launch_bounds__(256) void k_fit_digit_starts(FitDigits dg, int k, uint32_t *out)
+{
+    for (int j = threadIdx.x; j <= k; j += 256) out[j] = sort_digit_start(dg.hscan, dg.boff, dg.nblk, (uint32_t)j, dg.n);
+}
 __global__ __launch_bounds__(64) void k_fit_sum_lists(const double *__restrict__ X, int nb,
                                                       const uint32_t *__restrict__ rows,
                                                       const uint32_t *__restrict__ off,
@@ -1022,10 +1027,12 @@ static int run_fit_elkan(shp_ctx *ctx, const double *dX, XAt Xat, uint32_t n, in
         ep.scratch = (fused || upd_lds) ? nullptr : dscr; ep.tol = tol; ep.it = (uint32_t)it; ep.hist = hist;
         return ep;
     };
+    const bool check_digits = getenv("SHEPSEG_FIT_CHECK_DIGITS") && atoi(getenv("SHEPSEG_FIT_CHECK_DIGITS")) != 0;
+    uint32_t h_ctl_stop_seen = 0u;          // (the check above only judges iterations that really ran)
     bool strict = false, finished = false;
     int it_done = 0;
     while (it_done < max_iter && !finished) {
-        const int b_end = it_done + ELK_BATCH < max_iter ? it_done + ELK_BATCH : max_iter;
+        const int b_end = check_digits ? it_done + 1 : (it_done + ELK_BATCH < max_iter ? it_done + ELK_BATCH : max_iter);
         for (int it = it_done + 1; it <= b_end; it++) {
             CHK(estep(&dctl->nd[it & 1], dstop, it));
             // row lists: the row numbers sorted stably by label
@@ -1039,6 +1046,24 @@ static int run_fit_elkan(shp_ctx *ctx, const double *dX, XAt Xat, uint32_t n, in
             else {
                 hipLaunchKernelGGL(k_elk_offsets, dim3(grid_for((size_t)k + 1, 256)), dim3(256), 0, st, ks, n, k, doff,
                                    &dctl->nd[(it + 1) & 1], dstop); KCHK(ctx);
+            }
+            if (sd.passes == 1 && check_digits) {
+                // the ranges read off the sort's scanned histogram against a count of the labels themselves
+                std::vector<uint32_t> got((size_t)k + 1);
+                std::vector<int32_t> hl(n);
+                hipLaunchKernelGGL(k_fit_digit_starts, dim3(1), dim3(256), 0, st, dg, k, doff); KCHK(ctx);
+                HIPCHK(ctx, hipMemcpyAsync(got.data(), doff, ((size_t)k + 1) * 4, hipMemcpyDeviceToHost, st));
+                HIPCHK(ctx, hipMemcpyAsync(hl.data(), dlab, (size_t)n * 4, hipMemcpyDeviceToHost, st));
+                HIPCHK(ctx, hipStreamSynchronize(st));
+                if (h_ctl_stop_seen == 0u) {
+                    std::vector<uint32_t> want((size_t)k + 1, 0u);
+                    for (uint32_t i = 0; i < n; i++) if ((uint32_t)hl[i] < (uint32_t)k) want[(size_t)hl[i] + 1]++;
+                    for (int j = 0; j < k; j++) want[(size_t)j + 1] += want[j];
+                    for (int j = 0; j <= k; j++)
+                        if (got[j] != want[j])
+                            SHP_FAIL(ctx, SHP_ERR_STATE, "fit: cluster %d's row list starts at %u in the sort's histogram, %u by count "
+                                     "(the layout sort_digit_start assumes has changed)", j, got[j], want[j]);
+                }
             }
             if (nb <= 64)
                 hipLaunchKernelGGL(k_fit_sum_lists_staged, dim3(k), dim3(FIT_SUM_THREADS), 0, st, dX, nb, rows, doff, dS, dcnt, dstop, dg,
@@ -1055,6 +1080,7 @@ static int run_fit_elkan(shp_ctx *ctx, const double *dX, XAt Xat, uint32_t n, in
         HIPCHK(ctx, hipMemcpyAsync(h_ctl, dctl, sizeof(ElkCtl), hipMemcpyDeviceToHost, st));
         HIPCHK(ctx, hipStreamSynchronize(st));
         const uint32_t stop = h_ctl->stop;
+        h_ctl_stop_seen = stop;
         if (getenv("SHEPSEG_FIT_TRACE")) {
             std::vector<double> hs(k);
             HIPCHK(ctx, hipMemcpyAsync(hs.data(), dcshift, (size_t)k * 8, hipMemcpyDeviceToHost, st));

@@ -223,6 +223,10 @@ static inline int bits_for(uint32_t maxval)      // significant bits of the larg
 // the values, the last pass does not write the keys.
 // digits_out (optional): where the LAST pass's scanned digit histogram lies -- with a single pass (bits <= 8)
 // entry d * nblk of it (+ the scan's block offset) is the position of the first key equal to d.
+// (fit_elkan.h reads the clusters' ranges of the k-means row lists straight from these -- the LAST pass's scanned
+//  histogram in ctx->sort_hist / scan_tmp, entry d * nblk, NON-staged layout -- between sort_pairs and the sums
+//  kernel: whoever changes the histogram layout or lets another sort run in between must change sort_digit_start
+//  and its caller with it; SHEPSEG_FIT_CHECK_DIGITS=1 compares them with a binary search of the sorted keys)
 struct SortDigits { const uint32_t *hscan = nullptr, *boff = nullptr; uint32_t nblk = 0; int passes = 0; };
 __device__ __forceinline__ uint32_t sort_digit_start(const uint32_t *hscan, const uint32_t *boff, uint32_t nblk,
                                                      uint32_t d, uint32_t n)

@@ -708,16 +708,28 @@ class HipEngine(object):
 
     def renumberKept(self, stride, base, keptJobs, recvStrips):
         """provisional -> final ids in the output rows, in the recoded strips of the tiles that are kept
-        and in strips received from the previous rank (the partial redo of the parallel stitch)"""
+        and in EXACTLY the strips handed in (received from the previous rank with provisional ids: the
+        partial redo of the parallel stitch) -- a buffer received with final ids must not be touched again."""
         self.renumber(stride, base)
         base = numpy.ascontiguousarray(base, dtype=numpy.uint32)
-        for j in keptJobs:
-            n = j.ysize * min(self.overlap, j.xsize) + min(self.overlap, j.ysize) * j.xsize      # right | bottom
-            self.c.check(self.L.shp_renumber_dev(self.c.handle, ctypes.c_void_p(self.d_strips.value + 4 * j.rightOff),
+
+        def stripWords(j):
+            return j.ysize * min(self.overlap, j.xsize) + min(self.overlap, j.ysize) * j.xsize      # right | bottom
+        # the kept tiles' strips: runs of jobs whose strips are adjacent in the strip block go in one call
+        runs = []
+        for j in sorted(keptJobs, key=lambda q: q.rightOff):
+            n = stripWords(j)
+            if runs and runs[-1][0] + runs[-1][1] == j.rightOff:
+                runs[-1][1] += n
+            else:
+                runs.append([j.rightOff, n])
+        for (o, n) in runs:
+            self.c.check(self.L.shp_renumber_dev(self.c.handle, ctypes.c_void_p(self.d_strips.value + 4 * o),
                                                  n, int(stride), _lib.ptr(base), len(base)))
-        if recvStrips:
-            for (d, nbytes) in self.recvDev:
-                self.c.check(self.L.shp_renumber_dev(self.c.handle, d, nbytes // 4, int(stride), _lib.ptr(base), len(base)))
+        sizes = {d.value: nbytes for (d, nbytes) in self.recvDev}
+        for (ptr, _w) in recvStrips:
+            self.c.check(self.L.shp_renumber_dev(self.c.handle, ctypes.c_void_p(ptr), sizes[ptr] // 4, int(stride),
+                                                 _lib.ptr(base), len(base)))
 
     def sendStrip(self, comm, dst, item, a):
         (kind, _c, _r, h, w) = item

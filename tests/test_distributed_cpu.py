@@ -103,8 +103,10 @@ def test_shard_plan_random_grids():
 def _run_ranks(world, argv, tmp_path, timeout=600, extra_env=None):
     """start `world` rank processes with the environment a launcher sets; all must exit 0"""
     procs = []
+    import secrets
+    nonce = secrets.token_hex(8)
     for r in range(world):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world),
+        env = dict(os.environ, SHEPSEG_LAUNCH_NONCE=nonce, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world),
                    MASTER_ADDR='127.0.0.1', MASTER_PORT='0', OMP_NUM_THREADS='1',
                    SHEPSEG_COMM_DIR=str(tmp_path / 'comm'))
         env.update(extra_env or {})

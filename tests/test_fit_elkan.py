@@ -138,6 +138,14 @@ def test_device_elkan_path_equals_oracle(n, nb, k, shepseg, oracle, monkeypatch)
     assert km.n_iter_ == want_n
     assert np.array_equal(km.labels_, want_l)
     assert np.array_equal(km.cluster_centers_.view(np.uint64), want_c.view(np.uint64))
+    # the two other forms of the same path: round 3's exact table of bounds (k > 64 always takes it), and the
+    # run that checks, every iteration, the cluster ranges read off the sort's histogram against a label count
+    for (var, val) in (('SHEPSEG_ELK_TABLE', '1'), ('SHEPSEG_FIT_CHECK_DIGITS', '1'), ('SHEPSEG_ELK_UNFUSED', '1')):
+        monkeypatch.setenv(var, val)
+        km1 = shepseg._fit(xs, init)
+        monkeypatch.delenv(var)
+        assert km1.n_iter_ == want_n and np.array_equal(km1.labels_, want_l), var
+        assert np.array_equal(km1.cluster_centers_.view(np.uint64), want_c.view(np.uint64)), var
     monkeypatch.delenv('SHEPSEG_FIT_ALGO')
     km2 = shepseg._fit(xs, init)
     # whichever path the guard chose: the same partitions, the same row-order sums, the same bits

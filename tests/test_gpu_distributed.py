@@ -17,8 +17,10 @@ pytestmark = pytest.mark.gpu
 
 def _run_ranks(world, argv, tmp_path, timeout=900, extra=None):
     procs = []
+    import secrets
+    nonce = secrets.token_hex(8)
     for r in range(world):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world),
+        env = dict(os.environ, SHEPSEG_LAUNCH_NONCE=nonce, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world),
                    MASTER_ADDR='127.0.0.1', MASTER_PORT='0', SHEPSEG_COMM_DIR=str(tmp_path / 'comm'))
         env.update(extra or {})
         procs.append(subprocess.Popen([sys.executable] + argv, env=env, stdout=subprocess.PIPE,
