@@ -215,14 +215,16 @@ def spawn_ranks(args):
 
 
 def pmc_traffic(kernel_name, scale=1.0):
-    """HBM bytes per launch of a kernel from the committed PMC passes (rocprofv3 cannot run inside
-    this process): FETCH_SIZE + WRITE_SIZE, see profiles/README.md."""
-    for fn in ('r03_pmc_summary.json', 'r02_pmc_summary.json', 'r01_n_pmc_summary.json'):
+    """HBM bytes per launch of a kernel from the newest committed PMC passes (rocprofv3 cannot run inside this
+    process): raw FETCH_SIZE + WRITE_SIZE, with the file and the commit the passes were taken at -- see the
+    file's own note for the gfx950 corrections (profiles/README.md)."""
+    for fn in ('r04_pmc_summary.json', 'r03_pmc_summary.json', 'r02_pmc_summary.json', 'r01_n_pmc_summary.json'):
         try:
-            pmc = json.load(open(os.path.join(ROOT, 'profiles', fn)))['kernels']
-            k = pmc.get(kernel_name)
+            doc = json.load(open(os.path.join(ROOT, 'profiles', fn)))
+            k = doc['kernels'].get(kernel_name)
             if k:
-                return int((k['FETCH_SIZE_KB_per_launch'] + k['WRITE_SIZE_KB_per_launch']) * 1024 * scale), fn
+                return (int((k['FETCH_SIZE_KB_per_launch'] + k['WRITE_SIZE_KB_per_launch']) * 1024 * scale),
+                        '%s @ %s' % (fn, doc.get('taken_at_commit', 'commit not recorded')))
         except Exception:
             pass
     return None, None
