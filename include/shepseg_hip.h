@@ -100,6 +100,18 @@ int shp_kmeans_fit_planar(shp_ctx *ctx, const void *planes, int dtype, int64_t n
                           int max_iter, double tol_rel, double *centres_out, int32_t *labels_out,
                           int *n_iter_out, int64_t *nrows_out);
 
+/* The same with the E-step of the reference's algorithm SHARDED BY SAMPLE ROWS over the ranks of an RCCL
+ * communicator (shp_comm_create): every rank passes the SAME sample and receives the SAME model.  Rank r keeps
+ * the bounds of rows [r n/N, (r+1) n/N) and relabels them; the labels are all-gathered in place on the fit's
+ * stream every iteration (ncclAllGather, no host round trip) and every rank runs the M-step on all of them --
+ * same sums in the same order, so no broadcast of centres.  The reference's fit is one process
+ * (shepseg.py:305-312); bit-identical to shp_kmeans_fit_planar.  cm == NULL or one rank: that call. */
+struct shp_comm;
+int shp_kmeans_fit_planar_dist(shp_ctx *ctx, struct shp_comm *cm, const void *planes, int dtype, int64_t npix,
+                               int nbands, int has_null, int64_t null_val, int k, const double *init_centres,
+                               int max_iter, double tol_rel, double *centres_out, int32_t *labels_out,
+                               int *n_iter_out, int64_t *nrows_out);
+
 /* which path the context's last fit took: 0 Lloyd iterations (no near tie met), 1 Elkan's */
 int shp_last_fit_path(const shp_ctx *ctx);
 

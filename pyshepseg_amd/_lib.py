@@ -48,6 +48,9 @@ _SIGS = {
     'shp_kmeans_fit_planar': (_c.c_int, [_vp, _vp, _c.c_int, _c.c_int64, _c.c_int, _c.c_int, _c.c_int64, _c.c_int,
                                          _vp, _c.c_int, _c.c_double, _vp, _vp, _c.POINTER(_c.c_int),
                                          _c.POINTER(_c.c_int64)]),
+    'shp_kmeans_fit_planar_dist': (_c.c_int, [_vp, _vp, _vp, _c.c_int, _c.c_int64, _c.c_int, _c.c_int, _c.c_int64, _c.c_int,
+                                         _vp, _c.c_int, _c.c_double, _vp, _vp, _c.POINTER(_c.c_int),
+                                         _c.POINTER(_c.c_int64)]),
     'shp_last_fit_path': (_c.c_int, [_vp]),
     'shp_kmeans_assign': (_c.c_int, [_vp, _vp, _c.c_int, _c.c_int, _c.c_int, _c.c_int, _vp,
                                      _c.c_int, _c.c_int, _c.c_int64, _vp]),

@@ -219,6 +219,26 @@ API int shp_kmeans_fit_planar(shp_ctx *ctx, const void *planes, int dtype, int64
                           labels_out, n_iter_out, true, has_null, (long long)null_val, nrows_out);
 }
 
+// the same with the E-step sharded by sample rows over the ranks of a communicator: every rank passes the SAME
+// sample and gets the same model (fit_elkan.h: FitShard); cm == NULL: shp_kmeans_fit_planar
+API int shp_kmeans_fit_planar_dist(shp_ctx *ctx, shp_comm *cm, const void *planes, int dtype, int64_t npix, int nbands,
+                                   int has_null, int64_t null_val, int k, const double *init_centres,
+                                   int max_iter, double tol_rel, double *centres_out, int32_t *labels_out,
+                                   int *n_iter_out, int64_t *nrows_out)
+{
+    CHK(enter(ctx));
+    if (!planes || !centres_out) SHP_FAIL(ctx, SHP_ERR_ARG, "NULL argument");
+    if (dtype_size(dtype) == 0) SHP_FAIL(ctx, SHP_ERR_ARG, "bad pixel type %d", dtype);
+    if (nrows_out) *nrows_out = 0;
+    FitShard sh;
+    if (cm && cm->world > 1) {
+        if (cm->ctx->device != ctx->device) SHP_FAIL(ctx, SHP_ERR_ARG, "the communicator lives on another device");
+        sh.rank = cm->rank; sh.world = cm->world; sh.nc = (void *)cm->nc;
+    }
+    return run_kmeans_fit(ctx, planes, dtype, npix, nbands, k, init_centres, max_iter, tol_rel, centres_out,
+                          labels_out, n_iter_out, true, has_null, (long long)null_val, nrows_out, sh);
+}
+
 API int shp_kmeans_assign(shp_ctx *ctx, const void *img, int dtype, int nbands, int nrows, int ncols,
                           const double *centres, int k, int has_null, int64_t null_val,
                           int32_t *clusters_out)

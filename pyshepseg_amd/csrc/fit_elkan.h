@@ -28,6 +28,7 @@
 // Shared by both: empty-cluster relocation as numpy evaluates it (pairwise row sums, np.argpartition's
 // introselect), center_shift_tot as numpy's pairwise sum.
 #pragma once
+#include "comm.h"        // the row-sharded E-step all-gathers its labels with RCCL (FitShard)
 
 #define FIT_TIE_EPS 1e-12
 
@@ -876,6 +877,31 @@ __global__ __launch_bounds__(1024) void k_elk_update(double *__restrict__ S, con
 
 #define ELK_BATCH 8                 // iterations enqueued between two host synchronisations
 
+// The E-step sharded by sample rows over the ranks of a communicator (the one part of the fit that
+// shards; sklearn's fit itself is one process, shepseg.py:305-312).  Rank r runs init / filter / visit on rows
+// [r ns, (r + 1) ns) -- its own bounds, stamps, upper bounds; nothing of them ever leaves the rank -- then the
+// labels are all-gathered IN PLACE on the fit's stream (ncclAllGather of ns int32 per rank, no host round
+// trip), and every rank runs the M-step on the full label array: the same sort, the same row-order sums, the
+// same tail on the same bits, so the centres agree without a broadcast.  The count of changed labels comes
+// from comparing the gathered labels with the previous iteration's, on every rank alike.
+//   nc == nullptr with world > 1: ONE process plays all the ranks in turn (tests of the shard arithmetic on a
+// one-GPU box: SHEPSEG_FIT_SHARDS); only == r: it plays rank r alone (the timing of one rank's share:
+// SHEPSEG_FIT_SHARD_ONLY; the other shards' labels go stale, the result is not a fit).
+struct FitShard {
+    int rank = 0, world = 1;
+    void *nc = nullptr;             // ncclComm_t
+    int only = -1;
+};
+__global__ __launch_bounds__(256) void k_fit_count_diff(const int32_t *__restrict__ a, const int32_t *__restrict__ b,
+                                                        uint32_t n, uint32_t *count, const uint32_t *stop)
+{
+    if (stop && *stop) return;
+    uint32_t c = 0;
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) c += a[i] != b[i];
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    if (lane_id() == 0 && c) atomicAdd(count, c);
+}
+
 // The faithful path.  dX: the centred sample on the device (n rows of nb); X: the same on the host
 // through Xat; C: the centred initial centres in, the final centred centres out; dlab: n labels out.
 // Iterations run in batches of ELK_BATCH without a host round trip (k_elk_update owns the convergence
@@ -884,7 +910,7 @@ __global__ __launch_bounds__(1024) void k_elk_update(double *__restrict__ S, con
 template <class XAt>
 static int run_fit_elkan(shp_ctx *ctx, const double *dX, XAt Xat, uint32_t n, int nb, int k,
                          std::vector<double> &C, int max_iter, double tol, int32_t *dlab, double *ddist,
-                         int *n_iter_out)
+                         int *n_iter_out, FitShard shard = FitShard(), int32_t *dlab_prev = nullptr)
 {
     const int kn = k * nb;
     hipStream_t st = ctx->stream;
@@ -893,6 +919,9 @@ static int run_fit_elkan(shp_ctx *ctx, const double *dX, XAt Xat, uint32_t n, in
     // round-3 form (the exact table, cluster-major), which k > 64 always takes.
     const bool lazy = k <= 64 && nb <= 64 && max_iter < 65000 &&
                       !(getenv("SHEPSEG_ELK_TABLE") && atoi(getenv("SHEPSEG_ELK_TABLE")) != 0);
+    if (shard.world > 1 && (!lazy || !dlab_prev || shard.world > 64)) shard = FitShard();    // (the exact-table form is not sharded: every rank runs it whole)
+    const bool sharded = shard.world > 1;
+    const uint32_t ns = sharded ? (n + (uint32_t)shard.world - 1u) / (uint32_t)shard.world : n;      // rows per rank
     const size_t hist_rows = (size_t)max_iter + 3;
     const size_t hist_doubles = lazy ? hist_rows * ((size_t)3 * k + kn) : 0;
     if (lazy) CHK(buf_ensure(ctx, ctx->fit_lb, (size_t)n * k * 6 + 512 + (size_t)n * 8 * 3 + hist_doubles * 8 + 64));
@@ -986,7 +1015,16 @@ static int run_fit_elkan(shp_ctx *ctx, const double *dX, XAt Xat, uint32_t n, in
         HIPCHK(ctx, hipMemsetAsync(hist.cum, 0, (size_t)2 * k * 8, st));
         HIPCHK(ctx, hipMemsetAsync(ddiag, 0, 64, st));
         HIPCHK(ctx, hipMemcpyAsync(hist.cen + kn, dC, (size_t)kn * 8, hipMemcpyDeviceToDevice, st));
-        hipLaunchKernelGGL(k_elk2_init, dim3(g2), dim3(256), ((size_t)k * k + kn) * 8, st, dX, n, nb, dC, k, dhalf, dlab, dub, dA, dstamps); KCHK(ctx);
+        // (a shard = the same kernels on pointers moved to the shard's first row)
+        for (int r = 0; r < shard.world; r++) {
+            if (sharded && ((shard.nc && r != shard.rank) || (shard.only >= 0 && r != shard.only))) continue;
+            const uint32_t i0 = sharded ? (uint32_t)r * ns : 0u;
+            if (i0 >= n) continue;
+            const uint32_t m = sharded ? (n - i0 < ns ? n - i0 : ns) : n;
+            hipLaunchKernelGGL(k_elk2_init, dim3(g2), dim3(256), ((size_t)k * k + kn) * 8, st, dX + (size_t)i0 * nb, m, nb, dC, k, dhalf,
+                               dlab + i0, dub + i0, dA + (size_t)i0 * k, dstamps + (size_t)i0 * k); KCHK(ctx);
+        }
+        if (sharded) HIPCHK(ctx, hipMemcpyAsync(dlab_prev, dlab, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
     } else {
         HIPCHK(ctx, hipMemsetAsync(dlb, 0, (size_t)k * n * 8, st));
         hipLaunchKernelGGL(k_elk_init, dim3(g), dim3(256), 0, st, dX, n, nb, dC, k, dhalf, dlab, dub, dlb); KCHK(ctx);
@@ -994,17 +1032,29 @@ static int run_fit_elkan(shp_ctx *ctx, const double *dX, XAt Xat, uint32_t n, in
     auto estep = [&](uint32_t *nd, const uint32_t *stop, int it) -> int {
         if (lazy) {
             const double *csp = it > 1 ? hist.cs + (size_t)(it - 1) * k : (const double *)nullptr;
-            if (stop && getenv("SHEPSEG_ELK2_PROBE")) {        // timing experiments (fit_bounds.h)
-                hipLaunchKernelGGL(k_elk2_filter<1>, dim3(gf), dim3(256), lds_f, st, n, k, dhalf, dnext, csp, hist.cum + (size_t)it * k,
-                                   dlab, dub, dA, dcmask, dmmask, stop);
-                hipLaunchKernelGGL(k_elk2_filter<2>, dim3(gf), dim3(256), lds_f, st, n, k, dhalf, dnext, csp, hist.cum + (size_t)it * k,
-                                   dlab, dub, dA, dcmask, dmmask, stop);
+            for (int r = 0; r < shard.world; r++) {
+                if (sharded && ((shard.nc && r != shard.rank) || (shard.only >= 0 && r != shard.only))) continue;
+                const uint32_t i0 = sharded ? (uint32_t)r * ns : 0u;
+                if (i0 >= n) continue;
+                const uint32_t m = sharded ? (n - i0 < ns ? n - i0 : ns) : n;
+                unsigned gfr = (unsigned)grid_for(m, 256), gvr = (unsigned)grid_for(m, ELK2_VCHUNK);
+                if (gfr > gf) gfr = gf;
+                if (gvr > gv) gvr = gv;
+                hipLaunchKernelGGL(k_elk2_filter<0>, dim3(gfr), dim3(256), lds_f, st, m, k, dhalf, dnext, csp, hist.cum + (size_t)it * k,
+                                   dlab + i0, dub + i0, dA + (size_t)i0 * k, dcmask + i0, dmmask + i0, stop); KCHK(ctx);
+                hipLaunchKernelGGL(visit2, dim3(gvr), dim3(256), lds2, st, dX + (size_t)i0 * nb, m, nb, hist.cen + (size_t)it * kn, k, dhalf,
+                                   hist.cum + (size_t)it * k, dlab + i0, dub + i0, dA + (size_t)i0 * k, dstamps + (size_t)i0 * k,
+                                   dcmask + i0, dmmask + i0, hist, (uint32_t)it, sharded ? (uint32_t *)(ddiag + 6) : nd, stop,
+                                   want_diag ? ddiag : (unsigned long long *)nullptr);
             }
-            hipLaunchKernelGGL(k_elk2_filter<0>, dim3(gf), dim3(256), lds_f, st, n, k, dhalf, dnext, csp, hist.cum + (size_t)it * k,
-                               dlab, dub, dA, dcmask, dmmask, stop); KCHK(ctx);
-            hipLaunchKernelGGL(visit2, dim3(gv), dim3(256), lds2, st, dX, n, nb, hist.cen + (size_t)it * kn, k, dhalf,
-                               hist.cum + (size_t)it * k, dlab, dub, dA, dstamps, dcmask, dmmask, hist, (uint32_t)it, nd, stop,
-                               want_diag ? ddiag : (unsigned long long *)nullptr);
+            if (sharded) {
+                // every rank's labels on every rank (in place, on this stream), then the changed-label count from the
+                // labels themselves -- the same on all ranks
+                if (shard.nc)
+                    NCCLCHK(ctx, ncclAllGather(dlab + (size_t)shard.rank * ns, dlab, ns, ncclInt32, (ncclComm_t)shard.nc, st));
+                hipLaunchKernelGGL(k_fit_count_diff, dim3(256), dim3(256), 0, st, dlab, dlab_prev, n, nd, stop); KCHK(ctx);
+                HIPCHK(ctx, hipMemcpyAsync(dlab_prev, dlab, (size_t)n * 4, hipMemcpyDeviceToDevice, st));
+            }
         }
         else if (k <= 64)
             hipLaunchKernelGGL(k_elk_estep64, dim3(g), dim3(256), 0, st, dX, n, nb, dC, k, dhalf, dnext, dcshift, dlab,

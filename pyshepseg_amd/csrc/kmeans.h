@@ -562,7 +562,7 @@ __global__ __launch_bounds__(256) void k_fit_transpose(const double *__restrict_
 static int run_kmeans_fit(shp_ctx *ctx, const void *xin_any, int xdtype, int64_t nrows, int nb, int k,
                           const double *init, int max_iter, double tol_rel, double *centres_out,
                           int32_t *labels_out, int *n_iter_out, bool planar = false, int has_null = 0,
-                          long long null_val = 0, int64_t *nrows_kept_out = nullptr)
+                          long long null_val = 0, int64_t *nrows_kept_out = nullptr, FitShard shard = FitShard())
 {
     if (nrows < 1 || nrows > 0x7fffffffll || nb < 1 || k < 1)
         SHP_FAIL(ctx, SHP_ERR_ARG, "kmeans_fit: bad shape");
@@ -664,11 +664,12 @@ static int run_kmeans_fit(shp_ctx *ctx, const void *xin_any, int xdtype, int64_t
     if ((size_t)(2 * kn + 2 * k + 8) * 8 > SHP_PINNED_BYTES)
         SHP_FAIL(ctx, SHP_ERR_ARG, "k * nbands too large for the k-means fit (%d x %d)", k, nb);
     CHK(buf_ensure(ctx, ctx->fit_x, (size_t)n * nb * 8 + (size_t)n * 8));
-    CHK(buf_ensure(ctx, ctx->fit_lab, (size_t)n * 4 * 2 + 64));
+    CHK(buf_ensure(ctx, ctx->fit_lab, (size_t)n * 4 * 2 + 64 + 1024));        // (128 words between the two label arrays: the
+                                                                               //  sharded E-step's all-gather pads the first)
     CHK(buf_ensure(ctx, ctx->fit_part, (size_t)(kn + k) * 8 * 3 + ((size_t)2 * k + 4) * 4 + 512));
     CHK(buf_ensure(ctx, ctx->cen, (size_t)(kn + k) * 8 * 2));
     double *dX = bp<double>(ctx->fit_x), *ddist = dX + (size_t)n * nb;
-    int32_t *dlabA = bp<int32_t>(ctx->fit_lab), *dlabB = dlabA + n;
+    int32_t *dlabA = bp<int32_t>(ctx->fit_lab), *dlabB = dlabA + n + 128;
     FitCtl *dctl = (FitCtl *)(dlabB + n);
     // row-order sums | their counts as float64 (unused here) | S | w | counts | list offsets (k + 1) + a spare word
     double *dpart2 = bp<double>(ctx->fit_part), *dcntd = dpart2 + kn;
@@ -773,7 +774,13 @@ static int run_kmeans_fit(shp_ctx *ctx, const void *xin_any, int xdtype, int64_t
         // the reference's algorithm from the initial centres (whatever the fast path did is dropped)
         C = C0;
         dlab = dlabA;
-        CHK(run_fit_elkan(ctx, dX, Xat, n, nb, k, C, max_iter, tol, dlab, ddist, &it));
+        if (shard.world == 1 && getenv("SHEPSEG_FIT_SHARDS") && atoi(getenv("SHEPSEG_FIT_SHARDS")) > 1) {
+            // one process plays every rank in turn (or, SHEPSEG_FIT_SHARD_ONLY=r, rank r alone): fit_elkan.h FitShard
+            shard.world = atoi(getenv("SHEPSEG_FIT_SHARDS"));
+            shard.only = getenv("SHEPSEG_FIT_SHARD_ONLY") ? atoi(getenv("SHEPSEG_FIT_SHARD_ONLY")) : -1;
+            if (shard.world > 64 || (size_t)shard.world > (size_t)n) shard = FitShard();
+        }
+        CHK(run_fit_elkan(ctx, dX, Xat, n, nb, k, C, max_iter, tol, dlab, ddist, &it, shard, dlabB));
         ctx->fit_path = 1;
         HIPCHK(ctx, hipMemcpyAsync(dC, C.data(), (size_t)kn * 8, hipMemcpyHostToDevice, st));
         HIPCHK(ctx, hipStreamSynchronize(st));

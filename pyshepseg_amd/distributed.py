@@ -236,13 +236,22 @@ def runDistributed(engine, comm, nRows, nCols, tileSize, overlapSize, minSegment
         rx = tiling._subsample_indices(nCols, skip)
         mine = ry[(ry >= sLo) & (ry < sHi)]
         part = engine.subsample(mine, rx)                      # (nBands, len(mine), len(rx))
-        parts = comm.allgather_obj(part)
-        centres = None
-        if comm.rank == 0:
-            img = numpy.concatenate([p for p in parts if p.shape[1] > 0], axis=1)
-            km = engine.fit(img, numClusters, imgNullVal, fixedKMeansInit)
+        parts = [p[0].reshape(p[1]) for p in comm.allgather_arrays(
+            [numpy.ascontiguousarray(part), numpy.array(part.shape, dtype=numpy.int64)])]
+        img = numpy.concatenate([p for p in parts if p.shape[1] > 0], axis=1)
+        if (comm.world > 1 and getattr(comm, 'onDevice', False) and hasattr(comm, 'h') and fixedKMeansInit and
+                hasattr(engine, 'fitSharded') and os.environ.get('SHEPSEG_FIT_SHARDED', '1') != '0'):
+            # every rank holds the whole sample (12 MB for a 40000^2 raster); the E-step of the fit is sharded by
+            # sample rows over the ranks, its labels all-gathered on the device every iteration, the M-step run by
+            # all of them alike: the same model on every rank, no broadcast (shp_kmeans_fit_planar_dist)
+            km = engine.fitSharded(img, numClusters, imgNullVal, comm)
             centres = numpy.ascontiguousarray(km.cluster_centers_, dtype=numpy.float64)
-        centres = comm.bcast_obj(centres, src=0)
+        else:
+            centres = None
+            if comm.rank == 0:
+                km = engine.fit(img, numClusters, imgNullVal, fixedKMeansInit)
+                centres = numpy.ascontiguousarray(km.cluster_centers_, dtype=numpy.float64)
+            centres = comm.bcast_obj(centres, src=0)
         kmeansObj = shepseg.KMeansModel(centres)
     centres = numpy.ascontiguousarray(kmeansObj.cluster_centers_, dtype=numpy.float64)
     msd = shepseg.autoMaxSpectralDiff(kmeansObj, maxSpectralDiff, spectDistPcntile)
@@ -623,6 +632,10 @@ class HipEngine(object):
     def fit(self, img, numClusters, imgNullVal, fixedKMeansInit):
         with self.timings.interval('spectralclusters'):
             return shepseg.fitSpectralClusters(img, numClusters, 100, imgNullVal, fixedKMeansInit)
+
+    def fitSharded(self, img, numClusters, imgNullVal, comm):
+        with self.timings.interval('spectralclusters'):
+            return shepseg.fitSpectralClusters(img, numClusters, 100, imgNullVal, True, _commHandle=comm.h)
 
     def startSegmentation(self, centres, msd, imgNullVal, fourConnected, minSegmentSize):
         if not self.jobs:

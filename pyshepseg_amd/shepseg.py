@@ -186,7 +186,9 @@ def _fit(xSample, init, max_iter=300, tol=1e-4, wantInertia=False):
     return km
 
 
-def _fit_planar(img, numClusters, imgNullVal, init=None, max_iter=300, tol=1e-4):
+def _fit_planar(img, numClusters, imgNullVal, init=None, max_iter=300, tol=1e-4, commHandle=None):
+    """commHandle: an RCCL communicator of the C-ABI (comm.RcclComm.h) -- the E-step is then sharded by sample
+    rows over its ranks, every one of which must make this call with the same sample (shp_kmeans_fit_planar_dist)"""
     img = numpy.ascontiguousarray(img)
     nb = img.shape[0]
     npix = int(img.size // max(nb, 1))
@@ -197,27 +199,30 @@ def _fit_planar(img, numClusters, imgNullVal, init=None, max_iter=300, tol=1e-4)
     if init is not None:
         init = numpy.ascontiguousarray(init, dtype=numpy.float64)
     c = _lib.ctx()
-    c.check(c._L.shp_kmeans_fit_planar(
-        c.handle, _lib.ptr(img), _lib.SHP_DTYPES[img.dtype], npix, nb, int(imgNullVal is not None),
-        0 if imgNullVal is None else int(imgNullVal), int(numClusters),
-        None if init is None else _lib.ptr(init), int(max_iter), float(tol), _lib.ptr(centres),
-        _lib.ptr(labels), ctypes.byref(nit), ctypes.byref(nrows)))
+    args = (_lib.ptr(img), _lib.SHP_DTYPES[img.dtype], npix, nb, int(imgNullVal is not None),
+            0 if imgNullVal is None else int(imgNullVal), int(numClusters),
+            None if init is None else _lib.ptr(init), int(max_iter), float(tol), _lib.ptr(centres),
+            _lib.ptr(labels), ctypes.byref(nit), ctypes.byref(nrows))
+    if commHandle is not None:
+        c.check(c._L.shp_kmeans_fit_planar_dist(c.handle, commHandle, *args))
+    else:
+        c.check(c._L.shp_kmeans_fit_planar(c.handle, *args))
     km = KMeansModel(centres, nit.value, labels[:nrows.value], None)
     km.fit_path_ = ('lloyd', 'elkan')[c._L.shp_last_fit_path(c.handle)]
     return km
 
 
-def fitSpectralClusters(img, numClusters, subsamplePcnt, imgNullVal, fixedKMeansInit):
+def fitSpectralClusters(img, numClusters, subsamplePcnt, imgNullVal, fixedKMeansInit, _commHandle=None):
     """First step of Shepherd segmentation: k-means on a subsample of the pixels
     (reference shepseg.py:252-314).  Lloyd iterations run on the GPU (shp_kmeans_fit).
-    Returns a fitted :class:`KMeansModel`."""
+    Returns a fitted :class:`KMeansModel`.  (_commHandle: the sharded driver's RCCL communicator, see _fit_planar.)"""
     img = numpy.asarray(img)
     if (fixedKMeansInit and img.ndim == 3 and img.dtype in _lib.SHP_DTYPES and
             int(round(100. / subsamplePcnt)) == 1 and os.environ.get('SHEPSEG_FIT_PLANAR', '1') != '0'):
         # every pixel of img is a sample: the band-planar array goes down as it is (null rows are
         # dropped, the diagonal initial centres taken and the sample centred by one host thread per
         # band inside the library: the same arithmetic as the row form below, no transposition)
-        return _fit_planar(img, numClusters, imgNullVal)
+        return _fit_planar(img, numClusters, imgNullVal, commHandle=_commHandle)
     xSample, minmax = _sample_rows(img, subsamplePcnt, imgNullVal, wantMinMax=True)
     if fixedKMeansInit:
         init = diagonalClusterCentres(xSample, numClusters, minmax)

@@ -184,3 +184,29 @@ def test_device_elkan_path_stops_at_max_iter(max_iter, shepseg, oracle, monkeypa
     km = shepseg._fit(xs, init, max_iter=max_iter)
     assert km.n_iter_ == want_n and np.array_equal(km.labels_, want_l)
     assert np.array_equal(km.cluster_centers_.view(np.uint64), want_c.view(np.uint64))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('shards', [2, 3, 8])
+def test_device_sharded_estep_equals_reference(shards, ties, shepseg, oracle, monkeypatch):
+    """The E-step sharded by sample rows (the multi-GPU form of the fit: fit_elkan.h FitShard), ONE process playing
+    every rank in turn -- each shard its own bounds, the labels in one array as after the all-gather, the count of
+    changed labels from the labels themselves: bit for bit the unsharded fit, i.e. the reference's, on the
+    tie-decided fixtures and on a lattice sample with empty clusters."""
+    monkeypatch.setenv('SHEPSEG_FIT_SHARDS', str(shards))
+    for i in range(int(ties['ncases'])):
+        xs, init, n_iter, labels, centres = _case(ties, i)
+        km = shepseg._fit(xs, init)
+        assert km.fit_path_ == 'elkan', i
+        assert km.n_iter_ == n_iter, i
+        assert np.array_equal(km.labels_, labels), i
+        assert np.array_equal(km.cluster_centers_.view(np.uint64), centres.view(np.uint64)), i
+    rng = np.random.RandomState(77 + shards)
+    cent = rng.randint(0, 4000, size=(40, 6))
+    xs = (cent[rng.randint(0, 40, size=50001)] + rng.randint(-3, 4, size=(50001, 6))).astype(np.int16)
+    init = shepseg.diagonalClusterCentres(xs, 60).astype(np.float64)
+    want_c, want_l, want_n = oracle.kmeans_fit(xs.astype(np.float64), init, algorithm='elkan')
+    monkeypatch.setenv('SHEPSEG_FIT_ALGO', 'elkan')
+    km = shepseg._fit(xs, init)
+    assert km.n_iter_ == want_n and np.array_equal(km.labels_, want_l)
+    assert np.array_equal(km.cluster_centers_.view(np.uint64), want_c.view(np.uint64))

@@ -45,11 +45,14 @@ fit)        # the whole-image k-means fit on the benchmark sample: Elkan trace, 
       python3 tools/kstats.py --calls "$kn" "$(find gpurun_out/fitprof -name '*kernel_trace.csv' | head -1)" 10 | cut -c1-700
     done
     rm -f gpurun_out/fitprof/*/*kernel_trace.csv ;;
-fit-shard)  # one rank's share of a row-sharded E-step: the same fit on 1/N of the sample's rows (N = $1, default 8)
+fit-shard)  # one rank's share of the row-sharded E-step (fit_elkan.h FitShard): the benchmark fit with rank 0 of N (= $1,
+            # default 8) played alone -- its filter / visit on n / N rows, the full M-step (the other shards' labels go
+            # stale: a timing, not a fit); then the whole fit with ONE process playing all N ranks (bit-exact: tests)
     rm -rf gpurun_out/fitprof
-    SHEPSEG_FIT_TIMING=1 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/fitprof -- python3 tools/perf_fit.py 40000 6 ${1:-8} > gpurun_out/fitprof.log 2>&1
-    python3 tools/kstats.py --top 6 "$(find gpurun_out/fitprof -name '*kernel_stats.csv' | head -1)"
-    grep "kmeans fit: n=" gpurun_out/fitprof.log | tail -1; rm -f gpurun_out/fitprof/*/*kernel_trace.csv ;;
+    SHEPSEG_FIT_SHARDS=${1:-8} SHEPSEG_FIT_SHARD_ONLY=0 SHEPSEG_FIT_TIMING=1 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/fitprof -- python3 tools/perf_fit.py 40000 6 > gpurun_out/fitprof.log 2>&1
+    python3 tools/kstats.py --top 9 "$(find gpurun_out/fitprof -name '*kernel_stats.csv' | head -1)"
+    grep "kmeans fit: n=" gpurun_out/fitprof.log | tail -1; rm -f gpurun_out/fitprof/*/*kernel_trace.csv
+    SHEPSEG_FIT_SHARDS=${1:-8} SHEPSEG_FIT_TIMING=1 timeout -k 10 300 python3 tools/perf_fit.py 40000 6 2>&1 | grep "kmeans fit: n=" | tail -1 ;;
 tiletrace)  # kernel sequence (durations, gaps) of ONE tile run alone -> gpurun_out/tiletrace.txt
     rm -rf gpurun_out/tt
     timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/tt -o run -- python tools/perf_tile.py ${1:-4096} > gpurun_out/tt.log 2>&1 &&
