@@ -695,7 +695,7 @@ __device__ __forceinline__ void dfs_split_win(uint32_t *lab, const BigInfo &B, u
                 if (pr < nprow && lane < 2u && (c0 >> 5) + lane < wpr) {
                     const uint32_t wv = lane ? (uint32_t)(mm >> 32) : (uint32_t)mm;
                     bm[pr * wpr + (c0 >> 5) + lane] = wv;
-                    snap[pr * wpr + (c0 >> 5) + lane] = wv;       // the bitmap as of the last piece's end
+                    if (!GLB) snap[pr * wpr + (c0 >> 5) + lane] = wv;       // the bitmap as of the last piece's end
                 }
             }
         }
@@ -721,42 +721,19 @@ __device__ __forceinline__ void dfs_split_win(uint32_t *lab, const BigInfo &B, u
     const uint32_t trmax = nprow > 64u ? nprow - 64u : 0u;
     // (readfirstlane: the walker's window address comes from threadIdx.x / 64, uniform but not provably so)
     const uint32_t sw_addr = UNI((uint32_t)(uintptr_t)(__attribute__((address_space(3))) uint32_t *)sw);
-    // GLB: which parts of the (large) bitmap a piece has touched, for the sweep at its end -- a bit per CELL of
-    // (64 << vsr) rows x (2 << vsc) words, at most 8192 cells in two 64-bit words per lane; every tile that is
-    // loaded marks the cells it overlaps.  (The rows a piece stood on, which bound the sweep of a bitmap in LDS,
-    // do not do here: a piece that runs down one column of a 4096-pixel-wide component would sweep 900 rows x
-    // 129 words for its 10000 pixels.)
-    uint32_t vsr = 0, vsc = 0, vCR = (nprow + 63u) >> 6, vCC = (wpr + 1u) >> 1;
-    if (GLB) {
-        while (vCR * vCC > 8192u) {
-            if (vCR >= vCC) { vsr++; vCR = (vCR + 1u) >> 1; } else { vsc++; vCC = (vCC + 1u) >> 1; }
-        }
-    }
-    u64 vis0 = 0, vis1 = 0;
-#define DFSW_MARK_ONE(IDX)                                                                          \
-    do {                                                                                            \
-        const uint32_t ix_ = (IDX);                                                                 \
-        if (lane == (ix_ >> 7)) { if (ix_ & 64u) vis1 |= 1ull << (ix_ & 63u); else vis0 |= 1ull << (ix_ & 63u); } \
-    } while (0)
-#define DFSW_MARK()                                                                                 \
-    do {                                                                                            \
-        if (GLB) {                                                                                  \
-            const uint32_t ra_ = tr0 >> (6u + vsr);                                                 \
-            uint32_t rb_ = (tr0 + 63u) >> (6u + vsr);                                               \
-            rb_ = rb_ < vCR ? rb_ : vCR - 1u;                                                       \
-            const uint32_t ca_ = (twc32 >> 5) >> (1u + vsc), cb_ = ((twc32 >> 5) + 1u) >> (1u + vsc); \
-            DFSW_MARK_ONE(ra_ * vCC + ca_); DFSW_MARK_ONE(ra_ * vCC + cb_);                         \
-            DFSW_MARK_ONE(rb_ * vCC + ca_); DFSW_MARK_ONE(rb_ * vCC + cb_);                         \
-        }                                                                                           \
-    } while (0)
     // the tile (registers) and where it sits
     uint32_t tlo = 0, thi = 0, tr0 = 0, twc32 = 0;
-#define DFSW_TILE_LOAD(PR, PC)                                                                      \
+    uint32_t olo = 0, ohi = 0;                  // GLB: the tile as it was loaded / last written back
+    // (RB / CB: where in the tile the position is put -- 32 / 16 centres it; a walk that left the last tile through
+    //  its lower rim is put 8 rows below the new tile's top, and so on: a straight walk then re-centres every ~54
+    //  steps instead of every ~31, and a re-centring is a round trip to the bitmap)
+#define DFSW_TILE_LOAD(PR, PC) DFSW_TILE_LOAD_AT(PR, PC, 32, 16)
+#define DFSW_TILE_LOAD_AT(PR, PC, RB, CB)                                                           \
     do {                                                                                            \
-        int t_ = (int)(PR) - 32;                                                                    \
+        int t_ = (int)(PR) - (RB);                                                                  \
         t_ = t_ < 0 ? 0 : t_;                                                                       \
         tr0 = UNI((uint32_t)t_ > trmax ? trmax : (uint32_t)t_);                                     \
-        int w_ = ((int)(PC) - 16) >> 5;                                                             \
+        int w_ = ((int)(PC) - (CB)) >> 5;                                                           \
         w_ = w_ < 0 ? 0 : w_;                                                                       \
         const uint32_t twc_ = (uint32_t)w_ > wpr - 2u ? wpr - 2u : (uint32_t)w_;                    \
         twc32 = UNI(twc_ << 5);                                                                     \
@@ -765,8 +742,13 @@ __device__ __forceinline__ void dfs_split_win(uint32_t *lab, const BigInfo &B, u
         const uint32_t a_ = r_ * wpr + twc_;                                                        \
         tlo = ok_ ? BMLD(&bm[a_]) : 0u;                                                             \
         thi = ok_ ? BMLD(&bm[a_ + 1u]) : 0u;                                                        \
-        DFSW_MARK();                                                                                \
+        if (GLB) { olo = tlo; ohi = thi; }                                                          \
     } while (0)
+    // GLB: a piece's pixels are labelled HERE, from the registers -- the bits that went since the tile was loaded
+    // (or last written back).  Round 3 swept the bitmap against a snapshot at the piece's end, cell by cell with a
+    // lane per row: 256 cache-line transactions per cell of 64 rows x 64 columns, ~320 cells for a piece of a
+    // uniform region (one row plus a two-pixel strip of 3000 rows) -- 54 % of the time of a tile that is ONE
+    // component.  The difference costs nothing to form here, and only the label stores touch memory.
 #define DFSW_TILE_FLUSH()                                                                           \
     do {                                                                                            \
         const uint32_t r_ = tr0 + lane;                                                             \
@@ -774,7 +756,14 @@ __device__ __forceinline__ void dfs_split_win(uint32_t *lab, const BigInfo &B, u
             const uint32_t a_ = r_ * wpr + (twc32 >> 5);                                            \
             bm[a_] = tlo;                                                                           \
             bm[a_ + 1u] = thi;                                                                      \
+            if (GLB) {                                                                              \
+                uint32_t d0_ = olo & ~tlo, d1_ = ohi & ~thi;                                        \
+                const uint32_t pb_ = gbase + r_ * ncols + twc32;                                    \
+                while (d0_) { lab[pb_ + (uint32_t)__builtin_ctz(d0_)] = FL; d0_ &= d0_ - 1u; }      \
+                while (d1_) { lab[pb_ + 32u + (uint32_t)__builtin_ctz(d1_)] = FL; d1_ &= d1_ - 1u; } \
+            }                                                                                       \
         }                                                                                           \
+        if (GLB) { olo = tlo; ohi = thi; }                                                          \
         /* (GLB: no wait -- the loads that follow come from this wavefront too, and a wavefront's       \
             accesses to one address reach the L2 in program order) */                                \
         __builtin_amdgcn_wave_barrier();                                                            \
@@ -822,8 +811,8 @@ __device__ __forceinline__ void dfs_split_win(uint32_t *lab, const BigInfo &B, u
         uint32_t cnt = 0;
         uint32_t cpk = UNI((sy << 16) | sx);     // current position, packed padded coordinates
         uint32_t rmin = UNI(sy), rmax = rmin;    // rows the piece has stood on
-        vis0 = 0; vis1 = 0;
         DFSW_TILE_LOAD(sy, sx);
+        uint32_t lpr = sy, lpc = sx;              // where the walk stood when the tile was loaded
         uint32_t ry = UNI(sy - tr0), b = UNI(sx - twc32);        // both in 1 .. 62
         u64 U = DFSW_ROW_GET(ry - 1u), C = DFSW_ROW_GET(ry), D = DFSW_ROW_GET(ry + 1u);
         PF_LAP(pf_seed); PF_CNT(pf_npiece);
@@ -837,7 +826,7 @@ __device__ __forceinline__ void dfs_split_win(uint32_t *lab, const BigInfo &B, u
                 int lf_off = twc32 == 0u ? -big : 1, rt_off = (twc32 >> 5) + 2u >= wpr ? big : 62;
                 uint32_t rylo = UNI(ry + 1u), ryhi = rylo, why;
                 uint32_t ssp = UNI(sw_addr + (sp_l << 2)), sw_end = UNI(sw_addr + (DFS_SWN << 2)), sw_base = sw_addr;
-                uint32_t vcpk = cpk, vsp = ssp, vt, a_tr0 = UNI(tr0), a_twc = UNI(twc32);
+                uint32_t vcpk = cpk, vsp = ssp, vt, vt2, vlane = lane, a_tr0 = UNI(tr0), a_twc = UNI(twc32);
                 // (every scalar operand through readfirstlane: the register constraints need values
                 //  the compiler can PROVE uniform)
                 U = UNI64(U); C = UNI64(C); D = UNI64(D); cnt = UNI(cnt);
@@ -846,8 +835,9 @@ __device__ __forceinline__ void dfs_split_win(uint32_t *lab, const BigInfo &B, u
                 asm volatile(DFS_WALK4_ASM
                              : "+{s[64:65]}"(U), "+{s[66:67]}"(C), "+{s[68:69]}"(D), "+{s73}"(rylo), "+{s74}"(ryhi), "={s75}"(why),
                                "+{s88}"(cnt), "+{s89}"(ssp),
-                               [tlo] "+v"(tlo), [thi] "+v"(thi), [vcpk] "+v"(vcpk), [vsp] "+v"(vsp), [vt] "=&v"(vt)
-                             : "{s90}"(a_tr0), "{s91}"(a_twc), "{s92}"(up_off), "{s93}"(dn_off), "{s94}"(lf_off), "{s95}"(rt_off),
+                               [tlo] "+v"(tlo), [thi] "+v"(thi), [vcpk] "+v"(vcpk), [vsp] "+v"(vsp), [vt] "=&v"(vt),
+                               [vt2] "=&v"(vt2)
+                             : [vlane] "v"(vlane), "{s90}"(a_tr0), "{s91}"(a_twc), "{s92}"(up_off), "{s93}"(dn_off), "{s94}"(lf_off), "{s95}"(rt_off),
                                "{s96}"(sw_end), "{s99}"(sw_base)
                              : "s70", "s71", "s72", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86",
                                "s87", "s97", "s98", "scc", "memory");
@@ -880,7 +870,18 @@ __device__ __forceinline__ void dfs_split_win(uint32_t *lab, const BigInfo &B, u
                     const uint32_t pr = cpk >> 16, pc = cpk & 0xffffu;
                     rmin = pr < rmin ? pr : rmin;
                     rmax = pr > rmax ? pr : rmax;
-                    DFSW_TILE_LOAD(pr, pc);
+                    if (why == 1u) {
+                        // which rim was it (ry, b: the position inside the tile that is left), and did the walk come a
+                        // long way towards it since the tile was loaded?  (a walk that only turned round near the rim of
+                        // an off-centre tile gets a centred one, or two tiles would hand it back and forth)
+                        const int rb_ = (ry >= 50u && pr >= lpr + 24u) ? 8 : (ry <= 13u && lpr >= pr + 24u) ? 55 : 32;
+                        const int cb_ = (b >= 50u && pc >= lpc + 24u) ? 8 : (b <= 13u && lpc >= pc + 24u) ? 24 : 16;
+                        DFSW_TILE_LOAD_AT(pr, pc, rb_, cb_);
+                        lpr = pr; lpc = pc;
+                    } else {
+                        DFSW_TILE_LOAD(pr, pc);
+                        lpr = pr; lpc = pc;
+                    }
                     ry = UNI(pr - tr0); b = UNI(pc - twc32);
                     U = DFSW_ROW_GET(ry - 1u); C = DFSW_ROW_GET(ry); D = DFSW_ROW_GET(ry + 1u);
                     PF_LAP(pf_rim);
@@ -926,6 +927,7 @@ __device__ __forceinline__ void dfs_split_win(uint32_t *lab, const BigInfo &B, u
                         DFSW_TILE_FLUSH();
                         const uint32_t pr = cpk >> 16, pc = cpk & 0xffffu;
                         DFSW_TILE_LOAD(pr, pc);
+                        lpr = pr; lpc = pc;
                         ry = UNI(pr - tr0); b = UNI(pc - twc32);
                         U = DFSW_ROW_GET(ry - 1u); C = DFSW_ROW_GET(ry); D = DFSW_ROW_GET(ry + 1u);
                         PF_LAP(pf_rim);
@@ -989,6 +991,7 @@ __device__ __forceinline__ void dfs_split_win(uint32_t *lab, const BigInfo &B, u
                 ry = pr - tr0; b = pc - twc32;
                 if (!((ry - 1u) < 62u && (b - 1u) < 62u)) {
                     DFSW_TILE_LOAD(pr, pc);
+                    lpr = pr; lpc = pc;
                     ry = UNI(pr - tr0); b = UNI(pc - twc32);
                 }
             }
@@ -1006,45 +1009,8 @@ __device__ __forceinline__ void dfs_split_win(uint32_t *lab, const BigInfo &B, u
                 if (singles) singles[atomicAdd(nsingles, 1u)] = seed;
             }
         } else if (GLB) {
-            // the marked cells, one at a time: lane = row of the cell's block, two words per lane
-            for (int h = 0; h < 2; h++) {
-                u64 mine = h ? vis1 : vis0;
-                for (;;) {
-                    const u64 any = __ballot(mine != 0ull);
-                    if (!any) break;
-                    const int L = __builtin_ctzll(any);
-                    const uint32_t mlo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mine, L);
-                    const uint32_t mhi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mine >> 32), L);
-                    const uint32_t bpos = mlo ? (uint32_t)__builtin_ctz(mlo) : 32u + (uint32_t)__builtin_ctz(mhi);
-                    if ((int)lane == L) mine &= mine - 1ull;
-                    const uint32_t cell = ((uint32_t)L << 7) + ((uint32_t)h << 6) + bpos;
-                    const uint32_t cr = cell / vCC, cc = cell - cr * vCC;
-                    for (uint32_t rb = 0; rb < (1u << vsr); rb++) {
-                        const uint32_t row = (((cr << vsr) + rb) << 6) + lane;
-                        if ((((cr << vsr) + rb) << 6) >= nprow) break;                 // (uniform)
-                        for (uint32_t wp = 0; wp < (1u << vsc); wp++) {
-                            const uint32_t w = ((cc << vsc) + wp) << 1;
-                            if (w >= wpr) break;                                           // (uniform)
-                            const bool ok0 = row < nprow, ok1 = ok0 && w + 1u < wpr;
-                            const uint32_t i = row * wpr + w;
-                            const uint32_t s0 = ok0 ? __hip_atomic_load(&snap[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-                            const uint32_t s1 = ok1 ? __hip_atomic_load(&snap[i + 1u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-                            const uint32_t c0 = ok0 ? BMLD(&bm[i]) : 0u, c1 = ok1 ? BMLD(&bm[i + 1u]) : 0u;
-                            uint32_t d0 = s0 & ~c0, d1 = s1 & ~c1;
-                            const uint32_t pbase = gbase + row * ncols + (w << 5);
-                            if (d0) {
-                                snap[i] = c0;
-                                do { lab[pbase + (uint32_t)__builtin_ctz(d0)] = FL; d0 &= d0 - 1u; } while (d0);
-                            }
-                            if (d1) {
-                                snap[i + 1u] = c1;
-                                do { lab[pbase + 32u + (uint32_t)__builtin_ctz(d1)] = FL; d1 &= d1 - 1u; } while (d1);
-                            }
-                        }
-                    }
-                }
-            }
-            if (lane == 0) csize[seed] = cnt + 1u;
+            // (every pixel but the seed was labelled when its tile was written back: DFSW_TILE_FLUSH)
+            if (lane == 0) { lab[seed] = FL; csize[seed] = cnt + 1u; }
         } else {
             // the piece's pixels = the bits that went since the snapshot (the bitmap at the last piece's
             // end, in global memory), in the rows the piece stood on +- 1: a word per lane, four loads

@@ -25,6 +25,23 @@ dozen branches per step, ~950 cycles between two runs of steps.  Here:
     of it, no LDS traffic but the 4-byte pop -- and leaves for the bulk test of the stack top (64
     entries at a time, clump.h) only when that entry is dead too or lies outside the tile.
 
+  * RUNS.  The walk repeats itself: on the benchmark imagery 59 % of the steps continue a streak of the SAME mask,
+    34 % a streak of four or more (21 %: eight or more), and a tile that is one component is nothing else.  When a
+    block's dispatch finds its own mask again (masks 1, 4: straight left / right; 8, 9, 2, 3: straight down / up,
+    stacking the left neighbour or not) it first asks how long the streak is and takes it in one go:
+      - left / right: the run is the stretch of set bits of the C row next to the position that has no set bit
+        above or below it (the U and D rows): three 64-bit shifts and two bit scans on SGPRs; K bits of C are
+        cleared with one s_bfm_b64 / s_andn2_b64;
+      - down / up: a row continues the streak iff its three bits around the column read (left as stacked, self 1,
+        right 0); with the tile's lane = row that is ONE v_bfe_u32 + v_cmp over all 64 rows, and the streak's
+        length a shift and a bit scan of the compare mask.  The K rows are cleared under an exec mask of K lanes,
+        and the K stacked left neighbours are written by K lanes with ONE ds_write_b32 (lane i = the i-th step:
+        the order the single steps would have pushed them in).
+    K is capped by the step budget, so rim, cap and stack room hold as before; a streak shorter than two, or a
+    column whose three bits straddle the tile's two dwords, falls through to the plain block.  Equivalence with
+    the single steps: the same visiting sequence on 400 random bitmaps in a bit-level model (LABNOTES, round 4),
+    and every clump test on the device.
+
 Register contract (see the asm statement in clump.h):
   s[64:65] U, s[66:67] C, s[68:69] D   window rows (64 columns of the tile) above / at / below
   s73 / s74  (in/out) min / max of ryp = tile row + 1 the walk stood on
@@ -39,7 +56,8 @@ Register contract (see the asm statement in clump.h):
        s72 guard, s97 its start value, s[80:85] scratch, s[86:87] exec,
        m0 lane select of v_writelane
   %[tlo] %[thi] the tile (lane = row), %[vcpk] packed position (row << 16 | col), %[vsp] LDS byte
-  address of the stack top, %[vt] scratch -- lane 0 only is maintained inside (exec = 1)
+  address of the stack top, %[vt] %[vt2] scratch -- lane 0 only is maintained inside (exec = 1);
+  %[vlane] (in) the lane number, all lanes; s76..s79 more scratch (runs)
 m bit 0 = left, 1 = up, 2 = right, 3 = down.  Push order of the reference (shepseg.py:519-536, cx
 outer, cy inner): left, up, down, right; the walk moves to the last one pushed.
 """
@@ -75,10 +93,141 @@ def head(prev):
     for m in cand:
         if m not in seen:
             seen.append(m)
+    def target(m):
+        return '.Ldw4_r%d%%=' % m if (RUNS and m == prev and m in RUNNABLE) else '.Ldw4_b%d%%=' % m
     for m in seen[:-1]:
-        o += ['s_cmp_eq_u32 s80, %d' % m, 's_cbranch_scc1 .Ldw4_b%d%%=' % m]
+        o += ['s_cmp_eq_u32 s80, %d' % m, 's_cbranch_scc1 ' + target(m)]
     # the last candidate needs no test unless the mask may be 0 (dead end)
-    o += ['s_cmp_eq_u32 s80, %d' % seen[-1], 's_cbranch_scc1 .Ldw4_b%d%%=' % seen[-1], 's_branch .Ldw4_dead%=']
+    o += ['s_cmp_eq_u32 s80, %d' % seen[-1], 's_cbranch_scc1 ' + target(seen[-1]), 's_branch .Ldw4_dead%=']
+    return o
+
+
+RUNS = os.environ.get('DFS_WALK_RUNS', '1') != '0'
+RUNNABLE = (1, 4, 8, 9, 2, 3)
+
+
+def hrun(m):
+    """a streak of mask 1 (left) or 4 (right): K steps along the C row in one go"""
+    left = m == 1
+    o = ['.Ldw4_r%d%%=:' % m, 's_and_b32 s76, s98, 0xffff']                       # b
+    if left:
+        o += ['s_sub_u32 s77, 64, s76',
+              's_lshl_b64 s[80:81], s[66:67], s77',         # bit b - 1 of C -> bit 63
+              's_not_b64 s[80:81], s[80:81]',
+              's_flbit_i32_b64 s78, s[80:81]',              # set bits of C from b - 1 downwards
+              's_or_b64 s[82:83], s[64:65], s[68:69]',
+              's_sub_u32 s77, 63, s76',
+              's_lshl_b64 s[82:83], s[82:83], s77',         # bit b of U | D -> bit 63
+              's_flbit_i32_b64 s79, s[82:83]']              # clear bits of U | D from b downwards (-1: all)
+    else:
+        o += ['s_add_u32 s77, s76, 1',
+              's_lshr_b64 s[80:81], s[66:67], s77',         # bit b + 1 of C -> bit 0
+              's_not_b64 s[80:81], s[80:81]',
+              's_ff1_i32_b64 s78, s[80:81]',
+              's_or_b64 s[82:83], s[64:65], s[68:69]',
+              's_lshr_b64 s[82:83], s[82:83], s76',
+              's_ff1_i32_b64 s79, s[82:83]']
+    o += ['s_cmp_lt_i32 s79, 0',
+          's_cselect_b32 s79, 64, s79',
+          's_min_u32 s78, s78, s79',
+          's_min_u32 s78, s78, s72',                        # the step budget
+          's_cmp_lt_u32 s78, 2',
+          's_cbranch_scc1 .Ldw4_b%d%%=' % m]
+    if left:
+        o += ['s_sub_u32 s77, s76, s78',                    # lowest bit to clear: b - K
+              's_bfm_b64 s[80:81], s78, s77',
+              's_andn2_b64 s[66:67], s[66:67], s[80:81]',
+              's_sub_u32 s70, s70, s78', 's_sub_u32 s98, s98, s78',
+              'v_subrev_u32 %[vcpk], s78, %[vcpk]']
+    else:
+        o += ['s_bfm_b64 s[80:81], s78, s77',               # K bits from b + 1
+              's_andn2_b64 s[66:67], s[66:67], s[80:81]',
+              's_add_u32 s70, s70, s78', 's_add_u32 s98, s98, s78',
+              'v_add_u32 %[vcpk], s78, %[vcpk]']
+    o += ['s_sub_u32 s72, s72, s78']
+    return o + head(m)
+
+
+def vrun(m):
+    """a streak of mask 8 / 9 (down) or 2 / 3 (up; 9 and 3 stack the left neighbour): K steps in one go"""
+    stack_l, down = bool(m & 1), bool(m & 8)
+    want = 2 | (1 if stack_l else 0)
+
+    def body(tile, sfx):
+        o = ['s_sub_u32 m0, s71, 2',                        # the window goes back into the tile
+             'v_writelane_b32 %[tlo], s64, m0', 'v_writelane_b32 %[thi], s65, m0',
+             's_sub_u32 m0, s71, 1',
+             'v_writelane_b32 %[tlo], s66, m0', 'v_writelane_b32 %[thi], s67, m0',
+             's_mov_b32 m0, s71',
+             'v_writelane_b32 %[tlo], s68, m0', 'v_writelane_b32 %[thi], s69, m0',
+             's_mov_b64 exec, -1',
+             'v_bfe_u32 %%[vt], %s, s77, 3' % tile,         # every row's (left, self, right) around the column
+             'v_cmp_eq_u32_e64 s[80:81], %%[vt], %d' % want]
+        if down:
+            o += ['s_lshr_b64 s[80:81], s[80:81], s71',     # row ry + 1 -> bit 0
+                  's_not_b64 s[80:81], s[80:81]',
+                  's_ff1_i32_b64 s78, s[80:81]']
+        else:
+            o += ['s_sub_u32 s79, 65, s71',
+                  's_lshl_b64 s[80:81], s[80:81], s79',     # row ry - 1 -> bit 63
+                  's_not_b64 s[80:81], s[80:81]',
+                  's_flbit_i32_b64 s78, s[80:81]']
+        o += ['s_min_u32 s78, s78, s72',
+              's_cmp_lt_u32 s78, 2',
+              's_cbranch_scc1 .Ldw4_r%dno%s%%=' % (m, sfx),
+              's_lshl_b32 s84, 1, s77',                     # the left bit inside the dword, the self bit
+              's_lshl_b32 s85, s84, 1',
+              's_sub_u32 s79, s71, 1']                      # ry
+        if down:
+            if stack_l:
+                o += ['s_bfm_b64 exec, s78, s79', 's_not_b32 s82, s84', 'v_and_b32 %s, s82, %s' % (tile, tile)]
+            o += ['s_bfm_b64 exec, s78, s71', 's_not_b32 s82, s85', 'v_and_b32 %s, s82, %s' % (tile, tile)]
+        else:
+            o += ['s_sub_u32 s83, s79, s78']                # ry - K
+            if stack_l:
+                o += ['s_add_u32 s82, s83, 1', 's_bfm_b64 exec, s78, s82', 's_not_b32 s82, s84',
+                      'v_and_b32 %s, s82, %s' % (tile, tile)]
+            o += ['s_bfm_b64 exec, s78, s83', 's_not_b32 s82, s85', 'v_and_b32 %s, s82, %s' % (tile, tile)]
+        o += ['s_mov_b64 exec, 1']
+        if stack_l:
+            o += ['v_readfirstlane_b32 s82, %[vcpk]',
+                  'v_readfirstlane_b32 s83, %[vsp]',
+                  's_sub_u32 s82, s82, 1',                  # the left neighbour of the first step
+                  's_bfm_b64 exec, s78, 0']                 # lane i = step i
+            if down:
+                o += ['v_lshl_add_u32 %[vt], %[vlane], 16, s82']
+            else:
+                o += ['v_lshlrev_b32 %[vt], 16, %[vlane]', 'v_sub_u32 %[vt], s82, %[vt]']
+            o += ['v_lshl_add_u32 %[vt2], %[vlane], 2, s83',
+                  'ds_write_b32 %[vt2], %[vt]',
+                  's_mov_b64 exec, 1',
+                  's_lshl_b32 s83, s78, 2',
+                  'v_add_u32 %[vsp], s83, %[vsp]']
+        o += ['s_lshl_b32 s82, s78, 16']
+        if down:
+            o += ['v_add_u32 %[vcpk], s82, %[vcpk]', 's_add_u32 s71, s71, s78', 's_max_u32 s74, s74, s71']
+        else:
+            o += ['v_subrev_u32 %[vcpk], s82, %[vcpk]', 's_sub_u32 s71, s71, s78', 's_min_u32 s73, s73, s71']
+        o += ['s_sub_u32 s72, s72, s78',
+              's_sub_u32 s80, s71, 2', 's_sub_u32 s81, s71, 1',      # the window at the new row
+              'v_readlane_b32 s64, %[tlo], s80', 'v_readlane_b32 s65, %[thi], s80',
+              'v_readlane_b32 s66, %[tlo], s81', 'v_readlane_b32 s67, %[thi], s81',
+              'v_readlane_b32 s68, %[tlo], s71', 'v_readlane_b32 s69, %[thi], s71']
+        o += head(m)
+        o += ['.Ldw4_r%dno%s%%=:' % (m, sfx), 's_mov_b64 exec, 1', 's_branch .Ldw4_b%d%%=' % m]
+        return o
+
+    o = ['.Ldw4_r%d%%=:' % m,
+         's_and_b32 s76, s98, 0xffff',                      # b
+         's_cmp_gt_u32 s76, 30',
+         's_cbranch_scc1 .Ldw4_r%dhi%%=' % m,
+         's_sub_u32 s77, s76, 1']                           # bits b - 1 .. b + 1 in the low dword
+    o += body('%[tlo]', 'a')
+    o += ['.Ldw4_r%dhi%%=:' % m,
+          's_cmp_lt_u32 s76, 33',
+          's_cbranch_scc1 .Ldw4_b%d%%=' % m,                # the three bits straddle the dwords: a plain step
+          's_sub_u32 s77, s76, 33']
+    o += body('%[thi]', 'b')
     return o
 
 
@@ -234,6 +383,11 @@ def main():
         lines += ['.Ldw4_%s%%=:' % name, 's_mov_b32 s75, %d' % i, 's_branch .Ldw4_exit%=']
     for m in range(1, 16):
         lines += block(m)
+    if RUNS:
+        for m in (1, 4):
+            lines += hrun(m)
+        for m in (8, 9, 2, 3):
+            lines += vrun(m)
     lines += ['.Ldw4_exit%=:', 's_mov_b64 exec, s[86:87]']
     out = ['// GENERATED by tools/gen_dfs_walk4.py -- do not edit; see that script for the design.',
            '#pragma once', '#define DFS_WALK4_ASM \\']
