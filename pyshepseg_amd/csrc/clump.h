@@ -656,6 +656,12 @@ __device__ __forceinline__ void dfs_split_win(uint32_t *lab, const BigInfo &B, u
 {
     typedef unsigned long long u64;
 #define BMLD(P) (GLB ? __hip_atomic_load((P), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *(P))
+    // where word Wd of padded row R lives.  In LDS: row-major.  GLB: column-block-major (the 32-column word Wd of
+    // every row, then word Wd + 1 of every row), so that the 64 rows of a tile are two runs of 256 bytes -- four
+    // cache lines per tile load or write-back where the row-major bitmap took 64 to 128, and a re-centring is a
+    // round trip of exactly those transactions issued by one wavefront.  BML: the same for a raster word index.
+#define BMI(R, Wd) (GLB ? (Wd) * nprow + (R) : (R) * wpr + (Wd))
+#define BML(I) (GLB ? bml_(I) : (I))
 #ifdef DFS_PROF     // diagnostic build (make PROF=1): cycles per phase and event counts per component
     u64 pf_t = __builtin_readcyclecounter(), pf_build = 0, pf_dead = 0, pf_label = 0, pf_seed = 0, pf_rim = 0, pf_walk = 0, pf_asm = 0;
     u64 pf_nstep = 0, pf_ndead = 0, pf_nbulk = 0, pf_nrim = 0, pf_npiece = 0, pf_nrun = 0;
@@ -694,7 +700,7 @@ __device__ __forceinline__ void dfs_split_win(uint32_t *lab, const BigInfo &B, u
                 const u64 mm = __ballot(v[u] == root);
                 if (pr < nprow && lane < 2u && (c0 >> 5) + lane < wpr) {
                     const uint32_t wv = lane ? (uint32_t)(mm >> 32) : (uint32_t)mm;
-                    bm[pr * wpr + (c0 >> 5) + lane] = wv;
+                    bm[BMI(pr, (c0 >> 5) + lane)] = wv;
                     if (!GLB) snap[pr * wpr + (c0 >> 5) + lane] = wv;       // the bitmap as of the last piece's end
                 }
             }
@@ -703,6 +709,7 @@ __device__ __forceinline__ void dfs_split_win(uint32_t *lab, const BigInfo &B, u
     if (GLB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
     const uint32_t wpr_inv = 0xFFFFFFFFu / wpr + 1u;              // __umulhi(i, wpr_inv) == i / wpr for i < 2^32 / wpr
+    auto bml_ = [&](uint32_t i) { const uint32_t r = __umulhi(i, wpr_inv); return (i - r * wpr) * nprow + r; };
     // per-lane constants (8-connectivity and the dead-end test): lanes 0..nq-1 own the neighbours in
     // the reference's push order (cx outer, cy inner); dpk = offset in packed (row << 16 | col) form
     constexpr uint32_t NQ = FOUR ? 4u : 8u;
@@ -739,9 +746,9 @@ __device__ __forceinline__ void dfs_split_win(uint32_t *lab, const BigInfo &B, u
         twc32 = UNI(twc_ << 5);                                                                     \
         const uint32_t r_ = tr0 + lane;                                                             \
         const bool ok_ = r_ < nprow;                                                                \
-        const uint32_t a_ = r_ * wpr + twc_;                                                        \
+        const uint32_t a_ = BMI(r_, twc_), a1_ = BMI(r_, twc_ + 1u);                                \
         tlo = ok_ ? BMLD(&bm[a_]) : 0u;                                                             \
-        thi = ok_ ? BMLD(&bm[a_ + 1u]) : 0u;                                                        \
+        thi = ok_ ? BMLD(&bm[a1_]) : 0u;                                                            \
         if (GLB) { olo = tlo; ohi = thi; }                                                          \
     } while (0)
     // GLB: a piece's pixels are labelled HERE, from the registers -- the bits that went since the tile was loaded
@@ -752,18 +759,32 @@ __device__ __forceinline__ void dfs_split_win(uint32_t *lab, const BigInfo &B, u
 #define DFSW_TILE_FLUSH()                                                                           \
     do {                                                                                            \
         const uint32_t r_ = tr0 + lane;                                                             \
+        uint32_t d0_ = 0u, d1_ = 0u;                                                                \
         if (r_ < nprow) {                                                                           \
-            const uint32_t a_ = r_ * wpr + (twc32 >> 5);                                            \
-            bm[a_] = tlo;                                                                           \
-            bm[a_ + 1u] = thi;                                                                      \
-            if (GLB) {                                                                              \
-                uint32_t d0_ = olo & ~tlo, d1_ = ohi & ~thi;                                        \
+            bm[BMI(r_, twc32 >> 5)] = tlo;                                                          \
+            bm[BMI(r_, (twc32 >> 5) + 1u)] = thi;                                                   \
+            if (GLB) { d0_ = olo & ~tlo; d1_ = ohi & ~thi; }                                        \
+        }                                                                                           \
+        if (GLB) {                                                                                  \
+            /* few rows changed (a sweep along a row): a row at a time, lane = column, one store;   \
+               many (a run down a column: a bit or two per row): every lane walks its own bits */   \
+            u64 rows_ = __ballot((d0_ | d1_) != 0u);                                                \
+            if (__builtin_popcountll(rows_) <= 6) {                                                 \
+                while (rows_) {                                                                     \
+                    const int rr_ = __builtin_ctzll(rows_);                                         \
+                    rows_ &= rows_ - 1ull;                                                          \
+                    const uint32_t x0_ = (uint32_t)__builtin_amdgcn_readlane((int)d0_, rr_);        \
+                    const uint32_t x1_ = (uint32_t)__builtin_amdgcn_readlane((int)d1_, rr_);        \
+                    const uint32_t xb_ = lane < 32u ? x0_ >> lane : x1_ >> (lane - 32u);            \
+                    if (xb_ & 1u) lab[gbase + (tr0 + (uint32_t)rr_) * ncols + twc32 + lane] = FL;   \
+                }                                                                                   \
+            } else {                                                                                \
                 const uint32_t pb_ = gbase + r_ * ncols + twc32;                                    \
                 while (d0_) { lab[pb_ + (uint32_t)__builtin_ctz(d0_)] = FL; d0_ &= d0_ - 1u; }      \
                 while (d1_) { lab[pb_ + 32u + (uint32_t)__builtin_ctz(d1_)] = FL; d1_ &= d1_ - 1u; } \
             }                                                                                       \
+            olo = tlo; ohi = thi;                                                                   \
         }                                                                                           \
-        if (GLB) { olo = tlo; ohi = thi; }                                                          \
         /* (GLB: no wait -- the loads that follow come from this wavefront too, and a wavefront's       \
             accesses to one address reach the L2 in program order) */                                \
         __builtin_amdgcn_wave_barrier();                                                            \
@@ -790,7 +811,7 @@ __device__ __forceinline__ void dfs_split_win(uint32_t *lab, const BigInfo &B, u
         uint32_t sword = 0xFFFFFFFFu, sbits = 0;
         for (uint32_t w0 = wcur; w0 < nwords; w0 += 64u) {
             const uint32_t wi = w0 + lane;
-            const uint32_t v = wi < nwords ? BMLD(&bm[wi]) : 0u;
+            const uint32_t v = wi < nwords ? BMLD(&bm[BML(wi)]) : 0u;
             const u64 mm = __ballot(v != 0u);
             if (mm) {
                 const int fl = __builtin_ctzll(mm);
@@ -804,7 +825,7 @@ __device__ __forceinline__ void dfs_split_win(uint32_t *lab, const BigInfo &B, u
         const uint32_t sy = sword / wpr, sx = ((sword - sy * wpr) << 5) + (uint32_t)__builtin_ctz(sbits);
         const uint32_t seed = gbase + sy * ncols + sx;
         const uint32_t FL = seed | VIS_FLAG;
-        if (lane == 0) bm[sword] = sbits & (sbits - 1u);     // clear the seed's (lowest) bit
+        if (lane == 0) bm[BML(sword)] = sbits & (sbits - 1u);     // clear the seed's (lowest) bit
         if (GLB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // (the store has left before the tile is read)
         __builtin_amdgcn_wave_barrier();
         uint32_t sp_l = 0, sp_g = 0;             // stack entries in the LDS window / spilled
@@ -970,7 +991,7 @@ __device__ __forceinline__ void dfs_split_win(uint32_t *lab, const BigInfo &B, u
                         if (FOUR) { qy = (q == 1u) ? -1 : (q == 2u) ? 1 : 0; qx = (q == 0u) ? -1 : (q == 3u) ? 1 : 0; }
                         else { qx = (q < 3u) ? -1 : (q < 5u) ? 0 : 1; qy = (q == 0u || q == 3u || q == 5u) ? -1 : (q == 1u || q == 6u) ? 0 : 1; }
                         const uint32_t rr = (uint32_t)((int)er + qy), cc = (uint32_t)((int)ec + qx);
-                        alive = alive || (((BMLD(&bm[rr * wpr + (cc >> 5)]) >> (cc & 31u)) & 1u) != 0u);
+                        alive = alive || (((BMLD(&bm[BMI(rr, cc >> 5)]) >> (cc & 31u)) & 1u) != 0u);
                     }
                 }
                 const u64 am = __ballot(alive);
@@ -1005,7 +1026,7 @@ __device__ __forceinline__ void dfs_split_win(uint32_t *lab, const BigInfo &B, u
             if (lane == 0) {
                 lab[seed] = FL;
                 csize[seed] = 1u;
-                snap[sword] = sbits & (sbits - 1u);          // (the snapshot follows: only the seed's bit went)
+                if (!GLB) snap[sword] = sbits & (sbits - 1u);          // (the snapshot follows: only the seed's bit went)
                 if (singles) singles[atomicAdd(nsingles, 1u)] = seed;
             }
         } else if (GLB) {
@@ -1056,6 +1077,8 @@ __device__ __forceinline__ void dfs_split_win(uint32_t *lab, const BigInfo &B, u
 #undef PF_CNT
 #undef PF_ADD
 #undef BMLD
+#undef BMI
+#undef BML
 #undef DFSW_TILE_LOAD
 #undef DFSW_MARK
 #undef DFSW_MARK_ONE
@@ -1206,14 +1229,14 @@ __global__ __launch_bounds__(DFS_WAVES * 64) void k_dfs_pool(        // blockDim
                 __hip_atomic_fetch_and(mask, ~(ones << g0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             }
         } else {
-            // the bitmap does not fit the pool (or no room came free): bitmap and snapshot in global memory,
+            // the bitmap does not fit the pool (or no room came free): bitmap in global memory,
             // carved from the scratch block (counters[4] = words taken); the plain global walk when that is full
             uint32_t goff = 0xFFFFFFFFu;
             if (!oldwalk && words <= 0x3FFFFFFFull && gscratch) {
                 if (lane == 0) {
                     // a CAS loop that only advances on success: a counter that kept adding after the block was
                     // full could wrap in 32 bits and hand a later component an offset inside live bitmaps
-                    const uint32_t need2 = 2u * (uint32_t)words;
+                    const uint32_t need2 = (uint32_t)words;
                     uint32_t cur = __hip_atomic_load(&counters[4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     for (;;) {
                         if ((unsigned long long)cur + need2 > (unsigned long long)gscratch_words) break;
@@ -1225,7 +1248,7 @@ __global__ __launch_bounds__(DFS_WAVES * 64) void k_dfs_pool(        // blockDim
                 goff = (uint32_t)__builtin_amdgcn_readfirstlane((int)goff);
             }
             if (goff != 0xFFFFFFFFu) {
-                uint32_t *gbm = gscratch + goff, *gsnap = gbm + (uint32_t)words;
+                uint32_t *gbm = gscratch + goff, *gsnap = nullptr;      // (labels go out at tile write-back: no snapshot)
                 if (four) dfs_split_win<true, true>(lab, B, gbm, sw, stackbuf, ncols, singles, nsingles, csize, gsnap, dbg ? dbg + (size_t)idx * DFS_DBG_WORDS + 6u : nullptr);
                 else dfs_split_win<false, true>(lab, B, gbm, sw, stackbuf, ncols, singles, nsingles, csize, gsnap, dbg ? dbg + (size_t)idx * DFS_DBG_WORDS + 6u : nullptr);
             } else {

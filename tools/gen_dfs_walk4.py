@@ -27,7 +27,8 @@ dozen branches per step, ~950 cycles between two runs of steps.  Here:
 
   * RUNS.  The walk repeats itself: on the benchmark imagery 59 % of the steps continue a streak of the SAME mask,
     34 % a streak of four or more (21 %: eight or more), and a tile that is one component is nothing else.  When a
-    block's dispatch finds its own mask again (masks 1, 4: straight left / right; 8, 9, 2, 3: straight down / up,
+    block's dispatch finds its own mask again (masks 1, 4: straight left / right; 12, 6, 14: right, stacking the
+    neighbour below / above / both -- the sweep along the rim of a uniform region; 8, 9, 2, 3: straight down / up,
     stacking the left neighbour or not) it first asks how long the streak is and takes it in one go:
       - left / right: the run is the stretch of set bits of the C row next to the position that has no set bit
         above or below it (the U and D rows): three 64-bit shifts and two bit scans on SGPRs; K bits of C are
@@ -103,12 +104,14 @@ def head(prev):
 
 
 RUNS = os.environ.get('DFS_WALK_RUNS', '1') != '0'
-RUNNABLE = (1, 4, 8, 9, 2, 3)
+RUNNABLE = (1, 4, 12, 6, 14, 8, 9, 2, 3)
 
 
 def hrun(m):
-    """a streak of mask 1 (left) or 4 (right): K steps along the C row in one go"""
+    """a streak of mask 1 (left), 4 (right) or 12 / 6 / 14 (right, stacking the lower / upper / both neighbours):
+    K steps along the C row in one go"""
     left = m == 1
+    wu, wd = bool(m & 2), bool(m & 8)
     o = ['.Ldw4_r%d%%=:' % m, 's_and_b32 s76, s98, 0xffff']                       # b
     if left:
         o += ['s_sub_u32 s77, 64, s76',
@@ -120,11 +123,16 @@ def hrun(m):
               's_lshl_b64 s[82:83], s[82:83], s77',         # bit b of U | D -> bit 63
               's_flbit_i32_b64 s79, s[82:83]']              # clear bits of U | D from b downwards (-1: all)
     else:
+        # columns where the rows above / below do NOT read as the mask says end the streak
+        bad = {(False, False): 's_or_b64 s[82:83], s[64:65], s[68:69]',
+               (False, True): 's_orn2_b64 s[82:83], s[64:65], s[68:69]',          # U | ~D
+               (True, False): 's_orn2_b64 s[82:83], s[68:69], s[64:65]',          # D | ~U
+               (True, True): 's_nand_b64 s[82:83], s[64:65], s[68:69]'}[(wu, wd)]
         o += ['s_add_u32 s77, s76, 1',
               's_lshr_b64 s[80:81], s[66:67], s77',         # bit b + 1 of C -> bit 0
               's_not_b64 s[80:81], s[80:81]',
               's_ff1_i32_b64 s78, s[80:81]',
-              's_or_b64 s[82:83], s[64:65], s[68:69]',
+              bad,
               's_lshr_b64 s[82:83], s[82:83], s76',
               's_ff1_i32_b64 s79, s[82:83]']
     o += ['s_cmp_lt_i32 s79, 0',
@@ -141,8 +149,34 @@ def hrun(m):
               'v_subrev_u32 %[vcpk], s78, %[vcpk]']
     else:
         o += ['s_bfm_b64 s[80:81], s78, s77',               # K bits from b + 1
-              's_andn2_b64 s[66:67], s[66:67], s[80:81]',
-              's_add_u32 s70, s70, s78', 's_add_u32 s98, s98, s78',
+              's_andn2_b64 s[66:67], s[66:67], s[80:81]']
+        if wu or wd:
+            # the K neighbours above / below columns b .. b + K - 1 are marked and stacked: lane i = the i-th step,
+            # its entries where the single steps would have put them (up before down)
+            nst = int(wu) + int(wd)
+            o += ['s_bfm_b64 s[82:83], s78, s76']
+            if wu:
+                o += ['s_andn2_b64 s[64:65], s[64:65], s[82:83]']
+            if wd:
+                o += ['s_andn2_b64 s[68:69], s[68:69], s[82:83]']
+            o += ['v_readfirstlane_b32 s82, %[vcpk]',
+                  'v_readfirstlane_b32 s83, %[vsp]',
+                  's_bfm_b64 exec, s78, 0',
+                  'v_lshl_add_u32 %%[vt2], %%[vlane], %d, s83' % (2 if nst == 1 else 3)]
+            off = 0
+            if wu:
+                o += ['s_sub_u32 s84, s82, 0x10000',
+                      'v_add_u32 %[vt], s84, %[vlane]',
+                      'ds_write_b32 %[vt2], %[vt]']
+                off = 4
+            if wd:
+                o += ['s_add_u32 s84, s82, 0x10000',
+                      'v_add_u32 %[vt], s84, %[vlane]',
+                      'ds_write_b32 %%[vt2], %%[vt] offset:%d' % off]
+            o += ['s_mov_b64 exec, 1',
+                  's_lshl_b32 s83, s78, %d' % (2 if nst == 1 else 3),
+                  'v_add_u32 %[vsp], s83, %[vsp]']
+        o += ['s_add_u32 s70, s70, s78', 's_add_u32 s98, s98, s78',
               'v_add_u32 %[vcpk], s78, %[vcpk]']
     o += ['s_sub_u32 s72, s72, s78']
     return o + head(m)
@@ -251,7 +285,7 @@ RECOMP_ENTRY = [
     's_cmp_ge_u32 s88, 0x2710',
     's_cbranch_scc1 .Ldw4_xcap%=',
     's_sub_u32 s80, s96, s89',
-    's_cmp_lt_u32 s80, 400',                # a run stacks at most 3 * 32 entries
+    's_cmp_lt_u32 s80, 512',                # room for what the budget allows: 61 steps of two entries, and the seed's third
     's_cbranch_scc1 .Ldw4_xspill%=',
     'v_readfirstlane_b32 s81, %[vcpk]',
     's_lshr_b32 s82, s81, 16',
@@ -384,7 +418,7 @@ def main():
     for m in range(1, 16):
         lines += block(m)
     if RUNS:
-        for m in (1, 4):
+        for m in (1, 4, 12, 6, 14):
             lines += hrun(m)
         for m in (8, 9, 2, 3):
             lines += vrun(m)
