@@ -83,18 +83,22 @@ __device__ __forceinline__ void seg_stats_of_run(uint32_t s, uint32_t n, const u
         long long sum = 0;
         for (uint32_t i = 0; i < n; i++) sum += (long long)a[i] + bias;
         mean = (float)((double)sum / (double)n);
+        // one pass, closing a group of equal values at its last member (a nested "while the next one is equal" loop
+        // had the lanes of a wavefront -- a segment each -- wait for one another at every group)
         float var = 0.0f;
-        uint32_t bestc = 0;
-        uint32_t i = 0;
-        while (i < n) {
-            const uint32_t x = a[i];
-            uint32_t j = i + 1;
-            while (j < n && a[j] == x) j++;
-            const double d = (double)((long long)x + bias) - (double)mean;
-            const float term = (float)((double)(j - i) * (d * d));
-            var = var + term;
-            if (j - i > bestc) { bestc = j - i; vmode = (long long)x + bias; }
-            i = j;
+        uint32_t bestc = 0, c = 0;
+        uint32_t x = a[0];
+        for (uint32_t i = 0; i < n; i++) {
+            const uint32_t nx = i + 1u < n ? a[i + 1u] : ~x;
+            c++;
+            if (nx != x) {
+                const double d = (double)((long long)x + bias) - (double)mean;
+                const float term = (float)((double)c * (d * d));
+                var = var + term;
+                if (c > bestc) { bestc = c; vmode = (long long)x + bias; }
+                c = 0;
+            }
+            x = nx;
         }
         stddev = (float)sqrt((double)var / (double)n);
     }
@@ -266,7 +270,9 @@ __global__ __launch_bounds__(256) void k_stats_prefill(uint32_t S, long long bia
     seg_stats_of_run(s, 0u, nullptr, bias, sel, nstats, missing, intcols, fltcols, ns);
 }
 
-__global__ __launch_bounds__(256) void k_stats_patch(const uint32_t *__restrict__ seg, const void *__restrict__ band,
+// (eight workgroups per CU -- 64 VGPRs, 20 KiB of LDS -- is worth more here than any unrolling: 23.4 ms at five,
+//  21.5 at eight on C5 with the same instructions)
+__global__ __launch_bounds__(256, 8) void k_stats_patch(const uint32_t *__restrict__ seg, const void *__restrict__ band,
                                                      int dtype, uint32_t nrows, uint32_t ncols, uint32_t S,
                                                      int has_null, long long null_val, long long bias,
                                                      const uint32_t *__restrict__ tot, const uint32_t *__restrict__ sel,
@@ -275,14 +281,22 @@ __global__ __launch_bounds__(256) void k_stats_patch(const uint32_t *__restrict_
                                                      uint32_t *__restrict__ left_seg, uint32_t *__restrict__ left_val,
                                                      uint32_t *left_count)
 {
-    __shared__ uint32_t key[SPP_SLOTS], cnt[SPP_SLOTS], offs[SPP_SLOTS], fill[SPP_SLOTS];
-    __shared__ uint32_t runs[SPP_H * SPP_W];
+    // (LDS per workgroup sets how many of them a CU holds, and the kernel lives on that: the fill counters share
+    //  cnt[]'s low half once the pixel totals have been compared, the offsets are 16-bit)
+    __shared__ uint32_t key[SPP_SLOTS], cnt[SPP_SLOTS];
+    __shared__ uint16_t offs[SPP_SLOTS];
+    // (runs padded to 16 bytes for four-value LDS reads in the rank loop were tried: 23.6 ms on C5 against 21.5 --
+    //  the LDS the padding takes costs more in resident workgroups than the wider reads save)
+    // (and one unused entry behind every run: runs of equal length would start at multiples of it, and the labels of
+    //  a wavefront read the same few banks all through the rank loop)
+    __shared__ uint32_t runs[SPP_H * SPP_W + SPP_MAXDIST];
     __shared__ uint32_t s_ndist, s_left, s_leftbase, s_wsum[4], s_nc;
     __shared__ uint16_t clist[SPP_SLOTS];       // the complete labels' slots, compacted: consecutive threads take them
-    for (uint32_t i = threadIdx.x; i < SPP_SLOTS; i += 256u) { key[i] = SPP_EMPTY; cnt[i] = 0u; fill[i] = 0u; }
+    for (uint32_t i = threadIdx.x; i < SPP_SLOTS; i += 256u) { key[i] = SPP_EMPTY; cnt[i] = 0u; }
     if (threadIdx.x == 0) { s_ndist = 0u; s_left = 0u; s_nc = 0u; }
     __syncthreads();
     const uint32_t x0 = blockIdx.x * SPP_W, y0 = blockIdx.y * SPP_H;
+    const bool narrow = dtype != SHP_I32 && dtype != SHP_U32;       // biased values below 2^16
     // this thread's pixels: (segment, biased value, slot); the same thread keeps them through every phase
     uint32_t ps[SPP_PPT], pv[SPP_PPT], pslot[SPP_PPT];
     bool pvalid[SPP_PPT];
@@ -331,9 +345,10 @@ __global__ __launch_bounds__(256) void k_stats_patch(const uint32_t *__restrict_
         uint32_t nv = 0;
         if (kk != SPP_EMPTY) {
             const bool complete = !crowded && (c & 0xFFFFu) == tot[kk] && (c >> 16) <= SPP_MAXRUN;
-            if (complete) { nv = c >> 16; clist[atomicAdd(&s_nc, 1u)] = (uint16_t)sl; }
+            if (complete) { nv = (c >> 16) + 1u; clist[atomicAdd(&s_nc, 1u)] = (uint16_t)sl; }
             else flagged[kk] = 1;
-            cnt[sl] = complete ? (c | 0x80000000u) : (c & 0x7FFFFFFFu);      // bit 31: complete
+            // bit 31: complete; the low half (all pixels) has served and becomes the run's fill counter
+            cnt[sl] = complete ? ((c & 0x7FFF0000u) | 0x80000000u) : (c & 0x7FFFFFFFu);
         }
         mine[q] = nv;
         msum += nv;
@@ -350,7 +365,7 @@ __global__ __launch_bounds__(256) void k_stats_patch(const uint32_t *__restrict_
     uint32_t base = incl - msum;
     for (unsigned w2 = 0; w2 < wv; w2++) base += s_wsum[w2];
 #pragma unroll
-    for (uint32_t q = 0; q < 4u; q++) { offs[threadIdx.x * 4u + q] = base; base += mine[q]; }
+    for (uint32_t q = 0; q < 4u; q++) { offs[threadIdx.x * 4u + q] = (uint16_t)base; base += mine[q]; }
     __syncthreads();
     // ---- values of complete labels into their runs, the rest into the list ----
     uint32_t lidx[SPP_PPT], rpos[SPP_PPT];
@@ -360,8 +375,8 @@ __global__ __launch_bounds__(256) void k_stats_patch(const uint32_t *__restrict_
         if (ps[k] == 0u || !pvalid[k]) continue;           // (nodata pixels count for completeness only)
         const uint32_t sl = pslot[k];
         if (sl < SPP_SLOTS && (cnt[sl] & 0x80000000u)) {
-            rpos[k] = atomicAdd(&fill[sl], 1u);
-            runs[offs[sl] + rpos[k]] = pv[k];
+            rpos[k] = atomicAdd(&cnt[sl], 1u) & 0xFFFFu;
+            runs[offs[sl] + rpos[k]] = narrow ? (pv[k] << 6) | rpos[k] : pv[k];
         } else lidx[k] = atomicAdd(&s_left, 1u);
     }
     if (crowded) {                                          // pixels without a slot: their labels are flagged here
@@ -387,9 +402,24 @@ __global__ __launch_bounds__(256) void k_stats_patch(const uint32_t *__restrict_
         const uint32_t n = (cnt[sl] >> 16) & 0x7FFFu, o = offs[sl];
         const uint32_t v = pv[k];
         uint32_t r = 0;
-        for (uint32_t j = 0; j < n; j++) {
-            const uint32_t w = runs[o + j];
-            r += (w < v || (w == v && j < rpos[k])) ? 1u : 0u;
+        const uint32_t *q = &runs[o];
+        if (narrow) {
+            // 8/16-bit bands: the run holds value << 6 | position (positions < SPP_MAXRUN = 64), and "smaller, or equal
+            // and stored earlier" is ONE unsigned compare -- this loop is n iterations for each of the n values, a third
+            // of the kernel's instructions: plain offsets from one base, so that a value costs a compare and an add
+            const uint32_t me = (v << 6) | rpos[k];
+            uint32_t j = 0;
+            for (; j + 8u <= n; j += 8u) {
+#pragma unroll
+                for (uint32_t u = 0; u < 8u; u++) r += q[j + u] < me ? 1u : 0u;
+            }
+            for (; j < n; j++) r += q[j] < me ? 1u : 0u;
+        } else {
+            const uint32_t rp = rpos[k];
+            for (uint32_t j = 0; j < n; j++) {
+                const uint32_t w = q[j];
+                r += (w < v || (w == v && j < rp)) ? 1u : 0u;
+            }
         }
         rank[k] = r;
     }
