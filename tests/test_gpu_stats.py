@@ -261,3 +261,40 @@ def test_stats_patch_path_equals_sort_path(mode, oracle, monkeypatch):
             assert np.array_equal(r.columns[name], ic[i]), (mode, name)
         assert np.array_equal(r.columns['mean'].view(np.uint32), fc[0].view(np.uint32)), mode
         assert np.array_equal(r.columns['sd'].view(np.uint32), fc[1].view(np.uint32)), mode
+
+
+@pytest.mark.parametrize('dtype', ['uint8', 'int16', 'int32', 'uint32'])
+@pytest.mark.parametrize('mode', ['blocks', 'ragged'])
+def test_stats_patch_path_dtypes(mode, dtype, oracle, monkeypatch):
+    """the patch path's two rank forms -- value << 6 | position in one compare for 8/16-bit bands, (value, position)
+    for 32-bit ones -- on bands with many equal values (uint8), negative values (int16) and values that need all
+    32 bits, against the sort path and the oracle (segstats.h k_stats_patch)"""
+    from pyshepseg_amd import tilingstats
+    (nr, nc) = (161, 273)
+    if mode == 'blocks':
+        seg = ((np.arange(nr)[:, None] // 4) * ((nc + 7) // 8) + np.arange(nc)[None, :] // 8 + 1).astype(np.uint32)
+    else:
+        seg = ((np.arange(nr)[:, None] // 6) * 100 + np.arange(nc)[None, :] // 9 + 1).astype(np.uint32)
+        seg[-2:] = 0
+    base = oracle.synthimg(23, 1, nr, nc)[0].astype(np.int64)
+    if dtype == 'uint8':
+        band = (base >> 5).astype(np.uint8)                      # ~50 levels: ties everywhere, the mode matters
+    elif dtype == 'int16':
+        band = (base - 32768).astype(np.int16)
+    elif dtype == 'int32':
+        band = ((base - 2720) * 2500000).astype(np.int32)        # both signs, up to +-2.08e9
+        band[::3, ::2] = band[0, 0]                              # ties among wide values
+    else:
+        band = (base * 1200000).astype(np.uint32)                # up to 4.26e9
+        band[1::3, ::2] = np.uint32(0xFFFFFFFF)
+    null = int(band[3, 5])
+    sel = [('mn', 'min'), ('mx', 'max'), ('mean', 'mean'), ('sd', 'stddev'), ('med', 'median'),
+           ('mode', 'mode'), ('p80', 'percentile', 80), ('n', 'pixcount')]
+    ic, fc = oracle.segstats(seg, band, sel, null_val=null)
+    for flag in ('1', '0'):
+        monkeypatch.setenv('SHEPSEG_STATS_PATCH', flag)
+        r = tilingstats.calcPerSegmentStatsTiled(band, 1, seg, sel, imgNullVal=null)
+        for i, name in enumerate(['mn', 'mx', 'med', 'mode', 'p80', 'n']):
+            assert np.array_equal(r.columns[name], ic[i]), (mode, dtype, flag, name)
+        assert np.array_equal(r.columns['mean'].view(np.uint32), fc[0].view(np.uint32)), (mode, dtype, flag)
+        assert np.array_equal(r.columns['sd'].view(np.uint32), fc[1].view(np.uint32)), (mode, dtype, flag)
