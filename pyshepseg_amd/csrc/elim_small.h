@@ -50,7 +50,9 @@ __device__ __forceinline__ float f32_acc(float acc, long long v)
 #define SPECTRA_BG 8        // bands per pass
 #define SPECTRA_VAL 4       // ordered phase: image values are loaded this many 64-pixel steps ahead of their chain,
 #define SPECTRA_PIX 3       // their pixel indices this many steps ahead of the values (SPECTRA_PIX + 1 == SPECTRA_VAL)
+#ifndef SPECTRA_GRID
 #define SPECTRA_GRID 4096   // workgroups of the persistent k_spectra_big (latency-bound: fill the wave slots)
+#endif
 template <typename T> __device__ __forceinline__ T wave_sum_t(T v)
 {
 #pragma unroll
