@@ -959,6 +959,7 @@ def startSegmentationWorkers(src, jobs, d_tiles, centres, msd, imgNullVal, fourC
             with _lib.pooled_ctx() as c:
                 worker_loop(c)
         except Exception as e:          # no GPU, library missing ...
+            startLine.abort()
             forceExit.set()
             for jj in jobs:
                 if jj.error is None and not jj.done.is_set():
@@ -975,6 +976,10 @@ def startSegmentationWorkers(src, jobs, d_tiles, centres, msd, imgNullVal, fourC
             # size the pooled context for the job's largest tile now: a grow-only workspace that
             # regrows when it first meets that tile stalls the device in the middle of the run
             c.check(L.shp_ctx_reserve(c.handle, dtcode, nBandsAll, maxTilePx))
+        try:
+            startLine.wait(timeout=300.0)
+        except threading.BrokenBarrierError:
+            pass                            # (a worker failed to start: forceExit is set, or the wait timed out)
         while not forceExit.is_set():
             try:
                 j = inQue.get_nowait()
@@ -1045,6 +1050,9 @@ def startSegmentationWorkers(src, jobs, d_tiles, centres, msd, imgNullVal, fourC
         nThreads = _workersThatFit(nThreads, dtcode, nBandsAll, maxTilePx, verbose)
         if clusMap is not None:
             clusMap.workersLeft = nThreads
+    # every worker sizes its workspace BEFORE any of them launches a kernel: device allocations and frees
+    # (a pooled context regrowing for a larger tile) then never run beside the tiles' kernels
+    startLine = threading.Barrier(nThreads)
     with timings.interval('startworkers'):
         threads = [threading.Thread(target=worker, daemon=True) for _ in range(nThreads)]
         for t in threads:

@@ -113,8 +113,8 @@ class _ThreadDevComm(object):
     def __init__(self, rank, world, shared):
         import threading
         (self.rank, self.world, self.sh) = (rank, world, shared)
-        if rank == 0:
-            shared['bar'] = threading.Barrier(world)
+        if 'bar' not in shared:                # (made once, before the rank threads start: a second barrier
+            shared['bar'] = threading.Barrier(world)        # would strand whoever waits at the first)
             shared['slots'] = [None] * world
         self.c = None
 
