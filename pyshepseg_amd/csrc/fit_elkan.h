@@ -875,7 +875,9 @@ __global__ __launch_bounds__(1024) void k_elk_update(double *__restrict__ S, con
     elk_update_body(ep.scratch ? (double *)nullptr : sh_upd, 1024u, ep, S, cnt, k, nb);
 }
 
+#ifndef ELK_BATCH
 #define ELK_BATCH 8                 // iterations enqueued between two host synchronisations
+#endif
 
 // The E-step sharded by sample rows over the ranks of a communicator (the one part of the fit that
 // shards; sklearn's fit itself is one process, shepseg.py:305-312).  Rank r runs init / filter / visit on rows
