@@ -30,8 +30,10 @@ What shards and what does not
     with K_t != R_t (the reference then reuses ids: tests/golden/stitch_quirk_empties) or with
     more local segments than the stride sends every rank back to the sequential form.
   A final all-reduce sums the per-rank histograms.
-* The k-means fit runs on rank 0 from the sub-sample gathered from every rank's slice; the
-  centres (k x nBands float64) are broadcast.
+* The k-means fit: every rank gets the whole sub-sample (all-gathered from the ranks' slices).  On device
+  transports (RCCL) the fit's E-step is sharded by sample rows over the ranks, its labels all-gathered on the
+  device every iteration, and every rank runs the same M-step: the same model everywhere, no broadcast
+  (shp_kmeans_fit_planar_dist).  Other transports fit on rank 0 and broadcast the centres.
 
 The driver below is engine-agnostic: ``HipEngine`` drives libshepseg_hip.so on this rank's GPU;
 the CPU tests plug in an engine built on the oracle to exercise the sharding / exchange logic
@@ -996,6 +998,8 @@ def bench_main(args, rank, world, local_rank):
     dt = comm.max_f64((time.time() - t0) / max(args.steps, 1))
     tilesPerRank = [int(x) for x in comm.allgather_obj(int(r.tileRange[1] - r.tileRange[0]))]
     rcclRanks = comm.count() if hasattr(comm, 'count') else None      # what RCCL itself says (ncclCommCount)
+    fitShardedHere = (world > 1 and getattr(comm, 'onDevice', False) and hasattr(comm, 'h') and
+                      hasattr(engine, 'fitSharded') and os.environ.get('SHEPSEG_FIT_SHARDED', '1') != '0')
     if rank == 0:
         npix = args.size * args.size
         value = npix / dt / 1e6
@@ -1015,8 +1019,10 @@ def bench_main(args, rank, world, local_rank):
                        "tiles_per_rank": tilesPerRank,
                        "transport": getattr(comm, 'transport', type(comm).__name__),
                        "rccl_nranks": rcclRanks,
-                       "parallelism": "tiles sharded by area over %d ranks, one process per GPU; the k-means fit "
-                                      "on rank 0; overlap strips point to point, histogram all-reduced" % world},
+                       "parallelism": "tiles sharded by area over %d ranks, one process per GPU; the k-means fit %s; "
+                                      "overlap strips point to point, histogram all-reduced" % (
+                                          world, "with its E-step sharded by sample rows (labels all-gathered per iteration)"
+                                          if fitShardedHere else "on rank 0")},
             # (cpu_baseline is a one-GPU figure: `python bench.py` prints it; BASELINE.md: the reference's numba
             #  path does ~1.3 Mpixels/s per core)
             "reference_numba_mpx_per_core": 1.3,
