@@ -252,6 +252,53 @@ __global__ __launch_bounds__(256) void k_label_hist(const uint32_t *__restrict__
     }
 }
 
+// The same over a raster of known shape, a workgroup per 32 x 64-pixel patch (the patches of k_stats_patch): the runs'
+// counts are first combined in an LDS hash table, and a label costs ONE global atomic per patch it touches instead of
+// one per row run (C5: 4 x 8-pixel blocks, 200 M run heads -> 50 M atomics).  A label that finds no slot (a patch
+// with more than 1024 labels) is added directly.
+__global__ __launch_bounds__(256) void k_label_hist_patch(const uint32_t *__restrict__ seg, uint32_t nrows, uint32_t ncols,
+                                                          uint32_t S, uint32_t *tot)
+{
+    __shared__ uint32_t key[SPP_SLOTS], cnt[SPP_SLOTS];
+    for (uint32_t i = threadIdx.x; i < SPP_SLOTS; i += 256u) { key[i] = SPP_EMPTY; cnt[i] = 0u; }
+    __syncthreads();
+    const uint32_t x0 = blockIdx.x * SPP_W, y0 = blockIdx.y * SPP_H;
+    const unsigned lane = lane_id();
+    uint32_t sv[SPP_PPT];
+#pragma unroll
+    for (uint32_t k = 0; k < SPP_PPT; k++) {          // (a wavefront = one row of the patch)
+        const uint32_t pl = k * 256u + threadIdx.x;
+        const uint32_t y = y0 + pl / SPP_W, x = x0 + (pl % SPP_W);
+        sv[k] = (y < nrows && x < ncols) ? seg[(size_t)y * ncols + x] : 0u;
+    }
+#pragma unroll
+    for (uint32_t k = 0; k < SPP_PPT; k++) {
+        const uint32_t v = sv[k];
+        const uint32_t pv = __shfl_up(v, 1, 64);
+        const bool head = lane == 0 || pv != v;
+        const unsigned long long heads = __ballot(head);
+        if (!head || v == 0u || v > S) continue;
+        const unsigned long long nxt = (lane == 63) ? 0ull : (heads & ~((2ull << lane) - 1ull));
+        const uint32_t nl = (nxt ? (unsigned)__builtin_ctzll(nxt) : 64u) - lane;
+        uint32_t h = (v * 2654435761u) >> 22;
+        bool placed = false;
+        for (uint32_t probe = 0; probe < SPP_SLOTS && !placed; probe++) {
+            const uint32_t kk = key[h];
+            if (kk == v) placed = true;
+            else if (kk == SPP_EMPTY) {
+                const uint32_t old = atomicCAS(&key[h], SPP_EMPTY, v);
+                placed = old == SPP_EMPTY || old == v;
+            }
+            if (!placed) h = (h + 1u) & (SPP_SLOTS - 1u);
+        }
+        if (placed) atomicAdd(&cnt[h], nl);
+        else atomicAdd(&tot[v], nl);
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < SPP_SLOTS; i += 256u)
+        if (key[i] != SPP_EMPTY) atomicAdd(&tot[key[i]], cnt[i]);
+}
+
 // every row as for a segment without valid pixels; the paths below overwrite what they compute
 __global__ __launch_bounds__(256) void k_stats_prefill(uint32_t S, long long bias, const uint32_t *__restrict__ sel,
                                                        int nstats, long long missing, long long *__restrict__ intcols,
@@ -524,7 +571,8 @@ static int run_segstats(shp_ctx *ctx, const uint32_t *d_seg, const void *d_band,
         HIPCHK(ctx, hipMemsetAsync(tot, 0, ns * 4, st));
         HIPCHK(ctx, hipMemsetAsync(flagged, 0, ns, st));
         HIPCHK(ctx, hipMemsetAsync(d_left, 0, 4, st));
-        hipLaunchKernelGGL(k_label_hist, dim3(grid_for(n, 256)), dim3(256), 0, st, d_seg, n, S, tot); KCHK(ctx);
+        hipLaunchKernelGGL(k_label_hist_patch, dim3(grid_for(ncols, SPP_W), grid_for(nrows, SPP_H)), dim3(256), 0, st, d_seg,
+                           (uint32_t)nrows, (uint32_t)ncols, S, tot); KCHK(ctx);
         hipLaunchKernelGGL(k_stats_prefill, dim3(grid_for(ns, 256)), dim3(256), 0, st, S, bias, d_sel, nstats,
                            (long long)missing, d_int, d_flt); KCHK(ctx);
         hipLaunchKernelGGL(k_stats_patch, dim3(grid_for(ncols, SPP_W), grid_for(nrows, SPP_H)), dim3(256), 0, st,
