@@ -319,8 +319,11 @@ __global__ __launch_bounds__(256) void k_stats_prefill(uint32_t S, long long bia
 
 // (eight workgroups per CU -- 64 VGPRs, 20 KiB of LDS -- is worth more here than any unrolling: 23.4 ms at five,
 //  21.5 at eight on C5 with the same instructions)
-__global__ __launch_bounds__(256, 8) void k_stats_patch(const uint32_t *__restrict__ seg, const void *__restrict__ band,
-                                                     int dtype, uint32_t nrows, uint32_t ncols, uint32_t S,
+// (DT: the band's pixel type at compile time -- eight loads issued together instead of eight trips through a
+//  run-time switch, each with its own wait)
+template <int DT>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(7, 8))) void k_stats_patch(const uint32_t *__restrict__ seg, const void *__restrict__ band,
+                                                     uint32_t nrows, uint32_t ncols, uint32_t S,
                                                      int has_null, long long null_val, long long bias,
                                                      const uint32_t *__restrict__ tot, const uint32_t *__restrict__ sel,
                                                      int nstats, long long missing, long long *__restrict__ intcols,
@@ -343,7 +346,7 @@ __global__ __launch_bounds__(256, 8) void k_stats_patch(const uint32_t *__restri
     if (threadIdx.x == 0) { s_ndist = 0u; s_left = 0u; s_nc = 0u; }
     __syncthreads();
     const uint32_t x0 = blockIdx.x * SPP_W, y0 = blockIdx.y * SPP_H;
-    const bool narrow = dtype != SHP_I32 && dtype != SHP_U32;       // biased values below 2^16
+    constexpr bool narrow = DT != SHP_I32 && DT != SHP_U32;         // biased values below 2^16
     // this thread's pixels: (segment, biased value, slot); the same thread keeps them through every phase
     uint32_t ps[SPP_PPT], pv[SPP_PPT], pslot[SPP_PPT];
     bool pvalid[SPP_PPT];
@@ -355,7 +358,7 @@ __global__ __launch_bounds__(256, 8) void k_stats_patch(const uint32_t *__restri
         if (y < nrows && x < ncols) {
             const size_t p = (size_t)y * ncols + x;
             const uint32_t sg = seg[p];
-            const long long v = ld_px(band, dtype, p);
+            const long long v = ld_t<DT>(band, p);
             if (sg != 0u && sg <= S) {
                 ps[k] = sg;
                 pv[k] = (uint32_t)(v - bias);
@@ -415,16 +418,20 @@ __global__ __launch_bounds__(256, 8) void k_stats_patch(const uint32_t *__restri
     for (uint32_t q = 0; q < 4u; q++) { offs[threadIdx.x * 4u + q] = (uint16_t)base; base += mine[q]; }
     __syncthreads();
     // ---- values of complete labels into their runs, the rest into the list ----
-    uint32_t lidx[SPP_PPT], rpos[SPP_PPT];
+    // (a run's first lane probing and adding for the run -- one atomic per run instead of one per pixel -- was built
+    //  twice, rounds 3 and 4: 27.1 -> 30.7 ms and 15.9 -> 17.9 ms; the masks and shuffles cost more than the
+    //  eight-way same-address atomics they save)
+    // rpos[k]: the place in the label's run; 0x80000000 | place in the left-over list; 0xFFFFFFFF: neither
+    uint32_t rpos[SPP_PPT];
 #pragma unroll
     for (uint32_t k = 0; k < SPP_PPT; k++) {
-        lidx[k] = 0xFFFFFFFFu; rpos[k] = 0xFFFFFFFFu;
+        rpos[k] = 0xFFFFFFFFu;
         if (ps[k] == 0u || !pvalid[k]) continue;           // (nodata pixels count for completeness only)
         const uint32_t sl = pslot[k];
         if (sl < SPP_SLOTS && (cnt[sl] & 0x80000000u)) {
             rpos[k] = atomicAdd(&cnt[sl], 1u) & 0xFFFFu;
             runs[offs[sl] + rpos[k]] = narrow ? (pv[k] << 6) | rpos[k] : pv[k];
-        } else lidx[k] = atomicAdd(&s_left, 1u);
+        } else rpos[k] = 0x80000000u | atomicAdd(&s_left, 1u);
     }
     if (crowded) {                                          // pixels without a slot: their labels are flagged here
 #pragma unroll
@@ -436,14 +443,17 @@ __global__ __launch_bounds__(256, 8) void k_stats_patch(const uint32_t *__restri
     __syncthreads();
 #pragma unroll
     for (uint32_t k = 0; k < SPP_PPT; k++)
-        if (lidx[k] != 0xFFFFFFFFu) { left_seg[s_leftbase + lidx[k]] = ps[k]; left_val[s_leftbase + lidx[k]] = pv[k]; }
+        if (rpos[k] != 0xFFFFFFFFu && (rpos[k] & 0x80000000u)) {
+            const uint32_t li = s_leftbase + (rpos[k] & 0x7FFFFFFFu);
+            left_seg[li] = ps[k]; left_val[li] = pv[k];
+            rpos[k] = 0xFFFFFFFFu;                           // (not a member of a run)
+        }
     // ---- the runs sorted by RANK: every pixel counts the values of its run that come before it (smaller, or equal
     //      and stored earlier) -- all threads busy on independent LDS reads, where a thread per run doing an
     //      insertion sort was a chain of dependent LDS round trips on a quarter of the lanes ----
-    uint32_t rank[SPP_PPT];
+    // (the rank takes the place of rpos[k] once it is known, and the final place offs + rank the place of that)
 #pragma unroll
     for (uint32_t k = 0; k < SPP_PPT; k++) {
-        rank[k] = 0u;
         if (rpos[k] == 0xFFFFFFFFu) continue;
         const uint32_t sl = pslot[k];
         const uint32_t n = (cnt[sl] >> 16) & 0x7FFFu, o = offs[sl];
@@ -468,12 +478,12 @@ __global__ __launch_bounds__(256, 8) void k_stats_patch(const uint32_t *__restri
                 r += (w < v || (w == v && j < rp)) ? 1u : 0u;
             }
         }
-        rank[k] = r;
+        rpos[k] = o + r;
     }
     __syncthreads();
 #pragma unroll
     for (uint32_t k = 0; k < SPP_PPT; k++)
-        if (rpos[k] != 0xFFFFFFFFu) runs[offs[pslot[k]] + rank[k]] = pv[k];
+        if (rpos[k] != 0xFFFFFFFFu) runs[rpos[k]] = pv[k];
     __syncthreads();
     // ---- a thread per complete label -- consecutive threads take consecutive entries of the compacted list, so
     //      that a wavefront's lanes all work (a thread per SLOT left 4 lanes in 64 busy, four times over) ----
@@ -575,9 +585,11 @@ static int run_segstats(shp_ctx *ctx, const uint32_t *d_seg, const void *d_band,
                            (uint32_t)nrows, (uint32_t)ncols, S, tot); KCHK(ctx);
         hipLaunchKernelGGL(k_stats_prefill, dim3(grid_for(ns, 256)), dim3(256), 0, st, S, bias, d_sel, nstats,
                            (long long)missing, d_int, d_flt); KCHK(ctx);
-        hipLaunchKernelGGL(k_stats_patch, dim3(grid_for(ncols, SPP_W), grid_for(nrows, SPP_H)), dim3(256), 0, st,
-                           d_seg, d_band, dtype, nrows, ncols, S, has_null, (long long)null_val, bias, tot, d_sel,
-                           nstats, (long long)missing, d_int, d_flt, flagged, kseg, kval, d_left); KCHK(ctx);
+        DISPATCH_DTYPE(dtype, hipLaunchKernelGGL(k_stats_patch<DT>, dim3(grid_for(ncols, SPP_W), grid_for(nrows, SPP_H)),
+                                                 dim3(256), 0, st, d_seg, d_band, (uint32_t)nrows, (uint32_t)ncols, S, has_null,
+                                                 (long long)null_val, bias, tot, d_sel, nstats, (long long)missing, d_int,
+                                                 d_flt, flagged, kseg, kval, d_left));
+        KCHK(ctx);
         CHK(read_u32(ctx, d_left, &nsort));
         only = flagged;
     } else if (n) {
