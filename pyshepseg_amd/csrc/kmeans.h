@@ -18,7 +18,9 @@
 #include <chrono>
 #include <thread>
 
+#ifndef ASSIGN_PPT
 #define ASSIGN_PPT 4   // pixels per thread (amortises the scalar centroid loads)
+#endif
 
 // |c|^2 as numpy 1.26 evaluates row_norms(C, squared=True) = einsum('ij,ij->i') on x86-64 (baseline
 // SSE2, no fma): two lanes over the even / odd elements, products and sums rounded separately,
