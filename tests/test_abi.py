@@ -43,3 +43,17 @@ def test_product_never_imports_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert 'import oracle' not in src and 'from oracle' not in src, f
                 assert 'liboracle' not in src, f
+
+
+def test_walker_assembly_header_is_the_generators_output(tmp_path):
+    """pyshepseg_amd/csrc/dfs_walk4_asm.h is generated: the committed file must be what tools/gen_dfs_walk4.py writes
+    today (a hand edit of either would otherwise go unnoticed until the next regeneration)."""
+    import subprocess
+    import sys
+    out = tmp_path / 'dfs_walk4_asm.h'
+    env = dict(os.environ, DFS_WALK_OUT=str(out))
+    env.pop('DFS_WALK_RUNS', None)
+    subprocess.check_call([sys.executable, os.path.join(ROOT, 'tools', 'gen_dfs_walk4.py')], env=env,
+                          stdout=subprocess.DEVNULL)
+    committed = open(os.path.join(ROOT, 'pyshepseg_amd', 'csrc', 'dfs_walk4_asm.h')).read()
+    assert out.read_text() == committed

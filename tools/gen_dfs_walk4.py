@@ -429,6 +429,7 @@ def main():
         out.append('    "%s\\n" \\' % ln)
     out.append('    ""')
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), 'pyshepseg_amd', 'csrc', 'dfs_walk4_asm.h')
+    path = os.environ.get('DFS_WALK_OUT', path)             # (tests/test_abi.py: the committed header is this script's output)
     with open(path, 'w') as f:
         f.write('\n'.join(out) + '\n')
     print('wrote', path, len(lines), 'lines')
