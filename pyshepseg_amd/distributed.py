@@ -40,6 +40,7 @@ the CPU tests plug in an engine built on the oracle to exercise the sharding / e
 with world_size 2 over gloo.
 """
 import ctypes
+import sys
 import json
 import os
 import time
@@ -182,6 +183,14 @@ def runDistributed(engine, comm, nRows, nCols, tileSize, overlapSize, minSegment
     had to be redone -- chainStepsRedone says how many tiles, from the first one whose ids the
     provisional numbering cannot express; argument / SHEPSEG_STITCH: None = parallel when
     comm.world > 1)."""
+    import time as _time
+    _t = [_time.time()]
+    _marks = []
+
+    def _mark(what):                       # SHEPSEG_IO_TIMING: this rank's milestones of the step, to stderr at its end
+        now = _time.time()
+        _marks.append('%s %.3f' % (what, now - _t[0]))
+        _t[0] = now
     if stitchMode is None:
         stitchMode = os.environ.get('SHEPSEG_STITCH') or ('parallel' if comm.world > 1 else 'sequential')
     if stitchMode not in ('sequential', 'parallel'):
@@ -225,6 +234,7 @@ def runDistributed(engine, comm, nRows, nCols, tileSize, overlapSize, minSegment
     else:
         sLo = sHi = 0
     engine.setup(tileInfo, jobs, total, yLo, yHi, outLo, outHi, nCols, overlapSize)
+    _mark('setup')
 
     # ---- one global k-means model (reference tiling.py:154-226) ----
     if kmeansObj is None:
@@ -259,7 +269,9 @@ def runDistributed(engine, comm, nRows, nCols, tileSize, overlapSize, minSegment
     msd = shepseg.autoMaxSpectralDiff(kmeansObj, maxSpectralDiff, spectDistPcntile)
 
     # ---- segment this rank's tiles (asynchronously) ----
+    _mark('model')
     engine.startSegmentation(centres, msd, imgNullVal, fourConnected, minSegmentSize)
+    _mark('workers started')
 
     # ---- the stitch ----
     jobmap = {(j.col, j.row): j for j in jobs}
@@ -290,7 +302,9 @@ def runDistributed(engine, comm, nRows, nCols, tileSize, overlapSize, minSegment
                 engine.waitTile(j)
                 (top, left) = _neighbours(j, fromPrev)
                 engine.stitchTile(j, top, left, _winOf(j.col, j.row), simpleTileRecode)
+            _mark('chain issued')
             maxSegId = engine.getMaxSegId()
+            _mark('chain done')
             if nextRank is not None:
                 plan = boundaryPlan(tileInfo, shards, comm.rank, overlapSize)
                 engine.sendBoundary(comm, nextRank, maxSegId,
@@ -418,10 +432,17 @@ def runDistributed(engine, comm, nRows, nCols, tileSize, overlapSize, minSegment
             maxSegId = _resume(bad, base, mAfter, stride, fromPrevProv)
     else:
         maxSegId = _sequential()
+    _mark('tiles + stitch')
     hist = engine.histogram(maxSegId) if haveTiles else numpy.zeros(maxSegId + 1, numpy.int64)
     hist = comm.allreduce_sum_i64(numpy.asarray(hist, dtype=numpy.int64)).astype(numpy.uint32)
     hist[0] = 0
+    _mark('histogram')
     engine.finish()
+    _mark('finish')
+    if os.environ.get('SHEPSEG_IO_TIMING'):
+        tm = getattr(engine, 'timings', None)
+        sys.stderr.write('  [dist rank %d] %s%s\n' % (comm.rank, ', '.join(_marks),
+                                                      ' | worker timers %s' % tm.makeSummaryDict() if tm is not None else ''))
 
     res = DistResult()
     res.maxSegId = int(maxSegId)
