@@ -462,6 +462,10 @@ def main():
     os.environ.setdefault('SHEPSEG_DEVICE', str(local_rank))
     force_dist = os.environ.get('SHEPSEG_FORCE_DIST', '0') == '1' and 'RANK' in os.environ
     if world > 1 or force_dist:
+        # RCCL brings streams of its own: two walker streams fewer keep the process inside its hardware queues
+        # (LABNOTES, round 4: 522 -> 477 ms per step at world 1; must be set before the library loads)
+        if os.environ.get('SHEPSEG_COMM', 'rccl') == 'rccl':
+            os.environ.setdefault('SHEPSEG_WALK_STREAMS', '8')
         from pyshepseg_amd import distributed
         if args.workload == 'c5':
             return distributed.bench_stats_main(args, rank, world, local_rank)

@@ -355,7 +355,7 @@ class SocketComm(_ObjCollectives):
 
 
 class RcclComm(_ObjCollectives):
-    """RCCL communicator of this rank's GPU (device = LOCAL_RANK), bound to a context of its own.
+    """RCCL communicator of this rank's GPU (device = LOCAL_RANK), bound to a context of its own (on pooled streams).
     Device buffers go straight through ncclSend / ncclRecv; Python objects are pickled into a device
     staging buffer and travel by the same calls."""
     onDevice = True
@@ -365,7 +365,9 @@ class RcclComm(_ObjCollectives):
         self.world = int(os.environ.get('WORLD_SIZE', '1')) if world is None else world
         if device is None:
             device = int(os.environ.get('LOCAL_RANK', os.environ.get('SHEPSEG_DEVICE', '0')))
-        self.c = _lib.Context(device=device)
+        # (its stream comes from the library's pool: a process that is over its ~24 hardware queues pays for it on every
+        #  launch -- RCCL's own streams plus a context's two took the tiled driver from 462 to 522 ms per step)
+        self.c = _lib.Context(device=device, sharedStreams=True)
         self.L = self.c._L
         self.dir = rendezvousDir()
         idpath = os.path.join(self.dir, 'rccl_unique_id' + launchTag())
