@@ -196,17 +196,38 @@ __global__ __launch_bounds__(256) void k_ccl_border(const uint16_t *__restrict__
 
 // lab[p] = global root; a patch-local component that is not its own global root hands its size
 // (csize at its local root, 0 at every other pixel) to that root
+// (four pixels per thread, their chains of parent links followed side by side: one pixel per thread had one
+//  dependent load in flight per lane)
+#define FLAT_PPT 4u
 __global__ __launch_bounds__(256) void k_ccl_flatten(uint32_t *lab, uint32_t n, uint32_t *csize,
                                                      uint32_t *__restrict__ bigbits)
 {
-    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
-    if (p < n && (p & 31u) == 0u) bigbits[p >> 5] = 0u;      // the cut-able-root bitmap starts empty
-    if (p >= n || lab[p] == NULL_LAB) return;
-    const uint32_t r = uf_find(lab, p);
-    lab[p] = r;
-    if (r != p) {
-        const uint32_t s = csize[p];
-        if (s) atomicAdd(&csize[r], s);
+    uint32_t x[FLAT_PPT], px[FLAT_PPT], sz[FLAT_PPT];
+    bool on[FLAT_PPT];
+#pragma unroll
+    for (uint32_t q = 0; q < FLAT_PPT; q++) {
+        const uint32_t p = blockIdx.x * (256u * FLAT_PPT) + q * 256u + threadIdx.x;
+        x[q] = p;
+        px[q] = p < n ? lab[p] : NULL_LAB;
+        sz[q] = p < n ? csize[p] : 0u;
+        if (p < n && (p & 31u) == 0u) bigbits[p >> 5] = 0u;      // the cut-able-root bitmap starts empty
+    }
+#pragma unroll
+    for (uint32_t q = 0; q < FLAT_PPT; q++) on[q] = px[q] != NULL_LAB;
+    for (;;) {
+        bool any = false;
+#pragma unroll
+        for (uint32_t q = 0; q < FLAT_PPT; q++) {
+            if (on[q] && px[q] != x[q]) { x[q] = px[q]; px[q] = lab[x[q]]; any = true; }
+        }
+        if (!any) break;
+    }
+#pragma unroll
+    for (uint32_t q = 0; q < FLAT_PPT; q++) {
+        if (!on[q]) continue;
+        const uint32_t p = blockIdx.x * (256u * FLAT_PPT) + q * 256u + threadIdx.x, r = x[q];
+        lab[p] = r;
+        if (r != p && sz[q]) atomicAdd(&csize[r], sz[q]);
     }
 }
 
@@ -1379,7 +1400,7 @@ static int run_clump(shp_ctx *ctx, const uint16_t *d_clus, uint32_t nrows, uint3
                            four, ntop, npc, cpitch); KCHK(ctx);
     }
     uint32_t *bigbits = bp<uint32_t>(ctx->bigbits), *rank = bp<uint32_t>(ctx->aux2);
-    hipLaunchKernelGGL(k_ccl_flatten, dim3(g), dim3(256), 0, st, lab, n, csize, bigbits); KCHK(ctx);
+    hipLaunchKernelGGL(k_ccl_flatten, dim3(grid_for(n, 256u * FLAT_PPT)), dim3(256), 0, st, lab, n, csize, bigbits); KCHK(ctx);
     prof_end(ctx, ps);
     // (SHEPSEG_DBG_SKIP_DFS: diagnostic only -- no component is cut, wrong labels, times the rest)
     static const uint32_t bigmin = getenv("SHEPSEG_DBG_SKIP_DFS") ? 0x7fffffffu : MAX_CLUMP_SIZE + 2u;
