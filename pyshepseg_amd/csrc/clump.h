@@ -1294,6 +1294,13 @@ struct SeedFn {
         const uint32_t l = lab[p];
         return (l != NULL_LAB && (l & ~VIS_FLAG) == p) ? 1u : 0u;
     }
+    __device__ __forceinline__ bool get4(uint32_t base, uint32_t v[4]) const
+    {
+        if (!scan_load4(lab, base, v)) return false;
+#pragma unroll
+        for (uint32_t i = 0; i < 4u; i++) v[i] = (v[i] != NULL_LAB && (v[i] & ~VIS_FLAG) == base + i) ? 1u : 0u;
+        return true;
+    }
 };
 
 // seg[p] = raster rank of the piece's seed + 1, and the segment-size table of the clumps

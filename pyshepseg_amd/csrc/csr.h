@@ -18,6 +18,13 @@
 struct RunLenFn {
     const uint32_t *v;
     __device__ __forceinline__ uint32_t operator()(uint32_t i) const { return (v[i] >> RUN_POS_BITS) + 1u; }
+    __device__ __forceinline__ bool get4(uint32_t base, uint32_t o[4]) const
+    {
+        if (!scan_load4(v, base, o)) return false;
+#pragma unroll
+        for (uint32_t i = 0; i < 4u; i++) o[i] = (o[i] >> RUN_POS_BITS) + 1u;
+        return true;
+    }
 };
 
 __global__ __launch_bounds__(256) void k_run_tile_count(const uint32_t *__restrict__ seg, uint32_t n,

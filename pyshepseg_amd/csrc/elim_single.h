@@ -239,6 +239,13 @@ struct EmptyFn {      // f(i) = 1 if id i (>= 1) is unused; f(0) = 0
     {
         return (i >= 1u && segsz[i] == 0u) ? 1u : 0u;
     }
+    __device__ __forceinline__ bool get4(uint32_t base, uint32_t v[4]) const
+    {
+        if (!scan_load4(segsz, base, v)) return false;
+#pragma unroll
+        for (uint32_t i = 0; i < 4u; i++) v[i] = (base + i >= 1u && v[i] == 0u) ? 1u : 0u;
+        return true;
+    }
 };
 
 // sizes of the surviving ids under their new numbers (the reference recomputes makeSegSize)

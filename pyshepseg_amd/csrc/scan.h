@@ -3,11 +3,24 @@
 // 256-thread workgroup.  HBM-bound: 4 B read (whatever the functor reads) + 4 B written/item.
 #pragma once
 #include "common.h"
+#include <type_traits>
 
 #define SCAN_SUB 1024u                       // items per inner step of a workgroup (4 per thread)
 #define SCAN_STEPS 8u
 #define SCAN_ITEMS (SCAN_SUB * SCAN_STEPS)   // items per workgroup: two levels cover 67 M items, so the
                                              // scans of a tile need 2 + 1 launches instead of 3 + 2
+
+// A functor may offer get4(base, v): its four items base .. base + 3 (base a multiple of 4, all below n) from ONE
+// 16-byte load -- 4-byte accesses per lane stream at ~2.8 TB/s on this chip, 16-byte ones at ~4.5 (k_relabel: 47 -> 31 us)
+template <class F, class = void> struct scan_has_get4 : std::false_type {};
+template <class F> struct scan_has_get4<F, std::void_t<decltype(&F::get4)>> : std::true_type {};
+__device__ __forceinline__ bool scan_load4(const uint32_t *a, uint32_t base, uint32_t v[4])
+{
+    if (((uintptr_t)a & 15u) != 0u) return false;
+    const uint4 x = *(const uint4 *)(a + base);
+    v[0] = x.x; v[1] = x.y; v[2] = x.z; v[3] = x.w;
+    return true;
+}
 
 // block-local exclusive scan of SCAN_ITEMS items (those of block `blk`) in SCAN_STEPS coalesced
 // sub-tiles with a running carry; returns the block's total (in every thread)
@@ -21,8 +34,14 @@ __device__ __forceinline__ uint32_t scan_block(F f, uint32_t n, uint32_t *__rest
         const uint32_t base = blk * SCAN_ITEMS + st * SCAN_SUB + threadIdx.x * 4u;
         if (st * SCAN_SUB + blk * SCAN_ITEMS >= n) break;                 // uniform: nothing left
         uint32_t v[4];
+        bool got = false;
+        if constexpr (scan_has_get4<F>::value) {
+            if (base + 3u < n) got = f.get4(base, v);
+        }
+        if (!got) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) v[i] = (base + i < n) ? f(base + i) : 0u;
+            for (int i = 0; i < 4; i++) v[i] = (base + i < n) ? f(base + i) : 0u;
+        }
         const uint32_t tsum = v[0] + v[1] + v[2] + v[3];
         uint32_t incl = tsum;
 #pragma unroll
@@ -36,10 +55,14 @@ __device__ __forceinline__ uint32_t scan_block(F f, uint32_t n, uint32_t *__rest
         uint32_t woff = carry;
         for (unsigned i = 0; i < w; i++) woff += wsum[i];
         uint32_t run = woff + incl - tsum;
+        if (base + 3u < n && ((uintptr_t)out & 15u) == 0u) {
+            *(uint4 *)(out + base) = make_uint4(run, run + v[0], run + v[0] + v[1], run + v[0] + v[1] + v[2]);
+        } else {
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            if (base + i < n) out[base + i] = run;
-            run += v[i];
+            for (int i = 0; i < 4; i++) {
+                if (base + i < n) out[base + i] = run;
+                run += v[i];
+            }
         }
         carry += wsum[0] + wsum[1] + wsum[2] + wsum[3];
     }
@@ -104,6 +127,7 @@ __global__ __launch_bounds__(256) void k_scan_add(uint32_t *__restrict__ out, ui
 struct ArrFn {
     const uint32_t *a;
     __device__ __forceinline__ uint32_t operator()(uint32_t i) const { return a[i]; }
+    __device__ __forceinline__ bool get4(uint32_t base, uint32_t v[4]) const { return scan_load4(a, base, v); }
 };
 
 // bytes of scratch needed for scanning n items
