@@ -196,24 +196,31 @@ __global__ __launch_bounds__(256) void k_ccl_border(const uint16_t *__restrict__
 
 // lab[p] = global root; a patch-local component that is not its own global root hands its size
 // (csize at its local root, 0 at every other pixel) to that root
-// (four pixels per thread, their chains of parent links followed side by side: one pixel per thread had one
-//  dependent load in flight per lane)
+// (four CONSECUTIVE pixels per thread: labels and sizes come and go as 16-byte accesses, and the four chains of
+//  parent links are followed side by side -- one pixel per thread had one dependent 4-byte load in flight per lane)
 #define FLAT_PPT 4u
 __global__ __launch_bounds__(256) void k_ccl_flatten(uint32_t *lab, uint32_t n, uint32_t *csize,
                                                      uint32_t *__restrict__ bigbits)
 {
+    const uint32_t p0 = (blockIdx.x * 256u + threadIdx.x) * FLAT_PPT;
+    if (p0 >= n) return;
+    if ((p0 & 31u) == 0u) bigbits[p0 >> 5] = 0u;              // the cut-able-root bitmap starts empty
     uint32_t x[FLAT_PPT], px[FLAT_PPT], sz[FLAT_PPT];
+    const bool vec = p0 + FLAT_PPT <= n && (((uintptr_t)lab | (uintptr_t)csize) & 15u) == 0u;
+    if (vec) {
+        const uint4 l = *(const uint4 *)(lab + p0), c = *(const uint4 *)(csize + p0);
+        px[0] = l.x; px[1] = l.y; px[2] = l.z; px[3] = l.w;
+        sz[0] = c.x; sz[1] = c.y; sz[2] = c.z; sz[3] = c.w;
+    } else {
+#pragma unroll
+        for (uint32_t q = 0; q < FLAT_PPT; q++) {
+            px[q] = p0 + q < n ? lab[p0 + q] : NULL_LAB;
+            sz[q] = p0 + q < n ? csize[p0 + q] : 0u;
+        }
+    }
     bool on[FLAT_PPT];
 #pragma unroll
-    for (uint32_t q = 0; q < FLAT_PPT; q++) {
-        const uint32_t p = blockIdx.x * (256u * FLAT_PPT) + q * 256u + threadIdx.x;
-        x[q] = p;
-        px[q] = p < n ? lab[p] : NULL_LAB;
-        sz[q] = p < n ? csize[p] : 0u;
-        if (p < n && (p & 31u) == 0u) bigbits[p >> 5] = 0u;      // the cut-able-root bitmap starts empty
-    }
-#pragma unroll
-    for (uint32_t q = 0; q < FLAT_PPT; q++) on[q] = px[q] != NULL_LAB;
+    for (uint32_t q = 0; q < FLAT_PPT; q++) { x[q] = p0 + q; on[q] = px[q] != NULL_LAB; }
     for (;;) {
         bool any = false;
 #pragma unroll
@@ -222,13 +229,17 @@ __global__ __launch_bounds__(256) void k_ccl_flatten(uint32_t *lab, uint32_t n, 
         }
         if (!any) break;
     }
+    if (vec) {
+        *(uint4 *)(lab + p0) = make_uint4(on[0] ? x[0] : NULL_LAB, on[1] ? x[1] : NULL_LAB, on[2] ? x[2] : NULL_LAB,
+                                          on[3] ? x[3] : NULL_LAB);
+    } else {
 #pragma unroll
-    for (uint32_t q = 0; q < FLAT_PPT; q++) {
-        if (!on[q]) continue;
-        const uint32_t p = blockIdx.x * (256u * FLAT_PPT) + q * 256u + threadIdx.x, r = x[q];
-        lab[p] = r;
-        if (r != p && sz[q]) atomicAdd(&csize[r], sz[q]);
+        for (uint32_t q = 0; q < FLAT_PPT; q++)
+            if (on[q] && p0 + q < n) lab[p0 + q] = x[q];
     }
+#pragma unroll
+    for (uint32_t q = 0; q < FLAT_PPT; q++)
+        if (on[q] && x[q] != p0 + q && sz[q]) atomicAdd(&csize[x[q]], sz[q]);
 }
 
 // cnt[key[p]] += 1 for every pixel, one atomic per run of equal keys per wavefront.
