@@ -266,17 +266,31 @@ __global__ __launch_bounds__(256) void k_big_list(const uint32_t *__restrict__ l
                                                   BigInfo *big, uint32_t *counters, uint32_t *bigbits,
                                                   uint32_t bigmin)
 {
-    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
-    if (p >= n || lab[p] != p) return;
-    const uint32_t s = csize[p];
-    if (s < bigmin) return;
-    const uint32_t bi = atomicAdd(&counters[0], 1u);
-    const uint32_t off = atomicAdd(&counters[1], s);
-    BigInfo b;
-    b.root = p; b.size = s; b.off = off; b.minc = ncols; b.maxc = 0; b.maxr = 0;
-    big[bi] = b;
-    csize[p] = VIS_FLAG | bi;
-    atomicOr(&bigbits[p >> 5], 1u << (p & 31u));      // N-bit map of cut-able roots (L2-resident)
+    // (four consecutive pixels per thread, one 16-byte load: the kernel is a stream over the labels that stops at roots)
+    const uint32_t p0 = (blockIdx.x * 256u + threadIdx.x) * 4u;
+    if (p0 >= n) return;
+    uint32_t l[4];
+    if (p0 + 4u <= n && ((uintptr_t)lab & 15u) == 0u) {
+        const uint4 v = *(const uint4 *)(lab + p0);
+        l[0] = v.x; l[1] = v.y; l[2] = v.z; l[3] = v.w;
+    } else {
+#pragma unroll
+        for (uint32_t q = 0; q < 4u; q++) l[q] = p0 + q < n ? lab[p0 + q] : NULL_LAB;
+    }
+#pragma unroll
+    for (uint32_t q = 0; q < 4u; q++) {
+        const uint32_t p = p0 + q;
+        if (l[q] != p) continue;                      // (NULL_LAB is no pixel index)
+        const uint32_t s = csize[p];
+        if (s < bigmin) continue;
+        const uint32_t bi = atomicAdd(&counters[0], 1u);
+        const uint32_t off = atomicAdd(&counters[1], s);
+        BigInfo b;
+        b.root = p; b.size = s; b.off = off; b.minc = ncols; b.maxc = 0; b.maxr = 0;
+        big[bi] = b;
+        csize[p] = VIS_FLAG | bi;
+        atomicOr(&bigbits[p >> 5], 1u << (p & 31u));      // N-bit map of cut-able roots (L2-resident)
+    }
 }
 
 // Bounding box (min col, max col, max row; the min row is the root's) of every cut-able
@@ -1422,7 +1436,7 @@ static int run_clump(shp_ctx *ctx, const uint16_t *d_clus, uint32_t nrows, uint3
     prof_end(ctx, ps);
     // (SHEPSEG_DBG_SKIP_DFS: diagnostic only -- no component is cut, wrong labels, times the rest)
     static const uint32_t bigmin = getenv("SHEPSEG_DBG_SKIP_DFS") ? 0x7fffffffu : MAX_CLUMP_SIZE + 2u;
-    hipLaunchKernelGGL(k_big_list, dim3(g), dim3(256), 0, st, lab, csize, n, ncols, big, counters, bigbits, bigmin); KCHK(ctx);
+    hipLaunchKernelGGL(k_big_list, dim3(grid_for(n, 1024)), dim3(256), 0, st, lab, csize, n, ncols, big, counters, bigbits, bigmin); KCHK(ctx);
     hipLaunchKernelGGL(k_big_bbox, dim3(grid_for(ncols, 64), grid_for(nrows, AGG_ROWS)), dim3(256), 0, st, lab,
                        csize, nrows, ncols, big, bigbits); KCHK(ctx);
     uint32_t *order = (uint32_t *)((char *)ctx->big.p + (size_t)maxbig * sizeof(BigInfo) + 64);
