@@ -690,7 +690,7 @@ __device__ __forceinline__ void dfs_split_lds(uint32_t *lab, const BigInfo &B, u
 //     by the time they surface (mean run of 6-7 dead pops).
 // Bit-exact replay of shepseg.py:490-539 like the walk above.
 #include "dfs_walk4_asm.h"
-// GLB: the bitmap does not fit the walker pool and lives in global memory (with its snapshot): the same
+// GLB: the bitmap does not fit the walker pool and lives in global memory (column-block-major, no snapshot): the same
 // walk -- a step touches registers only, so the backing store's latency is paid at re-centrings, dead ends,
 // seeds and piece ends -- with the bitmap read past this CU's vector cache (agent scope: lanes read words
 // that other lanes of the wavefront stored).
