@@ -391,10 +391,14 @@ __global__ __launch_bounds__(256) void k_hist_patch(const uint32_t *__restrict__
     const uint32_t c = blockIdx.x * 64u + lane;
     const uint32_t r0 = blockIdx.y * AGG_ROWS + wv * (AGG_ROWS / 4u);
     const bool cin = c < ncols;
+    uint32_t sv[AGG_ROWS / 4u];                 // the wavefront's eight rows, their loads in flight together
+#pragma unroll
+    for (uint32_t i = 0; i < AGG_ROWS / 4u; i++) sv[i] = (cin && r0 + i < nrows) ? ras[(size_t)(r0 + i) * ncols + c] : 0u;
+#pragma unroll
     for (uint32_t i = 0; i < AGG_ROWS / 4u; i++) {
         const uint32_t r = r0 + i;
         if (r >= nrows) break;                               // uniform per wavefront
-        const uint32_t s = cin ? ras[(size_t)r * ncols + c] : 0u;
+        const uint32_t s = sv[i];
         const uint32_t pv = __shfl_up(s, 1, 64);
         const bool head = lane == 0 || pv != s;
         const unsigned long long heads = __ballot(head);
