@@ -436,12 +436,21 @@ __global__ __launch_bounds__(256) void k_meta_pixels(const uint32_t *__restrict_
     const uint32_t r0 = blockIdx.y * AGG_ROWS + wv * (AGG_ROWS / 4u);
     const bool cin = c < xs;
     uint32_t above = (cin && r0 > 0u && r0 <= ys) ? tile[(size_t)(r0 - 1u) * xs + c] : 0u;
+    // the wavefront's eight rows (and, in lane 0, the pixels left of them): all loads in flight together
+    uint32_t sv[AGG_ROWS / 4u], ev[AGG_ROWS / 4u];
+#pragma unroll
+    for (uint32_t i = 0; i < AGG_ROWS / 4u; i++) {
+        const uint32_t r = r0 + i;
+        sv[i] = (cin && r < ys) ? tile[(size_t)r * xs + c] : 0u;
+        ev[i] = (lane == 0 && cin && c > 0u && r < ys) ? tile[(size_t)r * xs + c - 1u] : 0u;
+    }
+#pragma unroll
     for (uint32_t i = 0; i < AGG_ROWS / 4u; i++) {
         const uint32_t r = r0 + i;
         if (r >= ys) break;                                  // uniform per wavefront
-        const uint32_t s = cin ? tile[(size_t)r * xs + c] : 0u;
+        const uint32_t s = sv[i];
         uint32_t lf = __shfl_up(s, 1, 64);
-        if (lane == 0) lf = (cin && c > 0u) ? tile[(size_t)r * xs + c - 1u] : 0u;
+        if (lane == 0) lf = ev[i];
         if (s != 0u) {
             const bool ldiff = c == 0u || lf != s;
             const bool udiff = r == 0u || above != s;
