@@ -40,16 +40,32 @@ __device__ __forceinline__ void strip_minmax_body(const uint32_t *__restrict__ t
     const uint32_t c = bx * 64u + lane;
     const uint32_t r0 = by * AGG_ROWS + wv * (AGG_ROWS / 4u);
     const bool cin = c < scols;
-    uint32_t above = (cin && r0 > 0u && r0 <= srows) ? tile[(size_t)(r0 - 1u) * xs + c] : 0u;
-    uint32_t cur = (cin && r0 < srows) ? tile[(size_t)r0 * xs + c] : 0u;
-    for (uint32_t i = 0; i < AGG_ROWS / 4u; i++) {
+    // the wavefront's rows r0 - 1 .. r0 + 8 and, in lanes 0 / 63, the pixels beside them: all loads in flight together
+    constexpr uint32_t NR = AGG_ROWS / 4u;
+    uint32_t rv[NR + 2u], ev[NR];
+#pragma unroll
+    for (uint32_t i = 0; i < NR + 2u; i++) {
+        const uint32_t r = r0 + i - 1u;                      // (r0 == 0: wraps, and the test fails)
+        rv[i] = (cin && r < srows) ? tile[(size_t)r * xs + c] : 0u;
+    }
+#pragma unroll
+    for (uint32_t i = 0; i < NR; i++) {
+        const uint32_t r = r0 + i;
+        ev[i] = 0u;
+        if (r < srows) {
+            if (lane == 0 && cin && c > 0u) ev[i] = tile[(size_t)r * xs + c - 1u];
+            if (lane == 63 && c + 1u < scols) ev[i] = tile[(size_t)r * xs + c + 1u];
+        }
+    }
+#pragma unroll
+    for (uint32_t i = 0; i < NR; i++) {
         const uint32_t r = r0 + i;
         if (r >= srows) break;                               // uniform per wavefront
-        const uint32_t below = (cin && r + 1u < srows) ? tile[(size_t)(r + 1u) * xs + c] : 0u;
-        const uint32_t s = cur;
+        const uint32_t above = rv[i], below = rv[i + 2u];
+        const uint32_t s = rv[i + 1u];
         uint32_t lf = __shfl_up(s, 1, 64), rt = __shfl_down(s, 1, 64);
-        if (lane == 0) lf = (cin && c > 0u) ? tile[(size_t)r * xs + c - 1u] : 0u;
-        if (lane == 63) rt = (c + 1u < scols) ? tile[(size_t)r * xs + c + 1u] : 0u;
+        if (lane == 0) lf = ev[i];
+        if (lane == 63) rt = ev[i];
         if (cin && c + 1u == scols) rt = 0u;                 // the strip ends here
         if (s != 0u) {
             const bool ldiff = lf != s, udiff = above != s;
@@ -68,8 +84,6 @@ __device__ __forceinline__ void strip_minmax_body(const uint32_t *__restrict__ t
                 }
             }
         }
-        above = cur;
-        cur = below;
     }
     __syncthreads();
     for (uint32_t i = threadIdx.x; i < AGG_SLOTS; i += 256u) {
@@ -492,14 +506,18 @@ __global__ __launch_bounds__(256) void k_cross_count(const uint32_t *__restrict_
     __shared__ uint32_t s_cnt;
     if (threadIdx.x == 0) s_cnt = 0;
     __syncthreads();
-    uint32_t mine = 0;
-    for (uint32_t i = blockIdx.x * 1024u + threadIdx.x, e = 0; e < 4u; e++, i += 256u) {
+    uint32_t mine = 0, sv[4];
+#pragma unroll
+    for (uint32_t e = 0; e < 4u; e++) {                      // the four labels first, then their flags: two round trips
+        const uint32_t i = blockIdx.x * 1024u + e * 256u + threadIdx.x;
+        sv[e] = 0u;
         if (i < srows * scols) {
             const uint32_t r = i / scols, c = i - r * scols;
-            const uint32_t s = tile[r * xs + c];
-            mine += (s != 0u && (flags[s] & bit)) ? 1u : 0u;
+            sv[e] = tile[r * xs + c];
         }
     }
+#pragma unroll
+    for (uint32_t e = 0; e < 4u; e++) mine += (sv[e] != 0u && (flags[sv[e]] & bit)) ? 1u : 0u;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) mine += __shfl_xor(mine, d, 64);
     if (lane_id() == 0 && mine) atomicAdd(&s_cnt, mine);
