@@ -394,7 +394,11 @@ def runDistributed(engine, comm, nRows, nCols, tileSize, overlapSize, minSegment
             ownsBad = t0 <= bad < t1
             # final ids for what is kept: output rows, the kept tiles' strips, and (on the rank that owns
             # `bad`) the previous rank's strips, which arrived with provisional ids
-            engine.renumberKept(stride, base, kept, list(fromPrevProv.values()) if (ownsBad and redo) else [])
+            # (a rank all of whose tiles are redone has nothing to renumber; one that redoes none never reads
+            #  its strips again: only its output rows get their final ids)
+            if kept:
+                engine.renumberKept(stride, base, kept if redo else [],
+                                    list(fromPrevProv.values()) if (ownsBad and redo) else [])
             if redo:
                 if ownsBad:
                     (maxSegId, fromPrev) = (mAfter, fromPrevProv)
