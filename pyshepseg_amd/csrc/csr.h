@@ -112,13 +112,30 @@ __global__ __launch_bounds__(256) void k_run_expand(const uint32_t *__restrict__
         v = rvals[r];
         o = roff[r] + (boffp ? boffp[r / SCAN_ITEMS] : 0u);
     }
-    const uint32_t wave0 = r - lane;
-    const uint32_t nr = wave0 < m ? (m - wave0 < 64u ? m - wave0 : 64u) : 0u;
-    for (uint32_t q = 0; q < nr; q++) {
-        const uint32_t vq = (uint32_t)__builtin_amdgcn_readlane((int)v, (int)q);
-        const uint32_t oq = (uint32_t)__builtin_amdgcn_readlane((int)o, (int)q);
-        const uint32_t len = (vq >> RUN_POS_BITS) + 1u;
-        if (lane < len) pix[oq + lane] = (vq & RUN_POS_MASK) + lane;
+    // the wavefront's 64 runs hold T pixels (5 a run on the benchmark raster): output pixel t of them is written by
+    // lane t % 64 -- it finds its run in the runs' prefix sums (six steps over a wavefront-private LDS row) -- so the
+    // wavefront stores 64 pixels per instruction, where a store per run wrote five
+    __shared__ uint32_t s_pre[4][64], s_v[4][64], s_o[4][64];
+    const unsigned wv = threadIdx.x >> 6;
+    const uint32_t len = r < m ? (v >> RUN_POS_BITS) + 1u : 0u;
+    uint32_t incl = len;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(incl, d, 64);
+        if ((int)lane >= d) incl += t;
+    }
+    s_pre[wv][lane] = incl - len;               // pixels of the wavefront's earlier runs
+    s_v[wv][lane] = v & RUN_POS_MASK;
+    s_o[wv][lane] = o;
+    const uint32_t T = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t t = lane; t < T; t += 64u) {
+        uint32_t q = 0;                         // the last run whose prefix is <= t
+#pragma unroll
+        for (uint32_t step = 32u; step >= 1u; step >>= 1)
+            if (s_pre[wv][q + step] <= t && q + step < 64u) q += step;
+        const uint32_t k = t - s_pre[wv][q];
+        pix[s_o[wv][q] + k] = s_v[wv][q] + k;
     }
 }
 
